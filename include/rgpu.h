@@ -1,0 +1,205 @@
+/*
+ * rgpu.h -- C ABI of the MI355X-native Godunov / MUSCL-Hancock unsplit time step
+ *           (hydro HLLC/approx/HLL, MHD HLLD + constrained transport, shearing box).
+ *
+ * This is the drop-in boundary for ONE hot path of pkestene/ramsesGPU: the body of
+ *   HydroRunBase::oneStepIntegration(int& nStep, real_t& t, real_t& dt)   (HydroRunBase.h:433)
+ *     = compute_dt[_mhd](nStep % 2) + godunov_unsplit(nStep, dt)          (MHDRunGodunov.cpp:4077-4089,
+ *                                                                           HydroRunGodunov.cpp:4082-4126)
+ * plus the ghost fill it calls (make_all_boundaries / make_all_boundaries_shear).
+ * The reference has no FFI; its seam is that C++ virtual interface with state in the protected members
+ * h_U,h_U2,d_U,d_U2 (HydroRunBase.h:556-566).  A maintainer binds these entry points from the run classes
+ * (see INTEGRATION.md).  Everything is plain C: pointers, sizes, doubles.  No torch / HIP types.
+ *
+ * Array layout (contract shared with the reference's HostArray/DeviceArray, Arrays.h:95-98,236-239):
+ *   U[ i + isize*( j + jsize*( k + ksize*ivar ) ) ],  fp64, ghost cells included,
+ *   isize = nx+2*ghostWidth, jsize = ny+2*ghostWidth, ksize = nz+2*ghostWidth (1 in 2D),
+ *   component order ID,IP,IU,IV,IW,IA,IB,IC (constants.h:59-71); hydro uses the first 4 (2D) / 5 (3D).
+ *   Sizes are 64-bit here (the reference's uint sizes overflow at 518^3 x 8).
+ *
+ * Error model: every int entry point returns 0 on success or a negative RGPU_E* code; the message is kept in
+ * the context (rgpu_last_error).  The reference exit()s on CUDA failure (cutil_inline_runtime.h:167-174); a
+ * library must not.  Not thread-safe per context (the reference is single-threaded per run object).
+ * All entry points return with their results visible to the next call (internally asynchronous on one stream).
+ */
+#ifndef RGPU_H_
+#define RGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGPU_ABI_VERSION 1
+
+/* component indexes -- constants.h:59-71 */
+enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
+
+/* BoundaryConditionType -- constants.h:209-217 */
+enum {
+  RGPU_BC_UNDEFINED = 0, RGPU_BC_DIRICHLET = 1, RGPU_BC_NEUMANN = 2, RGPU_BC_PERIODIC = 3,
+  RGPU_BC_SHEARINGBOX = 4, RGPU_BC_COPY = 5 /* ghost planes are supplied by a neighbour slab */,
+  RGPU_BC_Z_STRATIFIED = 6 /* not implemented: out of scope */
+};
+
+/* RiemannSolverType -- constants.h:140-146 */
+enum { RGPU_RS_APPROX = 0, RGPU_RS_HLL = 1, RGPU_RS_HLLC = 2, RGPU_RS_HLLD = 3, RGPU_RS_LLF = 4 };
+/* MagneticRiemannSolverType -- constants.h:149-156 */
+enum { RGPU_MAG_HLLD = 0, RGPU_MAG_HLLF = 1, RGPU_MAG_HLLA = 2, RGPU_MAG_ROE = 3, RGPU_MAG_LLF = 4, RGPU_MAG_UPWIND = 5 };
+
+/* direction ids used by rgpu_make_boundaries -- constants.h:220 (XDIR=1,YDIR=2,ZDIR=3) */
+enum { RGPU_XDIR = 1, RGPU_YDIR = 2, RGPU_ZDIR = 3 };
+
+/* error codes */
+enum {
+  RGPU_OK = 0, RGPU_EINVAL = -1, RGPU_ENODEVICE = -2, RGPU_ENOMEM = -3, RGPU_EHIP = -4, RGPU_EUNSUPPORTED = -5
+};
+
+/*
+ * Scalar knobs of one run: 1:1 with GlobalConstants (constants.h:277-317) and the HydroParameters members the
+ * path reads (HydroParameters.h:73-136), with the derivations of HydroParameters.h:196-325 ALREADY APPLIED by
+ * the host (float-parsed values widened to double, smallp/smallpp/gamma6 derived, MHD => ghostWidth 3, nbVar 8).
+ */
+typedef struct rgpu_params {
+  int32_t abi_version;          /* must be RGPU_ABI_VERSION */
+  int32_t nx, ny, nz;           /* interior cells of THIS domain (a z-slab when slab_count>1); nz=1 => 2D */
+  int32_t ghostWidth;           /* 2 hydro, 3 MHD (HydroParameters.h:260-271) */
+  int32_t nbVar;                /* 4 hydro 2D, 5 hydro 3D, 8 MHD (HydroParameters.h:204-235) */
+  int32_t mhdEnabled;
+  int32_t bc[6];                /* xmin,xmax,ymin,ymax,zmin,zmax (HydroParameters.h:253-258) */
+  double  xMin, xMax, yMin, yMax, zMin, zMax;   /* GLOBAL box (HydroParameters.h:238-243) */
+  double  dx, dy, dz;           /* HydroParameters.h:245-247 (dz from the GLOBAL nz) */
+  double  cfl;                  /* HydroParameters.h:274-282 */
+  double  gamma0, cIso, smallr, smallc, smalle, smallp, smallpp, gamma6;   /* HydroParameters.h:292-312 */
+  double  Omega0;               /* [MHD] omega0 (HydroParameters.h:313) */
+  double  slope_type;           /* HydroParameters.h:319-321 */
+  int32_t niter_riemann, iorder;
+  int32_t riemannSolver;        /* RGPU_RS_*  (HydroParameters.h:353-381) */
+  int32_t magRiemannSolver;     /* RGPU_MAG_* (HydroParameters.h:388-417) */
+  int32_t implementationVersion;/* [MHD] implementationVersion: 2D must be 1; 3D 3/4 (Omega0>0 forces 1/4, MHDRunGodunov.cpp:119-126) */
+  int32_t unsplitVersion;       /* [hydro] unsplitVersion: only 1 is implemented (HydroRunGodunov.cpp:1858-1860) */
+  int32_t shearingBoxEnabled;   /* bc xmin==xmax==4 and Omega0>0 (MHDRunGodunov.cpp:97-103) */
+  int32_t enableJet, ijet, offsetJet;  /* HydroParameters.h:435-444 */
+  double  djet, ujet, pjet, cjet;
+  /* z-slab decomposition (replaces the reference's MPI cartesian topology, HydroMpiParameters.cpp:44-80) */
+  int32_t slab_rank, slab_count;/* 0,1 for a single device */
+  int32_t nz_global;            /* == nz when slab_count==1 */
+  int32_t reserved0;
+} rgpu_params;
+
+typedef struct rgpu_ctx rgpu_ctx;
+
+/* ---- life cycle ------------------------------------------------------------------------------------------ */
+
+/* Allocates U, U2 and all scratch on the current HIP device.  Replaces the allocations of the HydroRunBase /
+ * MHDRunGodunov constructors (HydroRunBase.cpp:92-300, MHDRunGodunov.cpp:128-418).  Fails with RGPU_ENODEVICE when
+ * no GPU is present: there is NO CPU fallback. */
+int rgpu_create(const rgpu_params* p, rgpu_ctx** out);
+
+/* Same, but U and U2 are device buffers owned by the caller (e.g. torch tensors) of rgpu_state_elems() doubles
+ * each, and work is issued on the caller's hipStream_t (pass NULL for the default stream). */
+int rgpu_create_external(const rgpu_params* p, double* dU, double* dU2, void* hip_stream, rgpu_ctx** out);
+
+void rgpu_destroy(rgpu_ctx* c);
+
+/* number of doubles in one state array: isize*jsize*ksize*nbVar */
+size_t rgpu_state_elems(const rgpu_params* p);
+
+/* bytes of device memory rgpu_create will allocate (U, U2 and scratch) */
+size_t rgpu_device_bytes(const rgpu_params* p);
+
+const char* rgpu_last_error(rgpu_ctx* c);
+
+/* ---- host <-> device (init, output, history only; never inside the step) ---------------------------------- */
+
+/* == d_U.copyFromHost(h_U) [+ d_U2] (MHDRunBase.cpp:1346-1351) */
+int rgpu_upload(rgpu_ctx* c, const double* hU, int both);
+/* == copyGpuToCpu(nStep) + getDataHost(nStep) (HydroRunBase.cpp:7217-7229, 2442-2447); parity = nStep%2 */
+int rgpu_download(rgpu_ctx* c, double* hU, int parity);
+/* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */
+double* rgpu_device_state(rgpu_ctx* c, int parity);
+
+/* ---- the path ------------------------------------------------------------------------------------------- */
+
+/* Ghost fill of one direction: make_boundaries(U, idim) (HydroRunBase.cpp:2276-2316), incl. make_jet.
+ * Faces whose bc is RGPU_BC_COPY or RGPU_BC_SHEARINGBOX are left untouched. */
+int rgpu_make_boundaries(rgpu_ctx* c, int parity, int idim);
+
+/* Shearing-box remap of the x ghosts: MHDRunGodunov::make_boundaries_shear (MHDRunGodunov.cpp:3539-3759).
+ * totalTime is the time at the START of the step that produced U[parity], dt its time step
+ * (the remap uses totalTime+dt, :3554). */
+int rgpu_make_boundaries_shear(rgpu_ctx* c, int parity, double totalTime, double dt);
+
+/* make_all_boundaries (X,Y,Z; HydroRunBase.cpp:2333-2342) or, when shearingBoxEnabled and 3D,
+ * make_all_boundaries_shear (Y, shear, Z, Y; MHDRunGodunov.cpp:3779-3793). */
+int rgpu_make_all_boundaries(rgpu_ctx* c, int parity, double totalTime, double dt);
+
+/* max over the interior of the inverse time step: the invDt of compute_dt (HydroRunBase.cpp:372-426) /
+ * compute_dt_mhd (MHDRunBase.cpp:140-250) BEFORE "cfl / invDt"; with slabs the caller max-reduces it. */
+int rgpu_compute_inv_dt(rgpu_ctx* c, int parity, double* invDt);
+
+/* == compute_dt[_mhd](useU): cfl / invDt.  Returns NaN on error (see rgpu_last_error). */
+double rgpu_compute_dt(rgpu_ctx* c, int useU);
+
+/* == godunov_unsplit(nStep, dt) (MHDRunGodunov.cpp:572-617, HydroRunGodunov.cpp:419-441): reads U[nStep%2],
+ * writes U[(nStep+1)%2].  Plain path fills the ghosts of the INPUT at entry; the rotating path (Omega0>0) fills
+ * the ghosts of the OUTPUT at exit (MHDRunGodunov.cpp:2031-3440).  totalTime is needed by the shear remaps
+ * (:3213, :3554).  With RGPU_BC_COPY z faces use the three calls below instead. */
+int rgpu_godunov_unsplit(rgpu_ctx* c, int nStep, double dt, double totalTime);
+
+/* The same step cut at the points where a z-slab driver exchanges ghost planes:
+ *   plain   : pre (X,Y fill of input) -> [exchange z ghosts of input]  -> core -> post (nothing)
+ *   rotating: pre (nothing)           -> core -> post_a (Y fill, shear remap of output)
+ *                                     -> [exchange z ghosts of output] -> post_b (Y fill of output) */
+int rgpu_step_pre   (rgpu_ctx* c, int nStep, double dt, double totalTime);
+int rgpu_step_core  (rgpu_ctx* c, int nStep, double dt, double totalTime);
+int rgpu_step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime);
+int rgpu_step_post_b(rgpu_ctx* c, int nStep, double dt, double totalTime);
+
+/* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
+int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
+
+/* block until all queued work of this context is complete */
+int rgpu_synchronize(rgpu_ctx* c);
+
+/* ---- instrumentation (the reference's DO_TIMING phase timers, MHDRunGodunov.h:382-430) ------------------- */
+
+enum {
+  RGPU_T_BOUNDARIES = 0, RGPU_T_PRIM, RGPU_T_ELEC, RGPU_T_TRACE, RGPU_T_FLUX, RGPU_T_EMF, RGPU_T_UPDATE,
+  RGPU_T_SHEAR, RGPU_T_DT, RGPU_T_COUNT
+};
+/* enable!=0 brackets every phase with hipEvents (serialises the stream; off by default) */
+int rgpu_enable_timers(rgpu_ctx* c, int enable);
+/* accumulated seconds per phase since creation / last reset; n <= RGPU_T_COUNT */
+int rgpu_get_timers(rgpu_ctx* c, double* secs, int n);
+int rgpu_reset_timers(rgpu_ctx* c);
+const char* rgpu_timer_name(int which);
+
+/* name / average duration [ms] / launch count of the dominant kernel of the last timed steps, measured with
+ * hipEvents on the context's stream (used by bench.py's roofline object) */
+int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, long* launches);
+
+/* ---- host side of the reference interface (C++ lives in csrc/host; these are its C entry points) ---------- */
+
+/* Parse an .ini file exactly like ConfigMap + HydroParameters (float-parsed knobs, case-insensitive keys,
+ * ConfigMap.cpp:41-49, INIReader.cpp:94-101) with optional "section.key=value;..." overrides. */
+int rgpuh_params_from_ini(const char* ini_path, const char* overrides, rgpu_params* out, char* err, int err_len);
+
+/* Fill hU (rgpu_state_elems doubles, zeroed first) with the initial condition named by [hydro] problem:
+ * jet, implode (HydroRunBase.cpp:5282-5350, 5449-5536), Orszag-Tang, Brio-Wu, MRI
+ * (MHDRunBase.cpp:1378-1475, 1870-2080, 2677-2758).  For a slab, only planes of this slab are produced
+ * (the MRI drand48 stream is skipped ahead so that every slab draws the numbers the single-domain run would). */
+int rgpuh_init_condition(const char* ini_path, const char* overrides, const rgpu_params* p, double* hU,
+                         char* err, int err_len);
+
+/* Run [run] nstepmax / tend like MHDRunGodunov::start / HydroRunGodunov::start on one GPU; writes .vti outputs
+ * when [output] outputVtk=yes.  Returns steps done (>=0) or a negative error. Mcell-updates/s is printed like
+ * MHDRunGodunov.cpp:4064-4068. */
+int rgpuh_run(const char* ini_path, const char* overrides, double* mcell_per_s, char* err, int err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGPU_H_ */

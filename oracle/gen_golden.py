@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by RUNNING THE REFERENCE ITSELF (oracle/_ref/euler_cpu).
+
+Test infrastructure only.  Runs in the build container (where /root/reference exists and
+`make -C oracle -f Makefile.ref` has produced oracle/_ref/euler_cpu).  For every case in CASES it
+
+  1. writes a temporary .ini = configs/<base>.ini with the case's overrides applied,
+  2. runs the reference `euler_cpu --param tmp.ini` (g++ -O2, no OpenMP, no FMA: see Makefile.ref),
+  3. parses the hand-written VTI outputs (HydroRunBase.cpp:2681-2995: appended raw, uint32 byte count +
+     nx*ny*nz little-endian Float64 per variable, INTERIOR cells only),
+  4. stores the requested steps + the per-step dt log + the final time in tests/golden/<case>.npz.
+
+The fixtures are DATA (inputs = configs + overrides listed in tests/golden/cases.json, outputs = arrays).
+No reference source text is stored.
+
+usage: python oracle/gen_golden.py [case ...]
+"""
+import json
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_BIN = os.path.join(HERE, "_ref", "euler_cpu")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (base config, overrides, steps to keep)
+# every run uses nlog=1 so that the dt of every step is printed with 12 decimals (MHDRunGodunov.cpp:3925-3931)
+CASES = {
+    # --- 2D MHD (implementation 1): Orszag-Tang (periodic) ------------------------------------------------
+    "ot2d_32": ("orszag-tang", "mesh.nx=32;mesh.ny=32;run.nstepmax=50;run.noutput=10", [0, 10, 50]),
+    "ot2d_32_s1": ("orszag-tang", "mesh.nx=32;mesh.ny=32;run.nstepmax=1;run.noutput=10", [1]),
+    "ot2d_64": ("orszag-tang", "mesh.nx=64;mesh.ny=64;run.nstepmax=20;run.noutput=100", [20]),
+    "ot2d_48x24": ("orszag-tang", "mesh.nx=48;mesh.ny=24;run.nstepmax=7;run.noutput=100", [7]),
+    # --- 2D MHD Brio-Wu (Neumann) ---------------------------------------------------------------------------
+    "briowu_x_64": ("mhd_BrioWu", "mesh.nx=64;mesh.ny=64;BrioWu.direction=0;run.nstepmax=20;run.noutput=100", [0, 20]),
+    "briowu_y_64": ("mhd_BrioWu", "mesh.nx=64;mesh.ny=64;BrioWu.direction=1;run.nstepmax=20;run.noutput=100", [0, 20]),
+    # --- 3D hydro implode (Dirichlet), the three hydro Riemann solvers ---------------------------------------
+    "implode3d_16_approx": ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=16;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "implode3d_16_hllc": ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=16;hydro.riemannSolver=hllc;run.nstepmax=10;run.noutput=100", [10]),
+    "implode3d_16_hll": ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=16;hydro.riemannSolver=hll;run.nstepmax=10;run.noutput=100", [10]),
+    "implode3d_24x16x12_hllc_mc": ("implode3d", "mesh.nx=24;mesh.ny=16;mesh.nz=12;hydro.riemannSolver=hllc;hydro.slope_type=2.0;run.nstepmax=8;run.noutput=100", [8]),
+    # --- 2D hydro: implode 2D and the jet (inflow BC) ----------------------------------------------------------
+    "implode2d_32_hllc": ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=1;hydro.riemannSolver=hllc;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "implode2d_32_approx": ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=1;run.nstepmax=10;run.noutput=100", [10]),
+    "jet2d_20x80": ("jet2d_cpu", "mesh.nx=20;mesh.ny=80;jet.ijet=4;jet.offsetJet=3;run.nstepmax=20;run.noutput=100", [0, 20]),
+    # --- 3D MHD plain path (implementation 3/4) ----------------------------------------------------------------
+    "ot3d_16": ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=16;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "ot3d_16_s1": ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=16;run.nstepmax=1;run.noutput=100", [1]),
+    "ot3d_20x12x8_kt": ("orszag-tang3d", "mesh.nx=20;mesh.ny=12;mesh.nz=8;OrszagTang.kt=1.0;run.nstepmax=4;run.noutput=100", [4]),
+    # --- 3D MHD rotating + shearing box (MRI), the shipped size -------------------------------------------------
+    "mri_16x32x16": ("mhd_mri_3d", "run.nstepmax=20;run.noutput=5", [0, 5, 20]),
+    "mri_16x32x16_s1": ("mhd_mri_3d", "run.nstepmax=1;run.noutput=100", [1]),
+    "mri_8x16x8_long": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;run.nstepmax=60;run.noutput=1000", [60]),
+}
+
+VAR_NAMES = {
+    4: ["density", "energy", "mx", "my"],
+    5: ["density", "energy", "mx", "my", "mz"],
+    8: ["density", "energy", "mx", "my", "mz", "bx", "by", "bz"],
+}
+
+
+def apply_overrides(ini_text, overrides):
+    """Return ini_text with 'section.key=value;...' applied (keys are case-insensitive like the reference)."""
+    lines = ini_text.splitlines()
+    for ov in [o for o in overrides.split(";") if o.strip()]:
+        lhs, value = ov.split("=", 1)
+        section, key = lhs.strip().split(".", 1)
+        out, cur, done, sec_end = [], None, False, None
+        for ln in lines:
+            m = re.match(r"\s*\[(.+?)\]", ln)
+            if m:
+                if cur is not None and cur.lower() == section.lower() and not done and sec_end is None:
+                    sec_end = len(out)
+                cur = m.group(1)
+            elif cur is not None and cur.lower() == section.lower():
+                km = re.match(r"\s*([^=#;]+?)\s*=", ln)
+                if km and km.group(1).lower() == key.lower():
+                    ln = "%s=%s" % (key, value.strip())
+                    done = True
+            out.append(ln)
+        if not done:
+            if cur is not None and cur.lower() == section.lower() and sec_end is None:
+                sec_end = len(out)
+            if sec_end is None:
+                out += ["", "[%s]" % section, "%s=%s" % (key, value.strip())]
+            else:
+                out.insert(sec_end, "%s=%s" % (key, value.strip()))
+        lines = out
+    return "\n".join(lines) + "\n"
+
+
+def read_vti(path):
+    """Parse the reference's hand-written appended-raw VTI; returns dict name -> array[nz][ny][nx]."""
+    blob = open(path, "rb").read()
+    head_end = blob.index(b'<AppendedData encoding="raw">')
+    head = blob[:head_end].decode("ascii", "replace")
+    ext = re.search(r'WholeExtent="(\d+) (\d+) (\d+) (\d+) (\d+) (\d+)"', head)
+    e = [int(x) for x in ext.groups()]
+    nx, ny, nz = e[1] - e[0] + 1, e[3] - e[2] + 1, e[5] - e[4] + 1
+    start = blob.index(b"_", head_end) + 1
+    out = {}
+    for m in re.finditer(r'<DataArray type="Float64" Name="(\w+)" format="appended" offset="(\d+)"', head):
+        name, off = m.group(1), int(m.group(2))
+        (nbytes,) = struct.unpack_from("<I", blob, start + off)
+        assert nbytes == nx * ny * nz * 8, (name, nbytes, nx, ny, nz)
+        a = np.frombuffer(blob, dtype="<f8", count=nx * ny * nz, offset=start + off + 4)
+        out[name] = a.reshape(nz, ny, nx).copy()
+    return out, (nx, ny, nz)
+
+
+def run_case(name):
+    base, overrides, steps = CASES[name]
+    ini = open(os.path.join(ROOT, "configs", base + ".ini")).read()
+    ini = apply_overrides(ini, overrides + ";run.nlog=1;output.outputVtk=yes;output.outputHdf5=no;output.outputDir=./")
+    prefix = re.search(r"outputPrefix=(\S+)", ini).group(1)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "case.ini"), "w") as f:
+            f.write(ini)
+        res = subprocess.run([REF_BIN, "--param", "case.ini"], cwd=td, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, universal_newlines=True, check=True)
+        log = res.stdout
+        arrays = {}
+        for s in steps:
+            fields, dims = read_vti(os.path.join(td, "%s_%07d.vti" % (prefix, s)))
+            names = VAR_NAMES[len(fields)]
+            arrays["step_%d" % s] = np.stack([fields[n] for n in names])
+    # dt log: "step=  N t=  T dt=  D" lines; with nlog=1 the line printed at step N carries the dt of step N-1
+    # (the first one carries the initial compute_dt).  Duplicated lines (output + log) are collapsed on N.
+    dts = {}
+    for m in re.finditer(r"step=\s*(\d+)\s+t=\s*([-+0-9.eE]+)\s+dt=\s*([-+0-9.eE]+)", log):
+        dts[int(m.group(1))] = (float(m.group(2)), float(m.group(3)))
+    nmax = max(dts) if dts else -1
+    arrays["log_t"] = np.array([dts[i][0] for i in range(nmax + 1)])
+    arrays["log_dt"] = np.array([dts[i][1] for i in range(nmax + 1)])
+    tt = re.search(r"DEBUG : totalTime\s+([-+0-9.eE]+)", log)
+    # (the hydro run class does not print it; NaN then)
+    arrays["total_time"] = np.array(float(tt.group(1)) if tt else float("nan"))
+    os.makedirs(GOLDEN, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **arrays)
+    return {"base": base, "overrides": overrides, "steps": steps}
+
+
+def main(argv):
+    if not os.path.exists(REF_BIN):
+        sys.exit("oracle/_ref/euler_cpu missing: run `make -C oracle -f Makefile.ref` where /root/reference exists")
+    names = argv or list(CASES)
+    meta_path = os.path.join(GOLDEN, "cases.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    for n in names:
+        meta[n] = run_case(n)
+        print("golden:", n, meta[n]["steps"])
+    with open(meta_path, "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,96 @@
+// orc_api.cpp -- ORACLE (test infrastructure).  C entry points of the CPU restatement, loaded with ctypes by
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The product never links this.
+#include <cstdio>
+
+#include "orc_common.h"
+
+using namespace orc;
+
+extern "C" {
+
+// make_boundaries(U, idim)
+int orc_make_boundaries(const rgpu_params* p, double* U, int idim) {
+  Ctx c(*p);
+  make_boundaries(c, U, idim);
+  return 0;
+}
+
+// make_all_boundaries / make_all_boundaries_shear
+int orc_make_all_boundaries(const rgpu_params* p, double* U, double totalTime, double dt) {
+  Ctx c(*p);
+  make_all_boundaries(c, U, totalTime, dt);
+  return 0;
+}
+
+int orc_make_boundaries_shear(const rgpu_params* p, double* U, double totalTime, double dt) {
+  Ctx c(*p);
+  make_boundaries_shear(c, U, totalTime, dt);
+  return 0;
+}
+
+double orc_compute_inv_dt(const rgpu_params* p, const double* U) {
+  Ctx c(*p);
+  return compute_inv_dt(c, U);
+}
+
+// compute_dt[_mhd]
+double orc_compute_dt(const rgpu_params* p, const double* U) {
+  Ctx c(*p);
+  return p->cfl / compute_inv_dt(c, U);
+}
+
+static int check_scope(const rgpu_params* p) {
+  if (p->slope_type != 0 && p->slope_type != 1 && p->slope_type != 2) return RGPU_EUNSUPPORTED;
+  if (p->mhdEnabled) {
+    const bool three_d = p->nz_global != 1;
+    if (!three_d && p->implementationVersion != 1) return RGPU_EUNSUPPORTED;
+    if (!three_d && p->Omega0 > 0) return RGPU_EUNSUPPORTED;
+    if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) return RGPU_EUNSUPPORTED;
+  } else {
+    if (p->unsplitVersion != 1) return RGPU_EUNSUPPORTED;
+  }
+  return 0;
+}
+
+// godunov_unsplit(nStep, dt): Uold -> Unew (both ghost-inclusive, caller-owned)
+int orc_godunov_unsplit(const rgpu_params* p, double* Uold, double* Unew, double dt, double totalTime) {
+  const int rc = check_scope(p);
+  if (rc) return rc;
+  Ctx c(*p);
+  if (!p->mhdEnabled) hydro_step(c, Uold, Unew, dt);
+  else if (!c.three_d) mhd_step_2d(c, Uold, Unew, dt);
+  else mhd_step_3d(c, Uold, Unew, dt, totalTime);
+  return 0;
+}
+
+// The time loop of start() (MHDRunGodunov.cpp:3801-3989 / HydroRunGodunov.cpp:3857-...): initial ghost fill,
+// copy to U2, then oneStepIntegration until nStepmax / tEnd.  On return U holds the state of the LAST step
+// (whatever its parity), *nsteps_done and *t_final are set and dts[0..nsteps_done) the time steps used.
+int orc_run(const rgpu_params* p, double* U, int nStepmax, double tEnd, int* nsteps_done, double* t_final, double* dts) {
+  const int rc = check_scope(p);
+  if (rc) return rc;
+  Ctx c(*p);
+  const size_t n = c.ncell * c.nvar;
+  std::vector<double> U2(n);
+  make_all_boundaries(c, U, 0.0, 0.0);
+  std::memcpy(U2.data(), U, sizeof(double) * n);
+  double t = 0.0;
+  int nStep = 0;
+  while (t < tEnd && nStep < nStepmax) {
+    double* cur = (nStep % 2 == 0) ? U : U2.data();
+    double* nxt = (nStep % 2 == 0) ? U2.data() : U;
+    const double dt = p->cfl / compute_inv_dt(c, cur);
+    if (!p->mhdEnabled) hydro_step(c, cur, nxt, dt);
+    else if (!c.three_d) mhd_step_2d(c, cur, nxt, dt);
+    else mhd_step_3d(c, cur, nxt, dt, t);
+    if (dts) dts[nStep] = dt;
+    nStep++;
+    t += dt;
+  }
+  if (nStep % 2 == 1) std::memcpy(U, U2.data(), sizeof(double) * n);
+  if (nsteps_done) *nsteps_done = nStep;
+  if (t_final) *t_final = t;
+  return 0;
+}
+
+}  // extern "C"

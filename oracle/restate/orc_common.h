@@ -1,0 +1,68 @@
+// orc_common.h -- ORACLE (test infrastructure, NOT product code).
+//
+// CPU restatement of the reference's euler_cpu time step, used only by tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg as the checker of the HIP path.  Plain single-threaded C++; every loop keeps the
+// reference's iteration order and every expression its operand order, so that (built with the same flags as
+// oracle/_ref/euler_cpu: g++ -O2, no -march, no -ffast-math, no OpenMP) results are BIT-IDENTICAL to the
+// reference binary.  That identity is pinned by tests/test_oracle_golden.py against fixtures produced by the
+// reference itself (oracle/gen_golden.py).
+//
+// The only product file it sees is include/rgpu.h, for the parameter struct the checker and the checked
+// share.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rgpu.h"
+
+namespace orc {
+
+enum { ID = 0, IP = 1, IU = 2, IV = 3, IW = 4, IA = 5, IB = 6, IC = 7 };
+enum { IX = 0, IY = 1, IZ = 2 };
+// EmfIndex, constants.h:191-195 (EMFZ first)
+enum { I_EMFZ = 0, I_EMFY = 1, I_EMFX = 2 };
+
+// Geometry + knobs of one run (what the reference keeps in HydroParameters members and the global gParams).
+struct Ctx {
+  rgpu_params p;
+  int nx, ny, nz, gw, isize, jsize, ksize, nvar;
+  bool three_d;
+  size_t ncell;
+  double dx, dy, dz;
+  explicit Ctx(const rgpu_params& pp) : p(pp) {
+    nx = p.nx; ny = p.ny; nz = p.nz; gw = p.ghostWidth; nvar = p.nbVar;
+    three_d = (p.nz_global != 1);
+    isize = nx + 2 * gw; jsize = ny + 2 * gw; ksize = three_d ? nz + 2 * gw : 1;
+    ncell = (size_t)isize * jsize * ksize;
+    dx = p.dx; dy = p.dy; dz = p.dz;
+  }
+  size_t idx(int i, int j, int k) const { return (size_t)i + (size_t)isize * (j + (size_t)jsize * k); }
+};
+
+// A component-major field with the reference's HostArray index map (Arrays.h:95-98).
+struct Field {
+  const Ctx* c;
+  std::vector<double> own;
+  double* d;
+  int nv;
+  Field() : c(0), d(0), nv(0) {}
+  void alloc(const Ctx& ctx, int nvar) { c = &ctx; nv = nvar; own.assign(ctx.ncell * nvar, 0.0); d = own.data(); }
+  void wrap(const Ctx& ctx, double* ptr, int nvar) { c = &ctx; nv = nvar; d = ptr; }
+  double& operator()(int i, int j, int k, int v) { return d[c->idx(i, j, k) + c->ncell * v]; }
+  double operator()(int i, int j, int k, int v) const { return d[c->idx(i, j, k) + c->ncell * v]; }
+  double& operator()(int i, int j, int v) { return d[c->idx(i, j, 0) + c->ncell * v]; }
+  double operator()(int i, int j, int v) const { return d[c->idx(i, j, 0) + c->ncell * v]; }
+};
+
+// entry points of the individual translation units
+void make_boundaries(const Ctx& c, double* U, int idim);                               // orc_boundaries.cpp
+void make_boundaries_shear(const Ctx& c, double* U, double totalTime, double dt);      // orc_boundaries.cpp
+void make_all_boundaries(const Ctx& c, double* U, double totalTime, double dt);        // orc_boundaries.cpp
+double compute_inv_dt(const Ctx& c, const double* U);                                  // orc_dt.cpp
+void hydro_step(const Ctx& c, double* Uold, double* Unew, double dt);                  // orc_hydro.cpp
+void mhd_step_2d(const Ctx& c, double* Uold, double* Unew, double dt);                 // orc_mhd2d.cpp
+void mhd_step_3d(const Ctx& c, double* Uold, double* Unew, double dt, double totalTime);  // orc_mhd3d.cpp
+
+}  // namespace orc

@@ -1,0 +1,74 @@
+"""ctypes view of include/rgpu.h (the C ABI) -- plain structs and prototypes, no compute here."""
+import ctypes as C
+
+RGPU_ABI_VERSION = 1
+
+ID, IP, IU, IV, IW, IA, IB, IC = range(8)
+BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
+RS_APPROX, RS_HLL, RS_HLLC, RS_HLLD, RS_LLF = range(5)
+XDIR, YDIR, ZDIR = 1, 2, 3
+T_NAMES = ["boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt"]
+
+
+class RgpuParams(C.Structure):
+    """struct rgpu_params (include/rgpu.h) -- field order and types must match exactly."""
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+        ("ghostWidth", C.c_int32),
+        ("nbVar", C.c_int32),
+        ("mhdEnabled", C.c_int32),
+        ("bc", C.c_int32 * 6),
+        ("xMin", C.c_double), ("xMax", C.c_double), ("yMin", C.c_double), ("yMax", C.c_double),
+        ("zMin", C.c_double), ("zMax", C.c_double),
+        ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+        ("cfl", C.c_double),
+        ("gamma0", C.c_double), ("cIso", C.c_double), ("smallr", C.c_double), ("smallc", C.c_double),
+        ("smalle", C.c_double), ("smallp", C.c_double), ("smallpp", C.c_double), ("gamma6", C.c_double),
+        ("Omega0", C.c_double),
+        ("slope_type", C.c_double),
+        ("niter_riemann", C.c_int32), ("iorder", C.c_int32),
+        ("riemannSolver", C.c_int32),
+        ("magRiemannSolver", C.c_int32),
+        ("implementationVersion", C.c_int32),
+        ("unsplitVersion", C.c_int32),
+        ("shearingBoxEnabled", C.c_int32),
+        ("enableJet", C.c_int32), ("ijet", C.c_int32), ("offsetJet", C.c_int32),
+        ("djet", C.c_double), ("ujet", C.c_double), ("pjet", C.c_double), ("cjet", C.c_double),
+        ("slab_rank", C.c_int32), ("slab_count", C.c_int32),
+        ("nz_global", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+    @property
+    def three_d(self):
+        return self.nz_global != 1
+
+    @property
+    def shape(self):
+        """(nbVar, ksize, jsize, isize) of a ghost-inclusive state array."""
+        gw = self.ghostWidth
+        ks = self.nz + 2 * gw if self.three_d else 1
+        return (self.nbVar, ks, self.ny + 2 * gw, self.nx + 2 * gw)
+
+    def copy(self):
+        q = RgpuParams()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(RgpuParams))
+        return q
+
+
+c_double_p = C.POINTER(C.c_double)
+
+
+def declare_host_api(lib):
+    """prototypes of the rgpuh_* entry points + rgpu_state_elems"""
+    lib.rgpu_state_elems.restype = C.c_size_t
+    lib.rgpu_state_elems.argtypes = [C.POINTER(RgpuParams)]
+    lib.rgpuh_params_from_ini.restype = C.c_int
+    lib.rgpuh_params_from_ini.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_char_p, C.c_int]
+    lib.rgpuh_run_settings.restype = C.c_int
+    lib.rgpuh_run_settings.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int),
+                                       C.c_char_p, C.c_int]
+    lib.rgpuh_init_condition.restype = C.c_int
+    lib.rgpuh_init_condition.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
+    return lib

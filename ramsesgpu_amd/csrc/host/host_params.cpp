@@ -1,0 +1,152 @@
+#include "host_params.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace rgpu_host {
+
+static std::string lower(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+  return s;
+}
+
+void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgpu_params* p, RunSettings* rs) {
+  std::memset(p, 0, sizeof(*p));
+  p->abi_version = RGPU_ABI_VERSION;
+
+  // [run]  (HydroParameters.h:196-198)
+  rs->nStepmax = static_cast<int>(cfg.get_integer("run", "nstepmax", 1000));
+  rs->tEnd = cfg.get_float("run", "tend", 0.0f);
+  rs->nOutput = static_cast<int>(cfg.get_integer("run", "noutput", 100));
+  rs->nLog = static_cast<int>(cfg.get_integer("run", "nlog", 0));
+
+  // [mesh]  (HydroParameters.h:201-271)
+  const int nx = static_cast<int>(cfg.get_integer("mesh", "nx", 2));
+  const int ny = static_cast<int>(cfg.get_integer("mesh", "ny", 2));
+  const int nz = static_cast<int>(cfg.get_integer("mesh", "nz", 1));
+  const bool three_d = (nz != 1);
+  p->mhdEnabled = cfg.get_bool("MHD", "enable", false) ? 1 : 0;
+  p->nbVar = p->mhdEnabled ? 8 : (three_d ? 5 : 4);
+
+  p->xMin = cfg.get_float("mesh", "xmin", 0.0f);
+  p->xMax = cfg.get_float("mesh", "xmax", 1.0f);
+  p->yMin = cfg.get_float("mesh", "ymin", 0.0f);
+  p->yMax = cfg.get_float("mesh", "ymax", 1.0f);
+  p->zMin = cfg.get_float("mesh", "zmin", 0.0f);
+  p->zMax = cfg.get_float("mesh", "zmax", 1.0f);
+  p->dx = (p->xMax - p->xMin) / nx;
+  p->dy = (p->yMax - p->yMin) / ny;
+  p->dz = (p->zMax - p->zMin) / nz;
+
+  if (cfg.get_integer("mesh", "geometry", 0) != 0)
+    throw std::runtime_error("only cartesian geometry is implemented (mesh.geometry must be 0)");
+
+  static const char* bcnames[6] = {"boundary_xmin", "boundary_xmax", "boundary_ymin",
+                                   "boundary_ymax", "boundary_zmin", "boundary_zmax"};
+  for (int f = 0; f < 6; ++f) p->bc[f] = static_cast<int>(cfg.get_integer("mesh", bcnames[f], RGPU_BC_DIRICHLET));
+
+  int gw = static_cast<int>(cfg.get_integer("mesh", "ghostWidth", 2));
+  if (gw != 2 && gw != 3) gw = 2;
+  if (p->mhdEnabled) gw = 3;
+  p->ghostWidth = gw;
+
+  // [hydro]  (HydroParameters.h:274-321)
+  p->cfl = cfg.get_float("hydro", "cfl", 0.5f);
+  if (!p->cfl) p->cfl = 0.5;
+  rs->problem = cfg.get_string("hydro", "problem", "unknown");
+  p->cIso = cfg.get_float("hydro", "cIso", 0);
+  p->gamma0 = cfg.get_float("hydro", "gamma0", 1.4f);
+  p->smallr = cfg.get_float("hydro", "smallr", 1e-10f);
+  p->smallc = cfg.get_float("hydro", "smallc", 1e-10f);
+  p->niter_riemann = static_cast<int>(cfg.get_integer("hydro", "niter_riemann", 10));
+  p->iorder = static_cast<int>(cfg.get_integer("hydro", "iorder", 2));
+  p->smalle = 1e-7;
+  p->smallp = p->smallc * p->smallc / p->gamma0;
+  if (p->cIso > 0) p->smallp = p->smallr * p->cIso * p->cIso;
+  p->smallpp = p->smallr * p->smallp;
+  p->gamma6 = (p->gamma0 + 1.0f) / (2.0f * p->gamma0);
+  p->Omega0 = cfg.get_float("MHD", "omega0", 0.0f);
+  p->slope_type = cfg.get_float("hydro", "slope_type", 1.0f);
+  if (cfg.get_integer("hydro", "traceVersion", 1) == 0) p->slope_type = 0.0;
+
+  if (cfg.get_float("gravity", "static_field_x", 0.0f) != 0 || cfg.get_float("gravity", "static_field_y", 0.0f) != 0 ||
+      cfg.get_float("gravity", "static_field_z", 0.0f) != 0 || cfg.get_bool("gravity", "enabled", false))
+    throw std::runtime_error("gravity is outside the implemented scope");
+  if (cfg.get_float("hydro", "nu", 0.0f) > 0 || cfg.get_float("MHD", "eta", 0.0f) > 0)
+    throw std::runtime_error("viscosity / resistivity are outside the implemented scope");
+  if (lower(cfg.get_string("hydro", "scheme", "muscl")) != "muscl")
+    throw std::runtime_error("only scheme=muscl is implemented");
+
+  // Riemann solvers (HydroParameters.h:353-417): unknown strings silently fall back to the default
+  const std::string rs_str = lower(cfg.get_string("hydro", "riemannSolver", "approx"));
+  p->riemannSolver = RGPU_RS_APPROX;
+  if (rs_str == "approx") p->riemannSolver = RGPU_RS_APPROX;
+  else if (rs_str == "hll") p->riemannSolver = RGPU_RS_HLL;
+  else if (rs_str == "hllc") p->riemannSolver = RGPU_RS_HLLC;
+  else if (p->mhdEnabled && rs_str == "hlld") p->riemannSolver = RGPU_RS_HLLD;
+  else if (p->mhdEnabled && rs_str == "llf") p->riemannSolver = RGPU_RS_LLF;
+
+  p->magRiemannSolver = RGPU_MAG_HLLD;
+  if (p->mhdEnabled) {
+    const std::string ms = lower(cfg.get_string("MHD", "magRiemannSolver", "hlld"));
+    if (ms == "hlld") p->magRiemannSolver = RGPU_MAG_HLLD;
+    else if (ms == "hllf") p->magRiemannSolver = RGPU_MAG_HLLF;
+    else if (ms == "hlla") p->magRiemannSolver = RGPU_MAG_HLLA;
+    else if (ms == "roe") p->magRiemannSolver = RGPU_MAG_ROE;
+    else if (ms == "llf") p->magRiemannSolver = RGPU_MAG_LLF;
+    else if (ms == "upwind") p->magRiemannSolver = RGPU_MAG_UPWIND;
+  }
+
+  // [jet]  (HydroParameters.h:435-444)
+  p->enableJet = (rs->problem == "jet") ? 1 : 0;
+  p->ijet = static_cast<int>(cfg.get_integer("jet", "ijet", 0));
+  p->djet = cfg.get_float("jet", "djet", 1.0f);
+  p->ujet = cfg.get_float("jet", "ujet", 0.0f);
+  p->pjet = cfg.get_float("jet", "pjet", 0.0f);
+  p->cjet = std::sqrt(p->gamma0 * p->pjet / p->djet);
+  p->offsetJet = static_cast<int>(cfg.get_integer("jet", "offsetJet", 0));
+
+  // step variant selection
+  if (p->mhdEnabled) {
+    // MHDRunGodunov.cpp:97-103
+    p->shearingBoxEnabled = (p->bc[0] == RGPU_BC_SHEARINGBOX && p->bc[1] == RGPU_BC_SHEARINGBOX && p->Omega0 > 0) ? 1 : 0;
+    // MHDRunGodunov.cpp:161-181
+    int iv = static_cast<int>(cfg.get_integer("MHD", "implementationVersion", three_d ? 4 : 1));
+    if (iv < 0 || iv > 4) iv = three_d ? 4 : 1;
+    p->implementationVersion = iv;
+    p->unsplitVersion = 1;
+  } else {
+    if (!cfg.get_bool("hydro", "unsplit", true))
+      throw std::runtime_error("the directionally split Godunov scheme is outside the implemented scope");
+    int uv = static_cast<int>(cfg.get_integer("hydro", "unsplitVersion", 1));
+    if (uv != 0 && uv != 1 && uv != 2) uv = 1;  // HydroRunGodunov.cpp:74-84
+    p->unsplitVersion = uv;
+  }
+
+  // z-slab decomposition
+  if (slab_count < 1) slab_count = 1;
+  p->slab_rank = slab_rank;
+  p->slab_count = slab_count;
+  p->nz_global = nz;
+  p->nx = nx;
+  p->ny = ny;
+  p->nz = nz;
+  if (slab_count > 1) {
+    if (!three_d) throw std::runtime_error("2D problems do not shard: replicas only");
+    if (nz % slab_count != 0) throw std::runtime_error("nz must be a multiple of the number of slabs");
+    p->nz = nz / slab_count;
+    if (p->nz < gw) throw std::runtime_error("slab thinner than the ghost width");
+    const bool periodic_z = (p->bc[4] == RGPU_BC_PERIODIC && p->bc[5] == RGPU_BC_PERIODIC);
+    if (slab_rank > 0 || periodic_z) p->bc[4] = RGPU_BC_COPY;
+    if (slab_rank < slab_count - 1 || periodic_z) p->bc[5] = RGPU_BC_COPY;
+  }
+
+  rs->outputDir = cfg.get_string("output", "outputDir", "./");
+  rs->outputPrefix = cfg.get_string("output", "outputPrefix", "output");
+  rs->outputVtk = cfg.get_bool("output", "outputVtk", true);
+}
+
+}  // namespace rgpu_host

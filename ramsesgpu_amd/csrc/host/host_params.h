@@ -1,0 +1,28 @@
+// host_params.h -- derive the rgpu_params struct from a parameter file.
+// Mirrors the HydroParameters constructor (src/hydro/HydroParameters.h:166-525) and the parts of the
+// HydroRunGodunov / MHDRunGodunov constructors that select the step variant (HydroRunGodunov.cpp:63-90,
+// MHDRunGodunov.cpp:97-181).
+#pragma once
+#include <string>
+
+#include "../../../include/rgpu.h"
+#include "ini_config.h"
+
+namespace rgpu_host {
+
+// Run-level knobs that are not part of the device-side parameter block.
+struct RunSettings {
+  int nStepmax;
+  double tEnd;
+  int nOutput;
+  int nLog;
+  std::string problem;
+  std::string outputDir, outputPrefix;
+  bool outputVtk;
+};
+
+// Fills *p for slab `slab_rank` of `slab_count` (0,1 = whole domain).  Throws std::runtime_error on
+// configurations outside the implemented scope.
+void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgpu_params* p, RunSettings* rs);
+
+}  // namespace rgpu_host
