@@ -72,3 +72,67 @@ def declare_host_api(lib):
     lib.rgpuh_init_condition.restype = C.c_int
     lib.rgpuh_init_condition.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
     return lib
+
+
+def declare_device_api(lib):
+    """prototypes of the rgpu_* entry points (include/rgpu.h)"""
+    P = C.POINTER(RgpuParams)
+    ctx = C.c_void_p
+    lib.rgpu_create.restype = C.c_int
+    lib.rgpu_create.argtypes = [P, C.POINTER(ctx)]
+    lib.rgpu_create_external.restype = C.c_int
+    lib.rgpu_create_external.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ctx)]
+    lib.rgpu_destroy.restype = None
+    lib.rgpu_destroy.argtypes = [ctx]
+    lib.rgpu_device_bytes.restype = C.c_size_t
+    lib.rgpu_device_bytes.argtypes = [P]
+    lib.rgpu_last_error.restype = C.c_char_p
+    lib.rgpu_last_error.argtypes = [ctx]
+    lib.rgpu_upload.restype = C.c_int
+    lib.rgpu_upload.argtypes = [ctx, C.c_void_p, C.c_int]
+    lib.rgpu_download.restype = C.c_int
+    lib.rgpu_download.argtypes = [ctx, C.c_void_p, C.c_int]
+    lib.rgpu_device_state.restype = C.c_void_p
+    lib.rgpu_device_state.argtypes = [ctx, C.c_int]
+    lib.rgpu_make_boundaries.restype = C.c_int
+    lib.rgpu_make_boundaries.argtypes = [ctx, C.c_int, C.c_int]
+    lib.rgpu_make_boundaries_shear.restype = C.c_int
+    lib.rgpu_make_boundaries_shear.argtypes = [ctx, C.c_int, C.c_double, C.c_double]
+    lib.rgpu_make_all_boundaries.restype = C.c_int
+    lib.rgpu_make_all_boundaries.argtypes = [ctx, C.c_int, C.c_double, C.c_double]
+    lib.rgpu_compute_inv_dt.restype = C.c_int
+    lib.rgpu_compute_inv_dt.argtypes = [ctx, C.c_int, c_double_p]
+    lib.rgpu_compute_dt.restype = C.c_double
+    lib.rgpu_compute_dt.argtypes = [ctx, C.c_int]
+    for name in ("rgpu_godunov_unsplit", "rgpu_step_pre", "rgpu_step_core", "rgpu_step_post_a", "rgpu_step_post_b"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [ctx, C.c_int, C.c_double, C.c_double]
+    lib.rgpu_one_step_integration.restype = C.c_int
+    lib.rgpu_one_step_integration.argtypes = [ctx, C.POINTER(C.c_int), c_double_p, c_double_p]
+    lib.rgpu_synchronize.restype = C.c_int
+    lib.rgpu_synchronize.argtypes = [ctx]
+    lib.rgpu_enable_timers.restype = C.c_int
+    lib.rgpu_enable_timers.argtypes = [ctx, C.c_int]
+    lib.rgpu_get_timers.restype = C.c_int
+    lib.rgpu_get_timers.argtypes = [ctx, c_double_p, C.c_int]
+    lib.rgpu_reset_timers.restype = C.c_int
+    lib.rgpu_reset_timers.argtypes = [ctx]
+    lib.rgpu_timer_name.restype = C.c_char_p
+    lib.rgpu_timer_name.argtypes = [C.c_int]
+    lib.rgpu_dominant_kernel.restype = C.c_int
+    lib.rgpu_dominant_kernel.argtypes = [ctx, C.c_char_p, C.c_int, c_double_p, C.POINTER(C.c_long)]
+    lib.rgpu_backend_name.restype = C.c_char_p
+    lib.rgpu_backend_name.argtypes = []
+    return lib
+
+
+# every symbol include/rgpu.h declares (checked by tests/test_abi.py against the built library)
+DECLARED_SYMBOLS = [
+    "rgpu_create", "rgpu_create_external", "rgpu_destroy", "rgpu_state_elems", "rgpu_device_bytes", "rgpu_last_error",
+    "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
+    "rgpu_make_all_boundaries", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
+    "rgpu_step_core", "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
+    "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
+    "rgpu_backend_name", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_run",
+]

@@ -1,0 +1,66 @@
+"""Build the product library ramsesgpu_amd/librgpu.so (HIP, gfx950 only) and the euler_hip front end, in-tree.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off ...
+
+-ffp-contract=off is part of the parity contract: the reference CPU path is built without FMA contraction and the
+kernels reproduce its operand order, so results are bit-identical ("Exactness").
+hipcc cross-compiles without a GPU, so this also runs in the build container.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+HOST_SRC = ["ini_config.cpp", "host_params.cpp", "init_conditions.cpp", "host_capi.cpp", "run_driver.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(CSRC, "hip"), "-I", CSRC]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
+    out = os.path.join(HERE, out_name)
+    exe = os.path.join(HERE, "euler_hip")
+    srcs = [os.path.join(CSRC, "rgpu_api.cpp")] + [os.path.join(CSRC, "host", s) for s in HOST_SRC]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(CSRC, "hip", "rg_backend.h"), os.path.join(HERE, "..", "include", "rgpu.h")] + \
+        [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith(".h")]
+    if force or _newer(out, deps):
+        # one object per translation unit, then one link: mixing "-x hip" and "-x c++" inputs in a single hipcc
+        # invocation produced a library whose kernels crashed at launch (ROCm 7.2), so keep them apart
+        objdir = os.path.join(HERE, "..", "build", "obj_" + out_name.replace(".", "_"))
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for i, src in enumerate(srcs):
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            if i == 0:
+                cmd = [HIPCC, "--offload-arch=" + ARCH] + COMMON + list(extra_flags) + ["-x", "hip", "-c", src, "-o", obj]
+            else:
+                cmd = [HIPCC] + COMMON + ["-x", "c++", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            objs.append(obj)
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    main_src = os.path.join(CSRC, "host", "euler_hip_main.cpp")
+    if out_name == "librgpu.so" and (force or _newer(exe, [main_src, out])):
+        cmd = [HIPCC, "-O2", "-std=c++17", main_src, "-L", HERE, "-lrgpu", "-Wl,-rpath,$ORIGIN", "-o", exe]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

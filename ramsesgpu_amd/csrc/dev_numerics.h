@@ -1,0 +1,583 @@
+// dev_numerics.h -- per-cell numerics of the unsplit Godunov / MUSCL-Hancock step as gfx950 device functions.
+//
+// Everything here is straight-line fp64 VALU code (this path has no GEMM shape; MFMA is not used).  The
+// arithmetic follows the reference's operand order expression by expression, because the parity bar is
+// bit-identity with euler_cpu: with -ffp-contract=off, IEEE fp64 divide / sqrt and v_max/v_min_f64, every
+// value computed here equals the CPU value.  Each function cites the reference routine it stands in for.
+//
+// RG_DEVFN is supplied by the backend header (rg_backend.h): __device__ __forceinline__ for hipcc.
+#pragma once
+#include "rg_backend.h"
+
+namespace rgpu_dev {
+
+enum { ID = 0, IP = 1, IU = 2, IV = 3, IW = 4, IA = 5, IB = 6, IC = 7 };
+enum { XD = 0, YD = 1, ZD = 2 };
+
+// Kernel-argument block (passed by value; lives in SGPRs / kernarg segment).  Derived from rgpu_params.
+struct DevParams {
+  int isize, jsize, ksize, gw, nx, ny, nz, nvar;
+  int three_d, mhd, rot, shearbox;
+  unsigned sj, sk;             // flat strides of +1 in j and k
+  unsigned long long ncell;    // component stride
+  double dx, dy, dz, xMin, deltaX;   // deltaX = xMax - xMin
+  double gamma0, cIso, smallr, smallc, smallp, smallpp, gamma6, Omega0;
+  double slope_type, mag_slope_type;
+  int niter_riemann, riemannSolver, magRiemannSolver, pad0;
+};
+
+struct Prim8 {  // primitive MHD state in some frame: density, pressure, 3 velocities, 3 field components
+  double r, p, u, v, w, a, b, c;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// slopes
+// ---------------------------------------------------------------------------------------------------------
+
+// limiter of slope_unsplit_hydro_{2d,3d}, slope_unsplit_3d (type 2), slope_unsplit_mhd_{2d,3d}
+// (slope.h:118-145,386-425; slope_mhd.h:105-128,463-497,549-571,636-700)
+RG_DEVFN double tvd_slope(double st, double qm, double q0, double qp) {
+  const double dlft = st * (q0 - qm);
+  const double drgt = st * (qp - q0);
+  const double dcen = 0.5 * (qp - qm);
+  const double dsgn = (dcen >= 0.0) ? 1.0 : -1.0;
+  const double slop = fmin(fabs(dlft), fabs(drgt));
+  const double dlim = ((dlft * drgt) <= 0.0) ? 0.0 : slop;
+  return dsgn * fmin(dlim, fabs(dcen));
+}
+
+// slope_unsplit_3d, slope_type == 1 (slope.h:351-384)
+RG_DEVFN double minmod_slope(double qm, double q0, double qp) {
+  const double dlft = q0 - qm;
+  const double drgt = qp - q0;
+  if ((dlft * drgt) <= 0.0) return 0.0;
+  return (dlft > 0) ? fmin(dlft, drgt) : fmax(dlft, drgt);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// hydro: equation of state, Riemann solvers
+// ---------------------------------------------------------------------------------------------------------
+
+// constoprim_2D/3D + eos (constoprim.h:29-111).  q = {r,p,u,v,w}; returns the sound speed
+template <int NV>
+RG_DEVFN double hydro_prim(const DevParams& g, const double* u, double* q) {
+  q[ID] = fmax(u[ID], g.smallr);
+  q[IU] = u[IU] / q[ID];
+  q[IV] = u[IV] / q[ID];
+  if (NV == 5) q[IW] = u[IW] / q[ID];
+  double eken;
+  if (NV == 5) eken = 0.5 * (q[IU] * q[IU] + q[IV] * q[IV] + q[IW] * q[IW]);
+  else eken = 0.5 * (q[IU] * q[IU] + q[IV] * q[IV]);
+  if (g.cIso > 0) {
+    q[IP] = q[ID] * g.cIso * g.cIso;
+    return g.cIso;
+  }
+  const double eint = u[IP] / q[ID] - eken;
+  q[IP] = fmax((g.gamma0 - 1.0) * q[ID] * eint, q[ID] * g.smallp);
+  return sqrt(g.gamma0 * q[IP] / q[ID]);
+}
+
+// cmpflx (cmpflx.h:21-48)
+template <int NV>
+RG_DEVFN void hydro_flux_from_state(const DevParams& g, const double* qg, double* flux) {
+  flux[ID] = qg[ID] * qg[IU];
+  flux[IU] = flux[ID] * qg[IU] + qg[IP];
+  flux[IV] = flux[ID] * qg[IV];
+  if (NV == 5) flux[IW] = flux[ID] * qg[IW];
+  const double entho = 1.0 / (g.gamma0 - 1.0);
+  double ekin;
+  if (NV == 5) ekin = 0.5 * qg[ID] * (qg[IU] * qg[IU] + qg[IV] * qg[IV] + qg[IW] * qg[IW]);
+  else ekin = 0.5 * qg[ID] * (qg[IU] * qg[IU] + qg[IV] * qg[IV]);
+  const double etot = qg[IP] * entho + ekin;
+  flux[IP] = qg[IU] * (etot + qg[IP]);
+}
+
+// saturate_cpu (gpu_macros.cpp:25-30): clamp THROUGH FLOAT
+RG_DEVFN double saturate_via_float(double x) {
+  const float a = (float)x;
+  if (a != a) return 0.0;
+  return (double)(a >= 1.0f ? 1.0f : a <= 0.0f ? 0.0f : a);
+}
+
+// riemann_approx (riemann.h:29-159)
+template <int NV>
+RG_DEVFN void riemann_approx(const DevParams& g, const double* ql, const double* qr, double* flux) {
+  const double rl = fmax(ql[ID], g.smallr), ul = ql[IU], pl = fmax(ql[IP], rl * g.smallp);
+  const double rr = fmax(qr[ID], g.smallr), ur = qr[IU], pr = fmax(qr[IP], rr * g.smallp);
+  const double cl = g.gamma0 * pl * rl, cr = g.gamma0 * pr * rr;
+  double wl = sqrt(cl), wr = sqrt(cr);
+  double pstar = fmax(((wr * pl + wl * pr) + wl * wr * (ul - ur)) / (wl + wr), 0.0);
+  double pold = pstar, conv = 1.0;
+  for (int iter = 0; iter < g.niter_riemann && conv > 1e-6; ++iter) {
+    const double wwl = sqrt(cl * (1.0 + g.gamma6 * (pold - pl) / pl));
+    const double wwr = sqrt(cr * (1.0 + g.gamma6 * (pold - pr) / pr));
+    const double q_l = 2.0 * wwl * wwl * wwl / (wwl * wwl + cl);
+    const double q_r = 2.0 * wwr * wwr * wwr / (wwr * wwr + cr);
+    const double usl = ul - (pold - pl) / wwl;
+    const double usr = ur + (pold - pr) / wwr;
+    const double delp = fmax(q_r * q_l / (q_r + q_l) * (usl - usr), -pold);
+    pold = pold + delp;
+    conv = fabs(delp / (pold + g.smallpp));
+  }
+  pstar = pold;
+  wl = sqrt(cl * (1.0 + g.gamma6 * (pstar - pl) / pl));
+  wr = sqrt(cr * (1.0 + g.gamma6 * (pstar - pr) / pr));
+  const double ustar = 0.5 * (ul + (pl - pstar) / wl + ur - (pr - pstar) / wr);
+  const double sgnm = copysign(1.0, ustar);
+  const bool from_left = sgnm > 0.0;
+  const double ro = from_left ? rl : rr, uo = from_left ? ul : ur, po = from_left ? pl : pr, wo = from_left ? wl : wr;
+  const double co = fmax(g.smallc, sqrt(fabs(g.gamma0 * po / ro)));
+  const double rstar = fmax(ro / (1.0 + ro * (po - pstar) / (wo * wo)), g.smallr);
+  const double cstar = fmax(g.smallc, sqrt(fabs(g.gamma0 * pstar / rstar)));
+  double spout = co - sgnm * uo;
+  double spin = cstar - sgnm * ustar;
+  const double ushock = wo / ro - sgnm * uo;
+  if (pstar >= po) { spin = ushock; spout = ushock; }
+  const double scr = fmax(spout - spin, g.smallc + fabs(spout + spin));
+  double frac = 0.5 * (1.0 + (spout + spin) / scr);
+  frac = (frac != frac) ? 0.0 : saturate_via_float(frac);
+  double qg[NV];
+  qg[ID] = frac * rstar + (1.0 - frac) * ro;
+  qg[IU] = frac * ustar + (1.0 - frac) * uo;
+  qg[IP] = frac * pstar + (1.0 - frac) * po;
+  if (spout < 0.0) { qg[ID] = ro; qg[IU] = uo; qg[IP] = po; }
+  if (spin > 0.0) { qg[ID] = rstar; qg[IU] = ustar; qg[IP] = pstar; }
+  qg[IV] = from_left ? ql[IV] : qr[IV];
+  if (NV == 5) qg[IW] = from_left ? ql[IW] : qr[IW];
+  hydro_flux_from_state<NV>(g, qg, flux);
+}
+
+// riemann_hll (riemann.h:175-255)
+template <int NV>
+RG_DEVFN void riemann_hll(const DevParams& g, const double* ql, const double* qr, double* flux) {
+  const double entho = 1.0 / (g.gamma0 - 1.0);
+  const double rl = fmax(ql[ID], g.smallr), ul = ql[IU], pl = fmax(ql[IP], rl * g.smallp);
+  const double rr = fmax(qr[ID], g.smallr), ur = qr[IU], pr = fmax(qr[IP], rr * g.smallp);
+  const double cl = sqrt(g.gamma0 * pl / rl), cr = sqrt(g.gamma0 * pr / rr);
+  const double SL = fmin(fmin(ul, ur) - fmax(cl, cr), 0.0);
+  const double SR = fmax(fmax(ul, ur) + fmax(cl, cr), 0.0);
+  double uL[NV], uR[NV], fL[NV], fR[NV];
+  uL[ID] = ql[ID];
+  uR[ID] = qr[ID];
+  uL[IP] = ql[IP] * entho + 0.5 * ql[ID] * ql[IU] * ql[IU];
+  uR[IP] = qr[IP] * entho + 0.5 * qr[ID] * qr[IU] * qr[IU];
+  uL[IP] += 0.5 * ql[ID] * ql[IV] * ql[IV];
+  uR[IP] += 0.5 * qr[ID] * qr[IV] * qr[IV];
+  if (NV == 5) {
+    uL[IP] += 0.5 * ql[ID] * ql[IW] * ql[IW];
+    uR[IP] += 0.5 * qr[ID] * qr[IW] * qr[IW];
+  }
+  uL[IU] = ql[ID] * ql[IU];
+  uR[IU] = qr[ID] * qr[IU];
+  uL[IV] = ql[ID] * ql[IV];
+  uR[IV] = qr[ID] * qr[IV];
+  if (NV == 5) { uL[IW] = ql[ID] * ql[IW]; uR[IW] = qr[ID] * qr[IW]; }
+  fL[ID] = uL[IU];
+  fR[ID] = uR[IU];
+  fL[IP] = ql[IU] * (uL[IP] + ql[IP]);
+  fR[IP] = qr[IU] * (uR[IP] + qr[IP]);
+  fL[IU] = ql[IP] + uL[IU] * ql[IU];
+  fR[IU] = qr[IP] + uR[IU] * qr[IU];
+  fL[IV] = fL[ID] * ql[IV];
+  fR[IV] = fR[ID] * qr[IV];
+  if (NV == 5) { fL[IW] = fL[ID] * ql[IW]; fR[IW] = fR[ID] * qr[IW]; }
+#pragma unroll
+  for (int n = 0; n < NV; ++n) flux[n] = (SR * fL[n] - SL * fR[n] + SR * SL * (uR[n] - uL[n])) / (SR - SL);
+}
+
+// riemann_hllc (riemann.h:269-371)
+template <int NV>
+RG_DEVFN void riemann_hllc(const DevParams& g, const double* ql, const double* qr, double* flux) {
+  const double entho = 1.0 / (g.gamma0 - 1.0);
+  const double rl = fmax(ql[ID], g.smallr), pl = fmax(ql[IP], rl * g.smallp), ul = ql[IU];
+  double ecinl = 0.5 * rl * ul * ul;
+  ecinl += 0.5 * rl * ql[IV] * ql[IV];
+  if (NV == 5) ecinl += 0.5 * rl * ql[IW] * ql[IW];
+  const double etotl = pl * entho + ecinl;
+  const double rr = fmax(qr[ID], g.smallr), pr = fmax(qr[IP], rr * g.smallp), ur = qr[IU];
+  double ecinr = 0.5 * rr * ur * ur;
+  ecinr += 0.5 * rr * qr[IV] * qr[IV];
+  if (NV == 5) ecinr += 0.5 * rr * qr[IW] * qr[IW];
+  const double etotr = pr * entho + ecinr;
+  const double cfastl = sqrt(fmax(g.gamma0 * pl / rl, g.smallc * g.smallc));
+  const double cfastr = sqrt(fmax(g.gamma0 * pr / rr, g.smallc * g.smallc));
+  const double SL = fmin(ul, ur) - fmax(cfastl, cfastr);
+  const double SR = fmax(ul, ur) + fmax(cfastl, cfastr);
+  const double rcl = rl * (ul - SL), rcr = rr * (SR - ur);
+  const double ustar = (rcr * ur + rcl * ul + (pl - pr)) / (rcr + rcl);
+  const double ptotstar = (rcr * pl + rcl * pr + rcl * rcr * (ul - ur)) / (rcr + rcl);
+  const double rstarl = rl * (SL - ul) / (SL - ustar);
+  const double etotstarl = ((SL - ul) * etotl - pl * ul + ptotstar * ustar) / (SL - ustar);
+  const double rstarr = rr * (SR - ur) / (SR - ustar);
+  const double etotstarr = ((SR - ur) * etotr - pr * ur + ptotstar * ustar) / (SR - ustar);
+  double ro, uo, ptoto, etoto;
+  if (SL > 0.0) { ro = rl; uo = ul; ptoto = pl; etoto = etotl; }
+  else if (ustar > 0.0) { ro = rstarl; uo = ustar; ptoto = ptotstar; etoto = etotstarl; }
+  else if (SR > 0.0) { ro = rstarr; uo = ustar; ptoto = ptotstar; etoto = etotstarr; }
+  else { ro = rr; uo = ur; ptoto = pr; etoto = etotr; }
+  flux[ID] = ro * uo;
+  flux[IU] = ro * uo * uo + ptoto;
+  flux[IP] = (etoto + ptoto) * uo;
+  const bool upwind_left = flux[ID] > 0.0;
+  flux[IV] = flux[ID] * (upwind_left ? ql[IV] : qr[IV]);
+  if (NV == 5) flux[IW] = flux[ID] * (upwind_left ? ql[IW] : qr[IW]);
+}
+
+// riemann<NVAR> (riemann.h:388-401).  Other selections leave flux as passed in (callers zero it).
+template <int NV>
+RG_DEVFN void hydro_riemann(const DevParams& g, const double* ql, const double* qr, double* flux) {
+  if (g.riemannSolver == 0) riemann_approx<NV>(g, ql, qr, flux);
+  else if (g.riemannSolver == 1) riemann_hll<NV>(g, ql, qr, flux);
+  else if (g.riemannSolver == 2) riemann_hllc<NV>(g, ql, qr, flux);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MHD: primitive variables, wave speeds
+// ---------------------------------------------------------------------------------------------------------
+
+// constoprim_mhd (constoprim.h:137-199).  bnx/bny/bnz: left-face field of the +1 neighbours (bnz = 0 in 2D,
+// which makes Bz_cell = Bz/2 there: computePrimitives_MHD_2D, constoprim.h:405-409)
+RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double bny, double bnz, double dt) {
+  Prim8 q;
+  q.r = fmax(u[ID], g.smallr);
+  q.u = u[IU] / q.r;
+  q.v = u[IV] / q.r;
+  q.w = u[IW] / q.r;
+  q.a = 0.5 * (u[IA] + bnx);
+  q.b = 0.5 * (u[IB] + bny);
+  q.c = 0.5 * (u[IC] + bnz);
+  const double eken = 0.5 * (q.u * q.u + q.v * q.v + q.w * q.w);
+  const double emag = 0.5 * (q.a * q.a + q.b * q.b + q.c * q.c);
+  if (g.cIso > 0) {
+    q.p = q.r * g.cIso * g.cIso;
+  } else {
+    const double eint = (u[IP] - emag) / q.r - eken;
+    q.p = fmax((g.gamma0 - 1.0) * q.r * eint, q.r * g.smallp);
+  }
+  if (g.Omega0 > 0) {  // Coriolis half-step predictor: both increments from the un-updated velocities
+    const double dvx = 2.0 * g.Omega0 * q.v;
+    const double dvy = -0.5 * g.Omega0 * q.u;
+    q.u += dvx * dt * 0.5;
+    q.v += dvy * dt * 0.5;
+  }
+  return q;
+}
+
+// find_speed_fast<IX> (mhd_utils.h:28-52), bn = the field component along the wanted direction
+RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn) {
+  const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
+  const double c2 = g.gamma0 * q.p / q.r;
+  const double d2 = 0.5 * (b2 / q.r + c2);
+  return sqrt(d2 + sqrt(d2 * d2 - c2 * bn * bn / q.r));
+}
+
+// find_speed_info<NDIM> (mhd_utils.h:241-284): sum_d (cf_d + |v_d|)/delta_d is formed by the caller
+RG_DEVFN void info_speeds(const DevParams& g, const Prim8& q, double& sx, double& sy, double& sz) {
+  const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
+  const double c2 = g.gamma0 * q.p / q.r;
+  const double d2 = 0.5 * (b2 / q.r + c2);
+  sx = sqrt(d2 + sqrt(d2 * d2 - c2 * q.a * q.a / q.r)) + fabs(q.u);
+  sy = sqrt(d2 + sqrt(d2 * d2 - c2 * q.b * q.b / q.r)) + fabs(q.v);
+  sz = sqrt(d2 + sqrt(d2 * d2 - c2 * q.c * q.c / q.r)) + fabs(q.w);
+}
+
+// find_mhd_flux (mhd_utils.h:106-156): conservative vector and flux of a primitive state (normal frame)
+RG_DEVFN void mhd_physical_flux(const DevParams& g, const Prim8& q, double* cv, double* ff) {
+  const double p = (g.cIso > 0) ? q.r * g.cIso * g.cIso : q.p;
+  const double entho = 1.0 / (g.gamma0 - 1.0);
+  const double ecin = 0.5 * (q.u * q.u + q.v * q.v + q.w * q.w) * q.r;
+  const double emag = 0.5 * (q.a * q.a + q.b * q.b + q.c * q.c);
+  const double etot = p * entho + ecin + emag;
+  const double ptot = p + emag;
+  cv[ID] = q.r; cv[IP] = etot; cv[IU] = q.r * q.u; cv[IV] = q.r * q.v; cv[IW] = q.r * q.w;
+  cv[IA] = q.a; cv[IB] = q.b; cv[IC] = q.c;
+  ff[ID] = q.r * q.u;
+  ff[IP] = (etot + ptot) * q.u - q.a * (q.a * q.u + q.b * q.v + q.c * q.w);
+  ff[IU] = q.r * q.u * q.u - q.a * q.a + ptot;
+  ff[IV] = q.r * q.u * q.v - q.a * q.b;
+  ff[IW] = q.r * q.u * q.w - q.a * q.c;
+  ff[IA] = 0.0;
+  ff[IB] = q.b * q.u - q.a * q.v;
+  ff[IC] = q.c * q.u - q.a * q.w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MHD 1D Riemann solvers in the face-normal frame.  L and R are taken by reference: like the reference
+// routines they are left with the averaged normal field (and the isothermal pressure), which the rotating
+// path reuses for the shear correction of the y flux.
+// ---------------------------------------------------------------------------------------------------------
+
+// riemann_hlld (riemann_mhd.h:140-342), Miyoshi & Kusano 2005
+RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
+  const double entho = 1.0 / (g.gamma0 - 1.0);
+  const double a = 0.5 * (L.a + R.a);
+  const double sgnm = (a >= 0) ? 1.0 : -1.0;
+  L.a = a;
+  R.a = a;
+  if (g.cIso > 0) {
+    L.p = L.r * g.cIso * g.cIso;
+    R.p = R.r * g.cIso * g.cIso;
+  }
+  const double rl = L.r, pl = L.p, ul = L.u, vl = L.v, wl = L.w, bl = L.b, cl = L.c;
+  const double ecinl = 0.5 * (ul * ul + vl * vl + wl * wl) * rl;
+  const double emagl = 0.5 * (a * a + bl * bl + cl * cl);
+  const double etotl = pl * entho + ecinl + emagl;
+  const double ptotl = pl + emagl;
+  const double vdotbl = ul * a + vl * bl + wl * cl;
+  const double rr = R.r, pr = R.p, ur = R.u, vr = R.v, wr = R.w, br = R.b, cr = R.c;
+  const double ecinr = 0.5 * (ur * ur + vr * vr + wr * wr) * rr;
+  const double emagr = 0.5 * (a * a + br * br + cr * cr);
+  const double etotr = pr * entho + ecinr + emagr;
+  const double ptotr = pr + emagr;
+  const double vdotbr = ur * a + vr * br + wr * cr;
+  const double cfastl = fast_speed(g, L, L.a), cfastr = fast_speed(g, R, R.a);
+  const double sl = fmin(ul, ur) - fmax(cfastl, cfastr);
+  const double sr = fmax(ul, ur) + fmax(cfastl, cfastr);
+  const double rcl = rl * (ul - sl), rcr = rr * (sr - ur);
+  const double ustar = (rcr * ur + rcl * ul + (ptotl - ptotr)) / (rcr + rcl);
+  const double ptotstar = (rcr * ptotl + rcl * ptotr + rcl * rcr * (ul - ur)) / (rcr + rcl);
+  const double a2 = a * a;
+  // left star state
+  const double rstarl = rl * (sl - ul) / (sl - ustar);
+  const double estarl = rl * (sl - ul) * (sl - ustar) - a2;
+  const double el = rl * (sl - ul) * (sl - ul) - a2;
+  const bool degl = (a2 > 0) && (fabs(estarl / a2 - 1.0) <= 1e-8);
+  const double vstarl = degl ? vl : vl - a * bl * (ustar - ul) / estarl;
+  const double bstarl = degl ? bl : bl * el / estarl;
+  const double wstarl = degl ? wl : wl - a * cl * (ustar - ul) / estarl;
+  const double cstarl = degl ? cl : cl * el / estarl;
+  const double vdotbstarl = ustar * a + vstarl * bstarl + wstarl * cstarl;
+  const double etotstarl = ((sl - ul) * etotl - ptotl * ul + ptotstar * ustar + a * (vdotbl - vdotbstarl)) / (sl - ustar);
+  const double sqrrstarl = sqrt(rstarl);
+  const double sal = ustar - fabs(a) / sqrrstarl;
+  // right star state
+  const double rstarr = rr * (sr - ur) / (sr - ustar);
+  const double estarr = rr * (sr - ur) * (sr - ustar) - a2;
+  const double er = rr * (sr - ur) * (sr - ur) - a2;
+  const bool degr = (a2 > 0) && (fabs(estarr / a2 - 1.0) <= 1e-8);
+  const double vstarr = degr ? vr : vr - a * br * (ustar - ur) / estarr;
+  const double bstarr = degr ? br : br * er / estarr;
+  const double wstarr = degr ? wr : wr - a * cr * (ustar - ur) / estarr;
+  const double cstarr = degr ? cr : cr * er / estarr;
+  const double vdotbstarr = ustar * a + vstarr * bstarr + wstarr * cstarr;
+  const double etotstarr = ((sr - ur) * etotr - ptotr * ur + ptotstar * ustar + a * (vdotbr - vdotbstarr)) / (sr - ustar);
+  const double sqrrstarr = sqrt(rstarr);
+  const double sar = ustar + fabs(a) / sqrrstarr;
+  // double star state
+  const double sqsum = sqrrstarl + sqrrstarr;
+  const double vstarstar = (sqrrstarl * vstarl + sqrrstarr * vstarr + sgnm * (bstarr - bstarl)) / sqsum;
+  const double wstarstar = (sqrrstarl * wstarl + sqrrstarr * wstarr + sgnm * (cstarr - cstarl)) / sqsum;
+  const double bstarstar = (sqrrstarl * bstarr + sqrrstarr * bstarl + sgnm * sqrrstarl * sqrrstarr * (vstarr - vstarl)) / sqsum;
+  const double cstarstar = (sqrrstarl * cstarr + sqrrstarr * cstarl + sgnm * sqrrstarl * sqrrstarr * (wstarr - wstarl)) / sqsum;
+  const double vdotbstarstar = ustar * a + vstarstar * bstarstar + wstarstar * cstarstar;
+  const double etotstarstarl = etotstarl - sgnm * sqrrstarl * (vdotbstarl - vdotbstarstar);
+  const double etotstarstarr = etotstarr + sgnm * sqrrstarr * (vdotbstarr - vdotbstarstar);
+  // sample at x/t = 0
+  double ro, uo, vo, wo, bo, co, ptoto, etoto, vdotbo;
+  if (sl > 0) { ro = rl; uo = ul; vo = vl; wo = wl; bo = bl; co = cl; ptoto = ptotl; etoto = etotl; vdotbo = vdotbl; }
+  else if (sal > 0) { ro = rstarl; uo = ustar; vo = vstarl; wo = wstarl; bo = bstarl; co = cstarl; ptoto = ptotstar; etoto = etotstarl; vdotbo = vdotbstarl; }
+  else if (ustar > 0) { ro = rstarl; uo = ustar; vo = vstarstar; wo = wstarstar; bo = bstarstar; co = cstarstar; ptoto = ptotstar; etoto = etotstarstarl; vdotbo = vdotbstarstar; }
+  else if (sar > 0) { ro = rstarr; uo = ustar; vo = vstarstar; wo = wstarstar; bo = bstarstar; co = cstarstar; ptoto = ptotstar; etoto = etotstarstarr; vdotbo = vdotbstarstar; }
+  else if (sr > 0) { ro = rstarr; uo = ustar; vo = vstarr; wo = wstarr; bo = bstarr; co = cstarr; ptoto = ptotstar; etoto = etotstarr; vdotbo = vdotbstarr; }
+  else { ro = rr; uo = ur; vo = vr; wo = wr; bo = br; co = cr; ptoto = ptotr; etoto = etotr; vdotbo = vdotbr; }
+  flux[ID] = ro * uo;
+  flux[IP] = (etoto + ptoto) * uo - a * vdotbo;
+  flux[IU] = ro * uo * uo - a * a + ptoto;
+  flux[IV] = ro * uo * vo - a * bo;
+  flux[IW] = ro * uo * wo - a * co;
+  flux[IA] = 0.0;
+  flux[IB] = bo * uo - a * vo;
+  flux[IC] = co * uo - a * wo;
+}
+
+// riemann_hll (riemann_mhd.h:42-71)
+RG_DEVFN void mhd_hll(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
+  const double bx_mean = 0.5 * (L.a + R.a);
+  L.a = bx_mean;
+  R.a = bx_mean;
+  double uL[8], fL[8], uR[8], fR[8];
+  mhd_physical_flux(g, L, uL, fL);
+  mhd_physical_flux(g, R, uR, fR);
+  const double cfl = fast_speed(g, L, L.a), cfr = fast_speed(g, R, R.a);
+  const double sl = fmin(fmin(L.u, R.u) - fmax(cfl, cfr), 0.0);
+  const double sr = fmax(fmax(L.u, R.u) + fmax(cfl, cfr), 0.0);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) flux[n] = (sr * fL[n] - sl * fR[n] + sr * sl * (uR[n] - uL[n])) / (sr - sl);
+}
+
+// riemann_llf (riemann_mhd.h:87-118) -- including its mean of the STATES (not of the fluxes)
+RG_DEVFN void mhd_llf(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
+  const double bx_mean = 0.5 * (L.a + R.a);
+  L.a = bx_mean;
+  R.a = bx_mean;
+  double uL[8], fL[8], uR[8], fR[8];
+  mhd_physical_flux(g, L, uL, fL);
+  mhd_physical_flux(g, R, uR, fR);
+  const double ql[8] = {L.r, L.p, L.u, L.v, L.w, L.a, L.b, L.c};
+  const double qr[8] = {R.r, R.p, R.u, R.v, R.w, R.a, R.b, R.c};
+  const double vel_info = fmax(fast_speed(g, L, L.a) + fabs(L.u), fast_speed(g, R, R.a) + fabs(R.u));
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    flux[n] = (ql[n] + qr[n]) / 2 * 1.0;
+    flux[n] -= vel_info * (uR[n] - uL[n]) / 2;
+  }
+}
+
+// riemann_mhd (riemann_mhd.h:355-368): approx / hllc selections compute nothing (flux stays 0)
+RG_DEVFN void mhd_riemann(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
+  if (g.riemannSolver == 3) mhd_hlld(g, L, R, flux);
+  else if (g.riemannSolver == 1) mhd_hll(g, L, R, flux);
+  else if (g.riemannSolver == 4) mhd_llf(g, L, R, flux);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 2D magnetic Riemann problem at a cell edge (the EMF of constrained transport)
+// ---------------------------------------------------------------------------------------------------------
+RG_DEVFN double sel_max(double a0, double a1) { return (a1 > a0) ? a1 : a0; }
+RG_DEVFN double sel_min(double a0, double a1) { return (a1 < a0) ? a1 : a0; }
+RG_DEVFN double max_of4(double a0, double a1, double a2, double a3) { return sel_max(sel_max(sel_max(a0, a1), a2), a3); }
+RG_DEVFN double min_of4(double a0, double a1, double a2, double a3) { return sel_min(sel_min(sel_min(a0, a1), a2), a3); }
+
+// mag_riemann2d_hlld (riemann_mhd.h:616-821).  States are in the edge frame (u,v = the two in-plane
+// velocities, a,b = the two in-plane field components); E?? = u*b - v*a of each state.
+RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
+                            double ELL, double ERL, double ELR, double ERR) {
+  const double cFastLLx = fast_speed(g, LL, LL.a), cFastLRx = fast_speed(g, LR, LR.a);
+  const double cFastRLx = fast_speed(g, RL, RL.a), cFastRRx = fast_speed(g, RR, RR.a);
+  const double cFastLLy = fast_speed(g, LL, LL.b), cFastLRy = fast_speed(g, LR, LR.b);
+  const double cFastRLy = fast_speed(g, RL, RL.b), cFastRRy = fast_speed(g, RR, RR.b);
+  const double cxmax = max_of4(cFastLLx, cFastLRx, cFastRLx, cFastRRx);
+  const double cymax = max_of4(cFastLLy, cFastLRy, cFastRLy, cFastRRy);
+  const double SL = min_of4(LL.u, LR.u, RL.u, RR.u) - cxmax;
+  const double SR = max_of4(LL.u, LR.u, RL.u, RR.u) + cxmax;
+  const double SB = min_of4(LL.v, LR.v, RL.v, RR.v) - cymax;
+  const double ST = max_of4(LL.v, LR.v, RL.v, RR.v) + cymax;
+  const double PtotLL = LL.p + 0.5 * (LL.a * LL.a + LL.b * LL.b + LL.c * LL.c);
+  const double PtotLR = LR.p + 0.5 * (LR.a * LR.a + LR.b * LR.b + LR.c * LR.c);
+  const double PtotRL = RL.p + 0.5 * (RL.a * RL.a + RL.b * RL.b + RL.c * RL.c);
+  const double PtotRR = RR.p + 0.5 * (RR.a * RR.a + RR.b * RR.b + RR.c * RR.c);
+  const double rcLLx = LL.r * (LL.u - SL), rcRLx = RL.r * (SR - RL.u);
+  const double rcLRx = LR.r * (LR.u - SL), rcRRx = RR.r * (SR - RR.u);
+  const double rcLLy = LL.r * (LL.v - SB), rcLRy = LR.r * (ST - LR.v);
+  const double rcRLy = RL.r * (RL.v - SB), rcRRy = RR.r * (ST - RR.v);
+  const double ustar = (rcLLx * LL.u + rcLRx * LR.u + rcRLx * RL.u + rcRRx * RR.u + (PtotLL - PtotRL + PtotLR - PtotRR)) /
+                       (rcLLx + rcLRx + rcRLx + rcRRx);
+  const double vstar = (rcLLy * LL.v + rcLRy * LR.v + rcRLy * RL.v + rcRRy * RR.v + (PtotLL - PtotLR + PtotRL - PtotRR)) /
+                       (rcLLy + rcLRy + rcRLy + rcRRy);
+  // per-state star quantities.  rstar = r*(S-u)/(S-ustar) is needed twice in the reference (alone and inside
+  // the product with the y ratio); the identical sub-expression gives the identical value.
+  const double rstarLLx = LL.r * (SL - LL.u) / (SL - ustar);
+  const double BstarLL = LL.b * (SL - LL.u) / (SL - ustar);
+  const double rstarLLy = LL.r * (SB - LL.v) / (SB - vstar);
+  const double AstarLL = LL.a * (SB - LL.v) / (SB - vstar);
+  const double rstarLL = rstarLLx * (SB - LL.v) / (SB - vstar);
+  const double EstarLLx = ustar * BstarLL - LL.v * LL.a;
+  const double EstarLLy = LL.u * LL.b - vstar * AstarLL;
+  const double EstarLL = ustar * BstarLL - vstar * AstarLL;
+
+  const double rstarLRx = LR.r * (SL - LR.u) / (SL - ustar);
+  const double BstarLR = LR.b * (SL - LR.u) / (SL - ustar);
+  const double rstarLRy = LR.r * (ST - LR.v) / (ST - vstar);
+  const double AstarLR = LR.a * (ST - LR.v) / (ST - vstar);
+  const double rstarLR = rstarLRx * (ST - LR.v) / (ST - vstar);
+  const double EstarLRx = ustar * BstarLR - LR.v * LR.a;
+  const double EstarLRy = LR.u * LR.b - vstar * AstarLR;
+  const double EstarLR = ustar * BstarLR - vstar * AstarLR;
+
+  const double rstarRLx = RL.r * (SR - RL.u) / (SR - ustar);
+  const double BstarRL = RL.b * (SR - RL.u) / (SR - ustar);
+  const double rstarRLy = RL.r * (SB - RL.v) / (SB - vstar);
+  const double AstarRL = RL.a * (SB - RL.v) / (SB - vstar);
+  const double rstarRL = rstarRLx * (SB - RL.v) / (SB - vstar);
+  const double EstarRLx = ustar * BstarRL - RL.v * RL.a;
+  const double EstarRLy = RL.u * RL.b - vstar * AstarRL;
+  const double EstarRL = ustar * BstarRL - vstar * AstarRL;
+
+  const double rstarRRx = RR.r * (SR - RR.u) / (SR - ustar);
+  const double BstarRR = RR.b * (SR - RR.u) / (SR - ustar);
+  const double rstarRRy = RR.r * (ST - RR.v) / (ST - vstar);
+  const double AstarRR = RR.a * (ST - RR.v) / (ST - vstar);
+  const double rstarRR = rstarRRx * (ST - RR.v) / (ST - vstar);
+  const double EstarRRx = ustar * BstarRR - RR.v * RR.a;
+  const double EstarRRy = RR.u * RR.b - vstar * AstarRR;
+  const double EstarRR = ustar * BstarRR - vstar * AstarRR;
+
+  // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
+  const double calfvenL = sel_max(sel_max(sel_max(sel_max(fabs(LR.a) / sqrt(rstarLRx), fabs(AstarLR) / sqrt(rstarLR)),
+                                                  fabs(LL.a) / sqrt(rstarLLx)), fabs(AstarLL) / sqrt(rstarLL)), g.smallc);
+  const double calfvenR = sel_max(sel_max(sel_max(sel_max(fabs(RR.a) / sqrt(rstarRRx), fabs(AstarRR) / sqrt(rstarRR)),
+                                                  fabs(RL.a) / sqrt(rstarRLx)), fabs(AstarRL) / sqrt(rstarRL)), g.smallc);
+  const double calfvenB = sel_max(sel_max(sel_max(sel_max(fabs(LL.b) / sqrt(rstarLLy), fabs(BstarLL) / sqrt(rstarLL)),
+                                                  fabs(RL.b) / sqrt(rstarRLy)), fabs(BstarRL) / sqrt(rstarRL)), g.smallc);
+  const double calfvenT = sel_max(sel_max(sel_max(sel_max(fabs(LR.b) / sqrt(rstarLRy), fabs(BstarLR) / sqrt(rstarLR)),
+                                                  fabs(RR.b) / sqrt(rstarRRy)), fabs(BstarRR) / sqrt(rstarRR)), g.smallc);
+  const double SAL = fmin(ustar - calfvenL, 0.0);
+  const double SAR = fmax(ustar + calfvenR, 0.0);
+  const double SAB = fmin(vstar - calfvenB, 0.0);
+  const double SAT = fmax(vstar + calfvenT, 0.0);
+  const double AstarT = (SAR * AstarRR - SAL * AstarLR) / (SAR - SAL);
+  const double AstarB = (SAR * AstarRL - SAL * AstarLL) / (SAR - SAL);
+  const double BstarR = (SAT * BstarRR - SAB * BstarRL) / (SAT - SAB);
+  const double BstarL = (SAT * BstarLR - SAB * BstarLL) / (SAT - SAB);
+
+  // region selection by sign bits, evaluated as the reference's branch-free integer masks times doubles
+  // (riemann_mhd.h:759-787); a mask of 0 still multiplies its term (0*x), so the sum is reproduced as written
+  const int SB_pos = signbit(SB) ? 0 : 1, SB_neg = 1 - SB_pos;
+  const int ST_pos = signbit(ST) ? 0 : 1, ST_neg = 1 - ST_pos;
+  const int SL_pos = signbit(SL) ? 0 : 1, SL_neg = 1 - SL_pos;
+  const int SR_pos = signbit(SR) ? 0 : 1, SR_neg = 1 - SR_pos;
+  double E = 0, tmpE;
+  tmpE = (SAL * SAB * EstarRR - SAL * SAT * EstarRL - SAR * SAB * EstarLR + SAR * SAT * EstarLL) / (SAR - SAL) / (SAT - SAB) -
+         SAT * SAB / (SAT - SAB) * (AstarT - AstarB) + SAR * SAL / (SAR - SAL) * (BstarR - BstarL);
+  E += (double)(SB_neg * ST_pos * SL_neg * SR_pos) * tmpE;
+  tmpE = (SAR * EstarLLx - SAL * EstarRLx + SAR * SAL * (RL.b - LL.b)) / (SAR - SAL);
+  tmpE = (double)SL_pos * ELL + (double)(SL_neg * SR_neg) * ERL + (double)(SL_neg * SR_pos) * tmpE;
+  E += (double)SB_pos * tmpE;
+  tmpE = (SAR * EstarLRx - SAL * EstarRRx + SAR * SAL * (RR.b - LR.b)) / (SAR - SAL);
+  tmpE = (double)SL_pos * ELR + (double)(SL_neg * SR_neg) * ERR + (double)(SL_neg * SR_pos) * tmpE;
+  E += (double)(SB_neg * ST_neg) * tmpE;
+  tmpE = (SAT * EstarLLy - SAB * EstarLRy - SAT * SAB * (LR.a - LL.a)) / (SAT - SAB);
+  E += (double)(SB_neg * ST_pos * SL_pos) * tmpE;
+  tmpE = (SAT * EstarRLy - SAB * EstarRRy - SAT * SAB * (RR.a - RL.a)) / (SAT - SAB);
+  E += (double)(SB_neg * ST_pos * SL_neg * SR_neg) * tmpE;
+  return E;
+}
+
+// compute_emf<dir> (riemann_mhd.h:1054-1193) on four edge states ALREADY in the edge frame
+// (u,v,w = velocity along t1,t2,e ; a,b,c = field along t1,t2,e) and in the reference's slot order
+// sRT, sRB, sLT, sLB.  EDIR: 0 = EMFX, 1 = EMFY, 2 = EMFZ.
+template <int EDIR>
+RG_DEVFN double edge_emf(const DevParams& g, const Prim8& sRT, const Prim8& sRB, const Prim8& sLT, const Prim8& sLB,
+                         double xPos) {
+  Prim8 LL = sRT, RL = sLT, LR = sRB, RR = sLB;
+  if (g.cIso > 0) {
+    LL.p = LL.r * g.cIso * g.cIso;
+    RL.p = RL.r * g.cIso * g.cIso;
+    LR.p = LR.r * g.cIso * g.cIso;
+    RR.p = RR.r * g.cIso * g.cIso;
+  }
+  // enforce continuity of the two in-plane field components across the faces meeting at the edge
+  const double aT = 0.5 * (sRT.a + sLT.a), aB = 0.5 * (sRB.a + sLB.a);
+  const double bR = 0.5 * (sRT.b + sRB.b), bL = 0.5 * (sLT.b + sLB.b);
+  LL.a = aT; RL.a = aT; LR.a = aB; RR.a = aB;
+  LL.b = bR; RL.b = bL; LR.b = bR; RR.b = bL;
+  const double ELL = LL.u * LL.b - LL.v * LL.a;
+  const double ERL = RL.u * RL.b - RL.v * RL.a;
+  const double ELR = LR.u * LR.b - LR.v * LR.a;
+  const double ERR = RR.u * RR.b - RR.v * RR.a;
+  double emf = 0;
+  if (g.magRiemannSolver == 0) emf = mag_hlld_2d(g, LL, RL, LR, RR, ELL, ERL, ELR, ERR);
+  if (g.Omega0 > 0) {  // upwinded shear advection of the field in the shearing box
+    if (EDIR == 0) {
+      const double shear = -1.5 * g.Omega0 * xPos;
+      emf += shear * ((shear > 0) ? LL.b : RR.b);
+    }
+    if (EDIR == 2) {
+      const double shear = -1.5 * g.Omega0 * (xPos - g.dx / 2);
+      emf -= shear * ((shear > 0) ? LL.a : RR.a);
+    }
+  }
+  return emf;
+}
+
+}  // namespace rgpu_dev

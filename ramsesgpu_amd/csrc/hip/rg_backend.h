@@ -1,0 +1,101 @@
+// rg_backend.h (HIP / gfx950) -- the only backend of the product library.
+// Thin layer between the step driver (rgpu_api.cpp) and the HIP runtime: kernel launch of per-cell functors on a
+// flat 1D grid, a wave64 max-reduction for the CFL scan, device memory and event helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <string>
+
+#define RG_DEVFN __device__ __forceinline__
+#define RG_BACKEND_NAME "hip-gfx950"
+
+namespace rgpu {
+
+typedef hipStream_t rg_stream_t;
+typedef hipEvent_t rg_event_t;
+
+inline const char* rg_err_str(hipError_t e) { return hipGetErrorString(e); }
+
+// ---- flat per-cell kernels ---------------------------------------------------------------------------------
+// One thread per array element, x fastest: every SoA component load / store of a wave is one contiguous
+// 512-byte segment.  BLOCK is a multiple of the 64-lane wavefront.
+template <int BLOCK, class K>
+__global__ void __launch_bounds__(BLOCK) rg_kernel(unsigned n, K k) {
+  const unsigned idx = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+  if (idx < n) k(idx);
+}
+
+template <int BLOCK, class K>
+inline int rg_launch(rg_stream_t s, unsigned n, const K& k) {
+  if (n == 0) return 0;
+  const unsigned grid = (n + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL((rg_kernel<BLOCK, K>), dim3(grid), dim3(BLOCK), 0, s, n, k);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- max reduction (CFL scan) ---------------------------------------------------------------------------------
+// Grid-stride accumulation, wave64 butterfly with __shfl_down, one LDS slot per wave, one 64-bit atomicMax per
+// block.  All values are >= 0, so the IEEE bit pattern orders like an unsigned integer; max is exact and
+// order-independent, hence bit-identical to the reference's sequential scan.
+template <int BLOCK, class K>
+__global__ void __launch_bounds__(BLOCK) rg_reduce_max_kernel(unsigned n, K k, unsigned long long* out) {
+  double v = 0.0;
+  for (unsigned idx = blockIdx.x * (unsigned)BLOCK + threadIdx.x; idx < n; idx += gridDim.x * (unsigned)BLOCK)
+    v = fmax(v, k(idx));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  __shared__ double wave_max[BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_max[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    v = (lane < BLOCK / 64) ? wave_max[lane] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+template <class K>
+inline int rg_reduce_max(rg_stream_t s, unsigned n, const K& k, unsigned long long* d_out) {
+  const int BLOCK = 256;
+  unsigned grid = (n + BLOCK - 1) / BLOCK;
+  if (grid > 2048u) grid = 2048u;  // 256 CUs x 8 resident blocks; the rest is grid-strided
+  if (grid == 0) grid = 1;
+  if (hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+  hipLaunchKernelGGL((rg_reduce_max_kernel<BLOCK, K>), dim3(grid), dim3(BLOCK), 0, s, n, k, d_out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- memory / stream helpers ------------------------------------------------------------------------------------
+inline int rg_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+inline int rg_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess ? 0 : -1; }
+inline void rg_free(void* p) { if (p) (void)hipFree(p); }
+inline int rg_host_alloc(void** p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess ? 0 : -1; }
+inline void rg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+inline int rg_memset_async(void* p, int v, size_t bytes, rg_stream_t s) { return hipMemsetAsync(p, v, bytes, s) == hipSuccess ? 0 : -1; }
+inline int rg_copy_h2d(void* d, const void* h, size_t bytes, rg_stream_t s) { return hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1; }
+inline int rg_copy_d2h(void* h, const void* d, size_t bytes, rg_stream_t s) { return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
+inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t s) { return hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1; }
+inline rg_stream_t rg_stream_from_handle(void* h) { return (hipStream_t)h; }
+inline int rg_stream_sync(rg_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
+inline const char* rg_last_error_string() { return hipGetErrorString(hipGetLastError()); }
+
+inline int rg_event_create(rg_event_t* e) { return hipEventCreate(e) == hipSuccess ? 0 : -1; }
+inline void rg_event_destroy(rg_event_t e) { (void)hipEventDestroy(e); }
+inline int rg_event_record(rg_event_t e, rg_stream_t s) { return hipEventRecord(e, s) == hipSuccess ? 0 : -1; }
+inline double rg_event_elapsed_ms(rg_event_t a, rg_event_t b) {
+  float ms = 0.f;
+  if (hipEventSynchronize(b) != hipSuccess) return 0.0;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0;
+  return (double)ms;
+}
+
+}  // namespace rgpu

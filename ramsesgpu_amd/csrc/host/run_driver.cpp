@@ -1,0 +1,151 @@
+#include "run_driver.h"
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+#include "init_conditions.h"
+
+namespace rgpu_host {
+
+GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0) {
+  params_from_config(cfg_, 0, 1, &p_, &rs_);
+  const int rc = rgpu_create(&p_, &ctx_);
+  if (rc) {
+    const std::string msg = ctx_ ? rgpu_last_error(ctx_) : "allocation failure";
+    if (ctx_) rgpu_destroy(ctx_);
+    ctx_ = 0;
+    throw std::runtime_error("rgpu_create: " + msg);
+  }
+  h_U_.assign(rgpu_state_elems(&p_), 0.0);
+}
+
+GodunovRun::~GodunovRun() {
+  if (ctx_) rgpu_destroy(ctx_);
+}
+
+void GodunovRun::check(int rc, const char* what) {
+  if (rc) throw std::runtime_error(std::string(what) + ": " + rgpu_last_error(ctx_));
+}
+
+int GodunovRun::init_simulation() {
+  init_condition(cfg_, p_, h_U_.data());
+  check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
+  return 0;
+}
+
+void GodunovRun::make_all_boundaries(int parity) { check(rgpu_make_all_boundaries(ctx_, parity, totalTime_, 0.0), "make_all_boundaries"); }
+
+double GodunovRun::compute_dt(int useU) {
+  const double dt = rgpu_compute_dt(ctx_, useU);
+  if (!(dt == dt)) throw std::runtime_error(std::string("compute_dt: ") + rgpu_last_error(ctx_));
+  return dt;
+}
+
+void GodunovRun::godunov_unsplit(int nStep, double dt) { check(rgpu_godunov_unsplit(ctx_, nStep, dt, totalTime_), "godunov_unsplit"); }
+
+// MHDRunGodunov.cpp:4077-4089 / HydroRunGodunov.cpp:4082-4126 (unsplit branch)
+void GodunovRun::oneStepIntegration(int& nStep, double& t, double& dt) {
+  dt = compute_dt(nStep % 2);
+  godunov_unsplit(nStep, dt);
+  nStep++;
+  t += dt;
+}
+
+void GodunovRun::copyGpuToCpu(int nStep) { check(rgpu_download(ctx_, h_U_.data(), nStep % 2), "download"); }
+
+// Hand-written VTI writer of the reference (HydroRunBase.cpp:2681-2995): ImageData, PointData, appended raw
+// little-endian Float64, one uint32 byte count per array, INTERIOR cells only, names density..bz.
+void GodunovRun::outputVtk(int nStep) {
+  static const char* names[8] = {"density", "energy", "mx", "my", "mz", "bx", "by", "bz"};
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
+  const bool three_d = p_.nz_global != 1;
+  const int nz = three_d ? p_.nz : 1;
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1;
+  const size_t ncell = isize * jsize * ksize;
+  std::ostringstream fn;
+  fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".vti";
+  std::ofstream out(fn.str().c_str(), std::ios::binary);
+  if (!out) throw std::runtime_error("cannot write " + fn.str());
+  const uint32_t nbytes = static_cast<uint32_t>(sizeof(double) * nx * ny * nz);
+  out << "<?xml version=\"1.0\"?>\n<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
+  out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
+  out << "  <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\">\n    <PointData>\n";
+  for (int v = 0; v < p_.nbVar; ++v) {
+    const char* nm = (p_.nbVar == 4 && v == 3) ? "my" : names[v];
+    out << "     <DataArray type=\"Float64\" Name=\"" << nm << "\" format=\"appended\" offset=\""
+        << static_cast<size_t>(v) * (nbytes + sizeof(uint32_t)) << "\" />\n";
+  }
+  out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n  <AppendedData encoding=\"raw\">\n_";
+  std::vector<double> line(nx);
+  for (int v = 0; v < p_.nbVar; ++v) {
+    out.write(reinterpret_cast<const char*>(&nbytes), sizeof(nbytes));
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const size_t kk = three_d ? k + gw : 0;
+        const double* src = &h_U_[(gw) + isize * ((j + gw) + jsize * kk) + ncell * v];
+        out.write(reinterpret_cast<const char*>(src), sizeof(double) * nx);
+      }
+  }
+  out << "  </AppendedData>\n</VTKFile>\n";
+}
+
+// MHDRunGodunov.cpp:3801-4070 / HydroRunGodunov.cpp:3857-4080 (no restart, no history, VTI outputs only)
+int GodunovRun::start(double* mcell_per_s) {
+  int nStep = init_simulation();
+  make_all_boundaries(0);
+  // h_U.copyTo(h_U2): refresh both device arrays from the ghost-filled one
+  copyGpuToCpu(0);
+  check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
+  totalTime_ = 0.0;
+  double dt = compute_dt(0);
+  std::cout << "Initial dt : " << std::setprecision(8) << dt << std::endl;
+  double io_seconds = 0.0;
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
+    if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0)
+      std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
+    if ((nStep % rs_.nOutput) == 0) {
+      const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
+      if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
+      io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+      std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
+    }
+    oneStepIntegration(nStep, totalTime_, dt);
+  }
+  check(rgpu_synchronize(ctx_), "synchronize");
+  {
+    const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
+    if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
+    io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+  }
+  const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double nz = (p_.nz_global != 1) ? p_.nz : 1;
+  const double rate = 1.0 * nStep * p_.nx * p_.ny * nz / (total - io_seconds);
+  std::cout << "DEBUG : totalTime " << std::setprecision(12) << totalTime_ << std::endl;
+  std::cout << "####################################\nGlobal performance                  \n"
+            << rate << " cell updates per seconds (based on wall time)\n####################################\n";
+  if (mcell_per_s) *mcell_per_s = rate / 1e6;
+  return nStep;
+}
+
+}  // namespace rgpu_host
+
+extern "C" int rgpuh_run(const char* ini_path, const char* overrides, double* mcell_per_s, char* err, int err_len) {
+  try {
+    rgpu_host::IniConfig cfg;
+    const int rc = cfg.load_file(ini_path ? ini_path : "");
+    if (rc != 0) throw std::runtime_error(std::string("cannot read parameter file ") + (ini_path ? ini_path : "(null)"));
+    if (overrides) cfg.apply_overrides(overrides);
+    rgpu_host::GodunovRun run(cfg);
+    return run.start(mcell_per_s);
+  } catch (const std::exception& e) {
+    if (err && err_len > 0) std::snprintf(err, static_cast<size_t>(err_len), "%s", e.what());
+    return RGPU_EINVAL;
+  }
+}

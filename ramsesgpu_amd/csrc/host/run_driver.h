@@ -1,0 +1,47 @@
+// run_driver.h -- host-side run object mirroring the reference's run classes for the path in scope.
+//
+// class GodunovRun plays the role of HydroRunGodunov / MHDRunGodunov (HydroRunGodunov.h:91,177,
+// MHDRunGodunov.h:120,253): init_simulation(), make_all_boundaries(), compute_dt(useU), godunov_unsplit(nStep,dt),
+// oneStepIntegration(nStep,t,dt) -- the one pure virtual of HydroRunBase (HydroRunBase.h:433) -- and start().
+// State lives on the device behind the C ABI (include/rgpu.h); the host mirror h_U is refreshed only for outputs
+// (copyGpuToCpu, HydroRunBase.cpp:7217-7229).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/rgpu.h"
+#include "host_params.h"
+#include "ini_config.h"
+
+namespace rgpu_host {
+
+class GodunovRun {
+ public:
+  explicit GodunovRun(const IniConfig& cfg);
+  ~GodunovRun();
+
+  int init_simulation();                                   // initial condition -> h_U -> device U and U2
+  void make_all_boundaries(int parity);
+  double compute_dt(int useU);
+  void godunov_unsplit(int nStep, double dt);
+  void oneStepIntegration(int& nStep, double& t, double& dt);
+  void copyGpuToCpu(int nStep);
+  std::vector<double>& getDataHost() { return h_U_; }
+  // time loop of start(); returns the number of steps; *mcell = "cell updates per second" / 1e6
+  int start(double* mcell_per_s);
+  void outputVtk(int nStep);
+
+  const rgpu_params& params() const { return p_; }
+  double totalTime() const { return totalTime_; }
+
+ private:
+  IniConfig cfg_;
+  rgpu_params p_;
+  RunSettings rs_;
+  rgpu_ctx* ctx_;
+  std::vector<double> h_U_;
+  double totalTime_;
+  void check(int rc, const char* what);
+};
+
+}  // namespace rgpu_host

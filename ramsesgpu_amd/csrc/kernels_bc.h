@@ -1,0 +1,187 @@
+// kernels_bc.h -- ghost-cell fill, jet inflow, shearing-box ghost remap and the CFL scan, per-thread bodies.
+//   bc_face_cell        make_boundary2<bct,loc>          make_boundary_base.h:1040-1332
+//   jet_cell            make_jet                         HydroRunBase.cpp:2374-2408
+//   shear_ghost_cell    make_boundaries_shear            MHDRunGodunov.cpp:3539-3759
+//   hydro/mhd_invdt     compute_dt / compute_dt_mhd      HydroRunBase.cpp:372-426 / MHDRunBase.cpp:140-250
+#pragma once
+#include "kernels_mhd3d.h"
+
+namespace rgpu_dev {
+
+// One thread per ghost cell of one face; all variables in a loop.  The thread index is decoded so that x stays
+// the fastest-varying coordinate whenever the face is not an x face (coalesced rows).
+// dir 0,1,2 ; side 0 = min, 1 = max ; bct = 1 dirichlet, 2 neumann, 3 periodic
+RG_DEVFN void bc_face_cell(const DevParams& g, double* __restrict__ U, int dir, int side, int bct, unsigned idx) {
+  const int gw = g.gw;
+  int a, i, j, k;  // a = ghost layer 0..gw-1
+  if (dir == 0) {
+    a = (int)(idx % (unsigned)gw);
+    const unsigned t = idx / (unsigned)gw;
+    j = (int)(t % (unsigned)g.jsize);
+    k = (int)(t / (unsigned)g.jsize);
+    i = 0;
+  } else if (dir == 1) {
+    i = (int)(idx % (unsigned)g.isize);
+    const unsigned t = idx / (unsigned)g.isize;
+    a = (int)(t % (unsigned)gw);
+    k = (int)(t / (unsigned)gw);
+    j = 0;
+  } else {
+    i = (int)(idx % (unsigned)g.isize);
+    const unsigned t = idx / (unsigned)g.isize;
+    j = (int)(t % (unsigned)g.jsize);
+    a = (int)(t / (unsigned)g.jsize);
+    k = 0;
+  }
+  const int n = (dir == 0) ? g.nx : (dir == 1) ? g.ny : g.nz;
+  const int ghost = (side == 0) ? a : n + gw + a;
+  int src;
+  if (bct == 1) src = (side == 0) ? 2 * gw - 1 - ghost : 2 * n + 2 * gw - 1 - ghost;
+  else if (bct == 2) src = (side == 0) ? gw : n + gw - 1;
+  else src = (side == 0) ? n + ghost : ghost - n;
+  int io = i, jo = j, ko = k, ii = i, ji = j, ki = k;
+  if (dir == 0) { io = ghost; ii = src; } else if (dir == 1) { jo = ghost; ji = src; } else { ko = ghost; ki = src; }
+  const size_t N = g.ncell;
+  const size_t o_out = (size_t)io + (size_t)g.sj * jo + (size_t)g.sk * ko;
+  const size_t o_in = (size_t)ii + (size_t)g.sj * ji + (size_t)g.sk * ki;
+  const int normal_mom = (dir == 0) ? IU : (dir == 1) ? IV : IW;
+  for (int v = 0; v < g.nvar; ++v) {
+    const double sign = (bct == 1 && v == normal_mom) ? -1.0 : 1.0;
+    U[o_out + v * N] = U[o_in + v * N] * sign;
+  }
+}
+
+struct JetParams { int ijet, offsetJet; double djet, ejet, mjet; };  // ejet = pjet/(gamma0-1)+0.5*djet*ujet^2, mjet = djet*ujet
+
+// one thread per injected ghost cell: 2D idx over ijet*gw (low-y rows), 3D over ijet*ijet*gw (low-z planes)
+RG_DEVFN void jet_cell(const DevParams& g, const JetParams jp, double* __restrict__ U, unsigned idx) {
+  const size_t N = g.ncell;
+  const int gw = g.gw;
+  if (!g.three_d) {
+    const int ii = (int)(idx % (unsigned)jp.ijet), j = (int)(idx / (unsigned)jp.ijet);
+    const size_t o = (size_t)(gw + jp.offsetJet + ii) + (size_t)g.sj * j;
+    U[o + ID * N] = jp.djet; U[o + IP * N] = jp.ejet; U[o + IU * N] = 0.0; U[o + IV * N] = jp.mjet;
+  } else {
+    const int ii = (int)(idx % (unsigned)jp.ijet);
+    const unsigned t = idx / (unsigned)jp.ijet;
+    const int jj = (int)(t % (unsigned)jp.ijet), k = (int)(t / (unsigned)jp.ijet);
+    const size_t o = (size_t)(gw + jp.offsetJet + ii) + (size_t)g.sj * (gw + jp.offsetJet + jj) + (size_t)g.sk * k;
+    U[o + ID * N] = jp.djet; U[o + IP * N] = jp.ejet; U[o + IU * N] = 0.0; U[o + IV * N] = 0.0; U[o + IW * N] = jp.mjet;
+  }
+}
+
+// limited y slope of the copied border columns (MHDRunGodunov.cpp:3609-3619): note dcen = (dlft+drgt)/2/slope_type
+RG_DEVFN double shear_border_slope(double st, double bm, double b0, double bp) {
+  if (!(st == 1 || st == 2)) return 0.0;
+  const double dlft = st * (b0 - bm);
+  const double drgt = st * (bp - b0);
+  const double dcen = 0.5 * (dlft + drgt) / st;
+  const double dsgn = (dcen >= 0.0) ? 1.0 : -1.0;
+  const double slop = fmin(fabs(dlft), fabs(drgt));
+  const double dlim = ((dlft * drgt) <= 0.0) ? 0.0 : slop;
+  return dsgn * fmin(dlim, fabs(dcen));
+}
+
+struct ShearGhost { int jplus; double eps_min, eps_max; };  // from totalTime+dt on the host (:3554-3557)
+
+// One thread per (ghost column i in 0..gw-1, interior row j, any plane k); fills BOTH x sides.  The reference's
+// border copies and slope arrays are never materialised: sources are the gw innermost interior columns, read
+// directly (they are disjoint from the ghost columns being written as long as nx >= gw).
+RG_DEVFN void shear_ghost_cell(const DevParams& g, const ShearGhost sg, double* __restrict__ U, unsigned idx) {
+  const int gw = g.gw, nx = g.nx, ny = g.ny;
+  const int i = (int)(idx % (unsigned)gw);
+  const unsigned t = idx / (unsigned)gw;
+  const int j = gw + (int)(t % (unsigned)ny);
+  const int k = (int)(t / (unsigned)ny);
+  const size_t N = g.ncell;
+  const size_t krow = (size_t)g.sk * k;
+  const double st = g.slope_type;
+  // ---- inner (xmin) ghosts <- outer interior columns (nx + i), shifted by -(jplus+1) ----
+  {
+    int jr = j - sg.jplus - 1, jr1 = jr + 1;
+    const double eps = sg.eps_min;
+    if (jr < gw) jr += ny;
+    if (jr1 < gw) jr1 += ny;
+    const double lambda = 0.5 * eps * (eps - 1.0);
+    const size_t col = krow + (size_t)(nx + i);
+    for (int v = 0; v < 8; ++v) {
+      const double* b = U + col + v * N;
+      double out;
+      if (v == IB) {
+        // one-sided difference; like every slope it exists only for slope_type 1 or 2 (:3585-3604)
+        const double slope = (st == 1 || st == 2) ? b[(size_t)g.sj * (jr + 1)] - b[(size_t)g.sj * jr] : 0.0;
+        out = b[(size_t)g.sj * jr] + eps * slope;
+      } else {
+        const double s0 = shear_border_slope(st, b[(size_t)g.sj * (jr - 1)], b[(size_t)g.sj * jr], b[(size_t)g.sj * (jr + 1)]);
+        const double s1 = shear_border_slope(st, b[(size_t)g.sj * (jr1 - 1)], b[(size_t)g.sj * jr1], b[(size_t)g.sj * (jr1 + 1)]);
+        out = (1.0 - eps) * b[(size_t)g.sj * jr] + eps * b[(size_t)g.sj * jr1] + lambda * (s0 - s1);
+      }
+      U[krow + (size_t)g.sj * j + i + v * N] = out;
+    }
+  }
+  // ---- outer (xmax) ghosts <- inner interior columns (gw + i), shifted by +jplus ----
+  {
+    int jr = j + sg.jplus, jr1 = jr + 1;
+    const double eps = sg.eps_max;
+    if (jr > ny + gw - 1) jr -= ny;
+    if (jr1 > ny + gw - 1) jr1 -= ny;
+    const double lambda = 0.5 * eps * (eps - 1.0);
+    const size_t col = krow + (size_t)(gw + i);
+    for (int v = 0; v < 8; ++v) {
+      if (v == IA && i == 0) continue;  // the first outer Bx ghost is an evolved face value: keep it (:3727-3735)
+      const double* b = U + col + v * N;
+      double out;
+      if (v == IB) {
+        // one-sided difference; like every slope it exists only for slope_type 1 or 2 (:3585-3604)
+        const double slope = (st == 1 || st == 2) ? b[(size_t)g.sj * (jr + 1)] - b[(size_t)g.sj * jr] : 0.0;
+        out = b[(size_t)g.sj * jr] + eps * slope;
+      } else {
+        const double s0 = shear_border_slope(st, b[(size_t)g.sj * (jr - 1)], b[(size_t)g.sj * jr], b[(size_t)g.sj * (jr + 1)]);
+        const double s1 = shear_border_slope(st, b[(size_t)g.sj * (jr1 - 1)], b[(size_t)g.sj * jr1], b[(size_t)g.sj * (jr1 + 1)]);
+        out = (1.0 - eps) * b[(size_t)g.sj * jr] + eps * b[(size_t)g.sj * jr1] + lambda * (s1 - s0);
+      }
+      U[krow + (size_t)g.sj * j + (nx + gw + i) + v * N] = out;
+    }
+  }
+}
+
+// ---- CFL scan: value of one cell, 0 outside the interior (all contributions are >= 0) ----------------------
+template <int NV>
+RG_DEVFN double hydro_invdt_cell(const DevParams& g, const double* __restrict__ U, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  const int gw = g.gw;
+  if (c.i < gw || c.i >= g.isize - gw || c.j < gw || c.j >= g.jsize - gw) return 0.0;
+  if (NV == 5 && (c.k < gw || c.k >= g.ksize - gw)) return 0.0;
+  const size_t N = g.ncell;
+  double u[NV], q[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) u[v] = U[idx + v * N];
+  const double cs = hydro_prim<NV>(g, u, q);
+  const double vx = cs + fabs(q[IU]), vy = cs + fabs(q[IV]);
+  if (NV == 5) {
+    const double vz = cs + fabs(q[IW]);
+    return vx / g.dx + vy / g.dy + vz / g.dz;
+  }
+  return vx / g.dx + vy / g.dy;
+}
+
+RG_DEVFN double mhd_invdt_cell(const DevParams& g, const double* __restrict__ U, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  const int gw = g.gw;
+  if (c.i < gw || c.i >= g.isize - gw || c.j < gw || c.j >= g.jsize - gw) return 0.0;
+  if (g.three_d && (c.k < gw || c.k >= g.ksize - gw)) return 0.0;
+  const size_t N = g.ncell;
+  double u[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) u[v] = U[idx + v * N];
+  const double bnx = U[idx + 1 + IA * N], bny = U[idx + g.sj + IB * N];
+  const double bnz = g.three_d ? U[idx + g.sk + IC * N] : 0.0;
+  const Prim8 q = mhd_prim(g, u, bnx, bny, bnz, 0.0);
+  double sx, sy, sz;
+  info_speeds(g, q, sx, sy, sz);
+  if (!g.three_d) return sx / g.dx + sy / g.dy;
+  if (g.Omega0 > 0) sy += 1.5 * g.Omega0 * g.deltaX / 2;  // shear velocity at the box edge (MHDRunBase.cpp:223-225)
+  return sx / g.dx + sy / g.dy + sz / g.dz;
+}
+
+}  // namespace rgpu_dev

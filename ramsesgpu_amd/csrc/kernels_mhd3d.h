@@ -1,0 +1,525 @@
+// kernels_mhd3d.h -- per-cell bodies of the 3D MHD unsplit step (plain and rotating / shearing box).
+//
+// Pipeline (one launch each, flat 1D grid over the ghost-inclusive array, x fastest => fully coalesced SoA
+// loads; neighbour re-reads are served by L2 / Infinity Cache):
+//   mhd_prim_cell      U            -> Q   (8)    convertToPrimitives        MHDRunGodunov.cpp:519-560
+//   mhd_elec_cell      U,Q          -> E   (3)    edge electric field        mhd_godunov_unsplit_cpu_v3.cpp:36-101
+//                                                 (+ shear terms             MHDRunGodunov.cpp:2448-2525)
+//   mhd_trace3d_cell   U,Q,E        -> T   (38)   slopes + CTU trace         ..._cpu_v3.cpp:115-361, trace_mhd.h:1854-2248
+//   mhd_flux3d_cell    T            -> F   (15), emf (3)   3 HLLD + 3 2D-HLLD ..._cpu_v3.cpp:372-583
+//   mhd_update3d_cell  Uold,F,emf   -> Unew (8)   conservative + CT update   ..._cpu_v3.cpp:475-533,600-630
+//
+// T is the COMPACT traced state: instead of the reference's 18 face/edge state arrays (144 doubles per cell,
+// trace_mhd.h:2032-2246) we keep what they are all built from -- the time-advanced cell state, the three
+// advanced LOW-face field components and the limited half slopes (38 doubles) -- and rebuild qm/qp/qEdge on the
+// fly in the flux kernel with exactly the reference's additions.  The HIGH-face values of a cell are the LOW-face
+// values of its +1 neighbour (bit-identical expressions), so they are read from there.
+#pragma once
+#include "dev_numerics.h"
+
+namespace rgpu_dev {
+
+struct IJK { int i, j, k; };
+RG_DEVFN IJK unflatten(const DevParams& g, unsigned idx) {
+  IJK c;
+  c.i = (int)(idx % (unsigned)g.isize);
+  const unsigned t = idx / (unsigned)g.isize;
+  c.j = (int)(t % (unsigned)g.jsize);
+  c.k = (int)(t / (unsigned)g.jsize);
+  return c;
+}
+
+// slots of the compact traced state T
+enum {
+  T_R = 0, T_P, T_U, T_V, T_W, T_A, T_B, T_C,       // advanced cell-centred state
+  T_AL, T_BL, T_CL,                                  // advanced low-face field
+  T_DX,                                              // 11..17: x half slopes of r,p,u,v,w then B, C
+  T_DY = T_DX + 7,                                   // 18..24: y half slopes of r,p,u,v,w then A, C
+  T_DZ = T_DY + 7,                                   // 25..31: z half slopes of r,p,u,v,w then A, B
+  T_DALY = T_DZ + 7, T_DALZ, T_DBLX, T_DBLZ, T_DCLX, T_DCLY,   // 32..37: transverse half slopes of the low faces
+  T_COUNT                                            // 38
+};
+// flux array F: 5 hydro components per direction, in the FACE-NORMAL frame
+enum { F_X = 0, F_Y = 5, F_Z = 10, F_COUNT = 15 };
+enum { EMF_Z = 0, EMF_Y = 1, EMF_X = 2 };            // EmfIndex, constants.h:191-195
+
+// ------------------------------------------------------------------------------------------------------------
+// primitive variables (2D and 3D)
+// ------------------------------------------------------------------------------------------------------------
+RG_DEVFN void mhd_prim_cell(const DevParams& g, const double* __restrict__ U, double* __restrict__ Q, double dt, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (c.i >= g.isize - 1 || c.j >= g.jsize - 1) return;
+  if (g.three_d && c.k >= g.ksize - 1) return;
+  const size_t N = g.ncell;
+  double u[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) u[v] = U[idx + v * N];
+  const double bnx = U[idx + 1 + IA * N];
+  const double bny = U[idx + g.sj + IB * N];
+  const double bnz = g.three_d ? U[idx + g.sk + IC * N] : 0.0;
+  const Prim8 q = mhd_prim(g, u, bnx, bny, bnz, dt);
+  Q[idx + ID * N] = q.r; Q[idx + IP * N] = q.p; Q[idx + IU * N] = q.u; Q[idx + IV * N] = q.v;
+  Q[idx + IW * N] = q.w; Q[idx + IA * N] = q.a; Q[idx + IB * N] = q.b; Q[idx + IC * N] = q.c;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// edge-centred electric field, defined at the low corner edges of cell (i,j,k)
+// ------------------------------------------------------------------------------------------------------------
+RG_DEVFN void mhd_elec_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
+                            double* __restrict__ E, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (c.i < 1 || c.i >= g.isize - 1 || c.j < 1 || c.j >= g.jsize - 1 || c.k < 1 || c.k >= g.ksize - 1) return;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const double* Qu = Q + IU * N; const double* Qv = Q + IV * N; const double* Qw = Q + IW * N;
+  const double* Ua = U + IA * N; const double* Ub = U + IB * N; const double* Uc = U + IC * N;
+  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+  double u, v, w, A, B, C, e;
+  // Ex : average over the 4 cells around the x-edge (j-1..j, k-1..k)
+  v = 0.25 * (Qv[idx - sj - sk] + Qv[idx - sj] + Qv[idx - sk] + Qv[idx]);
+  w = 0.25 * (Qw[idx - sj - sk] + Qw[idx - sj] + Qw[idx - sk] + Qw[idx]);
+  B = 0.5 * (Ub[idx - sk] + Ub[idx]);
+  C = 0.5 * (Uc[idx - sj] + Uc[idx]);
+  e = v * C - w * B;
+  if (g.rot) { const double shear = -1.5 * g.Omega0 * xPos; e += shear * C; }
+  E[idx] = e;
+  // Ey
+  u = 0.25 * (Qu[idx - 1 - sk] + Qu[idx - 1] + Qu[idx - sk] + Qu[idx]);
+  w = 0.25 * (Qw[idx - 1 - sk] + Qw[idx - 1] + Qw[idx - sk] + Qw[idx]);
+  A = 0.5 * (Ua[idx - sk] + Ua[idx]);
+  C = 0.5 * (Uc[idx - 1] + Uc[idx]);
+  E[idx + N] = w * A - u * C;
+  // Ez
+  u = 0.25 * (Qu[idx - 1 - sj] + Qu[idx - 1] + Qu[idx - sj] + Qu[idx]);
+  v = 0.25 * (Qv[idx - 1 - sj] + Qv[idx - 1] + Qv[idx - sj] + Qv[idx]);
+  A = 0.5 * (Ua[idx - sj] + Ua[idx]);
+  B = 0.5 * (Ub[idx - 1] + Ub[idx]);
+  e = u * B - v * A;
+  if (g.rot) { const double shear = -1.5 * g.Omega0 * (xPos - g.dx / 2); e -= shear * A; }
+  E[idx + 2 * N] = e;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// slopes + MUSCL-Hancock / CTU trace -> compact state
+// ------------------------------------------------------------------------------------------------------------
+RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
+                               const double* __restrict__ E, double* __restrict__ T, double dtdx, double dtdy,
+                               double dtdz, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  const int lo = g.gw - 1;
+  if (c.i < lo || c.i > g.isize - g.gw || c.j < lo || c.j > g.jsize - g.gw || c.k < lo || c.k > g.ksize - g.gw) return;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const double st = g.slope_type;
+
+  // cell state and limited hydro slopes of the 8 primitive variables in the 3 directions
+  double q[8], dx_[8], dy_[8], dz_[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const double* Qv = Q + v * N;
+    q[v] = Qv[idx];
+    if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; dz_[v] = 0.0; }
+    else {
+      dx_[v] = tvd_slope(st, Qv[idx - 1], q[v], Qv[idx + 1]);
+      dy_[v] = tvd_slope(st, Qv[idx - sj], q[v], Qv[idx + sj]);
+      dz_[v] = tvd_slope(st, Qv[idx - sk], q[v], Qv[idx + sk]);
+    }
+  }
+  const double* Ua = U + IA * N; const double* Ub = U + IB * N; const double* Uc = U + IC * N;
+  double AL = Ua[idx], BL = Ub[idx], CL = Uc[idx];
+  const double AR = Ua[idx + 1], BR = Ub[idx + sj], CR = Uc[idx + sk];
+  // transverse slopes of the low-face field (slope_unsplit_mhd_3d: slope type capped at 2)
+  const double mst = g.mag_slope_type;
+  const double dALy = 0.5 * tvd_slope(mst, Ua[idx - sj], AL, Ua[idx + sj]);
+  const double dALz = 0.5 * tvd_slope(mst, Ua[idx - sk], AL, Ua[idx + sk]);
+  const double dBLx = 0.5 * tvd_slope(mst, Ub[idx - 1], BL, Ub[idx + 1]);
+  const double dBLz = 0.5 * tvd_slope(mst, Ub[idx - sk], BL, Ub[idx + sk]);
+  const double dCLx = 0.5 * tvd_slope(mst, Uc[idx - 1], CL, Uc[idx + 1]);
+  const double dCLy = 0.5 * tvd_slope(mst, Uc[idx - sj], CL, Uc[idx + sj]);
+
+  // electric field at the edges bounding the three low faces
+  const double* Ex = E; const double* Ey = E + N; const double* Ez = E + 2 * N;
+  const double ELL = Ex[idx], ELR = Ex[idx + sk], ERL = Ex[idx + sj];
+  const double FLL = Ey[idx], FLR = Ey[idx + sk], FRL = Ey[idx + 1];
+  const double GLL = Ez[idx], GLR = Ez[idx + sj], GRL = Ez[idx + 1];
+
+  double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = q[IW], A = q[IA], B = q[IB], C = q[IC];
+  const double drx = dx_[ID] * 0.5, dpx = dx_[IP] * 0.5, dux = dx_[IU] * 0.5, dvx = dx_[IV] * 0.5, dwx = dx_[IW] * 0.5,
+               dCx = dx_[IC] * 0.5, dBx = dx_[IB] * 0.5;
+  const double dry = dy_[ID] * 0.5, dpy = dy_[IP] * 0.5, duy = dy_[IU] * 0.5, dvy = dy_[IV] * 0.5, dwy = dy_[IW] * 0.5,
+               dCy = dy_[IC] * 0.5, dAy = dy_[IA] * 0.5;
+  const double drz = dz_[ID] * 0.5, dpz = dz_[IP] * 0.5, duz = dz_[IU] * 0.5, dvz = dz_[IV] * 0.5, dwz = dz_[IW] * 0.5,
+               dAz = dz_[IA] * 0.5, dBz = dz_[IB] * 0.5;
+  const double dAx = 0.5 * (AR - AL), dBy = 0.5 * (BR - BL), dCz = 0.5 * (CR - CL);
+  const double gamma = g.gamma0;
+
+  double sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy + (-w * drz - dwz * r) * dtdz;
+  double su0 = (-u * dux - (dpx + B * dBx + C * dCx) / r) * dtdx + (-v * duy + B * dAy / r) * dtdy + (-w * duz + C * dAz / r) * dtdz;
+  double sv0 = (-u * dvx + A * dBx / r) * dtdx + (-v * dvy - (dpy + A * dAy + C * dCy) / r) * dtdy + (-w * dvz + C * dBz / r) * dtdz;
+  double sw0 = (-u * dwx + A * dCx / r) * dtdx + (-v * dwy + B * dCy / r) * dtdy + (-w * dwz - (dpz + A * dAz + B * dBz) / r) * dtdz;
+  double sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy + (-w * dpz - dwz * gamma * p) * dtdz;
+  double sA0 = (u * dBy + B * duy - v * dAy - A * dvy) * dtdy + (u * dCz + C * duz - w * dAz - A * dwz) * dtdz;
+  double sB0 = (v * dAx + A * dvx - u * dBx - B * dux) * dtdx + (v * dCz + C * dvz - w * dBz - B * dwz) * dtdz;
+  double sC0 = (w * dAx + A * dwx - u * dCx - C * dux) * dtdx + (w * dBy + B * dwy - v * dCy - C * dvy) * dtdy;
+  if (g.Omega0 > 0) {
+    const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+    const double shear = -1.5 * g.Omega0 * xPos;
+    sr0 = sr0 - shear * dry * dtdy;
+    su0 = su0 - shear * duy * dtdy;
+    sv0 = sv0 - shear * dvy * dtdy;
+    sw0 = sw0 - shear * dwy * dtdy;
+    sp0 = sp0 - shear * dpy * dtdy;
+    sA0 = sA0 - shear * dAy * dtdy;
+    sB0 = sB0 + (shear * dAx - 1.5 * g.Omega0 * A * g.dx) * dtdx + shear * dBz * dtdz;
+    sC0 = sC0 - shear * dCy * dtdy;
+  }
+  const double sAL0 = +(GLR - GLL) * dtdy * 0.5 - (FLR - FLL) * dtdz * 0.5;
+  const double sBL0 = -(GRL - GLL) * dtdx * 0.5 + (ELR - ELL) * dtdz * 0.5;
+  const double sCL0 = +(FRL - FLL) * dtdx * 0.5 - (ERL - ELL) * dtdy * 0.5;
+
+  r = r + sr0; u = u + su0; v = v + sv0; w = w + sw0; p = p + sp0; A = A + sA0; B = B + sB0; C = C + sC0;
+  AL = AL + sAL0; BL = BL + sBL0; CL = CL + sCL0;
+
+  double* t = T + idx;
+  t[T_R * N] = r; t[T_P * N] = p; t[T_U * N] = u; t[T_V * N] = v; t[T_W * N] = w; t[T_A * N] = A; t[T_B * N] = B; t[T_C * N] = C;
+  t[T_AL * N] = AL; t[T_BL * N] = BL; t[T_CL * N] = CL;
+  t[(T_DX + 0) * N] = drx; t[(T_DX + 1) * N] = dpx; t[(T_DX + 2) * N] = dux; t[(T_DX + 3) * N] = dvx; t[(T_DX + 4) * N] = dwx;
+  t[(T_DX + 5) * N] = dBx; t[(T_DX + 6) * N] = dCx;
+  t[(T_DY + 0) * N] = dry; t[(T_DY + 1) * N] = dpy; t[(T_DY + 2) * N] = duy; t[(T_DY + 3) * N] = dvy; t[(T_DY + 4) * N] = dwy;
+  t[(T_DY + 5) * N] = dAy; t[(T_DY + 6) * N] = dCy;
+  t[(T_DZ + 0) * N] = drz; t[(T_DZ + 1) * N] = dpz; t[(T_DZ + 2) * N] = duz; t[(T_DZ + 3) * N] = dvz; t[(T_DZ + 4) * N] = dwz;
+  t[(T_DZ + 5) * N] = dAz; t[(T_DZ + 6) * N] = dBz;
+  t[T_DALY * N] = dALy; t[T_DALZ * N] = dALz; t[T_DBLX * N] = dBLx; t[T_DBLZ * N] = dBLz; t[T_DCLX * N] = dCLx; t[T_DCLY * N] = dCLy;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// rebuilding face and edge states from T
+// ------------------------------------------------------------------------------------------------------------
+
+// 3D trace floors: rho >= smallr, p >= smallp (no density factor, trace_mhd.h:2041-2042)
+RG_DEVFN void floor3d(const DevParams& g, Prim8& s) {
+  s.r = fmax(g.smallr, s.r);
+  s.p = fmax(g.smallp, s.p);
+}
+
+// Face state of cell m in direction D, in the face-NORMAL frame.  SIDE=+1: the reference's qm[D] (state at the
+// HIGH face of m, the LEFT state of face m+1); SIDE=-1: qp[D] (state at the LOW face of m, the RIGHT state).
+template <int D, int SIDE>
+RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
+  const size_t N = g.ncell;
+  const unsigned sD = (D == XD) ? 1u : (D == YD) ? g.sj : g.sk;
+  const double* t = T + m;
+  const int S = (D == XD) ? T_DX : (D == YD) ? T_DY : T_DZ;
+  const double s = (double)SIDE;
+  double r = t[T_R * N] + s * t[(S + 0) * N];
+  double p = t[T_P * N] + s * t[(S + 1) * N];
+  const double u = t[T_U * N] + s * t[(S + 2) * N];
+  const double v = t[T_V * N] + s * t[(S + 3) * N];
+  const double w = t[T_W * N] + s * t[(S + 4) * N];
+  // normal field: the advanced face value (own low face, or the +1 neighbour's low face for the high side)
+  const int TF = (D == XD) ? T_AL : (D == YD) ? T_BL : T_CL;
+  const double bn = (SIDE > 0) ? T[(m + sD) + (size_t)TF * N] : t[TF * N];
+  // the two transverse cell-centred components with their slopes along D (slots 5,6 of the slope group)
+  double b1, b2;  // in grid order: the two components other than D, ascending
+  if (D == XD) { b1 = t[T_B * N] + s * t[(S + 5) * N]; b2 = t[T_C * N] + s * t[(S + 6) * N]; }
+  else if (D == YD) { b1 = t[T_A * N] + s * t[(S + 5) * N]; b2 = t[T_C * N] + s * t[(S + 6) * N]; }
+  else { b1 = t[T_A * N] + s * t[(S + 5) * N]; b2 = t[T_B * N] + s * t[(S + 6) * N]; }
+  Prim8 o;
+  o.r = r; o.p = p;
+  // permutation into the normal frame: x: (u,v,w | A,B,C)  y: (v,u,w | B,A,C)  z: (w,v,u | C,B,A)
+  if (D == XD) { o.u = u; o.v = v; o.w = w; o.a = bn; o.b = b1; o.c = b2; }
+  else if (D == YD) { o.u = v; o.v = u; o.w = w; o.a = bn; o.b = b1; o.c = b2; }
+  else { o.u = w; o.v = v; o.w = u; o.a = bn; o.b = b2; o.c = b1; }
+  floor3d(g, o);
+  return o;
+}
+
+// Edge state of cell m for the edge along direction EDIR (0=x,1=y,2=z), at the corner given by the signs
+// (S1,S2) along the two transverse directions (t1,t2) = (y,z) | (z,x) | (x,y), returned in the EDGE frame
+// (u,v,w / a,b,c = components along t1, t2, e).  Reproduces qEdge of trace_mhd.h:2104-2246.
+template <int EDIR, int S1, int S2>
+RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
+  const size_t N = g.ncell;
+  const int t1 = (EDIR + 1) % 3, t2 = (EDIR + 2) % 3;
+  const unsigned st1 = (t1 == XD) ? 1u : (t1 == YD) ? g.sj : g.sk;
+  const unsigned st2 = (t2 == XD) ? 1u : (t2 == YD) ? g.sj : g.sk;
+  const int G1 = (t1 == XD) ? T_DX : (t1 == YD) ? T_DY : T_DZ;
+  const int G2 = (t2 == XD) ? T_DX : (t2 == YD) ? T_DY : T_DZ;
+  const double* t = T + m;
+  const double s1 = (double)S1, s2 = (double)S2;
+  // cell-centred quantities: q + (s1*d_t1 + s2*d_t2).  In the reference the x-direction slope always comes
+  // first inside the parenthesis, then y, then z; keep that operand order.
+  const bool t1_first = t1 < t2;
+#define RG_EDGE_SUM(base, k1, k2) \
+  ((base) + (t1_first ? (s1 * t[(G1 + (k1)) * N] + s2 * t[(G2 + (k2)) * N]) : (s2 * t[(G2 + (k2)) * N] + s1 * t[(G1 + (k1)) * N])))
+  double vel[3];
+  Prim8 o;
+  o.r = RG_EDGE_SUM(t[T_R * N], 0, 0);
+  o.p = RG_EDGE_SUM(t[T_P * N], 1, 1);
+  vel[0] = RG_EDGE_SUM(t[T_U * N], 2, 2);
+  vel[1] = RG_EDGE_SUM(t[T_V * N], 3, 3);
+  vel[2] = RG_EDGE_SUM(t[T_W * N], 4, 4);
+  // the field component along the edge is cell centred; its slope slot inside a direction group:
+  //   group X holds (B,C) at 5,6 ; group Y holds (A,C) at 5,6 ; group Z holds (A,B) at 5,6
+  const int Te = (EDIR == XD) ? T_A : (EDIR == YD) ? T_B : T_C;
+  const int k_in_G1 = (t1 == XD) ? ((EDIR == YD) ? 5 : 6) : (t1 == YD) ? ((EDIR == XD) ? 5 : 6) : ((EDIR == XD) ? 5 : 6);
+  const int k_in_G2 = (t2 == XD) ? ((EDIR == YD) ? 5 : 6) : (t2 == YD) ? ((EDIR == XD) ? 5 : 6) : ((EDIR == XD) ? 5 : 6);
+  const double be = RG_EDGE_SUM(t[Te * N], k_in_G1, k_in_G2);
+#undef RG_EDGE_SUM
+  // the two in-plane components are face centred: take the face on the signed side and add the signed
+  // transverse half slope of THAT face (stored with the cell owning the face)
+  const int TF1 = (t1 == XD) ? T_AL : (t1 == YD) ? T_BL : T_CL;   // face normal to t1
+  const int TF2 = (t2 == XD) ? T_AL : (t2 == YD) ? T_BL : T_CL;   // face normal to t2
+  // slope of face-t1 field along t2 / of face-t2 field along t1
+  const int TS1 = (t1 == XD) ? ((t2 == YD) ? T_DALY : T_DALZ) : (t1 == YD) ? ((t2 == XD) ? T_DBLX : T_DBLZ) : ((t2 == XD) ? T_DCLX : T_DCLY);
+  const int TS2 = (t2 == XD) ? ((t1 == YD) ? T_DALY : T_DALZ) : (t2 == YD) ? ((t1 == XD) ? T_DBLX : T_DBLZ) : ((t1 == XD) ? T_DCLX : T_DCLY);
+  const unsigned m1 = (S1 > 0) ? m + st1 : m;
+  const unsigned m2 = (S2 > 0) ? m + st2 : m;
+  const double b1 = T[m1 + (size_t)TF1 * N] + s2 * T[m1 + (size_t)TS1 * N];
+  const double b2 = T[m2 + (size_t)TF2 * N] + s1 * T[m2 + (size_t)TS2 * N];
+  o.u = vel[t1]; o.v = vel[t2]; o.w = vel[EDIR];
+  o.a = b1; o.b = b2; o.c = be;
+  floor3d(g, o);
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Riemann problems at the three low faces and the three low edges of cell (i,j,k)
+// ------------------------------------------------------------------------------------------------------------
+enum { DO_FLUX_X = 1, DO_FLUX_Y = 2, DO_FLUX_Z = 4, DO_EMF_X = 8, DO_EMF_Y = 16, DO_EMF_Z = 32, DO_ALL = 63 };
+
+template <int D>
+RG_DEVFN void store_flux(const DevParams& g, double* __restrict__ F, unsigned idx, const double* fl) {
+  const size_t N = g.ncell;
+  const int base = (D == XD) ? F_X : (D == YD) ? F_Y : F_Z;
+#pragma unroll
+  for (int v = 0; v < 5; ++v) F[idx + (size_t)(base + v) * N] = fl[v];
+}
+
+template <int MASK>
+RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F,
+                              double* __restrict__ emf, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw || c.k < g.gw || c.k > g.ksize - g.gw) return;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+  double fl[8];
+  if (MASK & DO_FLUX_X) {
+    Prim8 L = face_state3d<XD, +1>(g, T, idx - 1), R = face_state3d<XD, -1>(g, T, idx);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
+    mhd_riemann(g, L, R, fl);
+    store_flux<XD>(g, F, idx, fl);
+  }
+  if (MASK & DO_FLUX_Y) {
+    Prim8 L = face_state3d<YD, +1>(g, T, idx - sj), R = face_state3d<YD, -1>(g, T, idx);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
+    mhd_riemann(g, L, R, fl);
+    if (g.rot) {
+      // shear advection of the y flux with the upwind state as left by the Riemann solver
+      // (MHDRunGodunov.cpp:2861-2899); states are in the y-normal frame
+      const double shear_y = -1.5 * g.Omega0 * xPos;
+      const double bn_mean = 0.5 * (L.a + R.a);
+      const Prim8& s = (shear_y > 0) ? L : R;
+      const double eMag = 0.5 * (s.a * s.a + s.b * s.b + s.c * s.c);
+      const double eKin = 0.5 * (s.u * s.u + s.v * s.v + s.w * s.w);
+      const double eTot = eKin + eMag + s.p / (g.gamma0 - 1.0);
+      fl[ID] = fl[ID] + shear_y * s.r;
+      fl[IP] = fl[IP] + shear_y * (eTot + eMag - bn_mean * bn_mean);
+      fl[IU] = fl[IU] + shear_y * s.r * s.u;
+      fl[IV] = fl[IV] + shear_y * s.r * s.v;
+      fl[IW] = fl[IW] + shear_y * s.r * s.w;
+    }
+    store_flux<YD>(g, F, idx, fl);
+  }
+  if (MASK & DO_FLUX_Z) {
+    Prim8 L = face_state3d<ZD, +1>(g, T, idx - sk), R = face_state3d<ZD, -1>(g, T, idx);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
+    mhd_riemann(g, L, R, fl);
+    store_flux<ZD>(g, F, idx, fl);
+  }
+  // EMFs: slot order (RT, RB, LT, LB) = (+,+) from c-t1-t2, (+,-) from c-t1, (-,+) from c-t2, (-,-) from c
+  if (MASK & DO_EMF_Z) {  // t1 = x, t2 = y
+    const Prim8 rt = edge_state3d<2, +1, +1>(g, T, idx - 1 - sj), rb = edge_state3d<2, +1, -1>(g, T, idx - 1);
+    const Prim8 lt = edge_state3d<2, -1, +1>(g, T, idx - sj), lb = edge_state3d<2, -1, -1>(g, T, idx);
+    emf[idx + (size_t)EMF_Z * N] = edge_emf<2>(g, rt, rb, lt, lb, xPos);
+  }
+  if (MASK & DO_EMF_Y) {  // t1 = z, t2 = x
+    const Prim8 rt = edge_state3d<1, +1, +1>(g, T, idx - sk - 1), rb = edge_state3d<1, +1, -1>(g, T, idx - sk);
+    const Prim8 lt = edge_state3d<1, -1, +1>(g, T, idx - 1), lb = edge_state3d<1, -1, -1>(g, T, idx);
+    emf[idx + (size_t)EMF_Y * N] = edge_emf<1>(g, rt, rb, lt, lb, xPos);
+  }
+  if (MASK & DO_EMF_X) {  // t1 = y, t2 = z
+    const Prim8 rt = edge_state3d<0, +1, +1>(g, T, idx - sj - sk), rb = edge_state3d<0, +1, -1>(g, T, idx - sj);
+    const Prim8 lt = edge_state3d<0, -1, +1>(g, T, idx - sk), lb = edge_state3d<0, -1, -1>(g, T, idx);
+    emf[idx + (size_t)EMF_X * N] = edge_emf<0>(g, rt, rb, lt, lb, xPos);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// shearing box: remap of the x-border density flux and of emfY (MHDRunGodunov.cpp:3203-3300)
+// ------------------------------------------------------------------------------------------------------------
+struct ShearRemap {   // computed on the host from totalTime, dt (fmod / integer part), MHDRunGodunov.cpp:3213-3216
+  int jplus;
+  double eps_min;     // 1 - epsi/dy  (weight used for the inner / xmin border)
+  double eps_max;     // epsi/dy      (outer / xmax border)
+};
+
+// step 1: save the two emfY columns (they are rewritten in place by step 2).  idx2 = j + jsize*k
+RG_DEVFN void shear_save_emf_cell(const DevParams& g, const double* __restrict__ emf, double* __restrict__ save, unsigned idx2) {
+  const unsigned j = idx2 % (unsigned)g.jsize, k = idx2 / (unsigned)g.jsize;
+  const size_t N = g.ncell;
+  const size_t row = (size_t)g.sj * j + (size_t)g.sk * k;
+  const size_t P = (size_t)g.jsize * g.ksize;
+  save[idx2] = emf[row + g.gw + (size_t)EMF_Y * N];
+  save[idx2 + P] = emf[row + g.nx + g.gw + (size_t)EMF_Y * N];
+}
+
+// step 2: remapped density flux (into remap[0..P) for xmin, [P..2P) for xmax) and averaged emfY at both borders
+RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const double* __restrict__ F,
+                               double* __restrict__ emf, const double* __restrict__ save, double* __restrict__ remap,
+                               double dtdx, unsigned idx2) {
+  const int j = (int)(idx2 % (unsigned)g.jsize), k = (int)(idx2 / (unsigned)g.jsize);
+  const size_t N = g.ncell;
+  const size_t P = (size_t)g.jsize * g.ksize;
+  const int gw = g.gw, ny = g.ny, nx = g.nx;
+  const double* Fd = F + (size_t)(F_X + ID) * N;   // density flux through the low x face
+  const size_t krow = (size_t)g.sk * k;
+  const bool inner = (j >= gw && j < g.jsize - gw + 1 && k >= gw && k < g.ksize - gw + 1);
+  // ---- xmin border: looks at the xmax border, shifted by -(jplus+1) ----
+  {
+    int jremap = j - sr.jplus - 1, jremapp1 = jremap + 1;
+    const double eps = sr.eps_min;
+    if (jremap < gw) jremap += ny;
+    if (jremapp1 < gw) jremapp1 += ny;
+    if (inner) {
+      const double own = Fd[krow + (size_t)g.sj * j + gw] * dtdx;
+      const double o0 = Fd[krow + (size_t)g.sj * jremap + nx + gw] * dtdx;
+      const double o1 = Fd[krow + (size_t)g.sj * jremapp1 + nx + gw] * dtdx;
+      double rv = own + (1.0 - eps) * o0 + eps * o1;
+      rv *= 0.5;
+      remap[idx2] = rv;
+    }
+    double e = save[idx2];
+    e += (1.0 - eps) * save[P + jremap + (size_t)g.jsize * k] + eps * save[P + jremapp1 + (size_t)g.jsize * k];
+    e *= 0.5;
+    emf[krow + (size_t)g.sj * j + gw + (size_t)EMF_Y * N] = e;
+  }
+  // ---- xmax border: looks at the xmin border, shifted by +jplus ----
+  {
+    int jremap = j + sr.jplus, jremapp1 = jremap + 1;
+    const double eps = sr.eps_max;
+    if (jremap > ny + gw - 1) jremap -= ny;
+    if (jremapp1 > ny + gw - 1) jremapp1 -= ny;
+    if (inner) {
+      const double own = Fd[krow + (size_t)g.sj * j + nx + gw] * dtdx;
+      const double o0 = Fd[krow + (size_t)g.sj * jremap + gw] * dtdx;
+      const double o1 = Fd[krow + (size_t)g.sj * jremapp1 + gw] * dtdx;
+      double rv = own + (1.0 - eps) * o0 + eps * o1;
+      rv *= 0.5;
+      remap[P + idx2] = rv;
+    }
+    double e = save[P + idx2];
+    e += (1.0 - eps) * save[jremap + (size_t)g.jsize * k] + eps * save[jremapp1 + (size_t)g.jsize * k];
+    e *= 0.5;
+    emf[krow + (size_t)g.sj * j + nx + gw + (size_t)EMF_Y * N] = e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conservative update (gather form of the reference's scatter loop, same summation order per cell) + CT
+// ------------------------------------------------------------------------------------------------------------
+struct RotCoef { double lambda, ratio, alpha1, alpha2; };  // MHDRunGodunov.cpp:2039-2053
+
+template <bool ROT>
+RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
+                                double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
+                                const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
+                                unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const int gw = g.gw;
+  double u[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) u[v] = Uold[idx + v * N];
+  const bool in_i = c.i >= gw && c.i < g.isize - gw, in_j = c.j >= gw && c.j < g.jsize - gw, in_k = c.k >= gw && c.k < g.ksize - gw;
+  const bool shear = ROT && g.shearbox;
+  if (in_i && in_j && in_k) {
+    if (ROT) {  // Coriolis, before any flux is applied to this cell (MHDRunGodunov.cpp:2938-2945)
+      const double dsx = 2.0 * g.Omega0 * dt * u[IV] / (1.0 + rc.lambda);
+      const double dsy = -0.5 * g.Omega0 * dt * u[IU] / (1.0 + rc.lambda);
+      u[IU] = u[IU] * rc.ratio + dsx;
+      u[IV] = u[IV] * rc.ratio + dsy;
+    }
+    const double a1 = rc.alpha1, a2 = rc.alpha2;
+    double f[5];
+    // contributions in the order the reference's k,j,i loop delivers them to this cell:
+    // own iteration: +Fx, +Fy, +Fz ; then -Fx(i+1), -Fy(j+1), -Fz(k+1)
+#define RG_LOADF(base, off) _Pragma("unroll") for (int v = 0; v < 5; ++v) f[v] = F[(idx + (off)) + (size_t)((base) + v) * N]
+    RG_LOADF(F_X, 0);
+    if (!(shear && c.i == gw)) u[ID] += f[ID] * dtdx;
+    u[IP] += f[IP] * dtdx;
+    if (ROT) { u[IU] += (a1 * f[IU] + a2 * f[IV]) * dtdx; u[IV] += (a1 * f[IV] - 0.25 * a2 * f[IU]) * dtdx; }
+    else { u[IU] += f[IU] * dtdx; u[IV] += f[IV] * dtdx; }
+    u[IW] += f[IW] * dtdx;
+    RG_LOADF(F_Y, 0);   // y-normal frame: f[IU] is the y momentum flux, f[IV] the x momentum flux
+    u[ID] += f[ID] * dtdy;
+    u[IP] += f[IP] * dtdy;
+    if (ROT) { u[IU] += (a1 * f[IV] + a2 * f[IU]) * dtdy; u[IV] += (a1 * f[IU] - 0.25 * a2 * f[IV]) * dtdy; }
+    else { u[IU] += f[IV] * dtdy; u[IV] += f[IU] * dtdy; }
+    u[IW] += f[IW] * dtdy;
+    RG_LOADF(F_Z, 0);   // z-normal frame: f[IU] is the z momentum flux, f[IW] the x momentum flux
+    u[ID] += f[ID] * dtdz;
+    u[IP] += f[IP] * dtdz;
+    if (ROT) { u[IU] += (a1 * f[IW] + a2 * f[IV]) * dtdz; u[IV] += (a1 * f[IV] - 0.25 * a2 * f[IW]) * dtdz; }
+    else { u[IU] += f[IW] * dtdz; u[IV] += f[IV] * dtdz; }
+    u[IW] += f[IU] * dtdz;
+    RG_LOADF(F_X, 1);
+    if (!(shear && (c.i + 1) == (g.nx + gw))) u[ID] -= f[ID] * dtdx;
+    u[IP] -= f[IP] * dtdx;
+    if (ROT) { u[IU] -= (a1 * f[IU] + a2 * f[IV]) * dtdx; u[IV] -= (a1 * f[IV] - 0.25 * a2 * f[IU]) * dtdx; }
+    else { u[IU] -= f[IU] * dtdx; u[IV] -= f[IV] * dtdx; }
+    u[IW] -= f[IW] * dtdx;
+    RG_LOADF(F_Y, sj);
+    u[ID] -= f[ID] * dtdy;
+    u[IP] -= f[IP] * dtdy;
+    if (ROT) { u[IU] -= (a1 * f[IV] + a2 * f[IU]) * dtdy; u[IV] -= (a1 * f[IU] - 0.25 * a2 * f[IV]) * dtdy; }
+    else { u[IU] -= f[IV] * dtdy; u[IV] -= f[IU] * dtdy; }
+    u[IW] -= f[IW] * dtdy;
+    RG_LOADF(F_Z, sk);
+    u[ID] -= f[ID] * dtdz;
+    u[IP] -= f[IP] * dtdz;
+    if (ROT) { u[IU] -= (a1 * f[IW] + a2 * f[IV]) * dtdz; u[IV] -= (a1 * f[IV] - 0.25 * a2 * f[IW]) * dtdz; }
+    else { u[IU] -= f[IW] * dtdz; u[IV] -= f[IV] * dtdz; }
+    u[IW] -= f[IU] * dtdz;
+#undef RG_LOADF
+    if (shear) {  // remapped density flux at the two x borders, then the density floor (:3289-3300)
+      const size_t P = (size_t)g.jsize * g.ksize;
+      const size_t jk = (size_t)c.j + (size_t)g.jsize * c.k;
+      if (c.i == gw) u[ID] += remap[jk];
+      if (c.i == g.nx + gw - 1) u[ID] -= remap[P + jk];
+      if (c.i == gw || c.i == g.nx + gw - 1) u[ID] = fmax(u[ID], g.smallr);
+    }
+  }
+  // constrained transport on [gw, size-gw] in every direction (faces of the first high ghost layer included)
+  const bool ct_i = c.i >= gw && c.i <= g.isize - gw, ct_j = c.j >= gw && c.j <= g.jsize - gw, ct_k = c.k >= gw && c.k <= g.ksize - gw;
+  if (ct_i && ct_j && ct_k) {
+    const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
+    if (c.k < g.ksize - gw) {
+      u[IA] += (eZ[idx + sj] - eZ[idx]) * dtdy;
+      u[IB] -= (eZ[idx + 1] - eZ[idx]) * dtdx;
+    }
+    u[IA] -= (eY[idx + sk] - eY[idx]) * dtdz;
+    u[IB] += (eX[idx + sk] - eX[idx]) * dtdz;
+    u[IC] += (eY[idx + 1] - eY[idx]) * dtdx;
+    u[IC] -= (eX[idx + sj] - eX[idx]) * dtdy;
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) Unew[idx + v * N] = u[v];
+}
+
+}  // namespace rgpu_dev

@@ -1,0 +1,101 @@
+// launchers.h -- kernel functors: one small struct per launch, holding the launch's arguments by value and
+// calling the per-cell body.  rg_kernel<BLOCK, K_xxx> is the __global__ entry the profiler sees.
+#pragma once
+#include "kernels_bc.h"
+#include "kernels_hydro.h"
+#include "kernels_mhd2d.h"
+#include "kernels_mhd3d.h"
+
+namespace rgpu_dev {
+
+// ---- hydro -----------------------------------------------------------------------------------------------------
+template <int NV>
+struct K_hydro_prim {
+  DevParams g; const double* U; double* Q;
+  RG_DEVFN void operator()(unsigned idx) const { hydro_prim_cell<NV>(g, U, Q, idx); }
+};
+template <int ND, int NV>
+struct K_hydro_trace {
+  DevParams g; const double* Q; double* T; double dtdx, dtdy, dtdz;
+  RG_DEVFN void operator()(unsigned idx) const { hydro_trace_cell<ND, NV>(g, Q, T, dtdx, dtdy, dtdz, idx); }
+};
+template <int ND, int NV>
+struct K_hydro_flux {
+  DevParams g; const double* T; double* F;
+  RG_DEVFN void operator()(unsigned idx) const { hydro_flux_cell<ND, NV>(g, T, F, idx); }
+};
+template <int ND, int NV>
+struct K_hydro_update {
+  DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy, dtdz;
+  RG_DEVFN void operator()(unsigned idx) const { hydro_update_cell<ND, NV>(g, Uold, Unew, F, dtdx, dtdy, dtdz, idx); }
+};
+template <int NV>
+struct K_hydro_invdt {
+  DevParams g; const double* U;
+  RG_DEVFN double operator()(unsigned idx) const { return hydro_invdt_cell<NV>(g, U, idx); }
+};
+
+// ---- MHD -------------------------------------------------------------------------------------------------------
+struct K_mhd_prim {
+  DevParams g; const double* U; double* Q; double dt;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_prim_cell(g, U, Q, dt, idx); }
+};
+struct K_mhd_invdt {
+  DevParams g; const double* U;
+  RG_DEVFN double operator()(unsigned idx) const { return mhd_invdt_cell(g, U, idx); }
+};
+struct K_mhd_trace2d {
+  DevParams g; const double* U; const double* Q; double* T; double dtdx, dtdy;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_trace2d_cell(g, U, Q, T, dtdx, dtdy, idx); }
+};
+struct K_mhd_flux2d {
+  DevParams g; const double* T; double* F;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_flux2d_cell(g, T, F, idx); }
+};
+struct K_mhd_update2d {
+  DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell(g, Uold, Unew, F, dtdx, dtdy, idx); }
+};
+struct K_mhd_elec {
+  DevParams g; const double* U; const double* Q; double* E;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_elec_cell(g, U, Q, E, idx); }
+};
+struct K_mhd_trace3d {
+  DevParams g; const double* U; const double* Q; const double* E; double* T; double dtdx, dtdy, dtdz;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_trace3d_cell(g, U, Q, E, T, dtdx, dtdy, dtdz, idx); }
+};
+template <int MASK>
+struct K_mhd_flux3d {
+  DevParams g; const double* T; double* F; double* emf;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK>(g, T, F, emf, idx); }
+};
+struct K_shear_save_emf {
+  DevParams g; const double* emf; double* save;
+  RG_DEVFN void operator()(unsigned idx) const { shear_save_emf_cell(g, emf, save, idx); }
+};
+struct K_shear_remap {
+  DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx;
+  RG_DEVFN void operator()(unsigned idx) const { shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx); }
+};
+template <bool ROT>
+struct K_mhd_update3d {
+  DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
+  double dt, dtdx, dtdy, dtdz;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update3d_cell<ROT>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
+};
+
+// ---- boundaries -------------------------------------------------------------------------------------------------
+struct K_bc_face {
+  DevParams g; double* U; int dir, side, bct;
+  RG_DEVFN void operator()(unsigned idx) const { bc_face_cell(g, U, dir, side, bct, idx); }
+};
+struct K_jet {
+  DevParams g; JetParams jp; double* U;
+  RG_DEVFN void operator()(unsigned idx) const { jet_cell(g, jp, U, idx); }
+};
+struct K_shear_ghost {
+  DevParams g; ShearGhost sg; double* U;
+  RG_DEVFN void operator()(unsigned idx) const { shear_ghost_cell(g, sg, U, idx); }
+};
+
+}  // namespace rgpu_dev

@@ -1,0 +1,568 @@
+// rgpu_api.cpp -- implementation of the C ABI of include/rgpu.h: context, step driver, ghost fill, CFL scan.
+//
+// Compiled by hipcc (-x hip --offload-arch=gfx950 -ffp-contract=off).  All work of a context is issued on one
+// HIP stream in program order; the only host<->device traffic inside the path is the 8-byte result of the CFL
+// reduction (the reference copies <=192 partial maxima per step, MHDRunBase.cpp:103-128).
+#include "../../include/rgpu.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+
+#include "launchers.h"
+
+using namespace rgpu;
+using namespace rgpu_dev;
+
+namespace {
+const int kBlock = 256;      // streaming kernels
+const int kBlockHeavy = 128; // Riemann kernels (register heavy: smaller workgroups place more evenly)
+}
+
+struct rgpu_ctx {
+  rgpu_params p;
+  DevParams g;
+  rg_stream_t stream;
+  bool own_state;
+  double* U[2];
+  double *Q, *E, *T, *F, *emf, *shear_save, *shear_remap;
+  unsigned long long* d_red;
+  unsigned long long* h_red;
+  size_t ncell, scratch_bytes;
+  unsigned n32;
+  // instrumentation
+  bool timers_on;
+  double t_acc[RGPU_T_COUNT];
+  long t_calls[RGPU_T_COUNT];
+  rg_event_t ev0, ev1;
+  bool ev_ok;
+  std::string err;
+};
+
+namespace {
+
+int fail(rgpu_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+// ---- phase timer: events around one phase; resolved immediately (timers serialise the stream by design) ----
+struct Phase {
+  rgpu_ctx* c; int which;
+  Phase(rgpu_ctx* ctx, int w) : c(ctx), which(w) { if (c->timers_on && c->ev_ok) rg_event_record(c->ev0, c->stream); }
+  ~Phase() {
+    if (c->timers_on && c->ev_ok) {
+      rg_event_record(c->ev1, c->stream);
+      c->t_acc[which] += rg_event_elapsed_ms(c->ev0, c->ev1) * 1e-3;
+      c->t_calls[which] += 1;
+    }
+  }
+};
+
+int validate(const rgpu_params* p, std::string* why) {
+  if (!p) { *why = "params is NULL"; return RGPU_EINVAL; }
+  if (p->abi_version != RGPU_ABI_VERSION) { *why = "abi_version mismatch"; return RGPU_EINVAL; }
+  const bool three_d = p->nz_global != 1;
+  const int gw_needed = p->mhdEnabled ? 3 : 2;
+  if (p->ghostWidth < gw_needed || p->ghostWidth > 3) { *why = "ghostWidth must be 2 (hydro) or 3 (MHD)"; return RGPU_EINVAL; }
+  if (p->nx < p->ghostWidth || p->ny < p->ghostWidth || (three_d && p->nz < p->ghostWidth)) { *why = "domain thinner than the ghost width"; return RGPU_EINVAL; }
+  const int nv = p->mhdEnabled ? 8 : (three_d ? 5 : 4);
+  if (p->nbVar != nv) { *why = "nbVar inconsistent with MHD / dimension"; return RGPU_EINVAL; }
+  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2)) { *why = "slope_type 3 (positivity preserving) is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
+  if (p->mhdEnabled) {
+    if (!three_d && p->implementationVersion != 1) { *why = "2D MHD: only implementationVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }
+    if (!three_d && p->Omega0 > 0) { *why = "2D rotating frame is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
+    if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) { *why = "3D MHD: only implementationVersion 3/4 are implemented"; return RGPU_EUNSUPPORTED; }
+    if (p->magRiemannSolver != RGPU_MAG_HLLD) { *why = "magRiemannSolver: only hlld is implemented"; return RGPU_EUNSUPPORTED; }
+    if (p->shearingBoxEnabled && !three_d) { *why = "shearing box needs 3D"; return RGPU_EUNSUPPORTED; }
+  } else {
+    if (p->unsplitVersion != 1) { *why = "hydro: only unsplitVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }
+    if (p->riemannSolver != RGPU_RS_APPROX && p->riemannSolver != RGPU_RS_HLL && p->riemannSolver != RGPU_RS_HLLC) { *why = "hydro riemannSolver must be approx, hll or hllc"; return RGPU_EINVAL; }
+  }
+  for (int f = 0; f < 6; ++f) {
+    const int b = p->bc[f];
+    const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
+                    (b == RGPU_BC_SHEARINGBOX && f < 2);
+    if (!ok && (three_d || f < 4)) { *why = "unsupported boundary condition type"; return RGPU_EUNSUPPORTED; }
+  }
+  const double cells = (double)(p->nx + 2 * p->ghostWidth) * (p->ny + 2 * p->ghostWidth) * (three_d ? p->nz + 2 * p->ghostWidth : 1);
+  if (cells >= 4294967295.0) { *why = "more than 2^32 cells per device"; return RGPU_EUNSUPPORTED; }
+  return RGPU_OK;
+}
+
+void fill_dev_params(const rgpu_params& p, DevParams* g) {
+  std::memset(g, 0, sizeof(*g));
+  g->three_d = (p.nz_global != 1) ? 1 : 0;
+  g->gw = p.ghostWidth;
+  g->nx = p.nx; g->ny = p.ny; g->nz = p.nz;
+  g->isize = p.nx + 2 * p.ghostWidth;
+  g->jsize = p.ny + 2 * p.ghostWidth;
+  g->ksize = g->three_d ? p.nz + 2 * p.ghostWidth : 1;
+  g->nvar = p.nbVar;
+  g->mhd = p.mhdEnabled;
+  g->rot = (p.mhdEnabled && p.Omega0 > 0) ? 1 : 0;
+  g->shearbox = p.shearingBoxEnabled;
+  g->sj = (unsigned)g->isize;
+  g->sk = (unsigned)g->isize * (unsigned)g->jsize;
+  g->ncell = (unsigned long long)g->isize * g->jsize * g->ksize;
+  g->dx = p.dx; g->dy = p.dy; g->dz = p.dz; g->xMin = p.xMin; g->deltaX = p.xMax - p.xMin;
+  g->gamma0 = p.gamma0; g->cIso = p.cIso; g->smallr = p.smallr; g->smallc = p.smallc; g->smallp = p.smallp;
+  g->smallpp = p.smallpp; g->gamma6 = p.gamma6; g->Omega0 = p.Omega0;
+  g->slope_type = p.slope_type;
+  g->mag_slope_type = std::fmin(p.slope_type, 2.0);
+  g->niter_riemann = p.niter_riemann; g->riemannSolver = p.riemannSolver; g->magRiemannSolver = p.magRiemannSolver;
+}
+
+// number of scratch doubles per cell for each array of the active solver family
+struct ScratchPlan { int q, e, t, f, emf; };
+ScratchPlan plan_for(const rgpu_params& p) {
+  const bool three_d = p.nz_global != 1;
+  ScratchPlan s;
+  if (!p.mhdEnabled) {
+    const int nv = three_d ? 5 : 4, nd = three_d ? 3 : 2;
+    s.q = nv; s.e = 0; s.t = nv * (1 + nd); s.f = nv * nd; s.emf = 0;
+  } else if (!three_d) {
+    s.q = 8; s.e = 0; s.t = T2_COUNT; s.f = F2_COUNT; s.emf = 0;
+  } else {
+    s.q = 8; s.e = 3; s.t = T_COUNT; s.f = F_COUNT; s.emf = 3;
+  }
+  return s;
+}
+
+int alloc_zero(rgpu_ctx* c, double** ptr, size_t doubles) {
+  *ptr = 0;
+  if (doubles == 0) return 0;
+  if (rg_malloc((void**)ptr, doubles * sizeof(double))) return -1;
+  c->scratch_bytes += doubles * sizeof(double);
+  // zero once: cells outside a kernel's index range are never written but may be read by over-wide neighbours
+  return rg_memset_async(*ptr, 0, doubles * sizeof(double), c->stream);
+}
+
+int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_stream, bool external, rgpu_ctx** out) {
+  if (!out) return RGPU_EINVAL;
+  *out = 0;
+  std::string why;
+  const int vr = validate(p, &why);
+  rgpu_ctx* c = new (std::nothrow) rgpu_ctx();
+  if (!c) return RGPU_ENOMEM;
+  *out = c;  // returned even on failure so that rgpu_last_error can be read; caller destroys it
+  c->p = *p;
+  c->own_state = !external;
+  c->U[0] = c->U[1] = 0;
+  c->Q = c->E = c->T = c->F = c->emf = c->shear_save = c->shear_remap = 0;
+  c->d_red = 0; c->h_red = 0;
+  c->scratch_bytes = 0;
+  c->timers_on = false; c->ev_ok = false;
+  for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
+  c->stream = (rg_stream_t)0;
+  if (vr) return fail(c, vr, why);
+  if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
+  fill_dev_params(*p, &c->g);
+  c->ncell = (size_t)c->g.ncell;
+  c->n32 = (unsigned)c->ncell;
+  if (external) {
+    if (!dU || !dU2) return fail(c, RGPU_EINVAL, "external state pointers are NULL");
+    c->U[0] = dU; c->U[1] = dU2;
+    c->stream = rg_stream_from_handle(hip_stream);
+  } else {
+    const size_t n = c->ncell * (size_t)p->nbVar;
+    if (alloc_zero(c, &c->U[0], n) || alloc_zero(c, &c->U[1], n)) return fail(c, RGPU_ENOMEM, "device allocation of the state arrays failed");
+  }
+  const ScratchPlan sp = plan_for(*p);
+  if (alloc_zero(c, &c->Q, c->ncell * sp.q) || alloc_zero(c, &c->E, c->ncell * sp.e) || alloc_zero(c, &c->T, c->ncell * sp.t) ||
+      alloc_zero(c, &c->F, c->ncell * sp.f) || alloc_zero(c, &c->emf, c->ncell * sp.emf))
+    return fail(c, RGPU_ENOMEM, "device allocation of the scratch arrays failed");
+  if (c->g.shearbox) {
+    const size_t P = (size_t)c->g.jsize * c->g.ksize;
+    if (alloc_zero(c, &c->shear_save, 2 * P) || alloc_zero(c, &c->shear_remap, 2 * P))
+      return fail(c, RGPU_ENOMEM, "device allocation of the shear buffers failed");
+  }
+  if (rg_malloc((void**)&c->d_red, sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, sizeof(unsigned long long)))
+    return fail(c, RGPU_ENOMEM, "allocation of the reduction slot failed");
+  if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
+  if (rg_stream_sync(c->stream)) return fail(c, RGPU_EHIP, std::string("device error during creation: ") + rg_last_error_string());
+  return RGPU_OK;
+}
+
+// ---- boundaries -----------------------------------------------------------------------------------------------
+int launch_face(rgpu_ctx* c, double* U, int dir, int side) {
+  const int bct = c->p.bc[2 * dir + side];
+  if (bct != RGPU_BC_DIRICHLET && bct != RGPU_BC_NEUMANN && bct != RGPU_BC_PERIODIC) return 0;  // shear / copy: untouched
+  const DevParams& g = c->g;
+  unsigned n;
+  if (dir == 0) n = (unsigned)g.gw * g.jsize * g.ksize;
+  else if (dir == 1) n = (unsigned)g.isize * g.gw * g.ksize;
+  else n = (unsigned)g.isize * g.jsize * g.gw;
+  K_bc_face k = {g, U, dir, side, bct};
+  return rg_launch<kBlock>(c->stream, n, k);
+}
+
+int launch_jet(rgpu_ctx* c, double* U) {
+  const rgpu_params& p = c->p;
+  if (!p.enableJet || p.ijet <= 0) return 0;
+  JetParams jp;
+  jp.ijet = p.ijet; jp.offsetJet = p.offsetJet; jp.djet = p.djet;
+  jp.ejet = p.pjet / (p.gamma0 - 1.) + 0.5 * p.djet * p.ujet * p.ujet;   // HydroRunBase.cpp:2383
+  jp.mjet = p.djet * p.ujet;
+  const unsigned n = c->g.three_d ? (unsigned)p.ijet * p.ijet * c->g.gw : (unsigned)p.ijet * c->g.gw;
+  K_jet k = {c->g, jp, U};
+  return rg_launch<kBlock>(c->stream, n, k);
+}
+
+int do_make_boundaries(rgpu_ctx* c, double* U, int idim) {
+  const int dir = idim - 1;
+  if (dir < 0 || dir > 2) return -1;
+  if (!c->g.three_d && dir == 2) return 0;
+  if (launch_face(c, U, dir, 0) || launch_face(c, U, dir, 1)) return -1;
+  // the jet is re-imposed after the Y fill in 2D and after the Z fill in 3D (HydroRunBase.cpp:2286-2312)
+  if (c->p.enableJet && ((!c->g.three_d && dir == 1) || (c->g.three_d && dir == 2 && c->p.bc[4] != RGPU_BC_COPY)))
+    return launch_jet(c, U);
+  return 0;
+}
+
+int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt) {
+  const rgpu_params& p = c->p;
+  // MHDRunGodunov.cpp:3554-3557
+  double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt);
+  deltay = std::fmod(deltay, (p.dy * p.ny));
+  ShearGhost sg;
+  sg.jplus = (int)(deltay / p.dy);
+  const double epsi = std::fmod(deltay, p.dy);
+  sg.eps_min = 1.0 - epsi / p.dy;
+  sg.eps_max = epsi / p.dy;
+  const unsigned n = (unsigned)c->g.gw * c->g.ny * c->g.ksize;
+  K_shear_ghost k = {c->g, sg, U};
+  return rg_launch<kBlock>(c->stream, n, k);
+}
+
+// ---- the step -------------------------------------------------------------------------------------------------
+int step_pre(rgpu_ctx* c, int nStep) {
+  if (c->g.rot) return 0;
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  double* in = c->U[nStep % 2];
+  if (do_make_boundaries(c, in, RGPU_XDIR) || do_make_boundaries(c, in, RGPU_YDIR)) return -1;
+  if (c->g.three_d && do_make_boundaries(c, in, RGPU_ZDIR)) return -1;
+  return 0;
+}
+
+int step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  if (!c->g.rot) return 0;
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  double* out = c->U[(nStep + 1) % 2];
+  if (c->g.shearbox && c->g.three_d) {
+    if (do_make_boundaries(c, out, RGPU_YDIR)) return -1;
+    return do_make_boundaries_shear(c, out, totalTime, dt);
+  }
+  if (do_make_boundaries(c, out, RGPU_XDIR) || do_make_boundaries(c, out, RGPU_YDIR)) return -1;
+  return 0;
+}
+
+int step_post_b(rgpu_ctx* c, int nStep) {
+  if (!c->g.rot) return 0;
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  double* out = c->U[(nStep + 1) % 2];
+  if (c->g.three_d && do_make_boundaries(c, out, RGPU_ZDIR)) return -1;
+  if (c->g.shearbox && c->g.three_d) return do_make_boundaries(c, out, RGPU_YDIR);
+  return 0;
+}
+
+template <int ND, int NV>
+int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt) {
+  const DevParams& g = c->g;
+  const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
+  { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_FLUX); K_hydro_flux<ND, NV> k = {g, c->T, c->F}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_UPDATE); K_hydro_update<ND, NV> k = {g, in, out, c->F, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  return 0;
+}
+
+int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
+  const DevParams& g = c->g;
+  const double dtdx = dt / g.dx, dtdy = dt / g.dy;
+  { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_FLUX); K_mhd_flux2d k = {g, c->T, c->F}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_UPDATE); K_mhd_update2d k = {g, in, out, c->F, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  return 0;
+}
+
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime) {
+  const DevParams& g = c->g;
+  const rgpu_params& p = c->p;
+  const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
+  RotCoef rc = {0.0, 1.0, 1.0, 0.0};
+  if (g.rot) {  // MHDRunGodunov.cpp:2047-2053
+    double lambda = p.Omega0 * dt;
+    lambda = 0.25 * lambda * lambda;
+    rc.lambda = lambda;
+    rc.ratio = (1.0 - lambda) / (1.0 + lambda);
+    rc.alpha1 = 1.0 / (1.0 + lambda);
+    rc.alpha2 = p.Omega0 * dt / (1.0 + lambda);
+  }
+  { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_ELEC); K_mhd_elec k = {g, in, c->Q, c->E}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_TRACE); K_mhd_trace3d k = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  {
+    Phase ph(c, RGPU_T_FLUX);
+    K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z> k = {g, c->T, c->F, c->emf};
+    if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1;
+  }
+  {
+    Phase ph(c, RGPU_T_EMF);
+    K_mhd_flux3d<DO_EMF_X> kx = {g, c->T, c->F, c->emf};
+    K_mhd_flux3d<DO_EMF_Y> ky = {g, c->T, c->F, c->emf};
+    K_mhd_flux3d<DO_EMF_Z> kz = {g, c->T, c->F, c->emf};
+    if (rg_launch<kBlockHeavy>(c->stream, c->n32, kx) || rg_launch<kBlockHeavy>(c->stream, c->n32, ky) ||
+        rg_launch<kBlockHeavy>(c->stream, c->n32, kz))
+      return -1;
+  }
+  if (g.rot && g.shearbox) {
+    Phase ph(c, RGPU_T_SHEAR);
+    // MHDRunGodunov.cpp:3213-3216 (flux / emf remap uses totalTime + dt/2)
+    double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt / 2);
+    deltay = std::fmod(deltay, (p.dy * p.ny));
+    ShearRemap sr;
+    sr.jplus = (int)(deltay / p.dy);
+    const double epsi = std::fmod(deltay, p.dy);
+    sr.eps_min = 1.0 - epsi / p.dy;
+    sr.eps_max = epsi / p.dy;
+    const unsigned P = (unsigned)g.jsize * g.ksize;
+    K_shear_save_emf ks = {g, c->emf, c->shear_save};
+    K_shear_remap kr = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
+    if (rg_launch<kBlock>(c->stream, P, ks) || rg_launch<kBlock>(c->stream, P, kr)) return -1;
+  }
+  {
+    Phase ph(c, RGPU_T_UPDATE);
+    if (g.rot) {
+      K_mhd_update3d<true> k = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+      if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
+    } else {
+      K_mhd_update3d<false> k = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+      if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
+    }
+  }
+  return 0;
+}
+
+int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  const double* in = c->U[nStep % 2];
+  double* out = c->U[(nStep + 1) % 2];
+  if (!c->p.mhdEnabled) return c->g.three_d ? hydro_core<3, 5>(c, in, out, dt) : hydro_core<2, 4>(c, in, out, dt);
+  if (!c->g.three_d) return mhd2d_core(c, in, out, dt);
+  return mhd3d_core(c, in, out, dt, totalTime);
+}
+
+int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
+  Phase ph(c, RGPU_T_DT);
+  const double* U = c->U[parity & 1];
+  int rc;
+  if (c->p.mhdEnabled) { K_mhd_invdt k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
+  else if (c->g.three_d) { K_hydro_invdt<5> k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
+  else { K_hydro_invdt<4> k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
+  if (rc) return -1;
+  if (rg_copy_d2h(c->h_red, c->d_red, sizeof(unsigned long long), c->stream) || rg_stream_sync(c->stream)) return -1;
+  double v;
+  std::memcpy(&v, c->h_red, sizeof(double));
+  // seeds and jet term of the CPU paths (HydroRunBase.cpp:382,420-422 ; MHDRunBase.cpp:144,184-186,228-231)
+  const rgpu_params& p = c->p;
+  if (p.mhdEnabled) v = std::fmax(v, p.smallc / std::fmin(p.dx, p.dy));
+  if (p.enableJet) v = std::fmax(v, (p.ujet + p.cjet) / p.dx);
+  *invDt = v;
+  return 0;
+}
+
+#define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; } while (0)
+#define RG_HIPFAIL(c, what) fail((c), RGPU_EHIP, std::string(what) + ": " + rg_last_error_string())
+
+}  // namespace
+
+// =================================================================================================================
+extern "C" {
+
+int rgpu_create(const rgpu_params* p, rgpu_ctx** out) { return create_common(p, 0, 0, 0, false, out); }
+
+int rgpu_create_external(const rgpu_params* p, double* dU, double* dU2, void* hip_stream, rgpu_ctx** out) {
+  return create_common(p, dU, dU2, hip_stream, true, out);
+}
+
+void rgpu_destroy(rgpu_ctx* c) {
+  if (!c) return;
+  if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
+  rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap);
+  rg_free(c->d_red); rg_host_free(c->h_red);
+  if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
+  delete c;
+}
+
+size_t rgpu_device_bytes(const rgpu_params* p) {
+  if (!p) return 0;
+  const bool three_d = p->nz_global != 1;
+  const size_t isize = p->nx + 2 * p->ghostWidth, jsize = p->ny + 2 * p->ghostWidth, ksize = three_d ? p->nz + 2 * p->ghostWidth : 1;
+  const size_t ncell = isize * jsize * ksize;
+  const ScratchPlan sp = plan_for(*p);
+  size_t doubles = ncell * (size_t)(2 * p->nbVar + sp.q + sp.e + sp.t + sp.f + sp.emf);
+  if (p->shearingBoxEnabled) doubles += 4 * jsize * ksize;
+  return doubles * sizeof(double);
+}
+
+const char* rgpu_last_error(rgpu_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
+  RG_CHECK_CTX(c);
+  if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "upload: null pointer / context without state");
+  const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
+  if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");
+  if (both && rg_copy_d2d(c->U[1], c->U[0], bytes, c->stream)) return RG_HIPFAIL(c, "upload (copy to U2)");
+  if (rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "upload sync");
+  return RGPU_OK;
+}
+
+int rgpu_download(rgpu_ctx* c, double* hU, int parity) {
+  RG_CHECK_CTX(c);
+  if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "download: null pointer / context without state");
+  const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
+  if (rg_copy_d2h(hU, c->U[parity & 1], bytes, c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "download");
+  return RGPU_OK;
+}
+
+double* rgpu_device_state(rgpu_ctx* c, int parity) { return c ? c->U[parity & 1] : 0; }
+
+int rgpu_make_boundaries(rgpu_ctx* c, int parity, int idim) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (idim < RGPU_XDIR || idim > RGPU_ZDIR) return fail(c, RGPU_EINVAL, "idim must be 1,2,3");
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  if (do_make_boundaries(c, c->U[parity & 1], idim)) return RG_HIPFAIL(c, "make_boundaries");
+  return RGPU_OK;
+}
+
+int rgpu_make_boundaries_shear(rgpu_ctx* c, int parity, double totalTime, double dt) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (!(c->g.shearbox && c->g.three_d)) return fail(c, RGPU_EINVAL, "shearing box is not enabled");
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  if (do_make_boundaries_shear(c, c->U[parity & 1], totalTime, dt)) return RG_HIPFAIL(c, "make_boundaries_shear");
+  return RGPU_OK;
+}
+
+int rgpu_make_all_boundaries(rgpu_ctx* c, int parity, double totalTime, double dt) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  double* U = c->U[parity & 1];
+  int rc;
+  if (c->g.shearbox && c->g.three_d) {
+    rc = do_make_boundaries(c, U, RGPU_YDIR) || do_make_boundaries_shear(c, U, totalTime, dt) ||
+         do_make_boundaries(c, U, RGPU_ZDIR) || do_make_boundaries(c, U, RGPU_YDIR);
+  } else {
+    rc = do_make_boundaries(c, U, RGPU_XDIR) || do_make_boundaries(c, U, RGPU_YDIR) ||
+         (c->g.three_d && do_make_boundaries(c, U, RGPU_ZDIR));
+  }
+  if (rc) return RG_HIPFAIL(c, "make_all_boundaries");
+  return RGPU_OK;
+}
+
+int rgpu_compute_inv_dt(rgpu_ctx* c, int parity, double* invDt) {
+  RG_CHECK_CTX(c);
+  if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "compute_inv_dt: null pointer / context without state");
+  if (inv_dt(c, parity, invDt)) return RG_HIPFAIL(c, "compute_inv_dt");
+  return RGPU_OK;
+}
+
+double rgpu_compute_dt(rgpu_ctx* c, int useU) {
+  double v = 0;
+  if (!c || rgpu_compute_inv_dt(c, useU, &v) != RGPU_OK) return std::numeric_limits<double>::quiet_NaN();
+  return c->p.cfl / v;
+}
+
+int rgpu_step_pre(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  (void)dt; (void)totalTime;
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_pre(c, nStep)) return RG_HIPFAIL(c, "step_pre");
+  return RGPU_OK;
+}
+int rgpu_step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_core(c, nStep, dt, totalTime)) return RG_HIPFAIL(c, "step_core");
+  return RGPU_OK;
+}
+int rgpu_step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_post_a(c, nStep, dt, totalTime)) return RG_HIPFAIL(c, "step_post_a");
+  return RGPU_OK;
+}
+int rgpu_step_post_b(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  (void)dt; (void)totalTime;
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_post_b(c, nStep)) return RG_HIPFAIL(c, "step_post_b");
+  return RGPU_OK;
+}
+
+int rgpu_godunov_unsplit(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "slab contexts must use rgpu_step_pre/core/post_a/post_b around the halo exchange");
+  if (step_pre(c, nStep) || step_core(c, nStep, dt, totalTime) || step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
+    return RG_HIPFAIL(c, "godunov_unsplit");
+  return RGPU_OK;
+}
+
+int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt) {
+  RG_CHECK_CTX(c);
+  if (!nStep || !t || !dt) return fail(c, RGPU_EINVAL, "one_step_integration: null pointer");
+  const double d = rgpu_compute_dt(c, *nStep % 2);
+  if (!(d == d)) return RGPU_EHIP;
+  *dt = d;
+  const int rc = rgpu_godunov_unsplit(c, *nStep, d, *t);
+  if (rc) return rc;
+  *nStep += 1;
+  *t += d;
+  return RGPU_OK;
+}
+
+int rgpu_synchronize(rgpu_ctx* c) {
+  RG_CHECK_CTX(c);
+  if (rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "synchronize");
+  return RGPU_OK;
+}
+
+int rgpu_enable_timers(rgpu_ctx* c, int enable) { RG_CHECK_CTX(c); c->timers_on = enable != 0; return RGPU_OK; }
+int rgpu_get_timers(rgpu_ctx* c, double* secs, int n) {
+  RG_CHECK_CTX(c);
+  if (!secs) return RGPU_EINVAL;
+  for (int i = 0; i < n && i < RGPU_T_COUNT; ++i) secs[i] = c->t_acc[i];
+  return RGPU_OK;
+}
+int rgpu_reset_timers(rgpu_ctx* c) {
+  RG_CHECK_CTX(c);
+  for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
+  return RGPU_OK;
+}
+const char* rgpu_timer_name(int which) {
+  static const char* names[RGPU_T_COUNT] = {"boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt"};
+  return (which >= 0 && which < RGPU_T_COUNT) ? names[which] : "?";
+}
+
+int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, long* launches) {
+  RG_CHECK_CTX(c);
+  int best = -1;
+  for (int i = 0; i < RGPU_T_COUNT; ++i)
+    if (c->t_calls[i] > 0 && (best < 0 || c->t_acc[i] > c->t_acc[best])) best = i;
+  if (best < 0) return fail(c, RGPU_EINVAL, "no timed phase yet: call rgpu_enable_timers(ctx,1) and run steps");
+  if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s", rgpu_timer_name(best));
+  if (avg_ms) *avg_ms = c->t_acc[best] * 1e3 / (double)c->t_calls[best];
+  if (launches) *launches = c->t_calls[best];
+  return RGPU_OK;
+}
+
+const char* rgpu_backend_name(void) { return RG_BACKEND_NAME; }
+
+}  // extern "C"

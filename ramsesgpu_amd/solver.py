@@ -1,0 +1,214 @@
+"""Python mirror of the reference's run-class interface on top of the C ABI (include/rgpu.h).
+
+`Solver` keeps the reference's method names and argument meaning for the path in scope
+(HydroRunBase / MHDRunBase / *RunGodunov): make_all_boundaries, compute_dt(useU), godunov_unsplit(nStep, dt),
+oneStepIntegration, copyGpuToCpu / getDataHost.  No numerics live here: every call goes to librgpu.so, which
+fails loudly (RGPU_ENODEVICE) when there is no GPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import RgpuParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    if os.environ.get("RGPU_LIB"):
+        return os.environ["RGPU_LIB"]
+    """in-tree location of the product library (built by __graft_entry__.build / ramsesgpu_amd/build.py)"""
+    return os.path.join(_HERE, "librgpu.so")
+
+
+class RgpuError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded C-ABI library (product: librgpu.so)."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise RgpuError("%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        _capi.declare_host_api(self.lib)
+        _capi.declare_device_api(self.lib)
+
+    @property
+    def backend(self):
+        return self.lib.rgpu_backend_name().decode()
+
+    # ---- host side: parameter file and initial condition ------------------------------------------------------
+    def params_from_ini(self, ini_path, overrides="", slab=None):
+        p = RgpuParams()
+        err = C.create_string_buffer(512)
+        ov = overrides or ""
+        if slab is not None:
+            ov = (ov + ";" if ov else "") + "slab.rank=%d;slab.count=%d" % slab
+        rc = self.lib.rgpuh_params_from_ini(ini_path.encode(), ov.encode(), C.byref(p), err, 512)
+        if rc:
+            raise RgpuError("params_from_ini(%s): %s" % (ini_path, err.value.decode()))
+        return p
+
+    def run_settings(self, ini_path, overrides=""):
+        n, t, o = C.c_int(), C.c_double(), C.c_int()
+        err = C.create_string_buffer(512)
+        rc = self.lib.rgpuh_run_settings(ini_path.encode(), (overrides or "").encode(), C.byref(n), C.byref(t), C.byref(o), err, 512)
+        if rc:
+            raise RgpuError(err.value.decode())
+        return {"nStepmax": n.value, "tEnd": t.value, "nOutput": o.value}
+
+    def init_condition(self, ini_path, overrides, params):
+        U = np.zeros(params.shape, dtype=np.float64)
+        err = C.create_string_buffer(512)
+        rc = self.lib.rgpuh_init_condition(ini_path.encode(), (overrides or "").encode(), C.byref(params), U.ctypes.data, err, 512)
+        if rc:
+            raise RgpuError("init_condition: %s" % err.value.decode())
+        return U
+
+
+_default = None
+
+
+def load_library(path=None):
+    global _default
+    if path is None:
+        if _default is None:
+            _default = Library(lib_path())
+        return _default
+    return Library(path)
+
+
+class Solver:
+    """One run object == one rgpu_ctx (one GPU / one z-slab)."""
+
+    def __init__(self, params, library=None, external_state=None, stream=0):
+        self.L = library or load_library()
+        self.lib = self.L.lib
+        self.p = params
+        self.ctx = C.c_void_p()
+        if external_state is None:
+            rc = self.lib.rgpu_create(C.byref(params), C.byref(self.ctx))
+        else:
+            dU, dU2 = external_state
+            rc = self.lib.rgpu_create_external(C.byref(params), C.c_void_p(dU), C.c_void_p(dU2), C.c_void_p(stream), C.byref(self.ctx))
+        if rc:
+            msg = self.lib.rgpu_last_error(self.ctx).decode() if self.ctx else "?"
+            self.close()
+            raise RgpuError("rgpu_create failed (%d): %s" % (rc, msg))
+        self.nStep = 0
+        self.totalTime = 0.0
+        self.dt = 0.0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.rgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise RgpuError("%s failed (%d): %s" % (what, rc, self.lib.rgpu_last_error(self.ctx).decode()))
+
+    # ---- reference interface ----------------------------------------------------------------------------------
+    def upload(self, hU, both=True):
+        hU = np.ascontiguousarray(hU, dtype=np.float64)
+        assert hU.shape == tuple(self.p.shape), (hU.shape, self.p.shape)
+        self._chk(self.lib.rgpu_upload(self.ctx, hU.ctypes.data, int(both)), "upload")
+
+    def getDataHost(self, nStep=None):
+        """copyGpuToCpu(nStep) + getDataHost(nStep)"""
+        parity = (self.nStep if nStep is None else nStep) % 2
+        out = np.empty(self.p.shape, dtype=np.float64)
+        self._chk(self.lib.rgpu_download(self.ctx, out.ctypes.data, parity), "download")
+        return out
+
+    def make_boundaries(self, parity, idim):
+        self._chk(self.lib.rgpu_make_boundaries(self.ctx, parity, idim), "make_boundaries")
+
+    def make_all_boundaries(self, parity=0, totalTime=0.0, dt=0.0):
+        self._chk(self.lib.rgpu_make_all_boundaries(self.ctx, parity, totalTime, dt), "make_all_boundaries")
+
+    def compute_inv_dt(self, useU=0):
+        v = C.c_double()
+        self._chk(self.lib.rgpu_compute_inv_dt(self.ctx, useU, C.byref(v)), "compute_inv_dt")
+        return v.value
+
+    def compute_dt(self, useU=0):
+        d = self.lib.rgpu_compute_dt(self.ctx, useU)
+        if d != d:
+            raise RgpuError("compute_dt: " + self.lib.rgpu_last_error(self.ctx).decode())
+        return d
+
+    def godunov_unsplit(self, nStep, dt, totalTime=None):
+        t = self.totalTime if totalTime is None else totalTime
+        self._chk(self.lib.rgpu_godunov_unsplit(self.ctx, nStep, dt, t), "godunov_unsplit")
+
+    def oneStepIntegration(self):
+        n, t, d = C.c_int(self.nStep), C.c_double(self.totalTime), C.c_double(self.dt)
+        self._chk(self.lib.rgpu_one_step_integration(self.ctx, C.byref(n), C.byref(t), C.byref(d)), "oneStepIntegration")
+        self.nStep, self.totalTime, self.dt = n.value, t.value, d.value
+        return self.dt
+
+    def start(self, hU, nStepmax, tEnd=float("inf")):
+        """init part + time loop of start() (MHDRunGodunov.cpp:3801-3989) without outputs; returns the dt list"""
+        self.upload(hU, both=False)
+        self.nStep, self.totalTime = 0, 0.0
+        self.make_all_boundaries(0, 0.0, 0.0)
+        # h_U.copyTo(h_U2)
+        self.upload(self.getDataHost(0), both=True)
+        dts = []
+        while self.totalTime < tEnd and self.nStep < nStepmax:
+            dts.append(self.oneStepIntegration())
+        return dts
+
+    # ---- pieces used by the slab driver -------------------------------------------------------------------------
+    def step_pre(self, nStep, dt, t):
+        self._chk(self.lib.rgpu_step_pre(self.ctx, nStep, dt, t), "step_pre")
+
+    def step_core(self, nStep, dt, t):
+        self._chk(self.lib.rgpu_step_core(self.ctx, nStep, dt, t), "step_core")
+
+    def step_post_a(self, nStep, dt, t):
+        self._chk(self.lib.rgpu_step_post_a(self.ctx, nStep, dt, t), "step_post_a")
+
+    def step_post_b(self, nStep, dt, t):
+        self._chk(self.lib.rgpu_step_post_b(self.ctx, nStep, dt, t), "step_post_b")
+
+    def synchronize(self):
+        self._chk(self.lib.rgpu_synchronize(self.ctx), "synchronize")
+
+    # ---- instrumentation ----------------------------------------------------------------------------------------
+    def enable_timers(self, on=True):
+        self._chk(self.lib.rgpu_enable_timers(self.ctx, int(on)), "enable_timers")
+
+    def reset_timers(self):
+        self._chk(self.lib.rgpu_reset_timers(self.ctx), "reset_timers")
+
+    def timers(self):
+        a = (C.c_double * len(_capi.T_NAMES))()
+        self._chk(self.lib.rgpu_get_timers(self.ctx, a, len(_capi.T_NAMES)), "get_timers")
+        return dict(zip(_capi.T_NAMES, list(a)))
+
+    def dominant_kernel(self):
+        name = C.create_string_buffer(64)
+        ms, n = C.c_double(), C.c_long()
+        self._chk(self.lib.rgpu_dominant_kernel(self.ctx, name, 64, C.byref(ms), C.byref(n)), "dominant_kernel")
+        return name.value.decode(), ms.value, n.value
+
+
+def interior(U, p):
+    """strip the ghost cells of a [nvar][k][j][i] array"""
+    gw = p.ghostWidth
+    if p.three_d:
+        return U[:, gw:-gw, gw:-gw, gw:-gw]
+    return U[:, :, gw:-gw, gw:-gw]

@@ -1,0 +1,56 @@
+// rg_backend.h (TEST-ONLY host emulation) -- NOT part of the product.
+//
+// tests/ compile the per-cell kernel bodies of ramsesgpu_amd/csrc/kernels_*.h and the step driver against THIS
+// header instead of ramsesgpu_amd/csrc/hip/rg_backend.h, with g++, so that the device logic (index ranges,
+// gather order, compact-state reconstruction) can be unit-tested against the oracle on machines without a GPU.
+// The resulting tests/_build/librgpu_emu.so is only ever loaded by tests marked "not gpu"; the shipped
+// librgpu.so contains the HIP backend only and fails with RGPU_ENODEVICE when no GPU is present.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#define RG_DEVFN inline
+#define RG_BACKEND_NAME "host-emulation(test-only)"
+
+namespace rgpu_dev {
+using std::signbit;
+}
+
+namespace rgpu {
+
+typedef int rg_stream_t;
+typedef double rg_event_t;
+
+template <int BLOCK, class K>
+inline int rg_launch(rg_stream_t, unsigned n, const K& k) {
+  for (unsigned idx = 0; idx < n; ++idx) k(idx);
+  return 0;
+}
+template <class K>
+inline int rg_reduce_max(rg_stream_t, unsigned n, const K& k, unsigned long long* out) {
+  double v = 0.0;
+  for (unsigned idx = 0; idx < n; ++idx) v = std::fmax(v, k(idx));
+  std::memcpy(out, &v, sizeof(double));
+  return 0;
+}
+inline int rg_device_count() { return 1; }
+inline int rg_malloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? 0 : -1; }
+inline void rg_free(void* p) { std::free(p); }
+inline int rg_host_alloc(void** p, size_t bytes) { return rg_malloc(p, bytes); }
+inline void rg_host_free(void* p) { std::free(p); }
+inline int rg_memset_async(void* p, int v, size_t bytes, rg_stream_t) { std::memset(p, v, bytes); return 0; }
+inline int rg_copy_h2d(void* d, const void* h, size_t bytes, rg_stream_t) { std::memcpy(d, h, bytes); return 0; }
+inline int rg_copy_d2h(void* h, const void* d, size_t bytes, rg_stream_t) { std::memcpy(h, d, bytes); return 0; }
+inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t) { std::memcpy(d, s_, bytes); return 0; }
+inline rg_stream_t rg_stream_from_handle(void*) { return 0; }
+inline int rg_stream_sync(rg_stream_t) { return 0; }
+inline const char* rg_last_error_string() { return "emulation"; }
+inline int rg_event_create(rg_event_t* e) { *e = 0; return 0; }
+inline void rg_event_destroy(rg_event_t) {}
+inline int rg_event_record(rg_event_t, rg_stream_t) { return 0; }
+inline double rg_event_elapsed_ms(rg_event_t, rg_event_t) { return 0.0; }
+
+}  // namespace rgpu
