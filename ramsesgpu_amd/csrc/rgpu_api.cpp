@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -306,20 +307,10 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_ELEC); K_mhd_elec k = {g, in, c->Q, c->E}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace3d k = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  {
-    Phase ph(c, RGPU_T_FLUX);
-    K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z> k = {g, c->T, c->F, c->emf};
-    if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1;
-  }
-  {
-    Phase ph(c, RGPU_T_EMF);
-    K_mhd_flux3d<DO_EMF_X> kx = {g, c->T, c->F, c->emf};
-    K_mhd_flux3d<DO_EMF_Y> ky = {g, c->T, c->F, c->emf};
-    K_mhd_flux3d<DO_EMF_Z> kz = {g, c->T, c->F, c->emf};
-    if (rg_launch<kBlockHeavy>(c->stream, c->n32, kx) || rg_launch<kBlockHeavy>(c->stream, c->n32, ky) ||
-        rg_launch<kBlockHeavy>(c->stream, c->n32, kz))
-      return -1;
-  }
+  // Two launches: the three face Riemann problems, then the three edge (EMF) problems.  Both are fp64-ALU bound
+  // (divide / sqrt chains); fusing them into one launch was measured slower (256 VGPRs -> 2 waves per SIMD).
+  { Phase ph(c, RGPU_T_FLUX); K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z> k = {g, c->T, c->F, c->emf}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_EMF); K_mhd_flux3d<DO_EMF_X | DO_EMF_Y | DO_EMF_Z> k = {g, c->T, c->F, c->emf}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
   if (g.rot && g.shearbox) {
     Phase ph(c, RGPU_T_SHEAR);
     // MHDRunGodunov.cpp:3213-3216 (flux / emf remap uses totalTime + dt/2)

@@ -27,6 +27,21 @@ class RgpuError(RuntimeError):
     pass
 
 
+def _init_torch_hip_first():
+    """The PyTorch-ROCm wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's).  A process must end up with
+    ONE HIP runtime, or torch sees "No HIP GPUs" and torch-owned device pointers (slab driver) are foreign to our
+    kernels.  Whoever loads first wins, so let torch initialise HIP before librgpu.so is dlopen'ed; librgpu.so's
+    DT_NEEDED libamdhip64.so.7 then resolves to the already loaded runtime.  No-op without torch / without a GPU."""
+    if os.environ.get("RGPU_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 class Library:
     """A loaded C-ABI library (product: librgpu.so)."""
 
@@ -34,6 +49,7 @@ class Library:
         if not os.path.exists(path):
             raise RgpuError("%s not found: build it first (python -c 'import __graft_entry__ as g; g.build()')" % path)
         self.path = path
+        _init_torch_hip_first()
         self.lib = C.CDLL(path)
         _capi.declare_host_api(self.lib)
         _capi.declare_device_api(self.lib)

@@ -1,0 +1,58 @@
+"""ctypes wrapper of oracle/liboracle.so -- the CHECKER.  Imported by tests, smoke() and bench.py's cpu_baseline
+leg only; the product never touches it."""
+import ctypes as C
+
+import numpy as np
+
+from ramsesgpu_amd._capi import RgpuParams, c_double_p
+
+
+class Oracle:
+    def __init__(self, path):
+        self.lib = C.CDLL(path)
+        P = C.POINTER(RgpuParams)
+        self.lib.orc_make_boundaries.argtypes = [P, C.c_void_p, C.c_int]
+        self.lib.orc_make_all_boundaries.argtypes = [P, C.c_void_p, C.c_double, C.c_double]
+        self.lib.orc_make_boundaries_shear.argtypes = [P, C.c_void_p, C.c_double, C.c_double]
+        self.lib.orc_compute_inv_dt.restype = C.c_double
+        self.lib.orc_compute_inv_dt.argtypes = [P, C.c_void_p]
+        self.lib.orc_compute_dt.restype = C.c_double
+        self.lib.orc_compute_dt.argtypes = [P, C.c_void_p]
+        self.lib.orc_godunov_unsplit.argtypes = [P, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        self.lib.orc_run.argtypes = [P, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p, C.c_void_p]
+
+    @staticmethod
+    def _arr(U):
+        assert U.dtype == np.float64 and U.flags["C_CONTIGUOUS"]
+        return U.ctypes.data
+
+    def make_boundaries(self, p, U, idim):
+        assert self.lib.orc_make_boundaries(C.byref(p), self._arr(U), idim) == 0
+
+    def make_all_boundaries(self, p, U, totalTime=0.0, dt=0.0):
+        assert self.lib.orc_make_all_boundaries(C.byref(p), self._arr(U), totalTime, dt) == 0
+
+    def make_boundaries_shear(self, p, U, totalTime, dt):
+        assert self.lib.orc_make_boundaries_shear(C.byref(p), self._arr(U), totalTime, dt) == 0
+
+    def compute_dt(self, p, U):
+        return self.lib.orc_compute_dt(C.byref(p), self._arr(U))
+
+    def compute_inv_dt(self, p, U):
+        return self.lib.orc_compute_inv_dt(C.byref(p), self._arr(U))
+
+    def godunov_unsplit(self, p, Uold, dt, totalTime=0.0):
+        """returns Unew; Uold's ghosts are filled in place on the plain path, like the reference"""
+        Unew = np.empty_like(Uold)
+        rc = self.lib.orc_godunov_unsplit(C.byref(p), self._arr(Uold), self._arr(Unew), dt, totalTime)
+        assert rc == 0, rc
+        return Unew
+
+    def run(self, p, U0, nsteps, tEnd=1e300):
+        """start(): returns (U_final incl. ghosts, dts, t_final)"""
+        U = np.array(U0, dtype=np.float64, order="C", copy=True)
+        nd, tf = C.c_int(), C.c_double()
+        dts = np.zeros(max(nsteps, 1))
+        rc = self.lib.orc_run(C.byref(p), self._arr(U), nsteps, tEnd, C.byref(nd), C.byref(tf), dts.ctypes.data)
+        assert rc == 0, rc
+        return U, dts[:nd.value], tf.value

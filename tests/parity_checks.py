@@ -1,0 +1,190 @@
+"""Parity checks shared by the CPU emulation tests (tests/test_kernels_emu.py, not gpu) and the real thing
+(tests/test_gpu_parity.py, -m gpu).  Every check drives a library through the C ABI (ramsesgpu_amd.solver) and
+compares with the oracle (tests/oracle_api.py) or with fixtures produced by the reference binary.
+
+Bar (stated once, used everywhere): BIT-IDENTICAL doubles.  The path is fp64; north_star asks for
+"Orszag-Tang L2 error vs euler_cpu < 1e-12" -- `assert_same` reports that relative L2 too, and fails on the
+stricter bit-identity."""
+import numpy as np
+
+from conftest import golden_cases, ini, load_golden
+from ramsesgpu_amd import _capi
+from ramsesgpu_amd.solver import Solver, interior
+
+L2_TOLERANCE = 1e-12   # north_star's tolerance; the tests demand 0
+
+
+def rel_l2(a, b):
+    num = np.sqrt(((a - b) ** 2).sum())
+    den = np.sqrt((b ** 2).sum())
+    return num / den if den > 0 else num
+
+
+def assert_same(got, ref, what):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), "%s: non-finite values" % what
+    err = rel_l2(got, ref)
+    assert err < L2_TOLERANCE, "%s: relative L2 %.3e exceeds the stated tolerance %.0e" % (what, err, L2_TOLERANCE)
+    nbad = int((got != ref).sum())
+    assert nbad == 0, "%s: %d of %d doubles differ (max abs %.3e, rel L2 %.3e)" % (what, nbad, ref.size, np.abs(got - ref).max(), err)
+
+
+# ---- 1. fixtures produced by the reference binary --------------------------------------------------------------
+def check_golden_case(lib, name):
+    case = golden_cases()[name]
+    p = lib.params_from_ini(ini(case["base"]), case["overrides"])
+    g = load_golden(name)
+    for s in case["steps"]:
+        U0 = lib.init_condition(ini(case["base"]), case["overrides"], p)
+        sv = Solver(p, lib)
+        try:
+            sv.start(U0, s)
+            assert_same(interior(sv.getDataHost(), p), g["step_%d" % s], "%s step %d vs reference" % (name, s))
+            if s == max(case["steps"]) and np.isfinite(g["total_time"]):
+                assert abs(sv.totalTime - float(g["total_time"])) <= 1e-11 * max(1.0, abs(sv.totalTime))
+        finally:
+            sv.close()
+
+
+# ---- 2. against the oracle on the same seeded inputs ---------------------------------------------------------
+def random_state(p, seed, mach=1.5):
+    """a physically admissible but rough state (exercises limiter branches, supersonic Riemann fans, floors)"""
+    rng = np.random.RandomState(seed)
+    nv, ks, js, is_ = p.shape
+    rho = 0.5 + 1.5 * rng.rand(ks, js, is_)
+    vel = mach * (2 * rng.rand(3, ks, js, is_) - 1)
+    pres = 0.2 + rng.rand(ks, js, is_)
+    U = np.zeros(p.shape)
+    U[0] = rho
+    U[2] = rho * vel[0]
+    U[3] = rho * vel[1]
+    ekin = 0.5 * rho * (vel[0] ** 2 + vel[1] ** 2)
+    if nv >= 5:
+        if p.three_d or nv == 8:
+            U[4] = rho * vel[2]
+            ekin = ekin + 0.5 * rho * vel[2] ** 2
+    emag = 0.0
+    if nv == 8:
+        B = 0.7 * (2 * rng.rand(3, ks, js, is_) - 1)
+        U[5:8] = B
+        emag = 0.5 * (B ** 2).sum(0) * 1.5   # generous: cell-centred averages are smaller than face values
+    U[1] = pres / (p.gamma0 - 1.0) + ekin + emag
+    return U
+
+
+def check_boundaries(lib, oracle, base, ov, seed=1):
+    p = lib.params_from_ini(ini(base), ov)
+    U = random_state(p, seed)
+    sv = Solver(p, lib)
+    try:
+        for idim in (1, 2, 3) if p.three_d else (1, 2):
+            ref = U.copy()
+            oracle.make_boundaries(p, ref, idim)
+            sv.upload(U, both=False)
+            sv.make_boundaries(0, idim)
+            assert_same(sv.getDataHost(0), ref, "%s make_boundaries(dir %d)" % (base, idim))
+        ref = U.copy()
+        oracle.make_all_boundaries(p, ref, 3.7, 0.9)
+        sv.upload(U, both=False)
+        sv.make_all_boundaries(0, 3.7, 0.9)
+        assert_same(sv.getDataHost(0), ref, "%s make_all_boundaries" % base)
+    finally:
+        sv.close()
+
+
+def check_compute_dt(lib, oracle, base, ov, seed=2):
+    p = lib.params_from_ini(ini(base), ov)
+    U = random_state(p, seed)
+    sv = Solver(p, lib)
+    try:
+        sv.upload(U, both=True)
+        for useU in (0, 1):
+            got = sv.compute_dt(useU)
+            ref = oracle.compute_dt(p, U)
+            assert got == ref, "%s compute_dt(%d): %r != %r" % (base, useU, got, ref)
+    finally:
+        sv.close()
+
+
+def check_single_step_random(lib, oracle, base, ov, seed=3, mach=1.5, t0=2.0):
+    """one godunov_unsplit on a rough random state, interior (and evolved faces) compared"""
+    p = lib.params_from_ini(ini(base), ov)
+    U = random_state(p, seed, mach)
+    oracle.make_all_boundaries(p, U, t0, 0.0)
+    dt = 0.3 * oracle.compute_dt(p, U)
+    sv = Solver(p, lib)
+    try:
+        sv.upload(U, both=True)
+        sv.godunov_unsplit(0, dt, t0)
+        got = sv.getDataHost(1)
+        ref = oracle.godunov_unsplit(p, U.copy(), dt, t0)
+        assert_same(interior(got, p), interior(ref, p), "%s [%s] single step on random state" % (base, ov))
+        if p.mhdEnabled and p.Omega0 > 0:
+            # rotating path fills the ghosts of the OUTPUT at step end: the whole array is defined
+            assert_same(got, ref, "%s single rotating step incl. ghosts" % base)
+    finally:
+        sv.close()
+
+
+def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
+    p = lib.params_from_ini(ini(base), ov)
+    U0 = lib.init_condition(ini(base), ov, p)
+    ref, dts_ref, t_ref = oracle.run(p, U0, nsteps)
+    sv = Solver(p, lib)
+    try:
+        dts = sv.start(U0, nsteps)
+        assert np.array_equal(np.array(dts), dts_ref), "%s: dt sequences differ" % base
+        assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps))
+        assert sv.totalTime == t_ref
+    finally:
+        sv.close()
+    return p
+
+
+# configurations without a golden fixture: solver options / boundary types / shapes
+ORACLE_RUNS = [
+    # 2D MHD: other Riemann solvers, slope types, rectangular grids, smallest legal grid
+    ("orszag-tang", "mesh.nx=24;mesh.ny=16;hydro.riemannSolver=hll", 4),
+    ("orszag-tang", "mesh.nx=16;mesh.ny=24;hydro.riemannSolver=llf", 4),
+    ("orszag-tang", "mesh.nx=16;mesh.ny=16;hydro.slope_type=1.0", 4),
+    ("orszag-tang", "mesh.nx=16;mesh.ny=16;hydro.traceVersion=0", 3),          # slope_type forced to 0
+    ("orszag-tang", "mesh.nx=3;mesh.ny=3", 3),
+    ("orszag-tang", "mesh.nx=16;mesh.ny=16;hydro.riemannSolver=hllc", 2),       # MHD + hllc => zero hydro flux quirk
+    ("mhd_BrioWu", "mesh.nx=20;mesh.ny=12;BrioWu.direction=3", 5),
+    # 3D MHD plain: boundary types, solvers, isothermal
+    ("mhd_BrioWu", "mesh.nx=12;mesh.ny=10;mesh.nz=8;BrioWu.direction=0;MHD.implementationVersion=4", 4),
+    ("mhd_BrioWu", "mesh.nx=8;mesh.ny=12;mesh.nz=10;BrioWu.direction=2;MHD.implementationVersion=3;mesh.boundary_zmin=1;mesh.boundary_zmax=1", 4),
+    ("orszag-tang3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6;hydro.riemannSolver=hll", 3),
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8;hydro.cIso=0.9;hydro.slope_type=1.0", 3),
+    ("orszag-tang3d", "mesh.nx=3;mesh.ny=3;mesh.nz=3", 2),
+    # 3D MHD rotating: without shearing box (periodic x), other sizes
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=12;mesh.nz=6;MHD.omega0=0.05", 4),
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=10;MHD.omega0=0.01;MRI.amp=0.2", 6),
+    # hydro: 3D jet (inflow after the z fill), 2D solvers / slopes
+    ("jet2d_cpu", "mesh.nx=12;mesh.ny=12;mesh.nz=12;mesh.zmax=1;jet.ijet=3;jet.offsetJet=2", 6),
+    ("implode3d", "mesh.nx=12;mesh.ny=8;mesh.nz=1;hydro.riemannSolver=hll;hydro.slope_type=2.0", 5),
+    ("implode3d", "mesh.nx=10;mesh.ny=10;mesh.nz=10;hydro.traceVersion=0;hydro.riemannSolver=hllc", 4),
+    ("implode3d", "mesh.nx=2;mesh.ny=2;mesh.nz=2", 3),
+]
+
+RANDOM_STEPS = [
+    ("orszag-tang", "mesh.nx=20;mesh.ny=14", 1.5),
+    ("orszag-tang", "mesh.nx=14;mesh.ny=20;hydro.riemannSolver=hll", 3.0),
+    ("mhd_BrioWu", "mesh.nx=16;mesh.ny=16", 2.5),
+    ("orszag-tang3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6", 1.5),
+    ("orszag-tang3d", "mesh.nx=6;mesh.ny=10;mesh.nz=8;hydro.riemannSolver=llf", 3.0),
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=10;mesh.nz=6;hydro.cIso=0.8;MHD.omega0=0.3", 1.0),
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=10;mesh.nz=6;hydro.cIso=0.8;MHD.omega0=0.3;mesh.boundary_xmin=3;mesh.boundary_xmax=3", 1.0),
+    ("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6;hydro.riemannSolver=hllc", 3.0),
+    ("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6", 3.0),
+    ("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6;hydro.riemannSolver=hll;hydro.slope_type=2.0", 3.0),
+    ("implode3d", "mesh.nx=12;mesh.ny=10;mesh.nz=1;hydro.riemannSolver=hllc", 3.0),
+    ("jet2d_cpu", "mesh.nx=12;mesh.ny=16;jet.ijet=3;jet.offsetJet=2", 2.0),
+]
+
+BOUNDARY_CASES = [
+    ("orszag-tang", "mesh.nx=8;mesh.ny=6"), ("mhd_BrioWu", "mesh.nx=6;mesh.ny=8"), ("jet2d_cpu", "mesh.nx=10;mesh.ny=8;jet.ijet=3;jet.offsetJet=2"),
+    ("implode3d", "mesh.nx=6;mesh.ny=5;mesh.nz=4"), ("orszag-tang3d", "mesh.nx=6;mesh.ny=5;mesh.nz=4"),
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=4;MHD.omega0=0.4"),
+    ("mhd_BrioWu", "mesh.nx=4;mesh.ny=5;mesh.nz=6;mesh.boundary_xmin=1;mesh.boundary_ymax=1;mesh.boundary_zmin=3;mesh.boundary_zmax=3"),
+]

@@ -1,0 +1,52 @@
+"""Worker of tests/test_slab_gloo.py: one rank of a world_size-N z-slab run on CPU (gloo + TEST-ONLY emulation
+library).  Each rank steps its slab with halo exchange through ramsesgpu_amd.slab.SlabRun, then the slabs are
+gathered on rank 0 and compared, bit for bit, with the single-domain oracle run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle_api import Oracle  # noqa: E402
+from ramsesgpu_amd.slab import SlabRun  # noqa: E402
+from ramsesgpu_amd.solver import Library, interior  # noqa: E402
+
+
+def main():
+    base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+    ini = os.path.join(ROOT, "configs", base + ".ini")
+    run = SlabRun(ini, ov, library=lib, device="cpu")
+    run.init_simulation()
+    dts = [run.oneStepIntegration() for _ in range(nsteps)]
+    local = run.local_interior().contiguous()
+    parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, parts, dst=0)
+    ok = True
+    if rank == 0:
+        got = torch.cat(parts, dim=1).numpy()
+        oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+        p = lib.params_from_ini(ini, ov)
+        U0 = lib.init_condition(ini, ov, p)
+        ref, dts_ref, _ = oracle.run(p, U0, nsteps)
+        ref = interior(ref, p)
+        nbad = int((got != ref).sum())
+        ok = nbad == 0 and np.array_equal(np.array(dts), dts_ref)
+        with open(out, "w") as f:
+            f.write("OK\n" if ok else "MISMATCH %d doubles, dt equal=%s\n" % (nbad, np.array_equal(np.array(dts), dts_ref)))
+    dist.barrier()
+    run.close()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

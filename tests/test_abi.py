@@ -1,0 +1,77 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/rgpu.h declares;
+the device entry points refuse to run without a GPU (no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, ini
+from ramsesgpu_amd import _capi
+from ramsesgpu_amd.solver import RgpuError, Solver, lib_path
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "rgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgpuh?_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_python_binding_agree():
+    declared = header_functions()
+    assert declared, "no functions parsed from include/rgpu.h"
+    missing = [f for f in declared if f not in _capi.DECLARED_SYMBOLS]
+    assert not missing, "functions declared in rgpu.h but unknown to the binding: %s" % missing
+
+
+def test_library_exports_every_declared_symbol(product_lib):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", product_lib.path], universal_newlines=True)
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    for sym in header_functions():
+        assert sym in exported, "%s is declared in include/rgpu.h but not exported by %s" % (sym, product_lib.path)
+
+
+def test_params_struct_layout_matches_c(tmp_path):
+    """sizeof / offsets of rgpu_params as seen by a C compiler == the ctypes mirror"""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rgpu.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   'sizeof(rgpu_params),offsetof(rgpu_params,xMin),offsetof(rgpu_params,slope_type),'
+                   'offsetof(rgpu_params,djet),offsetof(rgpu_params,nz_global));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], universal_newlines=True).split()]
+    P = _capi.RgpuParams
+    assert got == [C.sizeof(P), P.xMin.offset, P.slope_type.offset, P.djet.offset, P.nz_global.offset]
+
+
+def test_product_is_the_hip_backend(product_lib):
+    assert product_lib.backend == "hip-gfx950"
+    assert os.path.samefile(product_lib.path, lib_path())
+
+
+def test_no_cpu_fallback_without_gpu(product_lib):
+    """On a machine without a GPU rgpu_create must fail with RGPU_ENODEVICE (-2), not compute on the host."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present: the failure path cannot be observed here")
+    except ImportError:
+        pass
+    p = product_lib.params_from_ini(ini("orszag-tang"), "mesh.nx=16;mesh.ny=16")
+    with pytest.raises(RgpuError) as e:
+        Solver(p, product_lib)
+    assert "(-2)" in str(e.value) and "no CPU fallback" in str(e.value)
+
+
+def test_rejects_out_of_scope_configurations(emu_lib):
+    L = emu_lib
+    for ov, frag in (("hydro.slope_type=3", "slope_type"), ("MHD.implementationVersion=0", "implementationVersion"),
+                     ("MHD.magRiemannSolver=hlla", "magRiemannSolver")):
+        p = L.params_from_ini(ini("orszag-tang"), "mesh.nx=16;mesh.ny=16;" + ov)
+        with pytest.raises(RgpuError) as e:
+            Solver(p, L)
+        assert frag in str(e.value)
+    for ov in ("hydro.nu=0.1", "gravity.static_field_x=1.0", "hydro.scheme=plmde"):
+        with pytest.raises(RgpuError):
+            L.params_from_ini(ini("orszag-tang"), ov)

@@ -1,0 +1,31 @@
+"""Kernel bodies + step driver of the product sources, executed through the TEST-ONLY host emulation of the launch
+layer (tests/emu/rg_backend.h, built into tests/_build/librgpu_emu.so), against the oracle and the reference's
+golden fixtures.  This is the CPU-side proof that index ranges, the compact traced state, the gather order of the
+update and the shearing-box remaps are right; tests/test_gpu_parity.py repeats the same checks on the HIP build."""
+import pytest
+
+import parity_checks as pc
+from conftest import golden_cases
+
+GOLDEN = sorted(golden_cases())
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden(name, emu_lib):
+    pc.check_golden_case(emu_lib, name)
+
+
+@pytest.mark.parametrize("base,ov,nsteps", pc.ORACLE_RUNS, ids=["%s[%s]" % (b, o) for b, o, _ in pc.ORACLE_RUNS])
+def test_run_vs_oracle(base, ov, nsteps, emu_lib, oracle):
+    pc.check_run_vs_oracle(emu_lib, oracle, base, ov, nsteps)
+
+
+@pytest.mark.parametrize("base,ov,mach", pc.RANDOM_STEPS, ids=["%s[%s]" % (b, o) for b, o, _ in pc.RANDOM_STEPS])
+def test_single_step_on_random_state(base, ov, mach, emu_lib, oracle):
+    pc.check_single_step_random(emu_lib, oracle, base, ov, mach=mach)
+
+
+@pytest.mark.parametrize("base,ov", pc.BOUNDARY_CASES, ids=["%s[%s]" % c for c in pc.BOUNDARY_CASES])
+def test_boundaries_and_dt(base, ov, emu_lib, oracle):
+    pc.check_boundaries(emu_lib, oracle, base, ov)
+    pc.check_compute_dt(emu_lib, oracle, base, ov)
