@@ -22,17 +22,33 @@ inline const char* rg_err_str(hipError_t e) { return hipGetErrorString(e); }
 // ---- flat per-cell kernels ---------------------------------------------------------------------------------
 // One thread per array element, x fastest: every SoA component load / store of a wave is one contiguous
 // 512-byte segment.  BLOCK is a multiple of the 64-lane wavefront.
-template <int BLOCK, class K>
-__global__ void __launch_bounds__(BLOCK) rg_kernel(unsigned n, K k) {
+// MINW = minimum waves per SIMD the register allocator must leave room for (__launch_bounds__ 2nd argument).
+template <int BLOCK, class K, int MINW = 1>
+__global__ void __launch_bounds__(BLOCK, MINW) rg_kernel(unsigned n, K k) {
   const unsigned idx = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
   if (idx < n) k(idx);
 }
 
-template <int BLOCK, class K>
+template <int BLOCK, int MINW = 1, class K>
 inline int rg_launch(rg_stream_t s, unsigned n, const K& k) {
   if (n == 0) return 0;
   const unsigned grid = (n + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((rg_kernel<BLOCK, K>), dim3(grid), dim3(BLOCK), 0, s, n, k);
+  hipLaunchKernelGGL((rg_kernel<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, n, k);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// same body over the flat index range [idx0, idx0 + n): used by the z-chunked, two-stream schedule
+template <int BLOCK, class K, int MINW = 1>
+__global__ void __launch_bounds__(BLOCK, MINW) rg_kernel_range(unsigned idx0, unsigned n, K k) {
+  const unsigned off = blockIdx.x * (unsigned)BLOCK + threadIdx.x;
+  if (off < n) k(idx0 + off);
+}
+
+template <int BLOCK, int MINW = 1, class K>
+inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k) {
+  if (n == 0) return 0;
+  const unsigned grid = (n + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL((rg_kernel_range<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, idx0, n, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -87,6 +103,20 @@ inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t s) { r
 inline rg_stream_t rg_stream_from_handle(void* h) { return (hipStream_t)h; }
 inline int rg_stream_sync(rg_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 inline const char* rg_last_error_string() { return hipGetErrorString(hipGetLastError()); }
+
+// second stream + ordering-only events for overlapping HBM-bound and VALU-bound kernels of one step
+// prio: -1 = lowest available priority, 0 = default, +1 = highest.  The VALU-bound Riemann kernels go to a LOW
+// priority queue: their long-lived waves otherwise take over the wave slots and starve the short HBM-bound kernels
+// that run next to them (measured: prim/elec 3-7x slower when co-scheduled at equal priority).
+inline int rg_stream_create(rg_stream_t* s, int prio = 0) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
+  const int p = prio < 0 ? least : prio > 0 ? greatest : 0;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess ? 0 : -1;
+}
+inline void rg_stream_destroy(rg_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+inline int rg_order_event_create(rg_event_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
+inline int rg_stream_wait_event(rg_stream_t s, rg_event_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : -1; }
 
 inline int rg_event_create(rg_event_t* e) { return hipEventCreate(e) == hipSuccess ? 0 : -1; }
 inline void rg_event_destroy(rg_event_t e) { (void)hipEventDestroy(e); }

@@ -24,9 +24,14 @@ namespace rgpu {
 typedef int rg_stream_t;
 typedef double rg_event_t;
 
-template <int BLOCK, class K>
+template <int BLOCK, int MINW = 1, class K>
 inline int rg_launch(rg_stream_t, unsigned n, const K& k) {
   for (unsigned idx = 0; idx < n; ++idx) k(idx);
+  return 0;
+}
+template <int BLOCK, int MINW = 1, class K>
+inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k) {
+  for (unsigned off = 0; off < n; ++off) k(idx0 + off);
   return 0;
 }
 template <class K>
@@ -48,6 +53,10 @@ inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t) { std
 inline rg_stream_t rg_stream_from_handle(void*) { return 0; }
 inline int rg_stream_sync(rg_stream_t) { return 0; }
 inline const char* rg_last_error_string() { return "emulation"; }
+inline int rg_stream_create(rg_stream_t* s, int = 0) { *s = 1; return 0; }
+inline void rg_stream_destroy(rg_stream_t) {}
+inline int rg_order_event_create(rg_event_t* e) { *e = 0; return 0; }
+inline int rg_stream_wait_event(rg_stream_t, rg_event_t) { return 0; }
 inline int rg_event_create(rg_event_t* e) { *e = 0; return 0; }
 inline void rg_event_destroy(rg_event_t) {}
 inline int rg_event_record(rg_event_t, rg_stream_t) { return 0; }
