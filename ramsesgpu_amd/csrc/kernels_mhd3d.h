@@ -102,29 +102,14 @@ RG_DEVFN void mhd_elec_cell(const DevParams& g, const double* __restrict__ U, co
 // ------------------------------------------------------------------------------------------------------------
 // slopes + MUSCL-Hancock / CTU trace -> compact state
 // ------------------------------------------------------------------------------------------------------------
-RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
-                               const double* __restrict__ E, double* __restrict__ T, double dtdx, double dtdy,
-                               double dtdz, unsigned idx) {
-  const IJK c = unflatten(g, idx);
-  const int lo = g.gw - 1;
-  if (c.i < lo || c.i > g.isize - g.gw || c.j < lo || c.j > g.jsize - g.gw || c.k < lo || c.k > g.ksize - g.gw) return;
+// Second half of the trace: from the cell state q, its limited full slopes in
+// x,y,z and the 9 edge electric fields E9 = {Ex(j,k),Ex(j,k+1),Ex(j+1,k), Ey(i,k),Ey(i,k+1),Ey(i+1,k),
+// Ez(i,j),Ez(i,j+1),Ez(i+1,j)} to the compact traced state.
+RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const double* __restrict__ U, double* __restrict__ T, const IJK c,
+                                 unsigned idx, const double* q, const double* dx_, const double* dy_, const double* dz_,
+                                 const double* E9, double dtdx, double dtdy, double dtdz) {
   const size_t N = g.ncell;
   const unsigned sj = g.sj, sk = g.sk;
-  const double st = g.slope_type;
-
-  // cell state and limited hydro slopes of the 8 primitive variables in the 3 directions
-  double q[8], dx_[8], dy_[8], dz_[8];
-#pragma unroll
-  for (int v = 0; v < 8; ++v) {
-    const double* Qv = Q + v * N;
-    q[v] = Qv[idx];
-    if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; dz_[v] = 0.0; }
-    else {
-      dx_[v] = tvd_slope(st, Qv[idx - 1], q[v], Qv[idx + 1]);
-      dy_[v] = tvd_slope(st, Qv[idx - sj], q[v], Qv[idx + sj]);
-      dz_[v] = tvd_slope(st, Qv[idx - sk], q[v], Qv[idx + sk]);
-    }
-  }
   const double* Ua = U + IA * N; const double* Ub = U + IB * N; const double* Uc = U + IC * N;
   double AL = Ua[idx], BL = Ub[idx], CL = Uc[idx];
   const double AR = Ua[idx + 1], BR = Ub[idx + sj], CR = Uc[idx + sk];
@@ -138,10 +123,9 @@ RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U,
   const double dCLy = 0.5 * tvd_slope(mst, Uc[idx - sj], CL, Uc[idx + sj]);
 
   // electric field at the edges bounding the three low faces
-  const double* Ex = E; const double* Ey = E + N; const double* Ez = E + 2 * N;
-  const double ELL = Ex[idx], ELR = Ex[idx + sk], ERL = Ex[idx + sj];
-  const double FLL = Ey[idx], FLR = Ey[idx + sk], FRL = Ey[idx + 1];
-  const double GLL = Ez[idx], GLR = Ez[idx + sj], GRL = Ez[idx + 1];
+  const double ELL = E9[0], ELR = E9[1], ERL = E9[2];
+  const double FLL = E9[3], FLR = E9[4], FRL = E9[5];
+  const double GLL = E9[6], GLR = E9[7], GRL = E9[8];
 
   double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = q[IW], A = q[IA], B = q[IB], C = q[IC];
   const double drx = dx_[ID] * 0.5, dpx = dx_[IP] * 0.5, dux = dx_[IU] * 0.5, dvx = dx_[IV] * 0.5, dwx = dx_[IW] * 0.5,
@@ -190,6 +174,39 @@ RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U,
   t[(T_DZ + 0) * N] = drz; t[(T_DZ + 1) * N] = dpz; t[(T_DZ + 2) * N] = duz; t[(T_DZ + 3) * N] = dvz; t[(T_DZ + 4) * N] = dwz;
   t[(T_DZ + 5) * N] = dAz; t[(T_DZ + 6) * N] = dBz;
   t[T_DALY * N] = dALy; t[T_DALZ * N] = dALz; t[T_DBLX * N] = dBLx; t[T_DBLZ * N] = dBLz; t[T_DCLX * N] = dCLx; t[T_DCLY * N] = dCLy;
+}
+
+RG_DEVFN bool trace3d_in_range(const DevParams& g, const IJK c) {
+  const int lo = g.gw - 1;
+  return !(c.i < lo || c.i > g.isize - g.gw || c.j < lo || c.j > g.jsize - g.gw || c.k < lo || c.k > g.ksize - g.gw);
+}
+
+// Front end: Q and E come from the arrays written by mhd_prim_cell and mhd_elec_cell.  (A variant that recomputes
+// them from U inside this kernel -- no Q/E round trip, no prim/elec launches -- was measured NOT faster: 240 VGPRs,
+// 77.6-78.3 vs 76.6-77.3 ms/step at 512^3; it was dropped.)
+RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
+                               const double* __restrict__ E, double* __restrict__ T, double dtdx, double dtdy,
+                               double dtdz, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (!trace3d_in_range(g, c)) return;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const double st = g.slope_type;
+  double q[8], dx_[8], dy_[8], dz_[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const double* Qv = Q + v * N;
+    q[v] = Qv[idx];
+    if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; dz_[v] = 0.0; }
+    else {
+      dx_[v] = tvd_slope(st, Qv[idx - 1], q[v], Qv[idx + 1]);
+      dy_[v] = tvd_slope(st, Qv[idx - sj], q[v], Qv[idx + sj]);
+      dz_[v] = tvd_slope(st, Qv[idx - sk], q[v], Qv[idx + sk]);
+    }
+  }
+  const double* Ex = E; const double* Ey = E + N; const double* Ez = E + 2 * N;
+  const double E9[9] = {Ex[idx], Ex[idx + sk], Ex[idx + sj], Ey[idx], Ey[idx + sk], Ey[idx + 1], Ez[idx], Ez[idx + sj], Ez[idx + 1]};
+  mhd_trace3d_finish(g, U, T, c, idx, q, dx_, dy_, dz_, E9, dtdx, dtdy, dtdz);
 }
 
 // ------------------------------------------------------------------------------------------------------------
