@@ -186,6 +186,8 @@ def main():
     value = args.steps * cells_global / elapsed / 1e6
     if rank == 0:
         step_bytes = ALGO_BYTES_PER_CELL * cells_local
+        # per step: a slab run launches the kernel once per plane range (two boundary ranges + the inner one)
+        dom_ms = dom_ms * dom_launches / nprof
         achieved = step_bytes / (dom_ms * 1e-3)
         step_ms_events = sum(tm.values()) / nprof * 1e3
         out = {
@@ -201,7 +203,7 @@ def main():
                        "parity": "bit-identical to euler_cpu on all golden fixtures (tests/)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(dom_name),
-                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_timed": dom_launches,
+                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
                          "note": "ALU-bound kernel (fp64 div/sqrt heavy Riemann solvers): see DESIGN.md"},
             "roofline_step": {"bound": "hbm", "achieved": step_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": step_bytes / (elapsed / args.steps) / HBM_PEAK,

@@ -158,8 +158,32 @@ int rgpu_step_core  (rgpu_ctx* c, int nStep, double dt, double totalTime);
 int rgpu_step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime);
 int rgpu_step_post_b(rgpu_ctx* c, int nStep, double dt, double totalTime);
 
+/* Plane-ranged pieces (3D contexts) for a slab driver that hides the halo exchange behind the update of the planes
+ * nobody else needs ("boundary planes first"): with every ghost of the INPUT valid at entry,
+ *   core_planes [0,2gw) and [nz,ksize)  -> fill_planes [gw,2gw) and [nz,nz+gw) -> start exchange of the OUTPUT
+ *   core_planes [2gw,nz)                -> fill_planes [2gw,nz)                -> wait -> physical z faces
+ * k_lo/k_hi are array plane indices (ghosts included), half open.
+ * rgpu_step_core_planes completes the update of planes [k_lo,k_hi) of U[(nStep+1)%2] (every intermediate stage is
+ * run on exactly the planes that update needs); rgpu_step_core == planes [0,ksize).
+ * rgpu_step_fill_planes applies the in-plane part of the ghost fill to planes [k_lo,k_hi) of the OUTPUT state:
+ * X,Y faces (HydroRunBase.cpp:2333-2342) or, shearing box, Y + shear remap + Y (MHDRunGodunov.cpp:3779-3793 with
+ * the z copy commuted out: all three act within one z plane). */
+int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
+int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
+
+/* rgpu_compute_inv_dt in pieces: accumulate the max over the cells of planes [k_lo,k_hi) into the context's device
+ * slot (reset != 0 starts a new maximum), asynchronously on the context stream; rgpu_inv_dt_result synchronises
+ * and returns it with the seeds of compute_dt[_mhd] applied.  Lets a slab driver scan each plane of the output
+ * BEFORE its ghosts are refilled, which is the state the reference's compute_dt sees on the plain path
+ * (oneStepIntegration: compute_dt, then godunov_unsplit fills the ghosts; MHDRunGodunov.cpp:4077-4089). */
+int rgpu_inv_dt_accumulate(rgpu_ctx* c, int parity, int k_lo, int k_hi, int reset);
+int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt);
+
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
+
+/* name of the device backend the library was built for ("hip-gfx950") */
+const char* rgpu_backend_name(void);
 
 /* block until all queued work of this context is complete */
 int rgpu_synchronize(rgpu_ctx* c);
@@ -186,6 +210,10 @@ int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, 
 /* Parse an .ini file exactly like ConfigMap + HydroParameters (float-parsed knobs, case-insensitive keys,
  * ConfigMap.cpp:41-49, INIReader.cpp:94-101) with optional "section.key=value;..." overrides. */
 int rgpuh_params_from_ini(const char* ini_path, const char* overrides, rgpu_params* out, char* err, int err_len);
+
+/* the [run] section the reference's start() loop reads: nstepmax, tend, noutput (HydroRunBase.cpp:224-232) */
+int rgpuh_run_settings(const char* ini_path, const char* overrides, int* nStepmax, double* tEnd, int* nOutput,
+                       char* err, int err_len);
 
 /* Fill hU (rgpu_state_elems doubles, zeroed first) with the initial condition named by [hydro] problem:
  * jet, implode (HydroRunBase.cpp:5282-5350, 5449-5536), Orszag-Tang, Brio-Wu, MRI

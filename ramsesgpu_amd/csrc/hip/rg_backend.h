@@ -57,10 +57,10 @@ inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k)
 // block.  All values are >= 0, so the IEEE bit pattern orders like an unsigned integer; max is exact and
 // order-independent, hence bit-identical to the reference's sequential scan.
 template <int BLOCK, class K>
-__global__ void __launch_bounds__(BLOCK) rg_reduce_max_kernel(unsigned n, K k, unsigned long long* out) {
+__global__ void __launch_bounds__(BLOCK) rg_reduce_max_kernel(unsigned idx0, unsigned n, K k, unsigned long long* out) {
   double v = 0.0;
-  for (unsigned idx = blockIdx.x * (unsigned)BLOCK + threadIdx.x; idx < n; idx += gridDim.x * (unsigned)BLOCK)
-    v = fmax(v, k(idx));
+  for (unsigned off = blockIdx.x * (unsigned)BLOCK + threadIdx.x; off < n; off += gridDim.x * (unsigned)BLOCK)
+    v = fmax(v, k(idx0 + off));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
   __shared__ double wave_max[BLOCK / 64];
@@ -75,14 +75,16 @@ __global__ void __launch_bounds__(BLOCK) rg_reduce_max_kernel(unsigned n, K k, u
   }
 }
 
+// max over the flat index range [idx0, idx0 + n); reset = false accumulates into the value already in *d_out
 template <class K>
-inline int rg_reduce_max(rg_stream_t s, unsigned n, const K& k, unsigned long long* d_out) {
+inline int rg_reduce_max(rg_stream_t s, unsigned n, const K& k, unsigned long long* d_out, unsigned idx0 = 0, bool reset = true) {
   const int BLOCK = 256;
   unsigned grid = (n + BLOCK - 1) / BLOCK;
   if (grid > 2048u) grid = 2048u;  // 256 CUs x 8 resident blocks; the rest is grid-strided
   if (grid == 0) grid = 1;
-  if (hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
-  hipLaunchKernelGGL((rg_reduce_max_kernel<BLOCK, K>), dim3(grid), dim3(BLOCK), 0, s, n, k, d_out);
+  if (reset && hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((rg_reduce_max_kernel<BLOCK, K>), dim3(grid), dim3(BLOCK), 0, s, idx0, n, k, d_out);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -211,16 +211,15 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
 }
 
 // ---- boundaries -----------------------------------------------------------------------------------------------
-int launch_face(rgpu_ctx* c, double* U, int dir, int side) {
+// x and y faces are indexed with k slowest, so planes [k_lo,k_hi) of a face are one contiguous index range
+int launch_face(rgpu_ctx* c, double* U, int dir, int side, int k_lo, int k_hi) {
   const int bct = c->p.bc[2 * dir + side];
   if (bct != RGPU_BC_DIRICHLET && bct != RGPU_BC_NEUMANN && bct != RGPU_BC_PERIODIC) return 0;  // shear / copy: untouched
   const DevParams& g = c->g;
-  unsigned n;
-  if (dir == 0) n = (unsigned)g.gw * g.jsize * g.ksize;
-  else if (dir == 1) n = (unsigned)g.isize * g.gw * g.ksize;
-  else n = (unsigned)g.isize * g.jsize * g.gw;
   K_bc_face k = {g, U, dir, side, bct};
-  return rg_launch<kBlock>(c->stream, n, k);
+  if (dir == 2) return rg_launch<kBlock>(c->stream, (unsigned)g.isize * g.jsize * g.gw, k);
+  const unsigned per_plane = (dir == 0) ? (unsigned)g.gw * g.jsize : (unsigned)g.isize * g.gw;
+  return rg_launch_range<kBlock>(c->stream, per_plane * (unsigned)k_lo, per_plane * (unsigned)(k_hi - k_lo), k);
 }
 
 int launch_jet(rgpu_ctx* c, double* U) {
@@ -235,18 +234,19 @@ int launch_jet(rgpu_ctx* c, double* U) {
   return rg_launch<kBlock>(c->stream, n, k);
 }
 
-int do_make_boundaries(rgpu_ctx* c, double* U, int idim) {
+int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi = -1) {
   const int dir = idim - 1;
   if (dir < 0 || dir > 2) return -1;
   if (!c->g.three_d && dir == 2) return 0;
-  if (launch_face(c, U, dir, 0) || launch_face(c, U, dir, 1)) return -1;
+  if (k_hi < 0) k_hi = c->g.ksize;
+  if (launch_face(c, U, dir, 0, k_lo, k_hi) || launch_face(c, U, dir, 1, k_lo, k_hi)) return -1;
   // the jet is re-imposed after the Y fill in 2D and after the Z fill in 3D (HydroRunBase.cpp:2286-2312)
   if (c->p.enableJet && ((!c->g.three_d && dir == 1) || (c->g.three_d && dir == 2 && c->p.bc[4] != RGPU_BC_COPY)))
     return launch_jet(c, U);
   return 0;
 }
 
-int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt) {
+int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt, int k_lo = 0, int k_hi = -1) {
   const rgpu_params& p = c->p;
   // MHDRunGodunov.cpp:3554-3557
   double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt);
@@ -256,9 +256,10 @@ int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt
   const double epsi = std::fmod(deltay, p.dy);
   sg.eps_min = 1.0 - epsi / p.dy;
   sg.eps_max = epsi / p.dy;
-  const unsigned n = (unsigned)c->g.gw * c->g.ny * c->g.ksize;
+  if (k_hi < 0) k_hi = c->g.ksize;
+  const unsigned per_plane = (unsigned)c->g.gw * c->g.ny;
   K_shear_ghost k = {c->g, sg, U};
-  return rg_launch<kBlock>(c->stream, n, k);
+  return rg_launch_range<kBlock>(c->stream, per_plane * (unsigned)k_lo, per_plane * (unsigned)(k_hi - k_lo), k);
 }
 
 // ---- the step -------------------------------------------------------------------------------------------------
@@ -292,14 +293,49 @@ int step_post_b(rgpu_ctx* c, int nStep) {
   return 0;
 }
 
+// In-plane part of the ghost fill of the step's OUTPUT state, restricted to planes [a,b): what a z-slab driver applies
+// to the planes it is about to send, so that the neighbour receives finished planes (x / y ghosts and corners
+// included) and never has to touch its z ghost planes again.  x and y fills (and the shear remap) act within one
+// z plane, hence plane-wise { Y, shear, Y } + copying planes equals the reference's { Y, shear, Z, Y } sequence.
+int step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
+  Phase ph(c, RGPU_T_BOUNDARIES);
+  double* out = c->U[(nStep + 1) % 2];
+  if (c->g.rot && c->g.shearbox) {
+    return do_make_boundaries(c, out, RGPU_YDIR, a, b) || do_make_boundaries_shear(c, out, totalTime, dt, a, b) ||
+           do_make_boundaries(c, out, RGPU_YDIR, a, b);
+  }
+  return do_make_boundaries(c, out, RGPU_XDIR, a, b) || do_make_boundaries(c, out, RGPU_YDIR, a, b);
+}
+
+// ---- plane-range helpers -----------------------------------------------------------------------------------------
+// Every kernel body works on a flat cell index and guards its own (i,j,k) validity, so a stage can be run on any
+// range of z planes.  The step is expressed as "complete the UPDATE of planes [a,b)"; each stage then has to cover
+//   update [a,b) <- flux/emf [a,b+1) <- trace [a-1,b+1) <- elec [a-1,b+2), prim [a-2,b+2)      (3D MHD)
+//   update [a,b) <- flux [a,b+1) <- trace [a-1,b+1) <- prim [a-2,b+2)                           (hydro)
+// clipped to the array.  Values are deterministic functions of the (unchanging) input state, so computing a plane
+// twice in two calls is harmless; a z-slab driver uses this to update the planes that do not depend on the
+// neighbours' ghost planes while the halo exchange is still in flight.
+struct PlaneRange { int lo, hi; };
+inline PlaneRange clip(int lo, int hi, int ksize) {
+  PlaneRange r = {lo < 0 ? 0 : lo, hi > ksize ? ksize : hi};
+  if (r.hi < r.lo) r.hi = r.lo;
+  return r;
+}
+template <int BLOCK, int MINW, class K>
+int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
+  if (r.hi <= r.lo) return 0;
+  return rg_launch_range<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, (unsigned)(r.hi - r.lo) * g.sk, k);
+}
+
 template <int ND, int NV>
-int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt) {
+int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int b) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
-  { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_FLUX); K_hydro_flux<ND, NV> k = {g, c->T, c->F}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_UPDATE); K_hydro_update<ND, NV> k = {g, in, out, c->F, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  const int ks = g.ksize;
+  { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
+  { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 1, b + 1, ks), k)) return -1; }
+  { Phase ph(c, RGPU_T_FLUX); K_hydro_flux<ND, NV> k = {g, c->T, c->F}; if (launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1; }
+  { Phase ph(c, RGPU_T_UPDATE); K_hydro_update<ND, NV> k = {g, in, out, c->F, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), k)) return -1; }
   return 0;
 }
 
@@ -313,10 +349,15 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   return 0;
 }
 
-int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime) {
+// 3D MHD: complete the update of planes [a,b).  The range is swept in chunks of ~8 planes; the HBM-bound stages
+// (prim, elec, trace, update) go to the context stream, the fp64-VALU-bound Riemann stages (flux, emf) to a second
+// stream, ordering-only events in between, so that trace of chunk c+1 runs next to flux/emf of chunk c.  With the
+// phase timers on (or RGPU_CHUNKS=1) everything is issued on the context stream in one chunk.
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b) {
   const DevParams& g = c->g;
   const rgpu_params& p = c->p;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
+  const int ks = g.ksize;
   RotCoef rc = {0.0, 1.0, 1.0, 0.0};
   if (g.rot) {  // MHDRunGodunov.cpp:2047-2053
     double lambda = p.Omega0 * dt;
@@ -326,64 +367,9 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     rc.alpha1 = 1.0 / (1.0 + lambda);
     rc.alpha2 = p.Omega0 * dt / (1.0 + lambda);
   }
-  { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_ELEC); K_mhd_elec k = {g, in, c->Q, c->E}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_TRACE); K_mhd_trace3d k = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  // Two launches: the three face Riemann problems, then the three edge (EMF) problems.  Both are fp64-ALU bound
-  // (divide / sqrt chains); fusing them into one launch was measured slower (256 VGPRs -> 2 waves per SIMD).
-  { Phase ph(c, RGPU_T_FLUX); K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z> k = {g, c->T, c->F, c->emf}; if (rg_launch<kBlockHeavy, 4>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_EMF); K_mhd_flux3d<DO_EMF_X | DO_EMF_Y | DO_EMF_Z> k = {g, c->T, c->F, c->emf}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
-  if (g.rot && g.shearbox) {
-    Phase ph(c, RGPU_T_SHEAR);
-    // MHDRunGodunov.cpp:3213-3216 (flux / emf remap uses totalTime + dt/2)
-    double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt / 2);
-    deltay = std::fmod(deltay, (p.dy * p.ny));
-    ShearRemap sr;
-    sr.jplus = (int)(deltay / p.dy);
-    const double epsi = std::fmod(deltay, p.dy);
-    sr.eps_min = 1.0 - epsi / p.dy;
-    sr.eps_max = epsi / p.dy;
-    const unsigned P = (unsigned)g.jsize * g.ksize;
-    K_shear_save_emf ks = {g, c->emf, c->shear_save};
-    K_shear_remap kr = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
-    if (rg_launch<kBlock>(c->stream, P, ks) || rg_launch<kBlock>(c->stream, P, kr)) return -1;
-  }
-  {
-    Phase ph(c, RGPU_T_UPDATE);
-    if (g.rot) {
-      K_mhd_update3d<true> k = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-      if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
-    } else {
-      K_mhd_update3d<false> k = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-      if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
-    }
-  }
-  return 0;
-}
-
-// The same 3D MHD step, cut into z-chunks and issued on TWO streams so that the HBM-bound kernels (prim, elec,
-// trace, update: "mem" stream = the context stream) run concurrently with the fp64-VALU-bound Riemann kernels
-// (flux, emf: "alu" stream) of a neighbouring chunk.  Plane-level dependencies of the pipeline:
-//   elec(k)  <- Q(k-1..k)          trace(k) <- Q(k-1..k+1), E(k..k+1)        flux/emf(k) <- T(k-1..k)
-//   shear remap(k) <- F(k), emf(k) (per (j,k), same k)                       update(k) <- F(k..k+1), emf(k..k+1)
-// Chunks are whole planes in increasing k; with the issue order below every consumer is enqueued after its
-// producers, cross-stream edges are ordering-only events, and no array is written twice within a step.
-int mhd3d_core_overlap(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime) {
-  const DevParams& g = c->g;
-  const rgpu_params& p = c->p;
-  const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
-  RotCoef rc = {0.0, 1.0, 1.0, 0.0};
-  if (g.rot) {
-    double lambda = p.Omega0 * dt;
-    lambda = 0.25 * lambda * lambda;
-    rc.lambda = lambda;
-    rc.ratio = (1.0 - lambda) / (1.0 + lambda);
-    rc.alpha1 = 1.0 / (1.0 + lambda);
-    rc.alpha2 = p.Omega0 * dt / (1.0 + lambda);
-  }
   ShearRemap sr = {0, 0.0, 0.0};
   const bool shear = g.rot && g.shearbox;
-  if (shear) {
+  if (shear) {  // MHDRunGodunov.cpp:3213-3216 (flux / emf remap uses totalTime + dt/2)
     double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt / 2);
     deltay = std::fmod(deltay, (p.dy * p.ny));
     sr.jplus = (int)(deltay / p.dy);
@@ -391,14 +377,6 @@ int mhd3d_core_overlap(rgpu_ctx* c, const double* in, double* out, double dt, do
     sr.eps_min = 1.0 - epsi / p.dy;
     sr.eps_max = epsi / p.dy;
   }
-  const int C = c->nchunks;
-  const unsigned plane = g.sk;
-  // chunk c covers planes [kb(c), kb(c+1))
-  auto kb = [&](int cc) -> unsigned { return (unsigned)(((long long)g.ksize * cc) / C); };
-  auto i0 = [&](int cc) -> unsigned { return kb(cc) * plane; };
-  auto nn = [&](int cc) -> unsigned { return (kb(cc + 1) - kb(cc)) * plane; };
-  rg_stream_t sm = c->stream, sa = c->stream2;
-
   K_mhd_prim k_prim = {g, in, c->Q, dt};
   K_mhd_elec k_elec = {g, in, c->Q, c->E};
   K_mhd_trace3d k_trace = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz};
@@ -408,53 +386,91 @@ int mhd3d_core_overlap(rgpu_ctx* c, const double* in, double* out, double dt, do
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
   K_mhd_update3d<true> k_upd_rot = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
   K_mhd_update3d<false> k_upd = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+  auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
+    if (!shear || r.hi <= r.lo) return 0;
+    const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
+    return rg_launch_range<kBlock>(s, j0, jn, k_ssave) || rg_launch_range<kBlock>(s, j0, jn, k_sremap);
+  };
+  auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+    return g.rot ? launch_planes<kBlock, 1>(s, g, r, k_upd_rot) : launch_planes<kBlock, 1>(s, g, r, k_upd);
+  };
 
-  // the alu stream must not start before earlier work of the context stream (ghost fill, previous step) is done
+  const bool serial = c->timers_on || c->nchunks <= 1 || (b - a) < 16;
+  if (serial) {
+    rg_stream_t s = c->stream;
+    { Phase ph(c, RGPU_T_PRIM); if (launch_planes<kBlock, 1>(s, g, clip(a - 2, b + 2, ks), k_prim)) return -1; }
+    { Phase ph(c, RGPU_T_ELEC); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 2, ks), k_elec)) return -1; }
+    { Phase ph(c, RGPU_T_TRACE); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 1, ks), k_trace)) return -1; }
+    { Phase ph(c, RGPU_T_FLUX); if (launch_planes<kBlockHeavy, 4>(s, g, clip(a, b + 1, ks), k_flux)) return -1; }
+    { Phase ph(c, RGPU_T_EMF); if (launch_planes<kBlockHeavy, 1>(s, g, clip(a, b + 1, ks), k_emf)) return -1; }
+    { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
+    { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
+    return 0;
+  }
+
+  // chunked two-stream schedule: stage s has completed planes [.., done_s); per chunk each stage advances to what
+  // the update of planes < kb needs
+  rg_stream_t sm = c->stream, sa = c->stream2;
+  const int span = b - a;
+  int C = (span + 7) / 8;
+  if (C > c->nchunks) C = c->nchunks;
+  if (C < 1) C = 1;
   if (rg_event_record(c->ev_fork, sm) || rg_stream_wait_event(sa, c->ev_fork)) return -1;
-  for (int it = 0; it < C + 3; ++it) {
-    if (it < C) {
-      if (rg_launch_range<kBlock>(sm, i0(it), nn(it), k_prim) || rg_launch_range<kBlock>(sm, i0(it), nn(it), k_elec)) return -1;
+  int d_prim = a - 2, d_elec = a - 1, d_trace = a - 1, d_flux = a, d_upd = a;
+  for (int ci = 0; ci <= C; ++ci) {
+    if (ci < C) {
+      const int kb = (ci + 1 == C) ? b : a + (int)(((long long)span * (ci + 1)) / C);
+      if (launch_planes<kBlock, 1>(sm, g, clip(d_prim, kb + 2, ks), k_prim)) return -1;
+      d_prim = kb + 2;
+      if (launch_planes<kBlock, 1>(sm, g, clip(d_elec, kb + 2, ks), k_elec)) return -1;
+      d_elec = kb + 2;
+      if (launch_planes<kBlock, 1>(sm, g, clip(d_trace, kb + 1, ks), k_trace)) return -1;
+      d_trace = kb + 1;
+      if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
+      const PlaneRange rf = clip(d_flux, kb + 1, ks);
+      if (launch_planes<kBlockHeavy, 4>(sa, g, rf, k_flux) || launch_planes<kBlockHeavy, 1>(sa, g, rf, k_emf) || shear_planes(sa, rf)) return -1;
+      d_flux = kb + 1;
+      if (rg_event_record(c->ev_flux[ci], sa)) return -1;
     }
-    const int ct = it - 1;  // trace of the previous chunk: its last plane needs Q,E of the first plane of chunk `it`
-    if (ct >= 0 && ct < C) {
-      if (rg_launch_range<kBlock>(sm, i0(ct), nn(ct), k_trace)) return -1;
-      if (rg_event_record(c->ev_trace[ct], sm) || rg_stream_wait_event(sa, c->ev_trace[ct])) return -1;
-      if (rg_launch_range<kBlockHeavy, 4>(sa, i0(ct), nn(ct), k_flux) || rg_launch_range<kBlockHeavy>(sa, i0(ct), nn(ct), k_emf)) return -1;
-      if (shear) {
-        const unsigned j0 = kb(ct) * (unsigned)g.jsize, jn = (kb(ct + 1) - kb(ct)) * (unsigned)g.jsize;
-        if (rg_launch_range<kBlock>(sa, j0, jn, k_ssave) || rg_launch_range<kBlock>(sa, j0, jn, k_sremap)) return -1;
-      }
-      if (rg_event_record(c->ev_flux[ct], sa)) return -1;
-    }
-    const int cu = it - 3;  // update of chunk cu needs the fluxes of chunk cu and of the first plane of cu+1
-    if (cu >= 0 && cu < C) {
-      const int need = (cu + 1 < C) ? cu + 1 : cu;
-      if (rg_stream_wait_event(sm, c->ev_flux[need])) return -1;
-      if (g.rot) { if (rg_launch_range<kBlock>(sm, i0(cu), nn(cu), k_upd_rot)) return -1; }
-      else { if (rg_launch_range<kBlock>(sm, i0(cu), nn(cu), k_upd)) return -1; }
+    if (ci >= 1) {  // update lags one chunk so that the next chunk's prim/elec/trace are queued ahead of it
+      const int kb_prev = (ci == C) ? b : a + (int)(((long long)span * ci) / C);
+      if (rg_stream_wait_event(sm, c->ev_flux[ci - 1])) return -1;
+      if (update_planes(sm, clip(d_upd, kb_prev, ks))) return -1;
+      d_upd = kb_prev;
     }
   }
   return 0;
 }
 
-int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
   const double* in = c->U[nStep % 2];
   double* out = c->U[(nStep + 1) % 2];
-  if (!c->p.mhdEnabled) return c->g.three_d ? hydro_core<3, 5>(c, in, out, dt) : hydro_core<2, 4>(c, in, out, dt);
-  if (!c->g.three_d) return mhd2d_core(c, in, out, dt);
-  // phase timers bracket whole-domain launches: they use the serial schedule
-  if (c->nchunks > 1 && !c->timers_on) return mhd3d_core_overlap(c, in, out, dt, totalTime);
-  return mhd3d_core(c, in, out, dt, totalTime);
+  if (!c->g.three_d) {  // 2D: no planes
+    if (!c->p.mhdEnabled) return hydro_core<2, 4>(c, in, out, dt, 0, 1);
+    return mhd2d_core(c, in, out, dt);
+  }
+  if (a < 0) a = 0;
+  if (b > c->g.ksize) b = c->g.ksize;
+  if (b <= a) return 0;
+  if (!c->p.mhdEnabled) return hydro_core<3, 5>(c, in, out, dt, a, b);
+  return mhd3d_core(c, in, out, dt, totalTime, a, b);
 }
 
-int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
+int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  return step_core_planes(c, nStep, dt, totalTime, 0, c->g.ksize);
+}
+
+// max of the per-cell 1/dt over the flat index range [idx0, idx0+n) into the device slot (reset or accumulate)
+int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) {
   Phase ph(c, RGPU_T_DT);
   const double* U = c->U[parity & 1];
-  int rc;
-  if (c->p.mhdEnabled) { K_mhd_invdt k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
-  else if (c->g.three_d) { K_hydro_invdt<5> k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
-  else { K_hydro_invdt<4> k = {c->g, U}; rc = rg_reduce_max(c->stream, c->n32, k, c->d_red); }
-  if (rc) return -1;
+  if (c->p.mhdEnabled) { K_mhd_invdt k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
+  if (c->g.three_d) { K_hydro_invdt<5> k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
+  K_hydro_invdt<4> k = {c->g, U};
+  return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset);
+}
+
+int inv_dt_fetch(rgpu_ctx* c, double* invDt) {
   if (rg_copy_d2h(c->h_red, c->d_red, sizeof(unsigned long long), c->stream) || rg_stream_sync(c->stream)) return -1;
   double v;
   std::memcpy(&v, c->h_red, sizeof(double));
@@ -464,6 +480,10 @@ int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
   if (p.enableJet) v = std::fmax(v, (p.ujet + p.cjet) / p.dx);
   *invDt = v;
   return 0;
+}
+
+int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
+  return inv_dt_scan(c, parity, 0, c->n32, true) || inv_dt_fetch(c, invDt);
 }
 
 #define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; } while (0)
@@ -569,6 +589,24 @@ int rgpu_compute_inv_dt(rgpu_ctx* c, int parity, double* invDt) {
   return RGPU_OK;
 }
 
+int rgpu_inv_dt_accumulate(rgpu_ctx* c, int parity, int k_lo, int k_hi, int reset) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (!c->g.three_d) return fail(c, RGPU_EINVAL, "inv_dt_accumulate: plane ranges need a 3D context");
+  if (k_lo < 0) k_lo = 0;
+  if (k_hi > c->g.ksize) k_hi = c->g.ksize;
+  if (k_hi < k_lo) k_hi = k_lo;
+  if (inv_dt_scan(c, parity, (unsigned)k_lo * c->g.sk, (unsigned)(k_hi - k_lo) * c->g.sk, reset != 0)) return RG_HIPFAIL(c, "inv_dt_accumulate");
+  return RGPU_OK;
+}
+
+int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt) {
+  RG_CHECK_CTX(c);
+  if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "inv_dt_result: null pointer / context without state");
+  if (inv_dt_fetch(c, invDt)) return RG_HIPFAIL(c, "inv_dt_result");
+  return RGPU_OK;
+}
+
 double rgpu_compute_dt(rgpu_ctx* c, int useU) {
   double v = 0;
   if (!c || rgpu_compute_inv_dt(c, useU, &v) != RGPU_OK) return std::numeric_limits<double>::quiet_NaN();
@@ -586,6 +624,22 @@ int rgpu_step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (step_core(c, nStep, dt, totalTime)) return RG_HIPFAIL(c, "step_core");
+  return RGPU_OK;
+}
+int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi)) return RG_HIPFAIL(c, "step_core_planes");
+  return RGPU_OK;
+}
+int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (!c->g.three_d) return fail(c, RGPU_EINVAL, "step_fill_planes: plane ranges need a 3D context");
+  if (k_lo < 0) k_lo = 0;
+  if (k_hi > c->g.ksize) k_hi = c->g.ksize;
+  if (k_hi <= k_lo) return RGPU_OK;
+  if (step_fill_planes(c, nStep, dt, totalTime, k_lo, k_hi)) return RG_HIPFAIL(c, "step_fill_planes");
   return RGPU_OK;
 }
 int rgpu_step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime) {

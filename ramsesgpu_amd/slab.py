@@ -12,6 +12,21 @@ fixed x borders, hence local to a slab.  The only collective is the MAX all-redu
 Order of the ghost fill, identical to the reference's once z-neighbours are other ranks:
    plain    : X, Y, then Z (exchange)                       HydroRunBase.cpp:2333-2342
    shearing : Y, shear remap of x ghosts, Z (exchange), Y   MHDRunGodunov.cpp:3779-3793
+
+Overlap (default): the exchange is hidden behind the update of the planes no neighbour needs.  With all ghosts of
+the input valid at entry, a step is
+
+   update planes [0,2gw) and [nz,ksize)       the planes the neighbours (and the physical z faces) read
+   in-plane ghost fill of the planes to send   X,Y  |  Y, shear, Y  -- they act within one z plane, so finishing a
+                                               plane before it is sent equals the reference's fill-then-copy order
+   start isend / irecv of the OUTPUT state     (asynchronous; RCCL runs on its own stream)
+   update planes [2gw,nz) + their in-plane fill
+   wait, physical z faces
+
+so the next step again starts with valid ghosts.  On the plain path the reference evaluates the CFL condition on
+the output BEFORE its ghosts are refilled (oneStepIntegration: compute_dt, then godunov_unsplit fills); the driver
+therefore scans 1/dt plane range by plane range right after each update and before each fill (max is order
+independent), which keeps the time step -- and hence everything -- bit-identical to the single-domain run.
 """
 import ctypes as C
 
@@ -23,7 +38,7 @@ from .solver import Solver, load_library
 
 
 class SlabRun:
-    def __init__(self, ini_path, overrides="", library=None, device="cuda", group=None):
+    def __init__(self, ini_path, overrides="", library=None, device="cuda", group=None, overlap=True):
         self.L = library or load_library()
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -41,6 +56,10 @@ class SlabRun:
         self.solver = Solver(self.p, self.L, external_state=(self.U[0].data_ptr(), self.U[1].data_ptr()), stream=stream)
         self._invdt = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.nStep, self.totalTime, self.dt = 0, 0.0, 0.0
+        self.overlap = overlap
+        self._ops = {}
+        self._primed = None      # parity of the state whose ghosts are all valid
+        self._scanned = None     # parity of the state whose 1/dt sits in the solver's device slot
         gw, nz = self.p.ghostWidth, self.p.nz
         self._lo_ghost, self._lo_int = slice(0, gw), slice(gw, 2 * gw)
         self._hi_int, self._hi_ghost = slice(nz, nz + gw), slice(nz + gw, nz + 2 * gw)
@@ -54,12 +73,13 @@ class SlabRun:
         self.make_all_boundaries(0, 0.0, 0.0)
         self.U[1].copy_(self.U[0])
         self.nStep, self.totalTime = 0, 0.0
+        self._scanned = None
 
     # ---- halo exchange -----------------------------------------------------------------------------------------
-    def exchange_z(self, parity):
-        """fill the z ghost planes that belong to a neighbour slab (faces with bc == BC_COPY)"""
-        if self.world == 1:
-            return
+    def _p2p_ops(self, parity):
+        """send / recv descriptors of one state array (built once per parity: the tensors never move)"""
+        if parity in self._ops:
+            return self._ops[parity]
         U = self.U[parity]
         prev, nxt = (self.rank - 1) % self.world, (self.rank + 1) % self.world
         has_prev = self.p.bc[4] == BC_COPY
@@ -78,10 +98,23 @@ class SlabRun:
                 ops.append(dist.P2POp(dist.irecv, U[v, self._hi_ghost], nxt, self.group, tag=2 * v))
             if has_prev:
                 ops.append(dist.P2POp(dist.irecv, U[v, self._lo_ghost], prev, self.group, tag=2 * v + 1))
-        if not ops:
-            return
-        for w in dist.batch_isend_irecv(ops):
+        self._ops[parity] = ops
+        return ops
+
+    def _exchange_start(self, parity):
+        """post the exchange of the z ghost planes that belong to a neighbour slab (faces with bc == BC_COPY)"""
+        if self.world == 1:
+            return []
+        ops = self._p2p_ops(parity)
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def _exchange_wait(pending):
+        for w in pending:
             w.wait()
+
+    def exchange_z(self, parity):
+        self._exchange_wait(self._exchange_start(parity))
 
     def make_all_boundaries(self, parity, totalTime, dt):
         s = self.solver
@@ -96,26 +129,80 @@ class SlabRun:
             s.make_boundaries(parity, 2)
             s.make_boundaries(parity, 3)
             self.exchange_z(parity)
+        self._primed = parity
 
     # ---- time step --------------------------------------------------------------------------------------------
-    def compute_dt(self, useU):
-        inv = self.solver.compute_inv_dt(useU)
+    def _all_reduce_inv_dt(self, inv):
         if self.world > 1:
             self._invdt[0] = inv
             dist.all_reduce(self._invdt, op=dist.ReduceOp.MAX, group=self.group)
             inv = float(self._invdt.item())
-        return self.p.cfl / inv
+        return inv
 
-    def godunov_unsplit(self, nStep, dt):
+    def compute_dt(self, useU):
+        if self._scanned == useU:      # 1/dt of this state was accumulated plane by plane during the last step
+            inv = self.solver.inv_dt_result()
+        else:
+            self._scanned = None       # the full scan reuses (and resets) the device slot
+            inv = self.solver.compute_inv_dt(useU)
+        return self.p.cfl / self._all_reduce_inv_dt(inv)
+
+    @property
+    def _rotating(self):
+        return bool(self.p.mhdEnabled and self.p.Omega0 > 0)
+
+    def godunov_unsplit_serial(self, nStep, dt):
+        """exchange between the step pieces, nothing overlapped (the layout of INTEGRATION.md's first recipe)"""
         s, t = self.solver, self.totalTime
         s.step_pre(nStep, dt, t)
-        if not (self.p.mhdEnabled and self.p.Omega0 > 0):
+        if not self._rotating:
             self.exchange_z(nStep % 2)          # plain path: ghosts of the INPUT
         s.step_core(nStep, dt, t)
         s.step_post_a(nStep, dt, t)
-        if self.p.mhdEnabled and self.p.Omega0 > 0:
+        if self._rotating:
             self.exchange_z((nStep + 1) % 2)    # rotating path: ghosts of the OUTPUT
         s.step_post_b(nStep, dt, t)
+        self._primed = (nStep + 1) % 2 if self._rotating else None
+        self._scanned = None
+
+    def _plane_ranges(self):
+        """(boundary update ranges, planes to finish and send, inner update range) in array plane indices"""
+        gw, nz = self.p.ghostWidth, self.p.nz
+        ks = nz + 2 * gw
+        if nz <= 2 * gw:
+            return [(0, ks)], [(gw, nz + gw)], None
+        return [(0, 2 * gw), (nz, ks)], [(gw, 2 * gw), (nz, nz + gw)], (2 * gw, nz)
+
+    def godunov_unsplit(self, nStep, dt):
+        if not self.overlap:
+            return self.godunov_unsplit_serial(nStep, dt)
+        s, t = self.solver, self.totalTime
+        pin, pout = nStep % 2, (nStep + 1) % 2
+        rot = self._rotating
+        if self._primed != pin and not rot:
+            # ghosts of the input not known to be valid (first step): fill them like the reference does at entry
+            s.step_pre(nStep, dt, t)
+            self.exchange_z(pin)
+        boundary, send, inner = self._plane_ranges()
+        scan = not rot          # rotating path: the reference's compute_dt sees the refilled ghosts -> full scan later
+        for a, b in boundary:
+            s.step_core_planes(nStep, dt, t, a, b)
+        if scan:
+            for n, (a, b) in enumerate(boundary):
+                s.inv_dt_accumulate(pout, a, b, reset=(n == 0))
+        for a, b in send:
+            s.step_fill_planes(nStep, dt, t, a, b)
+        pending = self._exchange_start(pout)
+        if inner is not None:
+            a, b = inner
+            s.step_core_planes(nStep, dt, t, a, b)
+            if scan:
+                s.inv_dt_accumulate(pout, a, b)
+            s.step_fill_planes(nStep, dt, t, a, b)
+        self._exchange_wait(pending)
+        s.make_boundaries(pout, 3)      # physical z faces (+ 3D jet); BC_COPY faces were filled by the exchange
+        self._primed = pout
+        self._scanned = pout if scan else None
 
     def oneStepIntegration(self):
         self.dt = self.compute_dt(self.nStep % 2)

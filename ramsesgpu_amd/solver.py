@@ -194,6 +194,20 @@ class Solver:
     def step_core(self, nStep, dt, t):
         self._chk(self.lib.rgpu_step_core(self.ctx, nStep, dt, t), "step_core")
 
+    def step_core_planes(self, nStep, dt, t, k_lo, k_hi):
+        self._chk(self.lib.rgpu_step_core_planes(self.ctx, nStep, dt, t, k_lo, k_hi), "step_core_planes")
+
+    def step_fill_planes(self, nStep, dt, t, k_lo, k_hi):
+        self._chk(self.lib.rgpu_step_fill_planes(self.ctx, nStep, dt, t, k_lo, k_hi), "step_fill_planes")
+
+    def inv_dt_accumulate(self, parity, k_lo, k_hi, reset=False):
+        self._chk(self.lib.rgpu_inv_dt_accumulate(self.ctx, parity, k_lo, k_hi, int(reset)), "inv_dt_accumulate")
+
+    def inv_dt_result(self):
+        v = C.c_double(0.0)
+        self._chk(self.lib.rgpu_inv_dt_result(self.ctx, C.byref(v)), "inv_dt_result")
+        return v.value
+
     def step_post_a(self, nStep, dt, t):
         self._chk(self.lib.rgpu_step_post_a(self.ctx, nStep, dt, t), "step_post_a")
 

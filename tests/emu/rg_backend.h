@@ -35,9 +35,10 @@ inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k) {
   return 0;
 }
 template <class K>
-inline int rg_reduce_max(rg_stream_t, unsigned n, const K& k, unsigned long long* out) {
+inline int rg_reduce_max(rg_stream_t, unsigned n, const K& k, unsigned long long* out, unsigned idx0 = 0, bool reset = true) {
   double v = 0.0;
-  for (unsigned idx = 0; idx < n; ++idx) v = std::fmax(v, k(idx));
+  if (!reset) std::memcpy(&v, out, sizeof(double));
+  for (unsigned off = 0; off < n; ++off) v = std::fmax(v, k(idx0 + off));
   std::memcpy(out, &v, sizeof(double));
   return 0;
 }

@@ -188,3 +188,27 @@ BOUNDARY_CASES = [
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=4;MHD.omega0=0.4"),
     ("mhd_BrioWu", "mesh.nx=4;mesh.ny=5;mesh.nz=6;mesh.boundary_xmin=1;mesh.boundary_ymax=1;mesh.boundary_zmin=3;mesh.boundary_zmax=3"),
 ]
+
+
+def check_core_plane_pieces(lib, base, ov):
+    """rgpu_step_core_planes over a partition of [0,ksize) (odd cuts, out of order) == rgpu_step_core"""
+    p = lib.params_from_ini(ini(base), ov)
+    U0 = lib.init_condition(ini(base), ov, p)
+    ks = p.nz + 2 * p.ghostWidth
+    outs = []
+    for cuts in (None, [0, 1, 7, 8, ks - 15, ks]):
+        sv = Solver(p, lib)
+        sv.upload(U0)
+        sv.make_all_boundaries(0, 0.0, 0.0)
+        dt = sv.compute_dt(0)
+        sv.step_pre(0, dt, 0.0)
+        if cuts is None:
+            sv.step_core(0, dt, 0.0)
+        else:
+            for a, b in reversed(list(zip(cuts[:-1], cuts[1:]))):
+                sv.step_core_planes(0, dt, 0.0, a, b)
+        sv.step_post_a(0, dt, 0.0)
+        sv.step_post_b(0, dt, 0.0)
+        outs.append(sv.getDataHost(1))
+        sv.close()
+    assert np.array_equal(outs[0], outs[1])

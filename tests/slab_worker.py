@@ -24,7 +24,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
     ini = os.path.join(ROOT, "configs", base + ".ini")
-    run = SlabRun(ini, ov, library=lib, device="cpu")
+    run = SlabRun(ini, ov, library=lib, device="cpu", overlap=os.environ.get("SLAB_OVERLAP", "1") != "0")
     run.init_simulation()
     dts = [run.oneStepIntegration() for _ in range(nsteps)]
     local = run.local_interior().contiguous()

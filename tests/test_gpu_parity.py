@@ -139,3 +139,36 @@ def test_external_state_and_stream(gpu_lib):
     ref = interior(sv.getDataHost(), p)
     sv.close()
     assert dts == dts_ref and np.array_equal(got, ref)
+
+
+SLAB1 = [
+    ("mhd_mri_3d", "mesh.nx=32;mesh.ny=48;mesh.nz=40", 5),           # chunked two-stream sweep inside each plane range
+    ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 4),
+    ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=24;mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_zmin=1;mesh.boundary_zmax=2", 4),
+    ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=32;hydro.riemannSolver=hllc", 5),
+]
+
+
+@pytest.mark.parametrize("base,ov,nsteps", SLAB1, ids=["%s[%s]" % (b, o) for b, o, _ in SLAB1])
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "serial"])
+def test_slab_schedule_world1(base, ov, nsteps, overlap, gpu_lib, oracle):
+    """SlabRun's step (boundary planes first, plane-wise ghost fill, 1/dt scanned per plane range; world 1, so the z
+    faces are the physical ones) == the single-call oracle run."""
+    import torch
+    from ramsesgpu_amd.slab import SlabRun
+    run = SlabRun(ini(base), ov, library=gpu_lib, device="cuda:0", overlap=overlap)
+    run.init_simulation()
+    dts = [run.oneStepIntegration() for _ in range(nsteps)]
+    torch.cuda.synchronize()
+    got = run.local_interior().cpu().numpy()
+    p = run.p
+    run.close()
+    ref, dts_ref, _ = oracle.run(p, gpu_lib.init_condition(ini(base), ov, p), nsteps)
+    assert np.array_equal(np.array(dts), dts_ref)
+    pc.assert_same(got, interior(ref, p), "slab schedule " + base)
+
+
+@pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=44"),
+                                     ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=30")], ids=["mri", "implode3d"])
+def test_step_core_in_plane_pieces(base, ov, gpu_lib):
+    pc.check_core_plane_pieces(gpu_lib, base, ov)

@@ -29,3 +29,9 @@ def test_single_step_on_random_state(base, ov, mach, emu_lib, oracle):
 def test_boundaries_and_dt(base, ov, emu_lib, oracle):
     pc.check_boundaries(emu_lib, oracle, base, ov)
     pc.check_compute_dt(emu_lib, oracle, base, ov)
+
+
+@pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=26"),
+                                     ("implode3d", "mesh.nx=10;mesh.ny=10;mesh.nz=20")], ids=["mri", "implode3d"])
+def test_step_core_in_plane_pieces(base, ov, emu_lib):
+    pc.check_core_plane_pieces(emu_lib, base, ov)

@@ -1,6 +1,8 @@
 """N>1 path on CPU: world_size 2 (and 3) z-slab runs over gloo, halo planes exchanged in place by
 ramsesgpu_amd.slab.SlabRun, stepping through the TEST-ONLY emulation library; result == single-domain oracle,
-bit for bit (plain path: ghosts of the input; rotating path: ghosts of the output; Dirichlet ends; dt all-reduce)."""
+bit for bit (plain path: ghosts of the input; rotating path: ghosts of the output; Dirichlet ends; dt all-reduce).
+Both schedules of SlabRun are covered: the overlapped one (boundary planes first, exchange in flight during the
+inner planes, 1/dt scanned plane range by plane range) and the serial one (exchange between the step pieces)."""
 import os
 import socket
 import subprocess
@@ -10,11 +12,21 @@ import pytest
 
 from conftest import ROOT
 
+OPEN_BC = ";mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_ymin=1;mesh.boundary_ymax=2;mesh.boundary_zmin=2;mesh.boundary_zmax=1"
+# (ini, overrides, steps, world, overlap)
 CASES = [
-    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2),                       # plain MHD, periodic ring
-    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.02", 4, 2),          # rotating + shearing box
-    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8;hydro.riemannSolver=hllc", 4, 2),     # hydro, Dirichlet ends
-    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12", 3, 3),                            # three slabs
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                      # plain MHD, periodic ring, no inner planes
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 4, 2, 1),                      # ... with inner planes [6,12)
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 3, 2, 0),                      # serial schedule
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=20" + OPEN_BC, 4, 2, 1),            # plain MHD, open / reflecting faces: dt sees unfilled ghosts
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.02", 4, 2, 1),        # rotating + shearing box, no inner planes
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=20;MHD.omega0=0.02", 4, 2, 1),        # ... inner planes [6,10)
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.02", 3, 2, 0),        # serial schedule
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;MHD.omega0=0.05", 3, 2, 1),      # rotating frame without shearing box
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8;hydro.riemannSolver=hllc", 4, 2, 1),  # hydro, Dirichlet ends
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 4, 2, 1),                          # hydro, inner planes [4,8)
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12", 3, 3, 1),                         # three slabs (nz=4 each < 2 gw)
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=27", 3, 3, 1),                         # three slabs, inner planes [6,9)
 ]
 
 
@@ -26,13 +38,14 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("base,ov,nsteps,world", CASES, ids=["%s-x%d" % (c[0], c[3]) for c in CASES])
-def test_slabs_match_single_domain(base, ov, nsteps, world, emu_lib, oracle, tmp_path):
+@pytest.mark.parametrize("base,ov,nsteps,world,overlap", CASES,
+                         ids=["%s-%d-x%d-%s" % (c[0], n, c[3], "overlap" if c[4] else "serial") for n, c in enumerate(CASES)])
+def test_slabs_match_single_domain(base, ov, nsteps, world, overlap, emu_lib, oracle, tmp_path):
     out = str(tmp_path / "result.txt")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "slab_worker.py"), base, ov, str(nsteps), out]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", SLAB_OVERLAP=str(overlap))
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert open(out).read().strip() == "OK", open(out).read()
