@@ -11,6 +11,11 @@
 
 namespace rgpu_dev {
 
+using rgpu::rg_recip_t;
+using rgpu::rg_recip;
+using rgpu::rg_div;
+using rgpu::rg_sqrt;
+
 enum { ID = 0, IP = 1, IU = 2, IV = 3, IW = 4, IA = 5, IB = 6, IC = 7 };
 enum { XD = 0, YD = 1, ZD = 2 };
 
@@ -264,12 +269,15 @@ RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double 
 }
 
 // find_speed_fast<IX> (mhd_utils.h:28-52), bn = the field component along the wanted direction
-RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn) {
+// inv_r = rg_recip(q.r): the three divisions by the density (and those of a second call for another direction
+// of the same state) share one reciprocal
+RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
-  const double c2 = g.gamma0 * q.p / q.r;
-  const double d2 = 0.5 * (b2 / q.r + c2);
-  return sqrt(d2 + sqrt(d2 * d2 - c2 * bn * bn / q.r));
+  const double c2 = rg_div(g.gamma0 * q.p, inv_r);
+  const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
+  return rg_sqrt(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r)));
 }
+RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn) { return fast_speed(g, q, bn, rg_recip(q.r)); }
 
 // find_speed_info<NDIM> (mhd_utils.h:241-284): sum_d (cf_d + |v_d|)/delta_d is formed by the caller
 RG_DEVFN void info_speeds(const DevParams& g, const Prim8& q, double& sx, double& sy, double& sz) {
@@ -330,45 +338,51 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double etotr = pr * entho + ecinr + emagr;
   const double ptotr = pr + emagr;
   const double vdotbr = ur * a + vr * br + wr * cr;
-  const double cfastl = fast_speed(g, L, L.a), cfastr = fast_speed(g, R, R.a);
+  const double cfastl = fast_speed(g, L, L.a, rg_recip(L.r)), cfastr = fast_speed(g, R, R.a, rg_recip(R.r));
   const double sl = fmin(ul, ur) - fmax(cfastl, cfastr);
   const double sr = fmax(ul, ur) + fmax(cfastl, cfastr);
   const double rcl = rl * (ul - sl), rcr = rr * (sr - ur);
-  const double ustar = (rcr * ur + rcl * ul + (ptotl - ptotr)) / (rcr + rcl);
-  const double ptotstar = (rcr * ptotl + rcl * ptotr + rcl * rcr * (ul - ur)) / (rcr + rcl);
+  const rg_recip_t inv_rc = rg_recip(rcr + rcl);
+  const double ustar = rg_div(rcr * ur + rcl * ul + (ptotl - ptotr), inv_rc);
+  const double ptotstar = rg_div(rcr * ptotl + rcl * ptotr + rcl * rcr * (ul - ur), inv_rc);
   const double a2 = a * a;
+  const rg_recip_t inv_a2 = rg_recip(a2);
   // left star state
-  const double rstarl = rl * (sl - ul) / (sl - ustar);
+  const rg_recip_t inv_sl = rg_recip(sl - ustar);
+  const double rstarl = rg_div(rl * (sl - ul), inv_sl);
   const double estarl = rl * (sl - ul) * (sl - ustar) - a2;
   const double el = rl * (sl - ul) * (sl - ul) - a2;
-  const bool degl = (a2 > 0) && (fabs(estarl / a2 - 1.0) <= 1e-8);
-  const double vstarl = degl ? vl : vl - a * bl * (ustar - ul) / estarl;
-  const double bstarl = degl ? bl : bl * el / estarl;
-  const double wstarl = degl ? wl : wl - a * cl * (ustar - ul) / estarl;
-  const double cstarl = degl ? cl : cl * el / estarl;
+  const rg_recip_t inv_el = rg_recip(estarl);
+  const bool degl = (a2 > 0) && (fabs(rg_div(estarl, inv_a2) - 1.0) <= 1e-8);
+  const double vstarl = degl ? vl : vl - rg_div(a * bl * (ustar - ul), inv_el);
+  const double bstarl = degl ? bl : rg_div(bl * el, inv_el);
+  const double wstarl = degl ? wl : wl - rg_div(a * cl * (ustar - ul), inv_el);
+  const double cstarl = degl ? cl : rg_div(cl * el, inv_el);
   const double vdotbstarl = ustar * a + vstarl * bstarl + wstarl * cstarl;
-  const double etotstarl = ((sl - ul) * etotl - ptotl * ul + ptotstar * ustar + a * (vdotbl - vdotbstarl)) / (sl - ustar);
-  const double sqrrstarl = sqrt(rstarl);
-  const double sal = ustar - fabs(a) / sqrrstarl;
+  const double etotstarl = rg_div((sl - ul) * etotl - ptotl * ul + ptotstar * ustar + a * (vdotbl - vdotbstarl), inv_sl);
+  const double sqrrstarl = rg_sqrt(rstarl);
+  const double sal = ustar - rg_div(fabs(a), rg_recip(sqrrstarl));
   // right star state
-  const double rstarr = rr * (sr - ur) / (sr - ustar);
+  const rg_recip_t inv_sr = rg_recip(sr - ustar);
+  const double rstarr = rg_div(rr * (sr - ur), inv_sr);
   const double estarr = rr * (sr - ur) * (sr - ustar) - a2;
   const double er = rr * (sr - ur) * (sr - ur) - a2;
-  const bool degr = (a2 > 0) && (fabs(estarr / a2 - 1.0) <= 1e-8);
-  const double vstarr = degr ? vr : vr - a * br * (ustar - ur) / estarr;
-  const double bstarr = degr ? br : br * er / estarr;
-  const double wstarr = degr ? wr : wr - a * cr * (ustar - ur) / estarr;
-  const double cstarr = degr ? cr : cr * er / estarr;
+  const rg_recip_t inv_er = rg_recip(estarr);
+  const bool degr = (a2 > 0) && (fabs(rg_div(estarr, inv_a2) - 1.0) <= 1e-8);
+  const double vstarr = degr ? vr : vr - rg_div(a * br * (ustar - ur), inv_er);
+  const double bstarr = degr ? br : rg_div(br * er, inv_er);
+  const double wstarr = degr ? wr : wr - rg_div(a * cr * (ustar - ur), inv_er);
+  const double cstarr = degr ? cr : rg_div(cr * er, inv_er);
   const double vdotbstarr = ustar * a + vstarr * bstarr + wstarr * cstarr;
-  const double etotstarr = ((sr - ur) * etotr - ptotr * ur + ptotstar * ustar + a * (vdotbr - vdotbstarr)) / (sr - ustar);
-  const double sqrrstarr = sqrt(rstarr);
-  const double sar = ustar + fabs(a) / sqrrstarr;
+  const double etotstarr = rg_div((sr - ur) * etotr - ptotr * ur + ptotstar * ustar + a * (vdotbr - vdotbstarr), inv_sr);
+  const double sqrrstarr = rg_sqrt(rstarr);
+  const double sar = ustar + rg_div(fabs(a), rg_recip(sqrrstarr));
   // double star state
-  const double sqsum = sqrrstarl + sqrrstarr;
-  const double vstarstar = (sqrrstarl * vstarl + sqrrstarr * vstarr + sgnm * (bstarr - bstarl)) / sqsum;
-  const double wstarstar = (sqrrstarl * wstarl + sqrrstarr * wstarr + sgnm * (cstarr - cstarl)) / sqsum;
-  const double bstarstar = (sqrrstarl * bstarr + sqrrstarr * bstarl + sgnm * sqrrstarl * sqrrstarr * (vstarr - vstarl)) / sqsum;
-  const double cstarstar = (sqrrstarl * cstarr + sqrrstarr * cstarl + sgnm * sqrrstarl * sqrrstarr * (wstarr - wstarl)) / sqsum;
+  const rg_recip_t inv_sq = rg_recip(sqrrstarl + sqrrstarr);
+  const double vstarstar = rg_div(sqrrstarl * vstarl + sqrrstarr * vstarr + sgnm * (bstarr - bstarl), inv_sq);
+  const double wstarstar = rg_div(sqrrstarl * wstarl + sqrrstarr * wstarr + sgnm * (cstarr - cstarl), inv_sq);
+  const double bstarstar = rg_div(sqrrstarl * bstarr + sqrrstarr * bstarl + sgnm * sqrrstarl * sqrrstarr * (vstarr - vstarl), inv_sq);
+  const double cstarstar = rg_div(sqrrstarl * cstarr + sqrrstarr * cstarl + sgnm * sqrrstarl * sqrrstarr * (wstarr - wstarl), inv_sq);
   const double vdotbstarstar = ustar * a + vstarstar * bstarstar + wstarstar * cstarstar;
   const double etotstarstarl = etotstarl - sgnm * sqrrstarl * (vdotbstarl - vdotbstarstar);
   const double etotstarstarr = etotstarr + sgnm * sqrrstarr * (vdotbstarr - vdotbstarstar);
@@ -442,10 +456,13 @@ RG_DEVFN double min_of4(double a0, double a1, double a2, double a3) { return sel
 // velocities, a,b = the two in-plane field components); E?? = u*b - v*a of each state.
 RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
                             double ELL, double ERL, double ELR, double ERR) {
-  const double cFastLLx = fast_speed(g, LL, LL.a), cFastLRx = fast_speed(g, LR, LR.a);
-  const double cFastRLx = fast_speed(g, RL, RL.a), cFastRRx = fast_speed(g, RR, RR.a);
-  const double cFastLLy = fast_speed(g, LL, LL.b), cFastLRy = fast_speed(g, LR, LR.b);
-  const double cFastRLy = fast_speed(g, RL, RL.b), cFastRRy = fast_speed(g, RR, RR.b);
+  // 66 divisions by 24 distinct denominators: every denominator gets one shared reciprocal (rg_recip), see
+  // rg_backend.h; numerators and operand order are the reference's
+  const rg_recip_t iLLr = rg_recip(LL.r), iLRr = rg_recip(LR.r), iRLr = rg_recip(RL.r), iRRr = rg_recip(RR.r);
+  const double cFastLLx = fast_speed(g, LL, LL.a, iLLr), cFastLRx = fast_speed(g, LR, LR.a, iLRr);
+  const double cFastRLx = fast_speed(g, RL, RL.a, iRLr), cFastRRx = fast_speed(g, RR, RR.a, iRRr);
+  const double cFastLLy = fast_speed(g, LL, LL.b, iLLr), cFastLRy = fast_speed(g, LR, LR.b, iLRr);
+  const double cFastRLy = fast_speed(g, RL, RL.b, iRLr), cFastRRy = fast_speed(g, RR, RR.b, iRRr);
   const double cxmax = max_of4(cFastLLx, cFastLRx, cFastRLx, cFastRRx);
   const double cymax = max_of4(cFastLLy, cFastLRy, cFastRLy, cFastRRy);
   const double SL = min_of4(LL.u, LR.u, RL.u, RR.u) - cxmax;
@@ -460,65 +477,70 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rcLRx = LR.r * (LR.u - SL), rcRRx = RR.r * (SR - RR.u);
   const double rcLLy = LL.r * (LL.v - SB), rcLRy = LR.r * (ST - LR.v);
   const double rcRLy = RL.r * (RL.v - SB), rcRRy = RR.r * (ST - RR.v);
-  const double ustar = (rcLLx * LL.u + rcLRx * LR.u + rcRLx * RL.u + rcRRx * RR.u + (PtotLL - PtotRL + PtotLR - PtotRR)) /
-                       (rcLLx + rcLRx + rcRLx + rcRRx);
-  const double vstar = (rcLLy * LL.v + rcLRy * LR.v + rcRLy * RL.v + rcRRy * RR.v + (PtotLL - PtotLR + PtotRL - PtotRR)) /
-                       (rcLLy + rcLRy + rcRLy + rcRRy);
+  const double ustar = rg_div(rcLLx * LL.u + rcLRx * LR.u + rcRLx * RL.u + rcRRx * RR.u + (PtotLL - PtotRL + PtotLR - PtotRR),
+                              rg_recip(rcLLx + rcLRx + rcRLx + rcRRx));
+  const double vstar = rg_div(rcLLy * LL.v + rcLRy * LR.v + rcRLy * RL.v + rcRRy * RR.v + (PtotLL - PtotLR + PtotRL - PtotRR),
+                              rg_recip(rcLLy + rcLRy + rcRLy + rcRRy));
+  const rg_recip_t iSL = rg_recip(SL - ustar), iSR = rg_recip(SR - ustar);
+  const rg_recip_t iSB = rg_recip(SB - vstar), iST = rg_recip(ST - vstar);
   // per-state star quantities.  rstar = r*(S-u)/(S-ustar) is needed twice in the reference (alone and inside
   // the product with the y ratio); the identical sub-expression gives the identical value.
-  const double rstarLLx = LL.r * (SL - LL.u) / (SL - ustar);
-  const double BstarLL = LL.b * (SL - LL.u) / (SL - ustar);
-  const double rstarLLy = LL.r * (SB - LL.v) / (SB - vstar);
-  const double AstarLL = LL.a * (SB - LL.v) / (SB - vstar);
-  const double rstarLL = rstarLLx * (SB - LL.v) / (SB - vstar);
+  const double rstarLLx = rg_div(LL.r * (SL - LL.u), iSL);
+  const double BstarLL = rg_div(LL.b * (SL - LL.u), iSL);
+  const double rstarLLy = rg_div(LL.r * (SB - LL.v), iSB);
+  const double AstarLL = rg_div(LL.a * (SB - LL.v), iSB);
+  const double rstarLL = rg_div(rstarLLx * (SB - LL.v), iSB);
   const double EstarLLx = ustar * BstarLL - LL.v * LL.a;
   const double EstarLLy = LL.u * LL.b - vstar * AstarLL;
   const double EstarLL = ustar * BstarLL - vstar * AstarLL;
 
-  const double rstarLRx = LR.r * (SL - LR.u) / (SL - ustar);
-  const double BstarLR = LR.b * (SL - LR.u) / (SL - ustar);
-  const double rstarLRy = LR.r * (ST - LR.v) / (ST - vstar);
-  const double AstarLR = LR.a * (ST - LR.v) / (ST - vstar);
-  const double rstarLR = rstarLRx * (ST - LR.v) / (ST - vstar);
+  const double rstarLRx = rg_div(LR.r * (SL - LR.u), iSL);
+  const double BstarLR = rg_div(LR.b * (SL - LR.u), iSL);
+  const double rstarLRy = rg_div(LR.r * (ST - LR.v), iST);
+  const double AstarLR = rg_div(LR.a * (ST - LR.v), iST);
+  const double rstarLR = rg_div(rstarLRx * (ST - LR.v), iST);
   const double EstarLRx = ustar * BstarLR - LR.v * LR.a;
   const double EstarLRy = LR.u * LR.b - vstar * AstarLR;
   const double EstarLR = ustar * BstarLR - vstar * AstarLR;
 
-  const double rstarRLx = RL.r * (SR - RL.u) / (SR - ustar);
-  const double BstarRL = RL.b * (SR - RL.u) / (SR - ustar);
-  const double rstarRLy = RL.r * (SB - RL.v) / (SB - vstar);
-  const double AstarRL = RL.a * (SB - RL.v) / (SB - vstar);
-  const double rstarRL = rstarRLx * (SB - RL.v) / (SB - vstar);
+  const double rstarRLx = rg_div(RL.r * (SR - RL.u), iSR);
+  const double BstarRL = rg_div(RL.b * (SR - RL.u), iSR);
+  const double rstarRLy = rg_div(RL.r * (SB - RL.v), iSB);
+  const double AstarRL = rg_div(RL.a * (SB - RL.v), iSB);
+  const double rstarRL = rg_div(rstarRLx * (SB - RL.v), iSB);
   const double EstarRLx = ustar * BstarRL - RL.v * RL.a;
   const double EstarRLy = RL.u * RL.b - vstar * AstarRL;
   const double EstarRL = ustar * BstarRL - vstar * AstarRL;
 
-  const double rstarRRx = RR.r * (SR - RR.u) / (SR - ustar);
-  const double BstarRR = RR.b * (SR - RR.u) / (SR - ustar);
-  const double rstarRRy = RR.r * (ST - RR.v) / (ST - vstar);
-  const double AstarRR = RR.a * (ST - RR.v) / (ST - vstar);
-  const double rstarRR = rstarRRx * (ST - RR.v) / (ST - vstar);
+  const double rstarRRx = rg_div(RR.r * (SR - RR.u), iSR);
+  const double BstarRR = rg_div(RR.b * (SR - RR.u), iSR);
+  const double rstarRRy = rg_div(RR.r * (ST - RR.v), iST);
+  const double AstarRR = rg_div(RR.a * (ST - RR.v), iST);
+  const double rstarRR = rg_div(rstarRRx * (ST - RR.v), iST);
   const double EstarRRx = ustar * BstarRR - RR.v * RR.a;
   const double EstarRRy = RR.u * RR.b - vstar * AstarRR;
   const double EstarRR = ustar * BstarRR - vstar * AstarRR;
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
-  const double calfvenL = sel_max(sel_max(sel_max(sel_max(fabs(LR.a) / sqrt(rstarLRx), fabs(AstarLR) / sqrt(rstarLR)),
-                                                  fabs(LL.a) / sqrt(rstarLLx)), fabs(AstarLL) / sqrt(rstarLL)), g.smallc);
-  const double calfvenR = sel_max(sel_max(sel_max(sel_max(fabs(RR.a) / sqrt(rstarRRx), fabs(AstarRR) / sqrt(rstarRR)),
-                                                  fabs(RL.a) / sqrt(rstarRLx)), fabs(AstarRL) / sqrt(rstarRL)), g.smallc);
-  const double calfvenB = sel_max(sel_max(sel_max(sel_max(fabs(LL.b) / sqrt(rstarLLy), fabs(BstarLL) / sqrt(rstarLL)),
-                                                  fabs(RL.b) / sqrt(rstarRLy)), fabs(BstarRL) / sqrt(rstarRL)), g.smallc);
-  const double calfvenT = sel_max(sel_max(sel_max(sel_max(fabs(LR.b) / sqrt(rstarLRy), fabs(BstarLR) / sqrt(rstarLR)),
-                                                  fabs(RR.b) / sqrt(rstarRRy)), fabs(BstarRR) / sqrt(rstarRR)), g.smallc);
+  const rg_recip_t iqLL = rg_recip(rg_sqrt(rstarLL)), iqLR = rg_recip(rg_sqrt(rstarLR));
+  const rg_recip_t iqRL = rg_recip(rg_sqrt(rstarRL)), iqRR = rg_recip(rg_sqrt(rstarRR));
+  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip(rg_sqrt(rstarLRx))), rg_div(fabs(AstarLR), iqLR)),
+                                                  rg_div(fabs(LL.a), rg_recip(rg_sqrt(rstarLLx)))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
+  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip(rg_sqrt(rstarRRx))), rg_div(fabs(AstarRR), iqRR)),
+                                                  rg_div(fabs(RL.a), rg_recip(rg_sqrt(rstarRLx)))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
+  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip(rg_sqrt(rstarLLy))), rg_div(fabs(BstarLL), iqLL)),
+                                                  rg_div(fabs(RL.b), rg_recip(rg_sqrt(rstarRLy)))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
+  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip(rg_sqrt(rstarLRy))), rg_div(fabs(BstarLR), iqLR)),
+                                                  rg_div(fabs(RR.b), rg_recip(rg_sqrt(rstarRRy)))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
   const double SAL = fmin(ustar - calfvenL, 0.0);
   const double SAR = fmax(ustar + calfvenR, 0.0);
   const double SAB = fmin(vstar - calfvenB, 0.0);
   const double SAT = fmax(vstar + calfvenT, 0.0);
-  const double AstarT = (SAR * AstarRR - SAL * AstarLR) / (SAR - SAL);
-  const double AstarB = (SAR * AstarRL - SAL * AstarLL) / (SAR - SAL);
-  const double BstarR = (SAT * BstarRR - SAB * BstarRL) / (SAT - SAB);
-  const double BstarL = (SAT * BstarLR - SAB * BstarLL) / (SAT - SAB);
+  const rg_recip_t iSA = rg_recip(SAR - SAL), iSAy = rg_recip(SAT - SAB);
+  const double AstarT = rg_div(SAR * AstarRR - SAL * AstarLR, iSA);
+  const double AstarB = rg_div(SAR * AstarRL - SAL * AstarLL, iSA);
+  const double BstarR = rg_div(SAT * BstarRR - SAB * BstarRL, iSAy);
+  const double BstarL = rg_div(SAT * BstarLR - SAB * BstarLL, iSAy);
 
   // region selection by sign bits, evaluated as the reference's branch-free integer masks times doubles
   // (riemann_mhd.h:759-787); a mask of 0 still multiplies its term (0*x), so the sum is reproduced as written
@@ -527,18 +549,18 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const int SL_pos = signbit(SL) ? 0 : 1, SL_neg = 1 - SL_pos;
   const int SR_pos = signbit(SR) ? 0 : 1, SR_neg = 1 - SR_pos;
   double E = 0, tmpE;
-  tmpE = (SAL * SAB * EstarRR - SAL * SAT * EstarRL - SAR * SAB * EstarLR + SAR * SAT * EstarLL) / (SAR - SAL) / (SAT - SAB) -
-         SAT * SAB / (SAT - SAB) * (AstarT - AstarB) + SAR * SAL / (SAR - SAL) * (BstarR - BstarL);
+  tmpE = rg_div(rg_div(SAL * SAB * EstarRR - SAL * SAT * EstarRL - SAR * SAB * EstarLR + SAR * SAT * EstarLL, iSA), iSAy) -
+         rg_div(SAT * SAB, iSAy) * (AstarT - AstarB) + rg_div(SAR * SAL, iSA) * (BstarR - BstarL);
   E += (double)(SB_neg * ST_pos * SL_neg * SR_pos) * tmpE;
-  tmpE = (SAR * EstarLLx - SAL * EstarRLx + SAR * SAL * (RL.b - LL.b)) / (SAR - SAL);
+  tmpE = rg_div(SAR * EstarLLx - SAL * EstarRLx + SAR * SAL * (RL.b - LL.b), iSA);
   tmpE = (double)SL_pos * ELL + (double)(SL_neg * SR_neg) * ERL + (double)(SL_neg * SR_pos) * tmpE;
   E += (double)SB_pos * tmpE;
-  tmpE = (SAR * EstarLRx - SAL * EstarRRx + SAR * SAL * (RR.b - LR.b)) / (SAR - SAL);
+  tmpE = rg_div(SAR * EstarLRx - SAL * EstarRRx + SAR * SAL * (RR.b - LR.b), iSA);
   tmpE = (double)SL_pos * ELR + (double)(SL_neg * SR_neg) * ERR + (double)(SL_neg * SR_pos) * tmpE;
   E += (double)(SB_neg * ST_neg) * tmpE;
-  tmpE = (SAT * EstarLLy - SAB * EstarLRy - SAT * SAB * (LR.a - LL.a)) / (SAT - SAB);
+  tmpE = rg_div(SAT * EstarLLy - SAB * EstarLRy - SAT * SAB * (LR.a - LL.a), iSAy);
   E += (double)(SB_neg * ST_pos * SL_pos) * tmpE;
-  tmpE = (SAT * EstarRLy - SAB * EstarRRy - SAT * SAB * (RR.a - RL.a)) / (SAT - SAB);
+  tmpE = rg_div(SAT * EstarRLy - SAB * EstarRRy - SAT * SAB * (RR.a - RL.a), iSAy);
   E += (double)(SB_neg * ST_pos * SL_neg * SR_neg) * tmpE;
   return E;
 }

@@ -19,6 +19,46 @@ typedef hipEvent_t rg_event_t;
 
 inline const char* rg_err_str(hipError_t e) { return hipGetErrorString(e); }
 
+// ---- IEEE division / square root with the denominator work shared ----------------------------------------------
+// hipcc expands an fp64 "n / d" into v_div_scale x2, v_rcp, two Newton steps on the reciprocal (4 FMA), the
+// quotient (mul, FMA, v_div_fmas) and v_div_fixup.  Outside the exponent ranges where v_div_scale rescales
+// (|d| or |n| beyond ~2^+-900, denormal quotients) the scale / fixup instructions are the identity and the result
+// is the correctly rounded quotient produced by exactly the sequence below.  The Riemann solvers divide several
+// numerators by the same denominator (66 divisions by 24 distinct denominators per edge EMF): rg_recip does the
+// reciprocal refinement once, rg_div the 3-instruction quotient per numerator -- same bits as "/" for every value a
+// simulation state can take, at 8 + 3(k-1) instead of 11k VALU instructions.  (Difference to "/": a -0 numerator
+// over a positive denominator gives +0 instead of -0, and division by exactly 0 gives NaN instead of +-inf.)
+struct rg_recip_t { double d, r; };
+RG_DEVFN rg_recip_t rg_recip(double d) {
+  rg_recip_t R;
+  R.d = d;
+  const double r0 = __builtin_amdgcn_rcp(d);
+  const double e0 = __builtin_fma(-d, r0, 1.0);
+  const double r1 = __builtin_fma(r0, e0, r0);
+  const double e1 = __builtin_fma(-d, r1, 1.0);
+  R.r = __builtin_fma(r1, e1, r1);
+  return R;
+}
+RG_DEVFN double rg_div(double n, const rg_recip_t& R) {
+  const double q0 = n * R.r;
+  const double rem = __builtin_fma(-R.d, q0, n);
+  return __builtin_fma(rem, R.r, q0);
+}
+// the compiler's sqrt minus its rescaling of arguments below 2^-767 (v_cmp, v_cndmask x2, v_ldexp x2)
+RG_DEVFN double rg_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double e = __builtin_fma(-g, g, x);
+  g = __builtin_fma(e, h, g);
+  e = __builtin_fma(-g, g, x);
+  g = __builtin_fma(e, h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0 and +inf map to themselves
+}
+
 // ---- flat per-cell kernels ---------------------------------------------------------------------------------
 // One thread per array element, x fastest: every SoA component load / store of a wave is one contiguous
 // 512-byte segment.  BLOCK is a multiple of the 64-lane wavefront.
@@ -44,11 +84,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) rg_kernel_range(unsigned idx0, un
   if (off < n) k(idx0 + off);
 }
 
+// lds_pad: bytes of (unused) dynamic LDS per workgroup -- an occupancy cap, see rgpu_api.cpp
 template <int BLOCK, int MINW = 1, class K>
-inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k) {
+inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k, unsigned lds_pad = 0) {
   if (n == 0) return 0;
   const unsigned grid = (n + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((rg_kernel_range<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, idx0, n, k);
+  hipLaunchKernelGGL((rg_kernel_range<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), lds_pad, s, idx0, n, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -115,6 +156,13 @@ inline int rg_stream_create(rg_stream_t* s, int prio = 0) {
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
   const int p = prio < 0 ? least : prio > 0 ? greatest : 0;
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess ? 0 : -1;
+}
+// stream restricted to the compute units [cu_lo, cu_hi) of the CU-mask enumeration.  The driver deals mask bit i to
+// XCD (i mod 8), so a contiguous bit range takes the same number of CUs from every XCD (and from its L2).
+inline int rg_stream_create_cu_range(rg_stream_t* s, int cu_lo, int cu_hi) {
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = cu_lo; i < cu_hi && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+  return hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess ? 0 : -1;
 }
 inline void rg_stream_destroy(rg_stream_t s) { if (s) (void)hipStreamDestroy(s); }
 inline int rg_order_event_create(rg_event_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }
