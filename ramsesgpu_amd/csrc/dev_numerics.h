@@ -15,6 +15,7 @@ using rgpu::rg_recip_t;
 using rgpu::rg_recip;
 using rgpu::rg_div;
 using rgpu::rg_sqrt;
+using rgpu::rg_sqrt_pos;
 
 enum { ID = 0, IP = 1, IU = 2, IV = 3, IW = 4, IA = 5, IB = 6, IC = 7 };
 enum { XD = 0, YD = 1, ZD = 2 };
@@ -67,9 +68,10 @@ RG_DEVFN double minmod_slope(double qm, double q0, double qp) {
 template <int NV>
 RG_DEVFN double hydro_prim(const DevParams& g, const double* u, double* q) {
   q[ID] = fmax(u[ID], g.smallr);
-  q[IU] = u[IU] / q[ID];
-  q[IV] = u[IV] / q[ID];
-  if (NV == 5) q[IW] = u[IW] / q[ID];
+  const rg_recip_t inv_r = rg_recip(q[ID]);
+  q[IU] = rg_div(u[IU], inv_r);
+  q[IV] = rg_div(u[IV], inv_r);
+  if (NV == 5) q[IW] = rg_div(u[IW], inv_r);
   double eken;
   if (NV == 5) eken = 0.5 * (q[IU] * q[IU] + q[IV] * q[IV] + q[IW] * q[IW]);
   else eken = 0.5 * (q[IU] * q[IU] + q[IV] * q[IV]);
@@ -77,9 +79,9 @@ RG_DEVFN double hydro_prim(const DevParams& g, const double* u, double* q) {
     q[IP] = q[ID] * g.cIso * g.cIso;
     return g.cIso;
   }
-  const double eint = u[IP] / q[ID] - eken;
+  const double eint = rg_div(u[IP], inv_r) - eken;
   q[IP] = fmax((g.gamma0 - 1.0) * q[ID] * eint, q[ID] * g.smallp);
-  return sqrt(g.gamma0 * q[IP] / q[ID]);
+  return rg_sqrt(rg_div(g.gamma0 * q[IP], inv_r));
 }
 
 // cmpflx (cmpflx.h:21-48)
@@ -110,36 +112,38 @@ RG_DEVFN void riemann_approx(const DevParams& g, const double* ql, const double*
   const double rl = fmax(ql[ID], g.smallr), ul = ql[IU], pl = fmax(ql[IP], rl * g.smallp);
   const double rr = fmax(qr[ID], g.smallr), ur = qr[IU], pr = fmax(qr[IP], rr * g.smallp);
   const double cl = g.gamma0 * pl * rl, cr = g.gamma0 * pr * rr;
-  double wl = sqrt(cl), wr = sqrt(cr);
-  double pstar = fmax(((wr * pl + wl * pr) + wl * wr * (ul - ur)) / (wl + wr), 0.0);
+  double wl = rg_sqrt(cl), wr = rg_sqrt(cr);
+  double pstar = fmax(rg_div((wr * pl + wl * pr) + wl * wr * (ul - ur), rg_recip(wl + wr)), 0.0);
+  const rg_recip_t inv_pl = rg_recip(pl), inv_pr = rg_recip(pr);   // reused by every Newton iteration
   double pold = pstar, conv = 1.0;
   for (int iter = 0; iter < g.niter_riemann && conv > 1e-6; ++iter) {
-    const double wwl = sqrt(cl * (1.0 + g.gamma6 * (pold - pl) / pl));
-    const double wwr = sqrt(cr * (1.0 + g.gamma6 * (pold - pr) / pr));
-    const double q_l = 2.0 * wwl * wwl * wwl / (wwl * wwl + cl);
-    const double q_r = 2.0 * wwr * wwr * wwr / (wwr * wwr + cr);
-    const double usl = ul - (pold - pl) / wwl;
-    const double usr = ur + (pold - pr) / wwr;
-    const double delp = fmax(q_r * q_l / (q_r + q_l) * (usl - usr), -pold);
+    const double wwl = rg_sqrt(cl * (1.0 + rg_div(g.gamma6 * (pold - pl), inv_pl)));
+    const double wwr = rg_sqrt(cr * (1.0 + rg_div(g.gamma6 * (pold - pr), inv_pr)));
+    const double q_l = rg_div(2.0 * wwl * wwl * wwl, rg_recip(wwl * wwl + cl));
+    const double q_r = rg_div(2.0 * wwr * wwr * wwr, rg_recip(wwr * wwr + cr));
+    const double usl = ul - rg_div(pold - pl, rg_recip(wwl));
+    const double usr = ur + rg_div(pold - pr, rg_recip(wwr));
+    const double delp = fmax(rg_div(q_r * q_l, rg_recip(q_r + q_l)) * (usl - usr), -pold);
     pold = pold + delp;
-    conv = fabs(delp / (pold + g.smallpp));
+    conv = fabs(rg_div(delp, rg_recip(pold + g.smallpp)));
   }
   pstar = pold;
-  wl = sqrt(cl * (1.0 + g.gamma6 * (pstar - pl) / pl));
-  wr = sqrt(cr * (1.0 + g.gamma6 * (pstar - pr) / pr));
-  const double ustar = 0.5 * (ul + (pl - pstar) / wl + ur - (pr - pstar) / wr);
+  wl = rg_sqrt(cl * (1.0 + rg_div(g.gamma6 * (pstar - pl), inv_pl)));
+  wr = rg_sqrt(cr * (1.0 + rg_div(g.gamma6 * (pstar - pr), inv_pr)));
+  const double ustar = 0.5 * (ul + rg_div(pl - pstar, rg_recip(wl)) + ur - rg_div(pr - pstar, rg_recip(wr)));
   const double sgnm = copysign(1.0, ustar);
   const bool from_left = sgnm > 0.0;
   const double ro = from_left ? rl : rr, uo = from_left ? ul : ur, po = from_left ? pl : pr, wo = from_left ? wl : wr;
-  const double co = fmax(g.smallc, sqrt(fabs(g.gamma0 * po / ro)));
-  const double rstar = fmax(ro / (1.0 + ro * (po - pstar) / (wo * wo)), g.smallr);
-  const double cstar = fmax(g.smallc, sqrt(fabs(g.gamma0 * pstar / rstar)));
+  const rg_recip_t inv_ro = rg_recip(ro);
+  const double co = fmax(g.smallc, rg_sqrt(fabs(rg_div(g.gamma0 * po, inv_ro))));
+  const double rstar = fmax(rg_div(ro, rg_recip(1.0 + rg_div(ro * (po - pstar), rg_recip(wo * wo)))), g.smallr);
+  const double cstar = fmax(g.smallc, rg_sqrt(fabs(rg_div(g.gamma0 * pstar, rg_recip(rstar)))));
   double spout = co - sgnm * uo;
   double spin = cstar - sgnm * ustar;
-  const double ushock = wo / ro - sgnm * uo;
+  const double ushock = rg_div(wo, inv_ro) - sgnm * uo;
   if (pstar >= po) { spin = ushock; spout = ushock; }
   const double scr = fmax(spout - spin, g.smallc + fabs(spout + spin));
-  double frac = 0.5 * (1.0 + (spout + spin) / scr);
+  double frac = 0.5 * (1.0 + rg_div(spout + spin, rg_recip(scr)));
   frac = (frac != frac) ? 0.0 : saturate_via_float(frac);
   double qg[NV];
   qg[ID] = frac * rstar + (1.0 - frac) * ro;
@@ -204,17 +208,19 @@ RG_DEVFN void riemann_hllc(const DevParams& g, const double* ql, const double* q
   ecinr += 0.5 * rr * qr[IV] * qr[IV];
   if (NV == 5) ecinr += 0.5 * rr * qr[IW] * qr[IW];
   const double etotr = pr * entho + ecinr;
-  const double cfastl = sqrt(fmax(g.gamma0 * pl / rl, g.smallc * g.smallc));
-  const double cfastr = sqrt(fmax(g.gamma0 * pr / rr, g.smallc * g.smallc));
+  const double cfastl = rg_sqrt(fmax(rg_div(g.gamma0 * pl, rg_recip(rl)), g.smallc * g.smallc));
+  const double cfastr = rg_sqrt(fmax(rg_div(g.gamma0 * pr, rg_recip(rr)), g.smallc * g.smallc));
   const double SL = fmin(ul, ur) - fmax(cfastl, cfastr);
   const double SR = fmax(ul, ur) + fmax(cfastl, cfastr);
   const double rcl = rl * (ul - SL), rcr = rr * (SR - ur);
-  const double ustar = (rcr * ur + rcl * ul + (pl - pr)) / (rcr + rcl);
-  const double ptotstar = (rcr * pl + rcl * pr + rcl * rcr * (ul - ur)) / (rcr + rcl);
-  const double rstarl = rl * (SL - ul) / (SL - ustar);
-  const double etotstarl = ((SL - ul) * etotl - pl * ul + ptotstar * ustar) / (SL - ustar);
-  const double rstarr = rr * (SR - ur) / (SR - ustar);
-  const double etotstarr = ((SR - ur) * etotr - pr * ur + ptotstar * ustar) / (SR - ustar);
+  const rg_recip_t inv_rc = rg_recip(rcr + rcl);
+  const double ustar = rg_div(rcr * ur + rcl * ul + (pl - pr), inv_rc);
+  const double ptotstar = rg_div(rcr * pl + rcl * pr + rcl * rcr * (ul - ur), inv_rc);
+  const rg_recip_t inv_sl = rg_recip(SL - ustar), inv_sr = rg_recip(SR - ustar);
+  const double rstarl = rg_div(rl * (SL - ul), inv_sl);
+  const double etotstarl = rg_div((SL - ul) * etotl - pl * ul + ptotstar * ustar, inv_sl);
+  const double rstarr = rg_div(rr * (SR - ur), inv_sr);
+  const double etotstarr = rg_div((SR - ur) * etotr - pr * ur + ptotstar * ustar, inv_sr);
   double ro, uo, ptoto, etoto;
   if (SL > 0.0) { ro = rl; uo = ul; ptoto = pl; etoto = etotl; }
   else if (ustar > 0.0) { ro = rstarl; uo = ustar; ptoto = ptotstar; etoto = etotstarl; }
@@ -245,9 +251,10 @@ RG_DEVFN void hydro_riemann(const DevParams& g, const double* ql, const double* 
 RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double bny, double bnz, double dt) {
   Prim8 q;
   q.r = fmax(u[ID], g.smallr);
-  q.u = u[IU] / q.r;
-  q.v = u[IV] / q.r;
-  q.w = u[IW] / q.r;
+  const rg_recip_t inv_r = rg_recip(q.r);
+  q.u = rg_div(u[IU], inv_r);
+  q.v = rg_div(u[IV], inv_r);
+  q.w = rg_div(u[IW], inv_r);
   q.a = 0.5 * (u[IA] + bnx);
   q.b = 0.5 * (u[IB] + bny);
   q.c = 0.5 * (u[IC] + bnz);
@@ -256,7 +263,7 @@ RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double 
   if (g.cIso > 0) {
     q.p = q.r * g.cIso * g.cIso;
   } else {
-    const double eint = (u[IP] - emag) / q.r - eken;
+    const double eint = rg_div(u[IP] - emag, inv_r) - eken;
     q.p = fmax((g.gamma0 - 1.0) * q.r * eint, q.r * g.smallp);
   }
   if (g.Omega0 > 0) {  // Coriolis half-step predictor: both increments from the un-updated velocities
@@ -275,18 +282,19 @@ RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn, const 
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
   const double c2 = rg_div(g.gamma0 * q.p, inv_r);
   const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
-  return rg_sqrt(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r)));
+  return rg_sqrt_pos(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r)));   // d2 > 0: p > 0
 }
 RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn) { return fast_speed(g, q, bn, rg_recip(q.r)); }
 
 // find_speed_info<NDIM> (mhd_utils.h:241-284): sum_d (cf_d + |v_d|)/delta_d is formed by the caller
 RG_DEVFN void info_speeds(const DevParams& g, const Prim8& q, double& sx, double& sy, double& sz) {
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
-  const double c2 = g.gamma0 * q.p / q.r;
-  const double d2 = 0.5 * (b2 / q.r + c2);
-  sx = sqrt(d2 + sqrt(d2 * d2 - c2 * q.a * q.a / q.r)) + fabs(q.u);
-  sy = sqrt(d2 + sqrt(d2 * d2 - c2 * q.b * q.b / q.r)) + fabs(q.v);
-  sz = sqrt(d2 + sqrt(d2 * d2 - c2 * q.c * q.c / q.r)) + fabs(q.w);
+  const rg_recip_t inv_r = rg_recip(q.r);
+  const double c2 = rg_div(g.gamma0 * q.p, inv_r);
+  const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
+  sx = rg_sqrt(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * q.a * q.a, inv_r))) + fabs(q.u);
+  sy = rg_sqrt(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * q.b * q.b, inv_r))) + fabs(q.v);
+  sz = rg_sqrt(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * q.c * q.c, inv_r))) + fabs(q.w);
 }
 
 // find_mhd_flux (mhd_utils.h:106-156): conservative vector and flux of a primitive state (normal frame)
@@ -360,7 +368,7 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double cstarl = degl ? cl : rg_div(cl * el, inv_el);
   const double vdotbstarl = ustar * a + vstarl * bstarl + wstarl * cstarl;
   const double etotstarl = rg_div((sl - ul) * etotl - ptotl * ul + ptotstar * ustar + a * (vdotbl - vdotbstarl), inv_sl);
-  const double sqrrstarl = rg_sqrt(rstarl);
+  const double sqrrstarl = rg_sqrt_pos(rstarl);
   const double sal = ustar - rg_div(fabs(a), rg_recip(sqrrstarl));
   // right star state
   const rg_recip_t inv_sr = rg_recip(sr - ustar);
@@ -375,7 +383,7 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double cstarr = degr ? cr : rg_div(cr * er, inv_er);
   const double vdotbstarr = ustar * a + vstarr * bstarr + wstarr * cstarr;
   const double etotstarr = rg_div((sr - ur) * etotr - ptotr * ur + ptotstar * ustar + a * (vdotbr - vdotbstarr), inv_sr);
-  const double sqrrstarr = rg_sqrt(rstarr);
+  const double sqrrstarr = rg_sqrt_pos(rstarr);
   const double sar = ustar + rg_div(fabs(a), rg_recip(sqrrstarr));
   // double star state
   const rg_recip_t inv_sq = rg_recip(sqrrstarl + sqrrstarr);
@@ -522,16 +530,16 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double EstarRR = ustar * BstarRR - vstar * AstarRR;
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
-  const rg_recip_t iqLL = rg_recip(rg_sqrt(rstarLL)), iqLR = rg_recip(rg_sqrt(rstarLR));
-  const rg_recip_t iqRL = rg_recip(rg_sqrt(rstarRL)), iqRR = rg_recip(rg_sqrt(rstarRR));
-  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip(rg_sqrt(rstarLRx))), rg_div(fabs(AstarLR), iqLR)),
-                                                  rg_div(fabs(LL.a), rg_recip(rg_sqrt(rstarLLx)))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
-  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip(rg_sqrt(rstarRRx))), rg_div(fabs(AstarRR), iqRR)),
-                                                  rg_div(fabs(RL.a), rg_recip(rg_sqrt(rstarRLx)))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
-  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip(rg_sqrt(rstarLLy))), rg_div(fabs(BstarLL), iqLL)),
-                                                  rg_div(fabs(RL.b), rg_recip(rg_sqrt(rstarRLy)))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
-  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip(rg_sqrt(rstarLRy))), rg_div(fabs(BstarLR), iqLR)),
-                                                  rg_div(fabs(RR.b), rg_recip(rg_sqrt(rstarRRy)))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
+  const rg_recip_t iqLL = rg_recip(rg_sqrt_pos(rstarLL)), iqLR = rg_recip(rg_sqrt_pos(rstarLR));
+  const rg_recip_t iqRL = rg_recip(rg_sqrt_pos(rstarRL)), iqRR = rg_recip(rg_sqrt_pos(rstarRR));
+  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip(rg_sqrt_pos(rstarLRx))), rg_div(fabs(AstarLR), iqLR)),
+                                                  rg_div(fabs(LL.a), rg_recip(rg_sqrt_pos(rstarLLx)))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
+  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip(rg_sqrt_pos(rstarRRx))), rg_div(fabs(AstarRR), iqRR)),
+                                                  rg_div(fabs(RL.a), rg_recip(rg_sqrt_pos(rstarRLx)))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
+  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip(rg_sqrt_pos(rstarLLy))), rg_div(fabs(BstarLL), iqLL)),
+                                                  rg_div(fabs(RL.b), rg_recip(rg_sqrt_pos(rstarRLy)))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
+  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip(rg_sqrt_pos(rstarLRy))), rg_div(fabs(BstarLR), iqLR)),
+                                                  rg_div(fabs(RR.b), rg_recip(rg_sqrt_pos(rstarRRy)))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
   const double SAL = fmin(ustar - calfvenL, 0.0);
   const double SAR = fmax(ustar + calfvenR, 0.0);
   const double SAB = fmin(vstar - calfvenB, 0.0);

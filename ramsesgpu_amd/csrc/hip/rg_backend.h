@@ -59,6 +59,20 @@ RG_DEVFN double rg_sqrt(double x) {
   return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0 and +inf map to themselves
 }
 
+// same for an argument known to be positive and finite (densities, d2 + sqrt(..) of the fast speed): no +-0 / inf test
+RG_DEVFN double rg_sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double e = __builtin_fma(-g, g, x);
+  g = __builtin_fma(e, h, g);
+  e = __builtin_fma(-g, g, x);
+  return __builtin_fma(e, h, g);
+}
+
 // ---- flat per-cell kernels ---------------------------------------------------------------------------------
 // One thread per array element, x fastest: every SoA component load / store of a wave is one contiguous
 // 512-byte segment.  BLOCK is a multiple of the 64-lane wavefront.
@@ -84,12 +98,51 @@ __global__ void __launch_bounds__(BLOCK, MINW) rg_kernel_range(unsigned idx0, un
   if (off < n) k(idx0 + off);
 }
 
-// lds_pad: bytes of (unused) dynamic LDS per workgroup -- an occupancy cap, see rgpu_api.cpp
 template <int BLOCK, int MINW = 1, class K>
-inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k, unsigned lds_pad = 0) {
+inline int rg_launch_range(rg_stream_t s, unsigned idx0, unsigned n, const K& k) {
   if (n == 0) return 0;
   const unsigned grid = (n + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL((rg_kernel_range<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), lds_pad, s, idx0, n, k);
+  hipLaunchKernelGGL((rg_kernel_range<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, idx0, n, k);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// same body over whole z planes [idx0 + p * plane_cells, +plane_cells), p < nplanes, with an XCD-aware order.
+// The dispatcher deals workgroup b to XCD (b mod 8), each XCD with its own 4 MB L2.  With the linear mapping a
+// cell's y and z stencil neighbours are fetched by other XCDs, so every stencil re-read misses L2 and goes to
+// Infinity Cache / HBM.  Here XCD x owns the y band x of every plane (band = 1/8 of the plane's workgroups) and
+// walks it in sub-bands of T workgroups: sub-band s of plane 0, 1, ... nplanes-1, then sub-band s+1.  The +-1 row
+// and +-1 plane neighbours of a sub-band were touched by the same XCD a few hundred workgroups earlier: the
+// working set (3 planes x sub-band x ~14 components ~ 1.5 MB at T*BLOCK = 4096 cells) stays in that XCD's L2.
+struct rg_plane_map {
+  unsigned idx0, plane_cells, nplanes, band, T;   // band = workgroups per XCD and plane, T = workgroups per sub-band
+};
+template <int BLOCK, class K, int MINW = 1>
+__global__ void __launch_bounds__(BLOCK, MINW) rg_kernel_planes(rg_plane_map m, K k) {
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b & 7u, slot = b >> 3;
+  const unsigned per_sub = m.nplanes * m.T;
+  const unsigned s = slot / per_sub, r = slot - s * per_sub;
+  const unsigned p = r / m.T, t = r - p * m.T;
+  const unsigned in_band = s * m.T + t;
+  const unsigned off = (xcd * m.band + in_band) * (unsigned)BLOCK + threadIdx.x;
+  if (in_band < m.band && off < m.plane_cells) k(m.idx0 + p * m.plane_cells + off);
+}
+inline unsigned& rg_xcd_sub_cells() { static unsigned v = 4096; return v; }   // 0: linear order
+template <int BLOCK, int MINW = 1, class K>
+inline int rg_launch_planes(rg_stream_t s, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k) {
+  if (nplanes == 0 || plane_cells == 0) return 0;
+  const unsigned sub = rg_xcd_sub_cells();
+  if (sub == 0) return rg_launch_range<BLOCK, MINW>(s, idx0, plane_cells * nplanes, k);
+  rg_plane_map m;
+  m.idx0 = idx0; m.plane_cells = plane_cells; m.nplanes = nplanes;
+  const unsigned bpp = (plane_cells + BLOCK - 1) / BLOCK;
+  m.band = (bpp + 7) / 8;
+  unsigned T = sub / BLOCK > 0 ? sub / BLOCK : 1;
+  if (T > m.band) T = m.band;
+  const unsigned nsub = (m.band + T - 1) / T;
+  m.T = (m.band + nsub - 1) / nsub;   // equal sub-bands: at most nsub-1 idle workgroup slots per band
+  const unsigned grid = 8u * nsub * nplanes * m.T;
+  hipLaunchKernelGGL((rg_kernel_planes<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, m, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -156,13 +209,6 @@ inline int rg_stream_create(rg_stream_t* s, int prio = 0) {
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; }
   const int p = prio < 0 ? least : prio > 0 ? greatest : 0;
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p) == hipSuccess ? 0 : -1;
-}
-// stream restricted to the compute units [cu_lo, cu_hi) of the CU-mask enumeration.  The driver deals mask bit i to
-// XCD (i mod 8), so a contiguous bit range takes the same number of CUs from every XCD (and from its L2).
-inline int rg_stream_create_cu_range(rg_stream_t* s, int cu_lo, int cu_hi) {
-  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = cu_lo; i < cu_hi && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
-  return hipExtStreamCreateWithCUMask(s, 8, mask) == hipSuccess ? 0 : -1;
 }
 inline void rg_stream_destroy(rg_stream_t s) { if (s) (void)hipStreamDestroy(s); }
 inline int rg_order_event_create(rg_event_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess ? 0 : -1; }

@@ -50,18 +50,19 @@ RG_DEVFN void hydro_trace_cell(const DevParams& g, const double* __restrict__ Q,
   const double drx = h[0][ID], dpx = h[0][IP], dux = h[0][IU], dvx = h[0][IV];
   const double dry = h[1][ID], dpy = h[1][IP], duy = h[1][IU], dvy = h[1][IV];
   double sr0, su0, sv0, sw0 = 0.0, sp0;
+  const rg_recip_t inv_r = rg_recip(r);
   if (ND == 2) {
     sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy;
-    su0 = (-u * dux - dpx / r) * dtdx + (-v * duy) * dtdy;
-    sv0 = (-u * dvx) * dtdx + (-v * dvy - dpy / r) * dtdy;
+    su0 = (-u * dux - rg_div(dpx, inv_r)) * dtdx + (-v * duy) * dtdy;
+    sv0 = (-u * dvx) * dtdx + (-v * dvy - rg_div(dpy, inv_r)) * dtdy;
     sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy;
   } else {
     const double dwx = h[0][NV - 1], dwy = h[1][NV - 1];
     const double drz = h[ND - 1][ID], dpz = h[ND - 1][IP], duz = h[ND - 1][IU], dvz = h[ND - 1][IV], dwz = h[ND - 1][NV - 1];
     sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy + (-w * drz - dwz * r) * dtdz;
-    su0 = (-u * dux - dpx / r) * dtdx + (-v * duy) * dtdy + (-w * duz) * dtdz;
-    sv0 = (-u * dvx) * dtdx + (-v * dvy - dpy / r) * dtdy + (-w * dvz) * dtdz;
-    sw0 = (-u * dwx) * dtdx + (-v * dwy) * dtdy + (-w * dwz - dpz / r) * dtdz;
+    su0 = (-u * dux - rg_div(dpx, inv_r)) * dtdx + (-v * duy) * dtdy + (-w * duz) * dtdz;
+    sv0 = (-u * dvx) * dtdx + (-v * dvy - rg_div(dpy, inv_r)) * dtdy + (-w * dvz) * dtdz;
+    sw0 = (-u * dwx) * dtdx + (-v * dwy) * dtdy + (-w * dwz - rg_div(dpz, inv_r)) * dtdz;
     sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy + (-w * dpz - dwz * gamma * p) * dtdz;
   }
   r = r + sr0; u = u + su0; v = v + sv0; w = w + sw0; p = p + sp0;

@@ -72,9 +72,10 @@ RG_DEVFN void mhd_trace2d_cell(const DevParams& g, const double* __restrict__ U,
   const double gamma = g.gamma0;
 
   const double sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy;
-  const double su0 = (-u * dux - dpx / r - B * dBx / r - C * dCx / r) * dtdx + (-v * duy + B * dAy / r) * dtdy;
-  const double sv0 = (-u * dvx + A * dBx / r) * dtdx + (-v * dvy - dpy / r - A * dAy / r - C * dCy / r) * dtdy;
-  const double sw0 = (-u * dwx + A * dCx / r) * dtdx + (-v * dwy + B * dCy / r) * dtdy;
+  const rg_recip_t inv_r = rg_recip(r);
+  const double su0 = (-u * dux - rg_div(dpx, inv_r) - rg_div(B * dBx, inv_r) - rg_div(C * dCx, inv_r)) * dtdx + (-v * duy + rg_div(B * dAy, inv_r)) * dtdy;
+  const double sv0 = (-u * dvx + rg_div(A * dBx, inv_r)) * dtdx + (-v * dvy - rg_div(dpy, inv_r) - rg_div(A * dAy, inv_r) - rg_div(C * dCy, inv_r)) * dtdy;
+  const double sw0 = (-u * dwx + rg_div(A * dCx, inv_r)) * dtdx + (-v * dwy + rg_div(B * dCy, inv_r)) * dtdy;
   const double sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy;
   const double sA0 = (u * dBy + B * duy - v * dAy - A * dvy) * dtdy;
   const double sB0 = (-u * dBx - B * dux + v * dAx + A * dvx) * dtdx;

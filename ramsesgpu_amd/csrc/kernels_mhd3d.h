@@ -138,9 +138,10 @@ RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const double* __restrict__ 
   const double gamma = g.gamma0;
 
   double sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy + (-w * drz - dwz * r) * dtdz;
-  double su0 = (-u * dux - (dpx + B * dBx + C * dCx) / r) * dtdx + (-v * duy + B * dAy / r) * dtdy + (-w * duz + C * dAz / r) * dtdz;
-  double sv0 = (-u * dvx + A * dBx / r) * dtdx + (-v * dvy - (dpy + A * dAy + C * dCy) / r) * dtdy + (-w * dvz + C * dBz / r) * dtdz;
-  double sw0 = (-u * dwx + A * dCx / r) * dtdx + (-v * dwy + B * dCy / r) * dtdy + (-w * dwz - (dpz + A * dAz + B * dBz) / r) * dtdz;
+  const rg_recip_t inv_r = rg_recip(r);   // nine divisions by the density
+  double su0 = (-u * dux - rg_div(dpx + B * dBx + C * dCx, inv_r)) * dtdx + (-v * duy + rg_div(B * dAy, inv_r)) * dtdy + (-w * duz + rg_div(C * dAz, inv_r)) * dtdz;
+  double sv0 = (-u * dvx + rg_div(A * dBx, inv_r)) * dtdx + (-v * dvy - rg_div(dpy + A * dAy + C * dCy, inv_r)) * dtdy + (-w * dvz + rg_div(C * dBz, inv_r)) * dtdz;
+  double sw0 = (-u * dwx + rg_div(A * dCx, inv_r)) * dtdx + (-v * dwy + rg_div(B * dCy, inv_r)) * dtdy + (-w * dwz - rg_div(dpz + A * dAz + B * dBz, inv_r)) * dtdz;
   double sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy + (-w * dpz - dwz * gamma * p) * dtdz;
   double sA0 = (u * dBy + B * duy - v * dAy - A * dvy) * dtdy + (u * dCz + C * duz - w * dAz - A * dwz) * dtdz;
   double sB0 = (v * dAx + A * dvx - u * dBx - B * dux) * dtdx + (v * dCz + C * dvz - w * dBz - B * dwz) * dtdz;
@@ -467,8 +468,9 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
   const bool shear = ROT && g.shearbox;
   if (in_i && in_j && in_k) {
     if (ROT) {  // Coriolis, before any flux is applied to this cell (MHDRunGodunov.cpp:2938-2945)
-      const double dsx = 2.0 * g.Omega0 * dt * u[IV] / (1.0 + rc.lambda);
-      const double dsy = -0.5 * g.Omega0 * dt * u[IU] / (1.0 + rc.lambda);
+      const rg_recip_t inv_l = rg_recip(1.0 + rc.lambda);
+      const double dsx = rg_div(2.0 * g.Omega0 * dt * u[IV], inv_l);
+      const double dsy = rg_div(-0.5 * g.Omega0 * dt * u[IU], inv_l);
       u[IU] = u[IU] * rc.ratio + dsx;
       u[IV] = u[IV] * rc.ratio + dsy;
     }

@@ -44,9 +44,6 @@ struct rgpu_ctx {
   enum { kMaxChunks = 256 };
   int nchunks;
   rg_stream_t stream2;
-  rg_stream_t stream_mem;   // optional CU-partitioned stream for the HBM-bound stages (0: use `stream`)
-  rg_event_t ev_join;
-  unsigned alu_lds_pad;
   rg_event_t ev_fork, ev_trace[kMaxChunks], ev_flux[kMaxChunks];
   std::string err;
 };
@@ -168,8 +165,6 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
   c->stream = (rg_stream_t)0;
   c->stream2 = (rg_stream_t)0;
-  c->stream_mem = (rg_stream_t)0;
-  c->alu_lds_pad = 0;
   c->nchunks = 1;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
@@ -197,6 +192,8 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     return fail(c, RGPU_ENOMEM, "allocation of the reduction slot failed");
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
+  // sub-band size (cells) of the XCD-aware workgroup order, 0 = linear order (rg_backend.h: rg_launch_planes)
+  if (std::getenv("RGPU_XCD_SUB")) rg_xcd_sub_cells() = (unsigned)std::atoi(std::getenv("RGPU_XCD_SUB"));
   if (p->mhdEnabled && c->g.three_d) {
     // default: chunks of ~8 planes (measured best at 512^3: 64 chunks 75.7 ms/step vs 82-84 ms serial; 128 chunks
     // 77.4, 256 chunks 82.6); RGPU_CHUNKS=1 selects the serial single-stream schedule.  Equal stream priorities
@@ -205,19 +202,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (want > c->g.ksize / 2) want = c->g.ksize / 2;
     if (want > rgpu_ctx::kMaxChunks) want = rgpu_ctx::kMaxChunks;
     const int alu_prio = std::getenv("RGPU_ALU_PRIO") ? std::atoi(std::getenv("RGPU_ALU_PRIO")) : 0;
-    // experimental: RGPU_CU_SPLIT=n gives the VALU-bound stages CUs [0,n) and the HBM-bound stages CUs [n,256)
-    const int cu_split = std::getenv("RGPU_CU_SPLIT") ? std::atoi(std::getenv("RGPU_CU_SPLIT")) : 0;
-    c->alu_lds_pad = std::getenv("RGPU_ALU_LDS") ? (unsigned)std::atoi(std::getenv("RGPU_ALU_LDS")) : 0u;
-    int s2 = -1;
-    if (want > 1) {
-      if (cu_split > 0 && cu_split < 256) {
-        s2 = rg_stream_create_cu_range(&c->stream2, 0, cu_split);
-        if (s2 == 0 && (rg_stream_create_cu_range(&c->stream_mem, cu_split, 256) || rg_order_event_create(&c->ev_join))) s2 = -1;
-      } else {
-        s2 = rg_stream_create(&c->stream2, alu_prio);
-      }
-    }
-    if (want > 1 && s2 == 0) {
+    if (want > 1 && rg_stream_create(&c->stream2, alu_prio) == 0) {
       bool ok = rg_order_event_create(&c->ev_fork) == 0;
       for (int i = 0; i < want && ok; ++i) ok = rg_order_event_create(&c->ev_trace[i]) == 0 && rg_order_event_create(&c->ev_flux[i]) == 0;
       if (ok) c->nchunks = want;
@@ -339,9 +324,9 @@ inline PlaneRange clip(int lo, int hi, int ksize) {
   return r;
 }
 template <int BLOCK, int MINW, class K>
-int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k, unsigned lds_pad = 0) {
+int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
   if (r.hi <= r.lo) return 0;
-  return rg_launch_range<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, (unsigned)(r.hi - r.lo) * g.sk, k, lds_pad);
+  return rg_launch_planes<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k);
 }
 
 template <int ND, int NV>
@@ -427,14 +412,12 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 
   // chunked two-stream schedule: stage s has completed planes [.., done_s); per chunk each stage advances to what
   // the update of planes < kb needs
-  rg_stream_t sm = c->stream_mem ? c->stream_mem : c->stream, sa = c->stream2;
+  rg_stream_t sm = c->stream, sa = c->stream2;
   const int span = b - a;
   int C = (span + 7) / 8;
   if (C > c->nchunks) C = c->nchunks;
   if (C < 1) C = 1;
-  if (rg_event_record(c->ev_fork, c->stream) || rg_stream_wait_event(sa, c->ev_fork)) return -1;
-  if (c->stream_mem && rg_stream_wait_event(sm, c->ev_fork)) return -1;
-  const unsigned pad = c->alu_lds_pad;
+  if (rg_event_record(c->ev_fork, sm) || rg_stream_wait_event(sa, c->ev_fork)) return -1;
   int d_prim = a - 2, d_elec = a - 1, d_trace = a - 1, d_flux = a, d_upd = a;
   for (int ci = 0; ci <= C; ++ci) {
     if (ci < C) {
@@ -447,7 +430,9 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_trace = kb + 1;
       if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
       const PlaneRange rf = clip(d_flux, kb + 1, ks);
-      if (launch_planes<kBlockHeavy, 4>(sa, g, rf, k_flux, pad) || launch_planes<kBlockHeavy, 1>(sa, g, rf, k_emf, pad) || shear_planes(sa, rf)) return -1;
+      if (launch_planes<kBlockHeavy, 4>(sa, g, rf, k_flux)) return -1;
+      if (launch_planes<kBlockHeavy, 1>(sa, g, rf, k_emf)) return -1;
+      if (shear_planes(sa, rf)) return -1;
       d_flux = kb + 1;
       if (rg_event_record(c->ev_flux[ci], sa)) return -1;
     }
@@ -458,7 +443,6 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_upd = kb_prev;
     }
   }
-  if (c->stream_mem && (rg_event_record(c->ev_join, sm) || rg_stream_wait_event(c->stream, c->ev_join))) return -1;
   return 0;
 }
 
@@ -530,7 +514,6 @@ void rgpu_destroy(rgpu_ctx* c) {
     rg_event_destroy(c->ev_fork);
     for (int i = 0; i < c->nchunks; ++i) { rg_event_destroy(c->ev_trace[i]); rg_event_destroy(c->ev_flux[i]); }
     rg_stream_destroy(c->stream2);
-    if (c->stream_mem) { rg_stream_destroy(c->stream_mem); rg_event_destroy(c->ev_join); }
   }
   delete c;
 }

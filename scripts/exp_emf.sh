@@ -1,0 +1,6 @@
+#!/bin/bash
+# experiment: EMF kernel split per edge direction / occupancy caps
+cd "$(dirname "$0")/.."
+run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value'],1),'Mcell/s', round(d['ms_per_step'],2),'ms', {k:round(v,2) for k,v in d['roofline_step']['phase_ms'].items()})"; }
+run X=1
+for v in e3 es1 es3 es4; do run RGPU_LIB=$PWD/build/librgpu_$v.so; done

@@ -29,6 +29,7 @@ struct rg_recip_t { double d; };
 inline rg_recip_t rg_recip(double d) { rg_recip_t R; R.d = d; return R; }
 inline double rg_div(double n, const rg_recip_t& R) { return n / R.d; }
 inline double rg_sqrt(double x) { return std::sqrt(x); }
+inline double rg_sqrt_pos(double x) { return std::sqrt(x); }
 
 template <int BLOCK, int MINW = 1, class K>
 inline int rg_launch(rg_stream_t, unsigned n, const K& k) {
@@ -36,8 +37,14 @@ inline int rg_launch(rg_stream_t, unsigned n, const K& k) {
   return 0;
 }
 template <int BLOCK, int MINW = 1, class K>
-inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k, unsigned = 0) {
+inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k) {
   for (unsigned off = 0; off < n; ++off) k(idx0 + off);
+  return 0;
+}
+inline unsigned& rg_xcd_sub_cells() { static unsigned v = 0; return v; }
+template <int BLOCK, int MINW = 1, class K>
+inline int rg_launch_planes(rg_stream_t, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k) {
+  for (unsigned off = 0; off < plane_cells * nplanes; ++off) k(idx0 + off);
   return 0;
 }
 template <class K>
@@ -61,7 +68,6 @@ inline rg_stream_t rg_stream_from_handle(void*) { return 0; }
 inline int rg_stream_sync(rg_stream_t) { return 0; }
 inline const char* rg_last_error_string() { return "emulation"; }
 inline int rg_stream_create(rg_stream_t* s, int = 0) { *s = 1; return 0; }
-inline int rg_stream_create_cu_range(rg_stream_t* s, int, int) { *s = 1; return 0; }
 inline void rg_stream_destroy(rg_stream_t) {}
 inline int rg_order_event_create(rg_event_t* e) { *e = 0; return 0; }
 inline int rg_stream_wait_event(rg_stream_t, rg_event_t) { return 0; }
