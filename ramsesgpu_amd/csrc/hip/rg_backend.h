@@ -11,6 +11,13 @@
 
 #define RG_DEVFN __device__ __forceinline__
 #define RG_BACKEND_NAME "hip-gfx950"
+// store of a value that is not read again before it has left the caches (T, F, emf, the new state): nontemporal,
+// so that it does not evict the stencil neighbourhood the same XCD re-reads from its L2
+#ifdef RG_NO_STREAM_STORE
+#define RG_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define RG_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
 
 namespace rgpu {
 

@@ -166,15 +166,15 @@ RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const double* __restrict__ 
   AL = AL + sAL0; BL = BL + sBL0; CL = CL + sCL0;
 
   double* t = T + idx;
-  t[T_R * N] = r; t[T_P * N] = p; t[T_U * N] = u; t[T_V * N] = v; t[T_W * N] = w; t[T_A * N] = A; t[T_B * N] = B; t[T_C * N] = C;
-  t[T_AL * N] = AL; t[T_BL * N] = BL; t[T_CL * N] = CL;
-  t[(T_DX + 0) * N] = drx; t[(T_DX + 1) * N] = dpx; t[(T_DX + 2) * N] = dux; t[(T_DX + 3) * N] = dvx; t[(T_DX + 4) * N] = dwx;
-  t[(T_DX + 5) * N] = dBx; t[(T_DX + 6) * N] = dCx;
-  t[(T_DY + 0) * N] = dry; t[(T_DY + 1) * N] = dpy; t[(T_DY + 2) * N] = duy; t[(T_DY + 3) * N] = dvy; t[(T_DY + 4) * N] = dwy;
-  t[(T_DY + 5) * N] = dAy; t[(T_DY + 6) * N] = dCy;
-  t[(T_DZ + 0) * N] = drz; t[(T_DZ + 1) * N] = dpz; t[(T_DZ + 2) * N] = duz; t[(T_DZ + 3) * N] = dvz; t[(T_DZ + 4) * N] = dwz;
-  t[(T_DZ + 5) * N] = dAz; t[(T_DZ + 6) * N] = dBz;
-  t[T_DALY * N] = dALy; t[T_DALZ * N] = dALz; t[T_DBLX * N] = dBLx; t[T_DBLZ * N] = dBLz; t[T_DCLX * N] = dCLx; t[T_DCLY * N] = dCLy;
+  RG_STREAM_STORE(&t[T_R * N], r); RG_STREAM_STORE(&t[T_P * N], p); RG_STREAM_STORE(&t[T_U * N], u); RG_STREAM_STORE(&t[T_V * N], v); RG_STREAM_STORE(&t[T_W * N], w); RG_STREAM_STORE(&t[T_A * N], A); RG_STREAM_STORE(&t[T_B * N], B); RG_STREAM_STORE(&t[T_C * N], C);
+  RG_STREAM_STORE(&t[T_AL * N], AL); RG_STREAM_STORE(&t[T_BL * N], BL); RG_STREAM_STORE(&t[T_CL * N], CL);
+  RG_STREAM_STORE(&t[(T_DX + 0) * N], drx); RG_STREAM_STORE(&t[(T_DX + 1) * N], dpx); RG_STREAM_STORE(&t[(T_DX + 2) * N], dux); RG_STREAM_STORE(&t[(T_DX + 3) * N], dvx); RG_STREAM_STORE(&t[(T_DX + 4) * N], dwx);
+  RG_STREAM_STORE(&t[(T_DX + 5) * N], dBx); RG_STREAM_STORE(&t[(T_DX + 6) * N], dCx);
+  RG_STREAM_STORE(&t[(T_DY + 0) * N], dry); RG_STREAM_STORE(&t[(T_DY + 1) * N], dpy); RG_STREAM_STORE(&t[(T_DY + 2) * N], duy); RG_STREAM_STORE(&t[(T_DY + 3) * N], dvy); RG_STREAM_STORE(&t[(T_DY + 4) * N], dwy);
+  RG_STREAM_STORE(&t[(T_DY + 5) * N], dAy); RG_STREAM_STORE(&t[(T_DY + 6) * N], dCy);
+  RG_STREAM_STORE(&t[(T_DZ + 0) * N], drz); RG_STREAM_STORE(&t[(T_DZ + 1) * N], dpz); RG_STREAM_STORE(&t[(T_DZ + 2) * N], duz); RG_STREAM_STORE(&t[(T_DZ + 3) * N], dvz); RG_STREAM_STORE(&t[(T_DZ + 4) * N], dwz);
+  RG_STREAM_STORE(&t[(T_DZ + 5) * N], dAz); RG_STREAM_STORE(&t[(T_DZ + 6) * N], dBz);
+  RG_STREAM_STORE(&t[T_DALY * N], dALy); RG_STREAM_STORE(&t[T_DALZ * N], dALz); RG_STREAM_STORE(&t[T_DBLX * N], dBLx); RG_STREAM_STORE(&t[T_DBLZ * N], dBLz); RG_STREAM_STORE(&t[T_DCLX * N], dCLx); RG_STREAM_STORE(&t[T_DCLY * N], dCLy);
 }
 
 RG_DEVFN bool trace3d_in_range(const DevParams& g, const IJK c) {
@@ -311,7 +311,7 @@ RG_DEVFN void store_flux(const DevParams& g, double* __restrict__ F, unsigned id
   const size_t N = g.ncell;
   const int base = (D == XD) ? F_X : (D == YD) ? F_Y : F_Z;
 #pragma unroll
-  for (int v = 0; v < 5; ++v) F[idx + (size_t)(base + v) * N] = fl[v];
+  for (int v = 0; v < 5; ++v) RG_STREAM_STORE(&F[idx + (size_t)(base + v) * N], fl[v]);
 }
 
 template <int MASK>
@@ -363,17 +363,17 @@ RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, 
   if (MASK & DO_EMF_Z) {  // t1 = x, t2 = y
     const Prim8 rt = edge_state3d<2, +1, +1>(g, T, idx - 1 - sj), rb = edge_state3d<2, +1, -1>(g, T, idx - 1);
     const Prim8 lt = edge_state3d<2, -1, +1>(g, T, idx - sj), lb = edge_state3d<2, -1, -1>(g, T, idx);
-    emf[idx + (size_t)EMF_Z * N] = edge_emf<2>(g, rt, rb, lt, lb, xPos);
+    RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_Y) {  // t1 = z, t2 = x
     const Prim8 rt = edge_state3d<1, +1, +1>(g, T, idx - sk - 1), rb = edge_state3d<1, +1, -1>(g, T, idx - sk);
     const Prim8 lt = edge_state3d<1, -1, +1>(g, T, idx - 1), lb = edge_state3d<1, -1, -1>(g, T, idx);
-    emf[idx + (size_t)EMF_Y * N] = edge_emf<1>(g, rt, rb, lt, lb, xPos);
+    RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_X) {  // t1 = y, t2 = z
     const Prim8 rt = edge_state3d<0, +1, +1>(g, T, idx - sj - sk), rb = edge_state3d<0, +1, -1>(g, T, idx - sj);
     const Prim8 lt = edge_state3d<0, -1, +1>(g, T, idx - sk), lb = edge_state3d<0, -1, -1>(g, T, idx);
-    emf[idx + (size_t)EMF_X * N] = edge_emf<0>(g, rt, rb, lt, lb, xPos);
+    RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, rt, rb, lt, lb, xPos));
   }
 }
 
@@ -538,7 +538,7 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
     u[IC] -= (eX[idx + sj] - eX[idx]) * dtdy;
   }
 #pragma unroll
-  for (int v = 0; v < 8; ++v) Unew[idx + v * N] = u[v];
+  for (int v = 0; v < 8; ++v) RG_STREAM_STORE(&Unew[idx + v * N], u[v]);
 }
 
 }  // namespace rgpu_dev

@@ -382,8 +382,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   K_mhd_prim k_prim = {g, in, c->Q, dt};
   K_mhd_elec k_elec = {g, in, c->Q, c->E};
   K_mhd_trace3d k_trace = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz};
-  K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z> k_flux = {g, c->T, c->F, c->emf};
-  K_mhd_flux3d<DO_EMF_X | DO_EMF_Y | DO_EMF_Z> k_emf = {g, c->T, c->F, c->emf};
+  // One launch for the three face (HLLD) and the three edge (2D HLLD) Riemann problems of a cell: they read the same
+  // traced states T, and T is 60 % of the step's HBM traffic.  (Two launches -- 128 VGPRs / 4 waves per SIMD for the
+  // faces, 205 / 2 for the edges -- were faster while the solvers were purely VALU bound; after the shared-reciprocal
+  // rewrite and the XCD-aware order the second read of T costs more: 64.4 -> 60.9 ms/step at 512^3.)
+  K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z | DO_EMF_X | DO_EMF_Y | DO_EMF_Z> k_riemann = {g, c->T, c->F, c->emf};
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
   K_mhd_update3d<true> k_upd_rot = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
@@ -403,8 +406,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     { Phase ph(c, RGPU_T_PRIM); if (launch_planes<kBlock, 1>(s, g, clip(a - 2, b + 2, ks), k_prim)) return -1; }
     { Phase ph(c, RGPU_T_ELEC); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 2, ks), k_elec)) return -1; }
     { Phase ph(c, RGPU_T_TRACE); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 1, ks), k_trace)) return -1; }
-    { Phase ph(c, RGPU_T_FLUX); if (launch_planes<kBlockHeavy, 4>(s, g, clip(a, b + 1, ks), k_flux)) return -1; }
-    { Phase ph(c, RGPU_T_EMF); if (launch_planes<kBlockHeavy, 1>(s, g, clip(a, b + 1, ks), k_emf)) return -1; }
+    { Phase ph(c, RGPU_T_FLUX); if (launch_planes<kBlockHeavy, 1>(s, g, clip(a, b + 1, ks), k_riemann)) return -1; }
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
     return 0;
@@ -430,8 +432,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_trace = kb + 1;
       if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
       const PlaneRange rf = clip(d_flux, kb + 1, ks);
-      if (launch_planes<kBlockHeavy, 4>(sa, g, rf, k_flux)) return -1;
-      if (launch_planes<kBlockHeavy, 1>(sa, g, rf, k_emf)) return -1;
+      if (launch_planes<kBlockHeavy, 1>(sa, g, rf, k_riemann)) return -1;
       if (shear_planes(sa, rf)) return -1;
       d_flux = kb + 1;
       if (rg_event_record(c->ev_flux[ci], sa)) return -1;

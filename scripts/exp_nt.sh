@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value'],1),'Mcell/s', round(d['ms_per_step'],2),'ms', {k:round(v,2) for k,v in d['roofline_step']['phase_ms'].items()})"; }
+run X=1
+run RGPU_LIB=$PWD/build/librgpu_nostream.so
+run X=1
+run RGPU_LIB=$PWD/build/librgpu_nostream.so

@@ -14,6 +14,7 @@
 
 #define RG_DEVFN inline
 #define RG_BACKEND_NAME "host-emulation(test-only)"
+#define RG_STREAM_STORE(ptr, val) (*(ptr) = (val))
 
 namespace rgpu_dev {
 using std::signbit;
