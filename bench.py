@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512, help="box edge (default: the 512^3 headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeline-only", action="store_true", help="stop after the timed region (for rocprofv3 --kernel-trace concurrency analysis)")
     ap.add_argument("--cpu-size", type=int, default=96)
     ap.add_argument("--cpu-steps", type=int, default=10)
     args = ap.parse_args()
@@ -207,6 +208,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.timeline_only:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
+        return
     # per-kernel durations: the same steps again with HIP events around every launch on the kernels' stream
     # (separate from the timed region: the events serialise host and device)
     timers_src.enable_timers(True)
