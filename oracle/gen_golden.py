@@ -58,6 +58,16 @@ CASES = {
     "mri_16x32x16": ("mhd_mri_3d", "run.nstepmax=20;run.noutput=5", [0, 5, 20]),
     "mri_16x32x16_s1": ("mhd_mri_3d", "run.nstepmax=1;run.noutput=100", [1]),
     "mri_8x16x8_long": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;run.nstepmax=60;run.noutput=1000", [60]),
+    # --- the other 2D magnetic Riemann solvers (riemann_mhd.h:417-609) and slope_type 3 -----------
+    "ot2d_32_hlla": ("orszag-tang", "mesh.nx=32;mesh.ny=32;MHD.magRiemannSolver=hlla;run.nstepmax=20;run.noutput=100", [20]),
+    "ot2d_32_hllf": ("orszag-tang", "mesh.nx=32;mesh.ny=32;MHD.magRiemannSolver=hllf;run.nstepmax=20;run.noutput=100", [20]),
+    "ot2d_32_llf": ("orszag-tang", "mesh.nx=32;mesh.ny=32;MHD.magRiemannSolver=llf;run.nstepmax=20;run.noutput=100", [20]),
+    "ot3d_12_hlla": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;MHD.magRiemannSolver=hlla;run.nstepmax=4;run.noutput=100", [4]),
+    "ot3d_12_llf": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;MHD.magRiemannSolver=llf;run.nstepmax=4;run.noutput=100", [4]),
+    "mri_8x16x8_hllf": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MHD.magRiemannSolver=hllf;run.nstepmax=10;run.noutput=1000", [10]),
+    "ot2d_32_slope3": ("orszag-tang", "mesh.nx=32;mesh.ny=32;hydro.slope_type=3.0;run.nstepmax=20;run.noutput=100", [20]),
+    "briowu_x_64_slope3": ("mhd_BrioWu", "mesh.nx=64;mesh.ny=64;BrioWu.direction=0;hydro.slope_type=3.0;run.nstepmax=20;run.noutput=100", [20]),
+    "ot3d_12_slope3": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.slope_type=3.0;run.nstepmax=4;run.noutput=100", [4]),
 }
 
 VAR_NAMES = {

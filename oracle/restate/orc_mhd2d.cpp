@@ -33,11 +33,18 @@ void trace_mhd_2d(const rgpu_params& g, double qNb[3][3][8], double bfNb[4][4][3
   double AL = bfNb[CENTER][CENTER][IX], AR = bfNb[CENTER + 1][CENTER][IX];
   double BL = bfNb[CENTER][CENTER][IY], BR = bfNb[CENTER][CENTER + 1][IY];
 
-  // hydro slopes of all 8 primitive variables (slope_unsplit_hydro_2d, slope_mhd.h:77-172; types 0,1,2)
+  // hydro slopes of all 8 primitive variables (slope_unsplit_hydro_2d, slope_mhd.h:77-172; types 0,1,2,3)
   double dq[2][8];
   for (int n = 0; n < 8; ++n) {
     if (g.slope_type == 0) { dq[IX][n] = 0.0; dq[IY][n] = 0.0; }
-    else {
+    else if (g.slope_type == 3) {
+      double nb[9], d[2];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) nb[3 * a + b] = qNb[a][b][n];
+      d[0] = 0.5 * (qNb[CENTER + 1][CENTER][n] - qNb[CENTER - 1][CENTER][n]);
+      d[1] = 0.5 * (qNb[CENTER][CENTER + 1][n] - qNb[CENTER][CENTER - 1][n]);
+      const double dlim = positivity_limiter(nb, 9, q[n], d, 2);
+      dq[IX][n] = dlim * d[0]; dq[IY][n] = dlim * d[1];
+    } else {
       dq[IX][n] = tvd_slope(g.slope_type, qNb[CENTER - 1][CENTER][n], q[n], qNb[CENTER + 1][CENTER][n]);
       dq[IY][n] = tvd_slope(g.slope_type, qNb[CENTER][CENTER - 1][n], q[n], qNb[CENTER][CENTER + 1][n]);
     }

@@ -207,7 +207,16 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
         for (int v = 0; v < 8; ++v) {
           q[v] = Q(i, j, k, v);
           if (p.slope_type == 0) { dq[IX][v] = 0.0; dq[IY][v] = 0.0; dq[IZ][v] = 0.0; }
-          else {
+          else if (p.slope_type == 3) {   // plain path only (mhd_godunov_unsplit_cpu_v3.cpp:196-211)
+            double nb[27], d[3];
+            int m = 0;
+            for (int a = -1; a < 2; ++a) for (int b = -1; b < 2; ++b) for (int c = -1; c < 2; ++c) nb[m++] = Q(i + a, j + b, k + c, v);
+            d[0] = 0.5 * (Q(i + 1, j, k, v) - Q(i - 1, j, k, v));
+            d[1] = 0.5 * (Q(i, j + 1, k, v) - Q(i, j - 1, k, v));
+            d[2] = 0.5 * (Q(i, j, k + 1, v) - Q(i, j, k - 1, v));
+            const double dlim = positivity_limiter(nb, 27, q[v], d, 3);
+            dq[IX][v] = dlim * d[0]; dq[IY][v] = dlim * d[1]; dq[IZ][v] = dlim * d[2];
+          } else {
             dq[IX][v] = tvd_slope(p.slope_type, Q(i - 1, j, k, v), q[v], Q(i + 1, j, k, v));
             dq[IY][v] = tvd_slope(p.slope_type, Q(i, j - 1, k, v), q[v], Q(i, j + 1, k, v));
             dq[IZ][v] = tvd_slope(p.slope_type, Q(i, j, k - 1, v), q[v], Q(i, j, k + 1, v));

@@ -499,6 +499,75 @@ inline double max5(double a0, double a1, double a2, double a3, double a4) {
   double r = a0; r = (a1 > r) ? a1 : r; r = (a2 > r) ? a2 : r; r = (a3 > r) ? a3 : r; r = (a4 > r) ? a4 : r; return r;
 }
 
+// find_speed_alfven(d, a) (mhd_utils.h:82-88)
+inline double find_speed_alfven(double d, double a) { return sqrt(a * a / d); }
+
+// the HLL average shared by mag_riemann2d_hlla / hllf (riemann_mhd.h:449-453, 497-501)
+inline double mag_hll_average(const double qLLRR[4][8], const double eLLRR[4], double SL, double SR, double SB, double ST) {
+  const double* qLL = qLLRR[0]; const double* qRR = qLLRR[3];
+  const double ELL = eLLRR[0], ERL = eLLRR[1], ELR = eLLRR[2], ERR = eLLRR[3];
+  return (SL * SB * ERR - SL * ST * ERL - SR * SB * ELR + SR * ST * ELL) / (SR - SL) / (ST - SB)
+         - ST * SB / (ST - SB) * (qRR[IA] - qLL[IA])
+         + SR * SL / (SR - SL) * (qRR[IB] - qLL[IB]);
+}
+
+// mag_riemann2d_hlla (riemann_mhd.h:417-457): Alfven speeds, floor smallc
+inline double mag_riemann2d_hlla(const rgpu_params& g, const double qLLRR[4][8], const double eLLRR[4]) {
+  const double* qLL = qLLRR[0]; const double* qRL = qLLRR[1]; const double* qLR = qLLRR[2]; const double* qRR = qLLRR[3];
+  const double cMaxx = max5(find_speed_alfven(qLL[ID], qLL[IA]), find_speed_alfven(qLR[ID], qLR[IA]),
+                            find_speed_alfven(qRL[ID], qRL[IA]), find_speed_alfven(qRR[ID], qRR[IA]), g.smallc);
+  const double cMaxy = max5(find_speed_alfven(qLL[ID], qLL[IB]), find_speed_alfven(qLR[ID], qLR[IB]),
+                            find_speed_alfven(qRL[ID], qRL[IB]), find_speed_alfven(qRR[ID], qRR[IB]), g.smallc);
+  const double SL = fmin(min4(qLL[IU], qLR[IU], qRL[IU], qRR[IU]) - cMaxx, 0.0);
+  const double SR = fmax(max4(qLL[IU], qLR[IU], qRL[IU], qRR[IU]) + cMaxx, 0.0);
+  const double SB = fmin(min4(qLL[IV], qLR[IV], qRL[IV], qRR[IV]) - cMaxy, 0.0);
+  const double ST = fmax(max4(qLL[IV], qLR[IV], qRL[IV], qRR[IV]) + cMaxy, 0.0);
+  return mag_hll_average(qLLRR, eLLRR, SL, SR, SB, ST);
+}
+
+// mag_riemann2d_hllf (riemann_mhd.h:463-505): fast magnetosonic speeds
+inline double mag_riemann2d_hllf(const rgpu_params& g, const double qLLRR[4][8], const double eLLRR[4]) {
+  const double* qLL = qLLRR[0]; const double* qRL = qLLRR[1]; const double* qLR = qLLRR[2]; const double* qRR = qLLRR[3];
+  const double cMaxx = max4(find_speed_fast<IX>(g, qLL), find_speed_fast<IX>(g, qLR), find_speed_fast<IX>(g, qRL), find_speed_fast<IX>(g, qRR));
+  const double cMaxy = max4(find_speed_fast<IY>(g, qLL), find_speed_fast<IY>(g, qLR), find_speed_fast<IY>(g, qRL), find_speed_fast<IY>(g, qRR));
+  const double SL = fmin(min4(qLL[IU], qLR[IU], qRL[IU], qRR[IU]) - cMaxx, 0.0);
+  const double SR = fmax(max4(qLL[IU], qLR[IU], qRL[IU], qRR[IU]) + cMaxx, 0.0);
+  const double SB = fmin(min4(qLL[IV], qLR[IV], qRL[IV], qRR[IV]) - cMaxy, 0.0);
+  const double ST = fmax(max4(qLL[IV], qLR[IV], qRL[IV], qRR[IV]) + cMaxy, 0.0);
+  return mag_hll_average(qLLRR, eLLRR, SL, SR, SB, ST);
+}
+
+// mag_riemann2d_llf (riemann_mhd.h:517-609): mean of the four corner E + two 1D LLF solves on face-averaged states
+inline double mag_riemann2d_llf(const rgpu_params& g, const double qLLRR[4][8], const double eLLRR[4]) {
+  const double* qLL = qLLRR[0]; const double* qRL = qLLRR[1]; const double* qLR = qLLRR[2]; const double* qRR = qLLRR[3];
+  double E = (eLLRR[0] + eLLRR[1] + eLLRR[2] + eLLRR[3]) / 4;
+  double ql[8], qr[8], fx[8], fy[8];
+  for (int n = 0; n < 8; ++n) { ql[n] = (qLL[n] + qLR[n]) / 2; qr[n] = (qRR[n] + qRL[n]) / 2; }
+  mhd_riemann_llf(g, ql, qr, fx, 0.0);
+  static const int swap[8] = {ID, IP, IV, IU, IW, IB, IA, IC};   // the y problem: u<->v, a<->b
+  for (int n = 0; n < 8; ++n) { ql[n] = (qLL[swap[n]] + qRL[swap[n]]) / 2; qr[n] = (qRR[swap[n]] + qLR[swap[n]]) / 2; }
+  mhd_riemann_llf(g, ql, qr, fy, 0.0);
+  E += (fx[IB] - fy[IB]);
+  return E;
+}
+
+// slope_type == 3, positivity preserving slopes: the limiter of slope_unsplit_hydro_2d / _3d
+// (slope_mhd.h:131-168, 336-407).  nb = 9 (2D) or 27 (3D) neighbourhood values INCLUDING the centre value qc;
+// d[] = centred half differences per direction; returns the common factor dlim (dq[dir] = dlim * d[dir])
+inline double positivity_limiter(const double* nb, int count, double qc, const double* d, int ndim) {
+  double vmin = nb[0] - qc, vmax = nb[0] - qc;
+  for (int n = 1; n < count; ++n) {
+    const double df = nb[n] - qc;
+    vmin = (df < vmin) ? df : vmin;
+    vmax = (df > vmax) ? df : vmax;
+  }
+  double dff = 0.0;
+  for (int n = 0; n < ndim; ++n) dff = dff + fabs(d[n]);     // FABS(dfx) + FABS(dfy) [+ FABS(dfz)], left to right
+  dff = 0.5 * dff;
+  if (dff > 0.0) return fmin(1.0, fmin(fabs(vmin), fabs(vmax)) / dff);
+  return 1.0;
+}
+
 // qLLRR order: ILL=0, IRL=1, ILR=2, IRR=3 (constants.h:176-181)
 inline double mag_riemann2d_hlld(const rgpu_params& g, const double qLLRR[4][8], const double eLLRR[4]) {
   const double* qLL = qLLRR[0]; const double* qRL = qLLRR[1]; const double* qLR = qLLRR[2]; const double* qRR = qLLRR[3];
@@ -635,7 +704,9 @@ inline double compute_emf(const rgpu_params& g, const double qEdge[4][8], double
   eLLRR[3] = qRR[IU] * qRR[IB] - qRR[IV] * qRR[IA];
   double emf = 0;
   if (g.magRiemannSolver == RGPU_MAG_HLLD) emf = mag_riemann2d_hlld(g, qLLRR, eLLRR);
-  // MAG_HLLA / HLLF / LLF: "next" scope -> emf stays 0 exactly as an unknown solver would
+  else if (g.magRiemannSolver == RGPU_MAG_HLLA) emf = mag_riemann2d_hlla(g, qLLRR, eLLRR);
+  else if (g.magRiemannSolver == RGPU_MAG_HLLF) emf = mag_riemann2d_hllf(g, qLLRR, eLLRR);
+  else if (g.magRiemannSolver == RGPU_MAG_LLF) emf = mag_riemann2d_llf(g, qLLRR, eLLRR);
   if (g.Omega0 > 0) {
     if (EMFDIR == 0) {
       const double shear = -1.5 * g.Omega0 * xPos;

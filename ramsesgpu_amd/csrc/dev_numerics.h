@@ -60,6 +60,16 @@ RG_DEVFN double minmod_slope(double qm, double q0, double qp) {
   return (dlft > 0) ? fmin(dlft, drgt) : fmax(dlft, drgt);
 }
 
+// slope_type 3, positivity preserving slopes of slope_unsplit_hydro_2d / _3d (slope_mhd.h:131-168, 336-407):
+// every centred half difference d of a variable is scaled by min(1, min(|vmin|,|vmax|) / (0.5 * sum|d|)), vmin / vmax
+// being the extreme differences to the 3x3(x3) neighbourhood.  lo / hi are the extreme neighbourhood VALUES
+// (centre included): subtraction is monotonic, so min_i fl(q_i - qc) == fl(min_i q_i - qc) bit for bit.
+RG_DEVFN double positivity_limiter(double lo, double hi, double qc, double sum_abs_d) {
+  const double dff = 0.5 * sum_abs_d;
+  if (dff > 0.0) return fmin(1.0, fmin(fabs(lo - qc), fabs(hi - qc)) / dff);
+  return 1.0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // hydro: equation of state, Riemann solvers
 // ---------------------------------------------------------------------------------------------------------
@@ -428,7 +438,7 @@ RG_DEVFN void mhd_hll(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
 }
 
 // riemann_llf (riemann_mhd.h:87-118) -- including its mean of the STATES (not of the fluxes)
-RG_DEVFN void mhd_llf(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
+RG_DEVFN void mhd_llf(const DevParams& g, Prim8& L, Prim8& R, double* flux, double zero_flux = 1.0) {
   const double bx_mean = 0.5 * (L.a + R.a);
   L.a = bx_mean;
   R.a = bx_mean;
@@ -440,7 +450,7 @@ RG_DEVFN void mhd_llf(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double vel_info = fmax(fast_speed(g, L, L.a) + fabs(L.u), fast_speed(g, R, R.a) + fabs(R.u));
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
-    flux[n] = (ql[n] + qr[n]) / 2 * 1.0;
+    flux[n] = (ql[n] + qr[n]) / 2 * zero_flux;
     flux[n] -= vel_info * (uR[n] - uL[n]) / 2;
   }
 }
@@ -573,6 +583,71 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   return E;
 }
 
+// the HLL average shared by mag_riemann2d_hlla / hllf (riemann_mhd.h:449-453, 497-501)
+RG_DEVFN double mag_hll_average(const Prim8& LL, const Prim8& RR, double ELL, double ERL, double ELR, double ERR,
+                                double SL, double SR, double SB, double ST) {
+  const rg_recip_t iS = rg_recip(SR - SL), iT = rg_recip(ST - SB);
+  return rg_div(rg_div(SL * SB * ERR - SL * ST * ERL - SR * SB * ELR + SR * ST * ELL, iS), iT) -
+         rg_div(ST * SB, iT) * (RR.a - LL.a) + rg_div(SR * SL, iS) * (RR.b - LL.b);
+}
+
+// mag_riemann2d_hlla (riemann_mhd.h:417-457): Alfven speeds sqrt(b*b/rho) (mhd_utils.h:82-88), floor smallc
+RG_DEVFN double mag_hlla_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
+                            double ELL, double ERL, double ELR, double ERR) {
+  const rg_recip_t iLL = rg_recip(LL.r), iLR = rg_recip(LR.r), iRL = rg_recip(RL.r), iRR = rg_recip(RR.r);
+  const double cMaxx = sel_max(max_of4(rg_sqrt(rg_div(LL.a * LL.a, iLL)), rg_sqrt(rg_div(LR.a * LR.a, iLR)),
+                                       rg_sqrt(rg_div(RL.a * RL.a, iRL)), rg_sqrt(rg_div(RR.a * RR.a, iRR))), g.smallc);
+  const double cMaxy = sel_max(max_of4(rg_sqrt(rg_div(LL.b * LL.b, iLL)), rg_sqrt(rg_div(LR.b * LR.b, iLR)),
+                                       rg_sqrt(rg_div(RL.b * RL.b, iRL)), rg_sqrt(rg_div(RR.b * RR.b, iRR))), g.smallc);
+  const double SL = fmin(min_of4(LL.u, LR.u, RL.u, RR.u) - cMaxx, 0.0);
+  const double SR = fmax(max_of4(LL.u, LR.u, RL.u, RR.u) + cMaxx, 0.0);
+  const double SB = fmin(min_of4(LL.v, LR.v, RL.v, RR.v) - cMaxy, 0.0);
+  const double ST = fmax(max_of4(LL.v, LR.v, RL.v, RR.v) + cMaxy, 0.0);
+  return mag_hll_average(LL, RR, ELL, ERL, ELR, ERR, SL, SR, SB, ST);
+}
+
+// mag_riemann2d_hllf (riemann_mhd.h:463-505): fast magnetosonic speeds
+RG_DEVFN double mag_hllf_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
+                            double ELL, double ERL, double ELR, double ERR) {
+  const rg_recip_t iLL = rg_recip(LL.r), iLR = rg_recip(LR.r), iRL = rg_recip(RL.r), iRR = rg_recip(RR.r);
+  const double cMaxx = max_of4(fast_speed(g, LL, LL.a, iLL), fast_speed(g, LR, LR.a, iLR), fast_speed(g, RL, RL.a, iRL), fast_speed(g, RR, RR.a, iRR));
+  const double cMaxy = max_of4(fast_speed(g, LL, LL.b, iLL), fast_speed(g, LR, LR.b, iLR), fast_speed(g, RL, RL.b, iRL), fast_speed(g, RR, RR.b, iRR));
+  const double SL = fmin(min_of4(LL.u, LR.u, RL.u, RR.u) - cMaxx, 0.0);
+  const double SR = fmax(max_of4(LL.u, LR.u, RL.u, RR.u) + cMaxx, 0.0);
+  const double SB = fmin(min_of4(LL.v, LR.v, RL.v, RR.v) - cMaxy, 0.0);
+  const double ST = fmax(max_of4(LL.v, LR.v, RL.v, RR.v) + cMaxy, 0.0);
+  return mag_hll_average(LL, RR, ELL, ERL, ELR, ERR, SL, SR, SB, ST);
+}
+
+// mag_riemann2d_llf (riemann_mhd.h:517-609): mean of the four corner E + the IB component of two 1D LLF fluxes
+// (zero_flux = 0) between face-averaged states, the second one with u<->v and a<->b swapped
+RG_DEVFN double mag_llf_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
+                           double ELL, double ERL, double ELR, double ERR) {
+  double E = (ELL + ERL + ELR + ERR) / 4;
+  double fx[8], fy[8];
+  Prim8 l, r;
+  l.r = (LL.r + LR.r) / 2; r.r = (RR.r + RL.r) / 2;
+  l.p = (LL.p + LR.p) / 2; r.p = (RR.p + RL.p) / 2;
+  l.u = (LL.u + LR.u) / 2; r.u = (RR.u + RL.u) / 2;
+  l.v = (LL.v + LR.v) / 2; r.v = (RR.v + RL.v) / 2;
+  l.w = (LL.w + LR.w) / 2; r.w = (RR.w + RL.w) / 2;
+  l.a = (LL.a + LR.a) / 2; r.a = (RR.a + RL.a) / 2;
+  l.b = (LL.b + LR.b) / 2; r.b = (RR.b + RL.b) / 2;
+  l.c = (LL.c + LR.c) / 2; r.c = (RR.c + RL.c) / 2;
+  mhd_llf(g, l, r, fx, 0.0);
+  l.r = (LL.r + RL.r) / 2; r.r = (RR.r + LR.r) / 2;
+  l.p = (LL.p + RL.p) / 2; r.p = (RR.p + LR.p) / 2;
+  l.u = (LL.v + RL.v) / 2; r.u = (RR.v + LR.v) / 2;
+  l.v = (LL.u + RL.u) / 2; r.v = (RR.u + LR.u) / 2;
+  l.w = (LL.w + RL.w) / 2; r.w = (RR.w + LR.w) / 2;
+  l.a = (LL.b + RL.b) / 2; r.a = (RR.b + LR.b) / 2;
+  l.b = (LL.a + RL.a) / 2; r.b = (RR.a + LR.a) / 2;
+  l.c = (LL.c + RL.c) / 2; r.c = (RR.c + LR.c) / 2;
+  mhd_llf(g, l, r, fy, 0.0);
+  E += (fx[IB] - fy[IB]);
+  return E;
+}
+
 // compute_emf<dir> (riemann_mhd.h:1054-1193) on four edge states ALREADY in the edge frame
 // (u,v,w = velocity along t1,t2,e ; a,b,c = field along t1,t2,e) and in the reference's slot order
 // sRT, sRB, sLT, sLB.  EDIR: 0 = EMFX, 1 = EMFY, 2 = EMFZ.
@@ -596,7 +671,11 @@ RG_DEVFN double edge_emf(const DevParams& g, const Prim8& sRT, const Prim8& sRB,
   const double ELR = LR.u * LR.b - LR.v * LR.a;
   const double ERR = RR.u * RR.b - RR.v * RR.a;
   double emf = 0;
+  // MagneticRiemannSolverType (constants.h:149-156): 0 hlld, 1 hllf, 2 hlla, 4 llf
   if (g.magRiemannSolver == 0) emf = mag_hlld_2d(g, LL, RL, LR, RR, ELL, ERL, ELR, ERR);
+  else if (g.magRiemannSolver == 2) emf = mag_hlla_2d(g, LL, RL, LR, RR, ELL, ERL, ELR, ERR);
+  else if (g.magRiemannSolver == 1) emf = mag_hllf_2d(g, LL, RL, LR, RR, ELL, ERL, ELR, ERR);
+  else if (g.magRiemannSolver == 4) emf = mag_llf_2d(g, LL, RL, LR, RR, ELL, ERL, ELR, ERR);
   if (g.Omega0 > 0) {  // upwinded shear advection of the field in the shearing box
     if (EDIR == 0) {
       const double shear = -1.5 * g.Omega0 * xPos;

@@ -53,7 +53,21 @@ RG_DEVFN void mhd_trace2d_cell(const DevParams& g, const double* __restrict__ U,
     const double* Qc = Q + v * N;
     q[v] = Qc[idx];
     if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; }
-    else {
+    else if (st == 3) {
+      double lo = q[v], hi = q[v];
+#pragma unroll
+      for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+        for (int di = -1; di <= 1; ++di) {
+          const double nb = Qc[(unsigned)((int)idx + di + dj * (int)sj)];
+          lo = (nb < lo) ? nb : lo;
+          hi = (nb > hi) ? nb : hi;
+        }
+      const double dfx = 0.5 * (Qc[idx + 1] - Qc[idx - 1]), dfy = 0.5 * (Qc[idx + sj] - Qc[idx - sj]);
+      const double dlim = positivity_limiter(lo, hi, q[v], fabs(dfx) + fabs(dfy));
+      dx_[v] = dlim * dfx;
+      dy_[v] = dlim * dfy;
+    } else {
       dx_[v] = tvd_slope(st, Qc[idx - 1], q[v], Qc[idx + 1]);
       dy_[v] = tvd_slope(st, Qc[idx - sj], q[v], Qc[idx + sj]);
     }

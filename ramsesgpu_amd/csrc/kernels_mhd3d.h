@@ -199,7 +199,23 @@ RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U,
     const double* Qv = Q + v * N;
     q[v] = Qv[idx];
     if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; dz_[v] = 0.0; }
-    else {
+    else if (st == 3) {   // plain path only (mhd_godunov_unsplit_cpu_v3.cpp:196-211); rejected at create for Omega0 > 0
+      double lo = q[v], hi = q[v];
+      for (int dk = -1; dk <= 1; ++dk)
+        for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+          for (int di = -1; di <= 1; ++di) {
+            const double nb = Qv[(unsigned)((int)idx + di + dj * (int)sj + dk * (int)sk)];
+            lo = (nb < lo) ? nb : lo;
+            hi = (nb > hi) ? nb : hi;
+          }
+      const double dfx = 0.5 * (Qv[idx + 1] - Qv[idx - 1]), dfy = 0.5 * (Qv[idx + sj] - Qv[idx - sj]);
+      const double dfz = 0.5 * (Qv[idx + sk] - Qv[idx - sk]);
+      const double dlim = positivity_limiter(lo, hi, q[v], fabs(dfx) + fabs(dfy) + fabs(dfz));
+      dx_[v] = dlim * dfx;
+      dy_[v] = dlim * dfy;
+      dz_[v] = dlim * dfz;
+    } else {
       dx_[v] = tvd_slope(st, Qv[idx - 1], q[v], Qv[idx + 1]);
       dy_[v] = tvd_slope(st, Qv[idx - sj], q[v], Qv[idx + sj]);
       dz_[v] = tvd_slope(st, Qv[idx - sk], q[v], Qv[idx + sk]);

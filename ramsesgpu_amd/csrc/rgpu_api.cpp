@@ -77,12 +77,16 @@ int validate(const rgpu_params* p, std::string* why) {
   if (p->nx < p->ghostWidth || p->ny < p->ghostWidth || (three_d && p->nz < p->ghostWidth)) { *why = "domain thinner than the ghost width"; return RGPU_EINVAL; }
   const int nv = p->mhdEnabled ? 8 : (three_d ? 5 : 4);
   if (p->nbVar != nv) { *why = "nbVar inconsistent with MHD / dimension"; return RGPU_EINVAL; }
-  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2)) { *why = "slope_type 3 (positivity preserving) is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
+  if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 3)) { *why = "slope_type must be 0, 1, 2 or 3"; return RGPU_EINVAL; }
+  // positivity preserving slopes exist in the 2D MHD and the plain 3D MHD steps only: the hydro steps and the rotating
+  // 3D step call slope routines that leave dq unset for type 3 (slope.h:97-147,324-427; slope_mhd.h:436-502)
+  if (p->slope_type == 3 && (!p->mhdEnabled || p->Omega0 > 0)) { *why = "slope_type 3 is defined for non-rotating MHD only (the reference leaves the slopes unset elsewhere)"; return RGPU_EUNSUPPORTED; }
   if (p->mhdEnabled) {
     if (!three_d && p->implementationVersion != 1) { *why = "2D MHD: only implementationVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }
     if (!three_d && p->Omega0 > 0) { *why = "2D rotating frame is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
     if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) { *why = "3D MHD: only implementationVersion 3/4 are implemented"; return RGPU_EUNSUPPORTED; }
-    if (p->magRiemannSolver != RGPU_MAG_HLLD) { *why = "magRiemannSolver: only hlld is implemented"; return RGPU_EUNSUPPORTED; }
+    if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLF && p->magRiemannSolver != RGPU_MAG_HLLA &&
+        p->magRiemannSolver != RGPU_MAG_LLF) { *why = "magRiemannSolver must be hlld, hllf, hlla or llf (roe / upwind do not exist in the reference either)"; return RGPU_EUNSUPPORTED; }
     if (p->shearingBoxEnabled && !three_d) { *why = "shearing box needs 3D"; return RGPU_EUNSUPPORTED; }
   } else {
     if (p->unsplitVersion != 1) { *why = "hydro: only unsplitVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }

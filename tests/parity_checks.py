@@ -165,6 +165,13 @@ ORACLE_RUNS = [
     ("implode3d", "mesh.nx=12;mesh.ny=8;mesh.nz=1;hydro.riemannSolver=hll;hydro.slope_type=2.0", 5),
     ("implode3d", "mesh.nx=10;mesh.ny=10;mesh.nz=10;hydro.traceVersion=0;hydro.riemannSolver=hllc", 4),
     ("implode3d", "mesh.nx=2;mesh.ny=2;mesh.nz=2", 3),
+    # the other EMF solvers and the positivity-preserving slopes on further paths
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=10;MHD.magRiemannSolver=hlla;MRI.amp=0.2", 5),     # rotating + shear terms of the EMF
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=6;MHD.magRiemannSolver=llf", 4),
+    ("mhd_BrioWu", "mesh.nx=16;mesh.ny=12;BrioWu.direction=1;MHD.magRiemannSolver=llf", 5),
+    ("mhd_BrioWu", "mesh.nx=16;mesh.ny=12;BrioWu.direction=1;MHD.magRiemannSolver=hllf;hydro.slope_type=3.0", 5),
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=6;mesh.nz=10;hydro.slope_type=3.0;MHD.magRiemannSolver=hllf;hydro.cIso=0.8", 3),
+    ("mhd_BrioWu", "mesh.nx=10;mesh.ny=8;mesh.nz=8;BrioWu.direction=2;MHD.implementationVersion=3;hydro.slope_type=3.0", 4),
 ]
 
 RANDOM_STEPS = [

@@ -66,9 +66,11 @@ def test_no_cpu_fallback_without_gpu(product_lib):
 
 def test_rejects_out_of_scope_configurations(emu_lib):
     L = emu_lib
-    for ov, frag in (("hydro.slope_type=3", "slope_type"), ("MHD.implementationVersion=0", "implementationVersion"),
-                     ("MHD.magRiemannSolver=hlla", "magRiemannSolver")):
-        p = L.params_from_ini(ini("orszag-tang"), "mesh.nx=16;mesh.ny=16;" + ov)
+    for base, ov, frag in (("orszag-tang", "MHD.implementationVersion=0", "implementationVersion"),
+                           ("orszag-tang", "MHD.magRiemannSolver=roe", "magRiemannSolver"),
+                           ("implode3d", "mesh.nz=16;hydro.slope_type=3", "slope_type"),      # hydro: slopes left unset by the reference
+                           ("mhd_mri_3d", "mesh.nz=16;hydro.slope_type=3", "slope_type")):    # rotating 3D step: same
+        p = L.params_from_ini(ini(base), "mesh.nx=16;mesh.ny=16;" + ov)
         with pytest.raises(RgpuError) as e:
             Solver(p, L)
         assert frag in str(e.value)
