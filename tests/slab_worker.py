@@ -22,12 +22,19 @@ def main():
     base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+    # default: the TEST-ONLY emulation library on CPU; SLAB_DEVICE=cuda:0 runs the product library (HIP) instead, all
+    # ranks sharing that GPU (gloo moves the ghost planes: RCCL refuses two ranks on one device)
+    device = os.environ.get("SLAB_DEVICE", "cpu")
+    if device == "cpu":
+        lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+    else:
+        from ramsesgpu_amd.solver import load_library
+        lib = load_library()
     ini = os.path.join(ROOT, "configs", base + ".ini")
-    run = SlabRun(ini, ov, library=lib, device="cpu", overlap=os.environ.get("SLAB_OVERLAP", "1") != "0")
+    run = SlabRun(ini, ov, library=lib, device=device, overlap=os.environ.get("SLAB_OVERLAP", "1") != "0")
     run.init_simulation()
     dts = [run.oneStepIntegration() for _ in range(nsteps)]
-    local = run.local_interior().contiguous()
+    local = run.local_interior().contiguous().cpu()
     parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
     dist.gather(local, parts, dst=0)
     ok = True

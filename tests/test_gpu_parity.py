@@ -172,3 +172,25 @@ def test_slab_schedule_world1(base, ov, nsteps, overlap, gpu_lib, oracle):
                                      ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=30")], ids=["mri", "implode3d"])
 def test_step_core_in_plane_pieces(base, ov, gpu_lib):
     pc.check_core_plane_pieces(gpu_lib, base, ov)
+
+
+@pytest.mark.parametrize("base,ov,nsteps", [("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=40", 4),
+                                            ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=32", 3),
+                                            ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=24;hydro.riemannSolver=hllc", 4)],
+                         ids=["mri", "ot3d", "implode3d"])
+def test_two_slab_processes_on_one_gpu(base, ov, nsteps, gpu_lib, oracle, tmp_path):
+    """world_size 2, both ranks on cuda:0 with the HIP library, ghost planes moved by gloo (RCCL needs one device per
+    rank): the slab driver's overlapped schedule with a real exchange in flight == single-domain oracle."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "result.txt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), base, ov, str(nsteps), out]
+    env = dict(os.environ, SLAB_DEVICE="cuda:0", SLAB_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert open(out).read().strip() == "OK", open(out).read()
