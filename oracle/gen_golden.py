@@ -68,6 +68,25 @@ CASES = {
     "ot2d_32_slope3": ("orszag-tang", "mesh.nx=32;mesh.ny=32;hydro.slope_type=3.0;run.nstepmax=20;run.noutput=100", [20]),
     "briowu_x_64_slope3": ("mhd_BrioWu", "mesh.nx=64;mesh.ny=64;BrioWu.direction=0;hydro.slope_type=3.0;run.nstepmax=20;run.noutput=100", [20]),
     "ot3d_12_slope3": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.slope_type=3.0;run.nstepmax=4;run.noutput=100", [4]),
+    # --- further shipped problems (initial conditions of the host side + the same step) -------------------------------
+    "rotor_32_ic": ("mhd_rotor", "mesh.nx=32;mesh.ny=32;run.nstepmax=0;run.noutput=100", [0]),   # IC only: with implementationVersion=1 the reference itself turns this problem into NaN within a few steps
+    "fieldloop2d_32x20": ("mhd_fieldloop2d", "mesh.nx=32;mesh.ny=20;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "fieldloop3d_16x8x8": ("mhd_fieldloop3d", "mesh.nx=16;mesh.ny=8;mesh.nz=8;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "currentsheet2d_24": ("mhd_currentSheet_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "currentsheet3d_12x12x8": ("mhd_currentSheet_3d", "mesh.nx=12;mesh.ny=12;mesh.nz=8;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "blast2d_24x36": ("blast2d", "mesh.nx=24;mesh.ny=36;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "blast3d_12": ("blast2d", "mesh.nx=12;mesh.ny=18;mesh.nz=12;run.nstepmax=6;run.noutput=100", [0, 6]),
+    "mhdjet2d_24": ("mhd_jet2d", "mesh.nx=24;mesh.ny=24;jet.ijet=4;jet.offsetJet=6;MHD.implementationVersion=1;run.nstepmax=12;run.noutput=100", [0, 12]),
+    "mhdjet2d_24_bfield": ("mhd_jet2d", "mesh.nx=24;mesh.ny=24;jet.ijet=4;jet.offsetJet=6;jet.BStatic_y=0.5;jet.BStatic_x=0.1;MHD.implementationVersion=1;run.nstepmax=12;run.noutput=100", [12]),
+    "mhdjet3d_10x10x20": ("mhd_jet3d", "mesh.nx=10;mesh.ny=10;mesh.nz=20;jet.ijet=3;jet.offsetJet=3;jet.BStatic_z=0.3;output.outputVtkAscii=no;run.nstepmax=8;run.noutput=100", [0, 8]),
+    "kh2d_rand_24": ("kelvin_helmholtz_cpu_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "kh2d_robertson_32x24": ("kelvin_helmholtz_gpu_2d", "mesh.nx=32;mesh.ny=24;hydro.unsplitVersion=1;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "kh2d_sine_24": ("kelvin_helmholtz_cpu_2d", "mesh.nx=24;mesh.ny=24;kelvin-helmholtz.perturbation_rand=no;kelvin-helmholtz.perturbation_sine=yes;kelvin-helmholtz.outer_size=0.3;run.nstepmax=6;run.noutput=100", [0, 6]),
+    "kh2d_athena_24": ("kelvin_helmholtz_cpu_2d", "mesh.nx=24;mesh.ny=24;kelvin-helmholtz.perturbation_rand=no;kelvin-helmholtz.perturbation_sine_athena=yes;run.nstepmax=6;run.noutput=100", [0, 6]),
+    "kh3d_rand_16x4x16": ("kelvin_helmholtz_gpu_3d", "mesh.nx=16;mesh.ny=4;mesh.nz=16;run.nstepmax=6;run.noutput=100", [0, 6]),
+    "kh3d_robertson_16x4x12": ("kelvin_helmholtz_gpu_3d", "mesh.nx=16;mesh.ny=4;mesh.nz=12;kelvin-helmholtz.perturbation_rand=no;kelvin-helmholtz.perturbation_sine_robertson=yes;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "mhdkh2d_24": ("mhd_kelvin_helmholtz_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 
 VAR_NAMES = {

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <vector>
 
 namespace rgpu_host {
 
@@ -19,6 +20,29 @@ void Rand48::skip(unsigned long long n) {
     n >>= 1;
   }
   x_ = (ra * x_ + rc) & kMask;
+}
+
+GlibcRand::GlibcRand(unsigned seed) {
+  if (seed == 0) seed = 1;
+  int word = static_cast<int>(seed);
+  r_[0] = seed;
+  for (int i = 1; i < 31; ++i) {   // 16807 * word mod (2^31 - 1) by Schrage's method, as srandom_r does
+    const long hi = word / 127773, lo = word % 127773;
+    long w = 16807 * lo - 2836 * hi;
+    if (w < 0) w += 2147483647;
+    word = static_cast<int>(w);
+    r_[i] = static_cast<unsigned>(word);
+  }
+  f_ = 3; b_ = 0;
+  for (int i = 0; i < 310; ++i) next();
+}
+
+int GlibcRand::next() {
+  r_[f_] += r_[b_];
+  const unsigned out = r_[f_] >> 1;
+  f_ = (f_ + 1) % 31;
+  b_ = (b_ + 1) % 31;
+  return static_cast<int>(out);
 }
 
 namespace {
@@ -248,6 +272,370 @@ void init_mri(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
       }
 }
 
+// ---- hydro: Sod tube along x (HydroRunBase.cpp:5358-5438; the ghost-corner copies of the gw==2 case are dropped:
+// the step refills every ghost before it reads one) --------------------------------------------------------------
+void init_hydro_sod(const rgpu_params& p, const Grid& g) {
+  const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
+  for (int k = k0; k < k1; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j)
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        if (i < g.isize / 2) {
+          g.at(i, j, k, RGPU_ID) = 1.0f;
+          g.at(i, j, k, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f);
+        } else {
+          g.at(i, j, k, RGPU_ID) = 0.125f;
+          g.at(i, j, k, RGPU_IP) = 0.1f / (p.gamma0 - 1.0f);
+        }
+        g.at(i, j, k, RGPU_IU) = 0.0f;
+        g.at(i, j, k, RGPU_IV) = 0.0f;
+        if (g.three_d) g.at(i, j, k, RGPU_IW) = 0.0f;
+      }
+}
+
+// ---- hydro: spherical blast (HydroRunBase.cpp:5551-5676) -------------------------------------------------------
+void init_hydro_blast(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  // every knob goes through getFloat, defaults included (float arithmetic on the defaults, HydroRunBase.cpp:5570-5577)
+  double radius = cfg.get_float("blast", "radius", (float)(0.25 * (p.xMax - p.xMin)));
+  const double center_x = cfg.get_float("blast", "center_x", (float)((p.xMax + p.xMin) / 2));
+  const double center_y = cfg.get_float("blast", "center_y", (float)((p.yMax + p.yMin) / 2));
+  const double center_z = cfg.get_float("blast", "center_z", (float)((p.zMax + p.zMin) / 2));
+  const double density_in = cfg.get_float("blast", "density_in", 1.0f);
+  const double density_out = cfg.get_float("blast", "density_out", 1.0f);
+  const double pressure_in = cfg.get_float("blast", "pressure_in", 10.0f);
+  const double pressure_out = cfg.get_float("blast", "pressure_out", 0.1f);
+  radius *= radius;
+  const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
+  for (int k = k0; k < k1; ++k) {
+    const double zPos = p.zMin + p.dz / 2 + (k + g.k_shift - g.gw) * p.dz;
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        double d2 = (xPos - center_x) * (xPos - center_x) + (yPos - center_y) * (yPos - center_y);
+        if (g.three_d) d2 = d2 + (zPos - center_z) * (zPos - center_z);
+        const bool inside = d2 < radius;
+        g.at(i, j, k, RGPU_ID) = inside ? density_in : density_out;
+        g.at(i, j, k, RGPU_IP) = (inside ? pressure_in : pressure_out) / (p.gamma0 - 1.0f);
+        g.at(i, j, k, RGPU_IU) = 0.0f;
+        g.at(i, j, k, RGPU_IV) = 0.0f;
+        if (g.three_d) g.at(i, j, k, RGPU_IW) = 0.0f;
+      }
+    }
+  }
+}
+
+// ---- hydro: Kelvin-Helmholtz (HydroRunBase.cpp:5857-6252): random (libc rand(), 2 / 3 draws per interior cell in
+// k,j,i order), sine, Athena-like and Robertson et al. perturbations ------------------------------------------------
+void init_hydro_kelvin_helmholtz(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const char* S = "kelvin-helmholtz";
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer(S, "seed", 1)));
+  const double amplitude = cfg.get_float(S, "amplitude", 0.01f);
+  const bool p_rand = cfg.get_bool(S, "perturbation_rand", true), p_sine = cfg.get_bool(S, "perturbation_sine", false);
+  const bool p_athena = cfg.get_bool(S, "perturbation_sine_athena", false);
+  const bool p_robertson = cfg.get_bool(S, "perturbation_sine_robertson", false);
+  const double rho_inner = cfg.get_float(S, "rho_inner", 2.0f), rho_outer = cfg.get_float(S, "rho_outer", 1.0f);
+  const double pressure = cfg.get_float(S, "pressure", 2.5f);
+  const double inner_size = cfg.get_float(S, "inner_size", 0.2f), outer_size = cfg.get_float(S, "outer_size", 0.2f);
+  const double vflow_in = cfg.get_float(S, "vflow_in", -0.5f), vflow_out = cfg.get_float(S, "vflow_out", 0.5f);
+  const double xSize = p.xMax - p.xMin, ySize = p.yMax - p.yMin, zSize = p.zMax - p.zMin;
+  const double yCenter = (p.yMin + p.yMax) * 0.5, zCenter = (p.zMin + p.zMax) * 0.5;
+  const double e0 = pressure / (p.gamma0 - 1.0f);
+  auto draw = [&]() { return 1.0 * rng.next() / GlibcRand::kRandMax - 0.5; };
+  auto sqr = [](double x) { return x * x; };
+  if (!g.three_d) {
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        double& d = g.at(i, j, 0, RGPU_ID); double& mu = g.at(i, j, 0, RGPU_IU); double& mv = g.at(i, j, 0, RGPU_IV);
+        if (p_rand) {
+          const bool outer = std::fabs(yPos - yCenter) > outer_size * ySize;
+          d = outer ? rho_outer : rho_inner;
+          mu = d * ((outer ? vflow_out : vflow_in) + amplitude * draw());
+          mv = d * (0.0f + amplitude * draw());
+        } else if (p_athena) {
+          const double a = 0.05, sigma = 0.2, vflow = 0.5;
+          d = rho_inner;
+          mu = rho_inner * vflow * std::tanh(yPos / a);
+          mv = rho_inner * amplitude * std::sin(2.0 * M_PI * xPos) * std::exp(-(yPos * yPos) / (sigma * sigma));
+        } else if (p_robertson) {
+          const int n = static_cast<int>(cfg.get_integer(S, "mode", 4));
+          const double w0 = cfg.get_float(S, "w0", 0.1f), deltaY = cfg.get_float(S, "deltaY", 0.03f);
+          const double y1 = p.yMin + 0.25 * ySize, y2 = p.yMin + 0.75 * ySize;
+          const double ramp = 1.0 / (1.0 + std::exp(2 * (yPos - y1) / deltaY)) + 1.0 / (1.0 + std::exp(2 * (y2 - yPos) / deltaY));
+          d = rho_inner + ramp * (rho_outer - rho_inner);
+          mu = d * (vflow_in + ramp * (vflow_out - vflow_in));
+          mv = d * w0 * std::sin(n * M_PI * xPos);
+        } else if (p_sine) {
+          const double perturb_vx = 0, perturb_vy = amplitude * std::sin(2.0 * M_PI * xPos / xSize);
+          if (std::fabs(yPos - yCenter) > outer_size * ySize) {
+            d = rho_outer; mu = rho_outer * vflow_out * (1.0 + perturb_vx); mv = rho_outer * perturb_vy;
+          } else if (std::fabs(yPos - yCenter) <= inner_size * ySize) {
+            d = rho_inner; mu = rho_inner * vflow_in * (1.0 + perturb_vx); mv = rho_inner * perturb_vy;
+          } else {
+            const double interpSize = outer_size - inner_size;
+            const double rho_slope = (rho_outer - rho_inner) / (interpSize * ySize), u_slope = (vflow_out - vflow_in) / (interpSize * ySize);
+            double deltaY, deltaRho, deltaU;
+            if (yPos > yCenter) { deltaY = yPos - (yCenter + inner_size * ySize); deltaRho = rho_slope * deltaY; deltaU = u_slope * deltaY; }
+            else { deltaY = yPos - (yCenter - inner_size * ySize); deltaRho = -rho_slope * deltaY; deltaU = -u_slope * deltaY; }
+            d = rho_inner + deltaRho;
+            mu = d * (vflow_in + deltaU) * (1.0 + perturb_vx);
+            mv = d * perturb_vy;
+          }
+        } else {
+          continue;   // no perturbation type selected: the reference leaves the state at zero
+        }
+        g.at(i, j, 0, RGPU_IP) = e0 + 0.5 * (sqr(mu) + sqr(mv)) / d;
+      }
+    }
+    return;
+  }
+  if (p_rand) for (long n = 0; n < 3L * g.k_shift * g.ny * g.nx; ++n) rng.next();   // draws of the slabs below
+  for (int k = g.gw; k < g.ksize - g.gw; ++k) {
+    const double zPos = p.zMin + p.dz / 2 + (k + g.k_shift - g.gw) * p.dz;
+    for (int j = g.gw; j < g.jsize - g.gw; ++j)
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        double& d = g.at(i, j, k, RGPU_ID); double& mu = g.at(i, j, k, RGPU_IU); double& mv = g.at(i, j, k, RGPU_IV);
+        double& mw = g.at(i, j, k, RGPU_IW);
+        const bool outer = std::fabs(zPos - zCenter) > outer_size * zSize;
+        if (p_rand) {
+          d = outer ? rho_outer : rho_inner;
+          mu = d * ((outer ? vflow_out : vflow_in) + amplitude * draw());
+          mv = d * (0.0 + amplitude * draw());
+          mw = d * (0.0 + amplitude * draw());
+        } else if (p_sine) {
+          const double perturb_vy = 0, perturb_vz = amplitude * std::sin(2.0 * M_PI * xPos / xSize);
+          d = outer ? rho_outer : rho_inner;
+          mu = d * (outer ? vflow_out : vflow_in);
+          mv = d * perturb_vy;
+          mw = d * perturb_vz;
+        } else if (p_robertson) {
+          const int n = static_cast<int>(cfg.get_integer(S, "mode", 4));
+          const double w0 = cfg.get_float(S, "w0", 0.1f), deltaZ = cfg.get_float(S, "deltaZ", 0.03f);
+          const double z1 = p.zMin + 0.25 * zSize, z2 = p.zMin + 0.75 * zSize;
+          const double ramp = 1.0 / (1.0 + std::exp(2 * (zPos - z1) / deltaZ)) + 1.0 / (1.0 + std::exp(2 * (z2 - zPos) / deltaZ));
+          d = rho_inner + ramp * (rho_outer - rho_inner);
+          mu = d * (vflow_in + ramp * (vflow_out - vflow_in));
+          mv = d * w0 * std::cos(n * M_PI * xPos);
+          mw = d * w0 * std::sin(n * M_PI * xPos);
+        } else {
+          continue;
+        }
+        g.at(i, j, k, RGPU_IP) = e0 + 0.5 * (sqr(mu) + sqr(mv) + sqr(mw)) / d;
+      }
+  }
+}
+
+// ---- MHD: Kelvin-Helmholtz (MHDRunBase.cpp:2814-2984) -- with its quirks: the switches are read with getFloat, the
+// pressure from a section spelled "kelvin_helmholtz", 2D positions from j / jsize (x too), rand() drawn in any case ---
+void init_mhd_kelvin_helmholtz(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const char* S = "kelvin-helmholtz";
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer(S, "seed", 1)));
+  const double amplitude = cfg.get_float(S, "amplitude", 0.01f);
+  const bool p_sine = cfg.get_float(S, "perturbation_sine", 0.0f) != 0.0f;
+  const bool p_rand = cfg.get_float(S, "perturbation_rand", 1.0f) != 0.0f;
+  const double rho_inner = cfg.get_float(S, "rho_inner", 2.0f), rho_outer = cfg.get_float(S, "rho_outer", 1.0f);
+  const double pressure = cfg.get_float("kelvin_helmholtz", "pressure", 2.5f);
+  const double v0 = cfg.get_float(S, "v0", 1.0f), b0 = cfg.get_float(S, "b0", 1.0f);
+  const double yMin = p.yMin, yMax = p.yMax, xMin = p.xMin, xMax = p.xMax;
+  auto draw = [&]() { return 1.0 * rng.next() / GlibcRand::kRandMax - 0.5; };
+  if (g.three_d) for (long n = 0; n < 3L * g.k_shift * g.ny * g.nx; ++n) rng.next();
+  const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
+  for (int k = k0; k < k1; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = g.three_d ? yMin + p.dy / 2 + (j - g.gw) * p.dy : yMin + (yMax - yMin) * j / g.jsize;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = g.three_d ? xMin + p.dx / 2 + (i - g.gw) * p.dx : xMin + (xMax - xMin) * j / g.jsize;
+        const bool outer = yPos < yMin + 0.25 * (yMax - yMin) || yPos > yMin + 0.75 * (yMax - yMin);
+        const double d = outer ? rho_outer : rho_inner;
+        g.at(i, j, k, RGPU_ID) = d;
+        g.at(i, j, k, RGPU_IU) = d * ((outer ? v0 : -v0) + p_rand * amplitude * draw() + p_sine * amplitude * std::sin(2 * M_PI * xPos));
+        g.at(i, j, k, RGPU_IV) = d * (p_rand * amplitude * draw() + p_sine * amplitude * std::sin(2 * M_PI * xPos));
+        if (g.three_d) g.at(i, j, k, RGPU_IW) = d * (p_rand * amplitude * draw() + p_sine * amplitude * std::sin(2 * M_PI * xPos));
+        else g.at(i, j, k, RGPU_IW) = 0.0;
+        g.at(i, j, k, RGPU_IA) = b0; g.at(i, j, k, RGPU_IB) = 0.0; g.at(i, j, k, RGPU_IC) = 0.0;
+        const double mu = g.at(i, j, k, RGPU_IU), mv = g.at(i, j, k, RGPU_IV), mw = g.at(i, j, k, RGPU_IW);
+        g.at(i, j, k, RGPU_IP) = pressure / (p.gamma0 - 1.0f) + 0.5 * (mu * mu + mv * mv + mw * mw) / d + 0.5 * b0 * b0;
+      }
+    }
+}
+
+// ---- MHD: jet medium with an optional static field (MHDRunBase.cpp:1747-1798) and Sod tube (:1806-1862) ----------
+void init_mhd_jet(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const double Bx = cfg.get_float("jet", "BStatic_x", 0.0f), By = cfg.get_float("jet", "BStatic_y", 0.0f);
+  const double Bz = cfg.get_float("jet", "BStatic_z", 0.0f);
+  const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
+  for (int k = k0; k < k1; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j)
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        g.at(i, j, k, RGPU_ID) = 1.0f;
+        g.at(i, j, k, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f) + (g.three_d ? 0.5 * (Bx * Bx + By * By + Bz * Bz) : 0.5 * (Bx * Bx + By * By));
+        g.at(i, j, k, RGPU_IU) = 0.0f; g.at(i, j, k, RGPU_IV) = 0.0f; g.at(i, j, k, RGPU_IW) = 0.0f;
+        g.at(i, j, k, RGPU_IA) = Bx; g.at(i, j, k, RGPU_IB) = By; g.at(i, j, k, RGPU_IC) = Bz;
+      }
+}
+
+void init_mhd_sod(const rgpu_params& p, const Grid& g) {
+  if (g.three_d) throw std::runtime_error("MHD sod in 3D: the reference writes the k=0 plane only (2D accessors in its 3D branch)");
+  for (int j = g.gw; j < g.jsize - g.gw; ++j)
+    for (int i = g.gw; i < g.isize - g.gw; ++i) {
+      if (i < g.isize / 2) { g.at(i, j, 0, RGPU_ID) = 1.0f; g.at(i, j, 0, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f); }
+      else { g.at(i, j, 0, RGPU_ID) = 0.125f; g.at(i, j, 0, RGPU_IP) = 0.1f / (p.gamma0 - 1.0f); }
+    }
+}
+
+// ---- MHD: rotor, 2D only (MHDRunBase.cpp:2117-2189) -- including the velocity (not momentum) written to the
+// momentum slots and the dx/2 offset of yPos ----------------------------------------------------------------------
+void init_mhd_rotor(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  if (g.three_d) return;   // the reference's 3D branch is empty: the state stays zero
+  const double FourPi = 8.0 * std::asin(1.0);
+  const double r0 = cfg.get_float("rotor", "r0", 0.1f);
+  const double r1 = cfg.get_float("rotor", "r1", 0.115f);
+  const double u0 = cfg.get_float("rotor", "u0", 2.0f);
+  const double p0 = cfg.get_float("rotor", "p0", 1.0f);
+  const double b0 = cfg.get_float("rotor", "b0", (float)(5.0 / std::sqrt(FourPi)));
+  const double xMax = cfg.get_float("mesh", "xmax", 1.0f), yMax = cfg.get_float("mesh", "ymax", 1.0f);
+  const double xCenter = (xMax + p.xMin) / 2, yCenter = (yMax + p.yMin) / 2;
+  const double gamma = p.gamma0;
+  for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+    const double yPos = p.yMin + p.dx / 2 + (j - g.gw) * p.dy;
+    for (int i = g.gw; i < g.isize - g.gw; ++i) {
+      const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+      const double r = std::sqrt((xPos - xCenter) * (xPos - xCenter) + (yPos - yCenter) * (yPos - yCenter));
+      const double f_r = (r1 - r) / (r1 - r0);
+      if (r <= r0) {
+        g.at(i, j, 0, RGPU_ID) = 10.0;
+        g.at(i, j, 0, RGPU_IU) = -u0 * (yPos - yCenter) / r0;
+        g.at(i, j, 0, RGPU_IV) = u0 * (xPos - xCenter) / r0;
+      } else if (r <= r1) {
+        g.at(i, j, 0, RGPU_ID) = 1 + 9 * f_r;
+        g.at(i, j, 0, RGPU_IU) = -f_r * u0 * (yPos - yCenter) / r;
+        g.at(i, j, 0, RGPU_IV) = f_r * u0 * (xPos - xCenter) / r;
+      } else {
+        g.at(i, j, 0, RGPU_ID) = 1.0;
+        g.at(i, j, 0, RGPU_IU) = 0.0;
+        g.at(i, j, 0, RGPU_IV) = 0.0;
+      }
+      g.at(i, j, 0, RGPU_IW) = 0.0;
+      g.at(i, j, 0, RGPU_IA) = b0;
+      g.at(i, j, 0, RGPU_IB) = 0.0;
+      g.at(i, j, 0, RGPU_IC) = 0.0;
+      const double mu = g.at(i, j, 0, RGPU_IU), mv = g.at(i, j, 0, RGPU_IV), mw = g.at(i, j, 0, RGPU_IW);
+      g.at(i, j, 0, RGPU_IP) = p0 / (gamma - 1.0) + (mu * mu + mv * mv + mw * mw) / 2 / g.at(i, j, 0, RGPU_ID) +
+                               (g.at(i, j, 0, RGPU_IA) * g.at(i, j, 0, RGPU_IA)) / 2;
+    }
+  }
+}
+
+// ---- MHD: field loop advection (MHDRunBase.cpp:2214-2408).  3D: the z component of the vector potential carries
+// drand48 noise, one draw per cell of the whole ghost-inclusive box in k,j,i order -------------------------------
+void init_mhd_field_loop(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const double radius = cfg.get_float("FieldLoop", "radius", 1.0f);
+  const double density_in = cfg.get_float("FieldLoop", "density_in", 1.0f);
+  const double amplitude = cfg.get_float("FieldLoop", "amplitude", 1.0f);
+  const double vflow = cfg.get_float("FieldLoop", "vflow", 1.0f);
+  const double cos_theta = 2.0 / std::sqrt(5.0);
+  const double sin_theta = std::sqrt(1 - cos_theta * cos_theta);
+  const double dx = p.dx, dy = p.dy, dz = p.dz;
+  if (!g.three_d) {
+    std::vector<double> Az(static_cast<size_t>(g.isize) * g.jsize, 0.0);
+    auto az = [&](int i, int j) -> double& { return Az[static_cast<size_t>(i) + static_cast<size_t>(g.isize) * j]; };
+    for (int j = g.gw; j < g.jsize - g.gw + 1; ++j) {
+      const double yPos = p.yMin + dy / 2 + (j - g.gw) * dy;
+      for (int i = g.gw; i < g.isize - g.gw + 1; ++i) {
+        const double xPos = p.xMin + dx / 2 + (i - g.gw) * dx;
+        const double r = std::sqrt(xPos * xPos + yPos * yPos);
+        az(i, j) = (r < radius) ? amplitude * (radius - r) : 0.0;
+      }
+    }
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = p.yMin + dy / 2 + (j - g.gw) * dy;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + dx / 2 + (i - g.gw) * dx;
+        const double diag = std::sqrt(1.0 * (p.nx * p.nx + p.ny * p.ny + p.nz * p.nz));   // nz = 1 in 2D
+        const double r = std::sqrt(xPos * xPos + yPos * yPos);
+        const double d = (r < radius) ? density_in : 1.0f;
+        g.at(i, j, 0, RGPU_ID) = d;
+        g.at(i, j, 0, RGPU_IU) = d * vflow * cos_theta;
+        g.at(i, j, 0, RGPU_IV) = d * vflow * sin_theta;
+        g.at(i, j, 0, RGPU_IW) = d * vflow * p.nz / diag;
+        g.at(i, j, 0, RGPU_IA) = (az(i, j + 1) - az(i, j)) / dy;
+        g.at(i, j, 0, RGPU_IB) = -(az(i + 1, j) - az(i, j)) / dx;
+        g.at(i, j, 0, RGPU_IC) = 0.0;
+        const double A = g.at(i, j, 0, RGPU_IA), B = g.at(i, j, 0, RGPU_IB);
+        const double mu = g.at(i, j, 0, RGPU_IU), mv = g.at(i, j, 0, RGPU_IV);
+        g.at(i, j, 0, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f) + 0.5 * (A * A + B * B) + 0.5 * (mu * mu + mv * mv) / d;
+      }
+    }
+    return;
+  }
+  const double amp = cfg.get_float("FieldLoop", "amp", 0.01f);
+  const long seed = cfg.get_integer("FieldLoop", "seed", 0);
+  Rand48 rng(seed);
+  rng.skip(static_cast<unsigned long long>(g.k_shift) * g.jsize * g.isize);   // planes of the slabs below
+  // only A_z is non-zero; local plane k is global plane k + k_shift
+  std::vector<double> Az(static_cast<size_t>(g.isize) * g.jsize * g.ksize, 0.0);
+  auto az = [&](int i, int j, int k) -> double& {
+    return Az[static_cast<size_t>(i) + static_cast<size_t>(g.isize) * (j + static_cast<size_t>(g.jsize) * k)];
+  };
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j) {
+      const double yPos = p.yMin + dy / 2 + (j - g.gw) * dy;
+      for (int i = 0; i < g.isize; ++i) {
+        const double xPos = p.xMin + dx / 2 + (i - g.gw) * dx;
+        az(i, j, k) = 0.0 + amp * (rng.next() - 0.5);
+        const double r = std::sqrt(xPos * xPos + yPos * yPos);
+        if (r < radius) az(i, j, k) = amplitude * (radius - r);
+      }
+    }
+  for (int k = g.gw; k < g.ksize - g.gw; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = p.yMin + dy / 2 + (j - g.gw) * dy;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + dx / 2 + (i - g.gw) * dx;
+        const double r = std::sqrt(xPos * xPos + yPos * yPos);
+        const double d = (r < radius) ? density_in : 1.0f;
+        g.at(i, j, k, RGPU_ID) = d;
+        g.at(i, j, k, RGPU_IU) = d * vflow * cos_theta;
+        g.at(i, j, k, RGPU_IV) = d * vflow * sin_theta;
+        g.at(i, j, k, RGPU_IW) = 0.0;
+        // curl of (0, 0, Az); the A_x = A_y = 0 terms are kept as the reference writes them
+        g.at(i, j, k, RGPU_IA) = (az(i, j + 1, k) - az(i, j, k)) / dy - (0.0 - 0.0) / dz;
+        g.at(i, j, k, RGPU_IB) = (0.0 - 0.0) / dz - (az(i + 1, j, k) - az(i, j, k)) / dx;
+        g.at(i, j, k, RGPU_IC) = (0.0 - 0.0) / dx - (0.0 - 0.0) / dy;
+        if (p.cIso > 0) {
+          g.at(i, j, k, RGPU_IP) = 0.0;
+        } else {
+          const double A = g.at(i, j, k, RGPU_IA), B = g.at(i, j, k, RGPU_IB), C = g.at(i, j, k, RGPU_IC);
+          const double mu = g.at(i, j, k, RGPU_IU), mv = g.at(i, j, k, RGPU_IV), mw = g.at(i, j, k, RGPU_IW);
+          g.at(i, j, k, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f) + 0.5 * (A * A + B * B + C * C) + 0.5 * (mu * mu + mv * mv + mw * mw) / d;
+        }
+      }
+    }
+}
+
+// ---- MHD: current sheet (MHDRunBase.cpp:2424-2487): every cell, ghosts included; the energy slot holds beta -----
+void init_mhd_current_sheet(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const double A = cfg.get_float("CurrentSheet", "A", 0.1f);
+  const double B0 = cfg.get_float("CurrentSheet", "B0", 1.0f);
+  const double beta = cfg.get_float("CurrentSheet", "beta", 0.1f);
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j)
+      for (int i = 0; i < g.isize; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+        g.at(i, j, k, RGPU_ID) = 1.0;
+        g.at(i, j, k, RGPU_IP) = beta;
+        g.at(i, j, k, RGPU_IU) = 1.0 * A * std::sin(M_PI * yPos);
+        g.at(i, j, k, RGPU_IV) = 0.0;
+        g.at(i, j, k, RGPU_IW) = 0.0;
+        g.at(i, j, k, RGPU_IA) = 0.0;
+        g.at(i, j, k, RGPU_IB) = (xPos < 0.5 || xPos > 1.5) ? B0 : -B0;
+        g.at(i, j, k, RGPU_IC) = 0.0;
+      }
+}
+
 }  // namespace
 
 void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
@@ -259,10 +647,19 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     if (problem == "Orszag-Tang" || problem == "OrszagTang") init_orszag_tang(cfg, p, g);
     else if (problem == "Brio-Wu" || problem == "BrioWu" || problem == "brio-wu" || problem == "briowu") init_brio_wu(cfg, p, g);
     else if (problem == "MRI" || problem == "Mri" || problem == "mri") init_mri(cfg, p, g);
+    else if (problem == "Kelvin-Helmholtz") init_mhd_kelvin_helmholtz(cfg, p, g);
+    else if (problem == "jet" || problem == "Jet") init_mhd_jet(cfg, p, g);
+    else if (problem == "sod") init_mhd_sod(p, g);
+    else if (problem == "Rotor" || problem == "rotor") init_mhd_rotor(cfg, p, g);
+    else if (problem == "FieldLoop" || problem == "fieldloop" || problem == "Fieldloop" || problem == "field-loop" || problem == "Field-Loop") init_mhd_field_loop(cfg, p, g);
+    else if (problem == "CurrentSheet" || problem == "currentsheet" || problem == "Currentsheet" || problem == "current-sheet" || problem == "Current-Sheet") init_mhd_current_sheet(cfg, p, g);
     else throw std::runtime_error("MHD problem '" + problem + "' is outside the implemented scope");
   } else {
     if (problem == "jet") init_hydro_jet(p, g);
     else if (problem == "implode") init_hydro_implode(cfg, p, g);
+    else if (problem == "sod") init_hydro_sod(p, g);
+    else if (problem == "Kelvin-Helmholtz") init_hydro_kelvin_helmholtz(cfg, p, g);
+    else if (problem == "blast") init_hydro_blast(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
 }

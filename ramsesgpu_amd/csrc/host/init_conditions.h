@@ -1,6 +1,9 @@
 // init_conditions.h -- initial conditions of the problems named by the scope contract:
 //   jet, implode                    HydroRunBase.cpp:5282-5350, 5449-5536
 //   Orszag-Tang, Brio-Wu, MRI       MHDRunBase.cpp:1378-1720, 1870-2080, 2677-2758
+// and, as the first widening beyond it (SURVEY.md 8f-1 "makes every shipped .ini runnable"), the problems of the other
+// shipped parameter files that need no source term: sod, blast, Kelvin-Helmholtz (hydro, HydroRunBase.cpp:5358-6252),
+// MHD jet, sod, rotor, field loop, current sheet, Kelvin-Helmholtz (MHDRunBase.cpp:1747-1862, 2117-2487, 2814-2984)
 // Written for z-slabs: local plane k of slab r is global plane k + r*nz_local, and the MRI random stream is
 // skipped ahead so that every slab draws exactly the numbers the single-domain reference run would.
 #pragma once
@@ -29,6 +32,19 @@ class Rand48 {
  private:
   static const unsigned long long kA = 0x5DEECE66DULL, kC = 0xBULL, kMask = (1ULL << 48) - 1;
   unsigned long long x_;
+};
+
+// glibc-compatible rand() after srand(seed): the TYPE_3 additive feedback generator (r[i] = r[i-3] + r[i-31] on 32-bit
+// words, 310 values discarded after seeding with the minimal-standard LCG, output = word >> 1; RAND_MAX = 2^31 - 1)
+class GlibcRand {
+ public:
+  explicit GlibcRand(unsigned seed);
+  int next();
+  static constexpr double kRandMax = 2147483647.0;
+
+ private:
+  unsigned r_[34];
+  int f_, b_;
 };
 
 }  // namespace rgpu_host

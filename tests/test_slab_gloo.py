@@ -27,6 +27,8 @@ CASES = [
     ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 4, 2, 1),                          # hydro, inner planes [4,8)
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12", 3, 3, 1),                         # three slabs (nz=4 each < 2 gw)
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=27", 3, 3, 1),                         # three slabs, inner planes [6,9)
+    ("kelvin_helmholtz_gpu_3d", "mesh.nx=8;mesh.ny=4;mesh.nz=16", 3, 2, 1),           # libc rand() stream continued across slabs
+    ("mhd_fieldloop3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 3, 2, 1),                    # drand48 noise of the vector potential
 ]
 
 
