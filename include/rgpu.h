@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 1
+#define RGPU_ABI_VERSION 2
 
 /* component indexes -- constants.h:59-71 */
 enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
@@ -86,7 +86,10 @@ typedef struct rgpu_params {
   /* z-slab decomposition (replaces the reference's MPI cartesian topology, HydroMpiParameters.cpp:44-80) */
   int32_t slab_rank, slab_count;/* 0,1 for a single device */
   int32_t nz_global;            /* == nz when slab_count==1 */
-  int32_t reserved0;
+  int32_t gravityEnabled;       /* [gravity] static=yes, or forced by problem=Rayleigh-Taylor (HydroRunBase.cpp:250-260) */
+  /* uniform static gravity field ([gravity] static_field_x/y/z, HydroParameters.h:322-324): the reference keeps it in a
+   * per-cell array h_gravity that its problems fill with exactly this vector (HydroRunBase.cpp:6336-6337, 6403-6405) */
+  double  gravity_x, gravity_y, gravity_z;
 } rgpu_params;
 
 typedef struct rgpu_ctx rgpu_ctx;

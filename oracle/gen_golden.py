@@ -86,6 +86,14 @@ CASES = {
     "kh3d_rand_16x4x16": ("kelvin_helmholtz_gpu_3d", "mesh.nx=16;mesh.ny=4;mesh.nz=16;run.nstepmax=6;run.noutput=100", [0, 6]),
     "kh3d_robertson_16x4x12": ("kelvin_helmholtz_gpu_3d", "mesh.nx=16;mesh.ny=4;mesh.nz=12;kelvin-helmholtz.perturbation_rand=no;kelvin-helmholtz.perturbation_sine_robertson=yes;run.nstepmax=5;run.noutput=100", [0, 5]),
     "mhdkh2d_24": ("mhd_kelvin_helmholtz_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
+    # --- static gravity (predictor on the traced states + momentum source) ---------------------------
+    "rt2d_16x48": ("rayleigh_taylor_gpu_2d", "mesh.nx=16;mesh.ny=48;run.nstepmax=12;run.noutput=100", [0, 12]),
+    "rt2d_16x48_hllc_rand": ("rayleigh_taylor_gpu_2d", "mesh.nx=16;mesh.ny=48;hydro.riemannSolver=hllc;rayleigh-taylor.randomEnabled=yes;gravity.static_field_x=0.03;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "rt3d_8x8x32": ("rayleigh_taylor_gpu_3d", "mesh.nx=8;mesh.ny=8;mesh.nz=32;run.nstepmax=8;run.noutput=100", [0, 8]),
+    "rt3d_mhd_8x8x24": ("rayleigh_taylor_gpu_3d_mhd", "mesh.nx=8;mesh.ny=8;mesh.nz=24;rayleigh-taylor.bx=0.05;run.nstepmax=6;run.noutput=100", [0, 6]),
+    "rt2d_mhd_12x36": ("rayleigh_taylor_cpu_2d_mhd", "mesh.nx=12;mesh.ny=36;MHD.implementationVersion=1;run.nstepmax=8;run.noutput=100", [0, 8]),
+    "implode3d_12_gravity": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.riemannSolver=hllc;gravity.static=yes;gravity.static_field_x=0.2;gravity.static_field_y=-0.1;gravity.static_field_z=0.4;run.nstepmax=6;run.noutput=100", [6]),
+    "ot3d_12_gravity": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;gravity.static=yes;gravity.static_field_x=0.1;gravity.static_field_y=0.2;gravity.static_field_z=-0.3;run.nstepmax=4;run.noutput=100", [4]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 

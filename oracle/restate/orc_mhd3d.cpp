@@ -232,6 +232,14 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
         E[IY][0][0] = elec(i, j, k, IY); E[IY][0][1] = elec(i, j, k + 1, IY); E[IY][1][0] = elec(i + 1, j, k, IY); E[IY][1][1] = elec(i + 1, j, k + 1, IY);
         E[IZ][0][0] = elec(i, j, k, IZ); E[IZ][0][1] = elec(i, j + 1, k, IZ); E[IZ][1][0] = elec(i + 1, j, k, IZ); E[IZ][1][1] = elec(i + 1, j + 1, k, IZ);
         trace_mhd_3d(p, q, dq, bfNb, dbf, E, dtdx, dtdy, dtdz, xPos, tqm, tqp, tqe);
+        if (p.gravityEnabled) {   // gravity predictor on all 18 traced states (..._cpu_v3.cpp:277-332, MHDRunGodunov.cpp:2684-2740)
+          const double grav_x = 0.5 * dt * p.gravity_x, grav_y = 0.5 * dt * p.gravity_y, grav_z = 0.5 * dt * p.gravity_z;
+          for (int d = 0; d < 3; ++d) {
+            tqm[d][IU] += grav_x; tqm[d][IV] += grav_y; tqm[d][IW] += grav_z;
+            tqp[d][IU] += grav_x; tqp[d][IV] += grav_y; tqp[d][IW] += grav_z;
+            for (int e = 0; e < 4; ++e) { tqe[e][d][IU] += grav_x; tqe[e][d][IV] += grav_y; tqe[e][d][IW] += grav_z; }
+          }
+        }
         for (int v = 0; v < 8; ++v) {
           for (int d = 0; d < 3; ++d) { qm[d](i, j, k, v) = tqm[d][v]; qp[d](i, j, k, v) = tqp[d][v]; }
           for (int e = 0; e < 4; ++e) for (int d = 0; d < 3; ++d) qE[e][d](i, j, k, v) = tqe[e][d][v];
@@ -356,6 +364,18 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
         const double emfX = compute_emf<0>(p, qe, xPos);
         if (!rot || in_i) emf(i, j, k, I_EMFX) = emfX;
       }
+
+  // gravity source term on the momenta (compute_gravity_source_term, HydroRunBase.cpp:1925-1985; called at
+  // ..._cpu_v3.cpp:586-588 and, rotating path, MHDRunGodunov.cpp:3190-3192 -- before the shear remap of the density)
+  if (p.gravityEnabled)
+    for (int k = gw; k < ksize - gw; k++)
+      for (int j = gw; j < jsize - gw; j++)
+        for (int i = gw; i < isize - gw; i++) {
+          const double rhoOld = U(i, j, k, ID), rhoNew = Unew(i, j, k, ID);
+          Unew(i, j, k, IU) += 0.5 * dt * p.gravity_x * (rhoOld + rhoNew);
+          Unew(i, j, k, IV) += 0.5 * dt * p.gravity_y * (rhoOld + rhoNew);
+          Unew(i, j, k, IW) += 0.5 * dt * p.gravity_z * (rhoOld + rhoNew);
+        }
 
   if (rot && shearbox) {
     // flux / emf remap across the sheared x boundary (Dumses bval_shear_flux / bval_shear_emf)

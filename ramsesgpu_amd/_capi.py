@@ -1,7 +1,7 @@
 """ctypes view of include/rgpu.h (the C ABI) -- plain structs and prototypes, no compute here."""
 import ctypes as C
 
-RGPU_ABI_VERSION = 1
+RGPU_ABI_VERSION = 2
 
 ID, IP, IU, IV, IW, IA, IB, IC = range(8)
 BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
@@ -37,7 +37,8 @@ class RgpuParams(C.Structure):
         ("djet", C.c_double), ("ujet", C.c_double), ("pjet", C.c_double), ("cjet", C.c_double),
         ("slab_rank", C.c_int32), ("slab_count", C.c_int32),
         ("nz_global", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("gravityEnabled", C.c_int32),
+        ("gravity_x", C.c_double), ("gravity_y", C.c_double), ("gravity_z", C.c_double),
     ]
 
     @property

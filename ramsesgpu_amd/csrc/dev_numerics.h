@@ -29,7 +29,10 @@ struct DevParams {
   double dx, dy, dz, xMin, deltaX;   // deltaX = xMax - xMin
   double gamma0, cIso, smallr, smallc, smallp, smallpp, gamma6, Omega0;
   double slope_type, mag_slope_type;
-  int niter_riemann, riemannSolver, magRiemannSolver, pad0;
+  int niter_riemann, riemannSolver, magRiemannSolver, grav_on;
+  // static gravity: (0.5 * dt) * g of the CURRENT step, set by the step driver before it launches (the reference's
+  // "HALF_F * dt * h_gravity(i,j,k,d)" with the uniform field its problems fill in)
+  double hgx, hgy, hgz;
 };
 
 struct Prim8 {  // primitive MHD state in some frame: density, pressure, 3 velocities, 3 field components

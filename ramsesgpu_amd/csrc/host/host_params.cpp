@@ -72,9 +72,24 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   p->slope_type = cfg.get_float("hydro", "slope_type", 1.0f);
   if (cfg.get_integer("hydro", "traceVersion", 1) == 0) p->slope_type = 0.0;
 
-  if (cfg.get_float("gravity", "static_field_x", 0.0f) != 0 || cfg.get_float("gravity", "static_field_y", 0.0f) != 0 ||
-      cfg.get_float("gravity", "static_field_z", 0.0f) != 0 || cfg.get_bool("gravity", "enabled", false))
-    throw std::runtime_error("gravity is outside the implemented scope");
+  // static gravity (HydroRunBase.cpp:250-260, HydroParameters.h:322-324); self gravity needs a Poisson solver: out of scope
+  if (cfg.get_bool("gravity", "self", false)) throw std::runtime_error("self gravity is outside the implemented scope");
+  {
+    const std::string prob = cfg.get_string("hydro", "problem", "unknown");
+    if (prob == "Keplerian-disk") throw std::runtime_error("problem Keplerian-disk (central point-mass gravity field) is outside the implemented scope");
+    p->gravityEnabled = (cfg.get_bool("gravity", "static", false) || prob == "Rayleigh-Taylor") ? 1 : 0;
+    // The reference's steps read the per-cell array h_gravity, which only the Rayleigh-Taylor (and falling-bubble)
+    // initial conditions fill with the [gravity] static_field vector; for every other problem it stays at its
+    // zero-initialised allocation, i.e. "static=yes" switches the code path on with g = 0 (verified against the
+    // reference binary: tests/golden/*_gravity).
+    if (p->gravityEnabled && (prob == "MRI" || prob == "Mri" || prob == "mri"))
+      throw std::runtime_error("MRI with gravity (vertically stratified box, MHDRunBase.cpp:3163-3211) is outside the implemented scope");
+    if (prob == "falling-bubble") throw std::runtime_error("problem falling-bubble is outside the implemented scope");
+    const bool filled = (prob == "Rayleigh-Taylor");
+    p->gravity_x = filled ? cfg.get_float("gravity", "static_field_x", 0.0f) : 0.0f;
+    p->gravity_y = filled ? cfg.get_float("gravity", "static_field_y", 0.0f) : 0.0f;
+    p->gravity_z = filled ? cfg.get_float("gravity", "static_field_z", 0.0f) : 0.0f;
+  }
   if (cfg.get_float("hydro", "nu", 0.0f) > 0 || cfg.get_float("MHD", "eta", 0.0f) > 0)
     throw std::runtime_error("viscosity / resistivity are outside the implemented scope");
   if (lower(cfg.get_string("hydro", "scheme", "muscl")) != "muscl")

@@ -461,6 +461,50 @@ void init_mhd_kelvin_helmholtz(const IniConfig& cfg, const rgpu_params& p, const
     }
 }
 
+// ---- hydro + MHD: Rayleigh-Taylor (HydroRunBase.cpp:6262-6434, MHDRunBase.cpp:2995-3037): every cell, ghosts
+// included; the energy slot receives P0 + rho * (g . x) as written there; optional libc rand() perturbation ---------
+void init_rayleigh_taylor(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const char* S = "rayleigh-taylor";
+  const double amplitude = cfg.get_float(S, "amplitude", 0.01f);
+  const double d0 = cfg.get_float(S, "d0", 1.0f), d1 = cfg.get_float(S, "d1", 2.0f);
+  const bool randomEnabled = cfg.get_bool(S, "randomEnabled", false);
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer(S, "random_seed", 33)));
+  const double gx = p.gravity_x, gy = p.gravity_y, gz = p.gravity_z;
+  const double P0 = 1.0f / (p.gamma0 - 1.0f);
+  const double Lx = p.xMax - p.xMin, Ly = p.yMax - p.yMin, Lz = p.zMax - p.zMin;
+  if (randomEnabled && g.three_d) for (long n = 0; n < (long)g.k_shift * g.jsize * g.isize; ++n) rng.next();
+  for (int k = 0; k < g.ksize; ++k) {
+    const double z = p.zMin + p.dz / 2 + (k + g.k_shift - g.gw) * p.dz;
+    for (int j = 0; j < g.jsize; ++j) {
+      const double y = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = 0; i < g.isize; ++i) {
+        const double x = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        if (!g.three_d) {
+          const double d = (y > (p.yMin + p.yMax) / 2) ? d1 : d0;
+          g.at(i, j, 0, RGPU_ID) = d;
+          g.at(i, j, 0, RGPU_IP) = P0 + d * (gx * x + gy * y);
+          g.at(i, j, 0, RGPU_IU) = 0.0f;
+          if (randomEnabled) g.at(i, j, 0, RGPU_IV) = amplitude * (rng.next() * 1.0 / GlibcRand::kRandMax - 0.5);
+          else g.at(i, j, 0, RGPU_IV) = amplitude * (1 + std::cos(2 * M_PI * x / Lx)) * (1 + std::cos(2 * M_PI * y / Ly)) / 4;
+        } else {
+          const double d = (z > (p.zMin + p.zMax) / 2) ? d1 : d0;
+          g.at(i, j, k, RGPU_ID) = d;
+          g.at(i, j, k, RGPU_IP) = P0 + d * (gx * x + gy * y + gz * z);
+          g.at(i, j, k, RGPU_IU) = 0.0f;
+          g.at(i, j, k, RGPU_IV) = 0.0f;
+          if (randomEnabled) g.at(i, j, k, RGPU_IW) = amplitude * (rng.next() * 1.0 / GlibcRand::kRandMax - 0.5);
+          else g.at(i, j, k, RGPU_IW) = amplitude * (1 + std::cos(2 * M_PI * x / Lx)) * (1 + std::cos(2 * M_PI * y / Ly)) * (1 + std::cos(2 * M_PI * z / Lz)) / 8;
+        }
+        if (p.mhdEnabled) {
+          const double Bx0 = cfg.get_float(S, "bx", 1e-8f), By0 = cfg.get_float(S, "by", 1e-8f), Bz0 = cfg.get_float(S, "bz", 1e-8f);
+          g.at(i, j, k, RGPU_IA) = Bx0; g.at(i, j, k, RGPU_IB) = By0; g.at(i, j, k, RGPU_IC) = Bz0;
+          g.at(i, j, k, RGPU_IP) += 0.5 * (Bx0 * Bx0 + By0 * By0 + Bz0 * Bz0);
+        }
+      }
+    }
+  }
+}
+
 // ---- MHD: jet medium with an optional static field (MHDRunBase.cpp:1747-1798) and Sod tube (:1806-1862) ----------
 void init_mhd_jet(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   const double Bx = cfg.get_float("jet", "BStatic_x", 0.0f), By = cfg.get_float("jet", "BStatic_y", 0.0f);
@@ -648,6 +692,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "Brio-Wu" || problem == "BrioWu" || problem == "brio-wu" || problem == "briowu") init_brio_wu(cfg, p, g);
     else if (problem == "MRI" || problem == "Mri" || problem == "mri") init_mri(cfg, p, g);
     else if (problem == "Kelvin-Helmholtz") init_mhd_kelvin_helmholtz(cfg, p, g);
+    else if (problem == "Rayleigh-Taylor") init_rayleigh_taylor(cfg, p, g);
     else if (problem == "jet" || problem == "Jet") init_mhd_jet(cfg, p, g);
     else if (problem == "sod") init_mhd_sod(p, g);
     else if (problem == "Rotor" || problem == "rotor") init_mhd_rotor(cfg, p, g);
@@ -659,6 +704,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "implode") init_hydro_implode(cfg, p, g);
     else if (problem == "sod") init_hydro_sod(p, g);
     else if (problem == "Kelvin-Helmholtz") init_hydro_kelvin_helmholtz(cfg, p, g);
+    else if (problem == "Rayleigh-Taylor") init_rayleigh_taylor(cfg, p, g);
     else if (problem == "blast") init_hydro_blast(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }

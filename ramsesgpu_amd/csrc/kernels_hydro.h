@@ -86,6 +86,11 @@ RG_DEVFN void hydro_face_state(const DevParams& g, const double* __restrict__ T,
   for (int n = 0; n < NV; ++n) qv[n] = t[(size_t)n * N] + s * t[(size_t)(NV * (1 + D) + n) * N];
   qv[ID] = fmax(g.smallr, qv[ID]);
   qv[IP] = fmax(g.smallp * qv[ID], qv[IP]);
+  if (g.grav_on) {  // gravity predictor on the traced state (HydroRunGodunov.cpp:2485-2497, 2705-2734)
+    qv[IU] += g.hgx;
+    qv[IV] += g.hgy;
+    if (NV == 5) qv[NV - 1] += g.hgz;
+  }
   const int swp = (D == 0) ? IU : (D == 1) ? IV : IW;  // swap IU with the normal velocity
 #pragma unroll
   for (int n = 0; n < NV; ++n) o[n] = qv[(n == IU) ? swp : (n == swp) ? IU : n];
@@ -155,6 +160,12 @@ RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ U
           if (pass == 0) u[v] += f; else u[v] -= f;
         }
       }
+    if (g.grav_on) {  // momentum source (compute_gravity_source_term, HydroRunBase.cpp:1925-1985); energy untouched
+      const double rho_sum = Uold[idx + ID * N] + u[ID];
+      u[IU] += g.hgx * rho_sum;
+      u[IV] += g.hgy * rho_sum;
+      if (NV == 5) u[NV - 1] += g.hgz * rho_sum;
+    }
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) Unew[idx + v * N] = u[v];

@@ -124,6 +124,7 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   g->slope_type = p.slope_type;
   g->mag_slope_type = std::fmin(p.slope_type, 2.0);
   g->niter_riemann = p.niter_riemann; g->riemannSolver = p.riemannSolver; g->magRiemannSolver = p.magRiemannSolver;
+  g->grav_on = 0; g->hgx = 0.0; g->hgy = 0.0; g->hgz = 0.0;   // per step: step_core_planes
 }
 
 // number of scratch doubles per cell for each array of the active solver family
@@ -452,6 +453,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 }
 
 int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
+  // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; the 2D MHD step has none
+  c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d)) ? 1 : 0;
+  c->g.hgx = 0.5 * dt * c->p.gravity_x;
+  c->g.hgy = 0.5 * dt * c->p.gravity_y;
+  c->g.hgz = 0.5 * dt * c->p.gravity_z;
   const double* in = c->U[nStep % 2];
   double* out = c->U[(nStep + 1) % 2];
   if (!c->g.three_d) {  // 2D: no planes
