@@ -94,6 +94,10 @@ CASES = {
     "rt2d_mhd_12x36": ("rayleigh_taylor_cpu_2d_mhd", "mesh.nx=12;mesh.ny=36;MHD.implementationVersion=1;run.nstepmax=8;run.noutput=100", [0, 8]),
     "implode3d_12_gravity": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.riemannSolver=hllc;gravity.static=yes;gravity.static_field_x=0.2;gravity.static_field_y=-0.1;gravity.static_field_z=0.4;run.nstepmax=6;run.noutput=100", [6]),
     "ot3d_12_gravity": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;gravity.static=yes;gravity.static_field_x=0.1;gravity.static_field_y=0.2;gravity.static_field_z=-0.3;run.nstepmax=4;run.noutput=100", [4]),
+    "gresho2d_32": ("Gresho_vortex2d", "mesh.nx=32;mesh.ny=32;hydro.unsplitVersion=1;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "gresho3d_16x16x6": ("Gresho_vortex2d", "mesh.nx=16;mesh.ny=16;mesh.nz=6;hydro.unsplitVersion=1;Gresho_vortex.v_bulk_z=0.25;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "bubble2d_24": ("falling_bubble_gpu_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
+    "shearwave_16x8x4": ("mhd_shearWave_3d", "mesh.nx=16;mesh.ny=8;mesh.nz=4;output.outputVtkAscii=no;run.nstepmax=8;run.noutput=100", [0, 8]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 

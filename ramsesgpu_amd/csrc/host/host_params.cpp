@@ -77,15 +77,14 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   {
     const std::string prob = cfg.get_string("hydro", "problem", "unknown");
     if (prob == "Keplerian-disk") throw std::runtime_error("problem Keplerian-disk (central point-mass gravity field) is outside the implemented scope");
-    p->gravityEnabled = (cfg.get_bool("gravity", "static", false) || prob == "Rayleigh-Taylor") ? 1 : 0;
+    p->gravityEnabled = (cfg.get_bool("gravity", "static", false) || prob == "Rayleigh-Taylor") ? 1 : 0;   // falling-bubble is NOT forced
     // The reference's steps read the per-cell array h_gravity, which only the Rayleigh-Taylor (and falling-bubble)
     // initial conditions fill with the [gravity] static_field vector; for every other problem it stays at its
     // zero-initialised allocation, i.e. "static=yes" switches the code path on with g = 0 (verified against the
     // reference binary: tests/golden/*_gravity).
     if (p->gravityEnabled && (prob == "MRI" || prob == "Mri" || prob == "mri"))
       throw std::runtime_error("MRI with gravity (vertically stratified box, MHDRunBase.cpp:3163-3211) is outside the implemented scope");
-    if (prob == "falling-bubble") throw std::runtime_error("problem falling-bubble is outside the implemented scope");
-    const bool filled = (prob == "Rayleigh-Taylor");
+    const bool filled = (prob == "Rayleigh-Taylor" || prob == "falling-bubble");
     p->gravity_x = filled ? cfg.get_float("gravity", "static_field_x", 0.0f) : 0.0f;
     p->gravity_y = filled ? cfg.get_float("gravity", "static_field_y", 0.0f) : 0.0f;
     p->gravity_z = filled ? cfg.get_float("gravity", "static_field_z", 0.0f) : 0.0f;

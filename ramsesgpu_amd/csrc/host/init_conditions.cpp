@@ -505,6 +505,90 @@ void init_rayleigh_taylor(const IniConfig& cfg, const rgpu_params& p, const Grid
   }
 }
 
+// ---- hydro: Gresho vortex (HydroRunBase.cpp:5688-5838) ------------------------------------------------------------
+void init_hydro_gresho(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const char* S = "Gresho_vortex";
+  const double center_x = cfg.get_float(S, "center_x", (float)((p.xMax + p.xMin) / 2));
+  const double center_y = cfg.get_float(S, "center_y", (float)((p.yMax + p.yMin) / 2));
+  const double vbx = cfg.get_float(S, "v_bulk_x", 0.0f), vby = cfg.get_float(S, "v_bulk_y", 0.0f), vbz = cfg.get_float(S, "v_bulk_z", 0.0f);
+  const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
+  for (int k = k0; k < k1; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        const double r = std::sqrt((xPos - center_x) * (xPos - center_x) + (yPos - center_y) * (yPos - center_y));
+        const double phi = std::atan2(yPos - center_y, xPos - center_x);
+        double P, v_phi;
+        if (r < 0.2) { P = 5 + 12.5 * r * r; v_phi = 5 * r; }
+        else if (r < 0.4) { P = 9 + 12.5 * r * r - 20 * r + 4 * std::log(5 * r); v_phi = 2 - 5 * r; }
+        else { P = 3 + 4 * std::log(2); v_phi = 0.0; }
+        const double mu = -std::sin(phi) * v_phi + vbx, mv = std::cos(phi) * v_phi + vby;
+        g.at(i, j, k, RGPU_ID) = 1.0;
+        g.at(i, j, k, RGPU_IU) = mu;
+        g.at(i, j, k, RGPU_IV) = mv;
+        if (g.three_d) {
+          g.at(i, j, k, RGPU_IW) = vbz;
+          g.at(i, j, k, RGPU_IP) = P / (p.gamma0 - 1.0f) + 0.5 * (mu * mu + mv * mv + vbz * vbz) / 1.0;
+        } else {
+          g.at(i, j, k, RGPU_IP) = P / (p.gamma0 - 1.0f) + 0.5 * (mu * mu + mv * mv) / 1.0;
+        }
+      }
+    }
+}
+
+// ---- hydro: falling bubble, 2D (HydroRunBase.cpp:6633-6714; the 3D branch of the reference writes the density of
+// the k=0 plane only and is not reproduced) ------------------------------------------------------------------------
+void init_hydro_falling_bubble(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  if (g.three_d) throw std::runtime_error("falling-bubble in 3D is outside the implemented scope");
+  const char* S = "falling-bubble";
+  const double P0 = 1.0f / (p.gamma0 - 1.0f);
+  const double Ly = p.yMax - p.yMin;
+  const double radius = cfg.get_float(S, "radius", 0.1f);
+  const double x_c = cfg.get_float(S, "center_x", (float)((p.xMin + p.xMax) / 2));
+  const double y_c = cfg.get_float(S, "center_y", (float)(p.yMin + 0.8 * Ly));
+  const double v0 = cfg.get_float(S, "v0", 0.0f), d0 = cfg.get_float(S, "d0", 2.0f), d1 = cfg.get_float(S, "d1", 1.0f);
+  for (int j = 0; j < g.jsize; ++j) {
+    const double y = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+    for (int i = 0; i < g.isize; ++i) {
+      const double x = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+      double d = (y < p.yMin + 0.3 * Ly) ? d0 : d1;
+      const double r2 = (x - x_c) * (x - x_c) + (y - y_c) * (y - y_c);
+      if (r2 < radius * radius) d = d0;
+      g.at(i, j, 0, RGPU_ID) = d;
+      g.at(i, j, 0, RGPU_IP) = P0 + d * (p.gravity_x * x + p.gravity_y * y);
+      g.at(i, j, 0, RGPU_IU) = 0.0;
+      g.at(i, j, 0, RGPU_IV) = (r2 < radius * radius) ? v0 : 0.0;
+    }
+  }
+}
+
+// ---- MHD: compressive shear wave in the shearing box (MHDRunBase.cpp:2574-2658), every cell, ghosts included --------
+void init_mhd_shear_wave(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  if (!(p.bc[0] == RGPU_BC_SHEARINGBOX && p.bc[1] == RGPU_BC_SHEARINGBOX))
+    throw std::runtime_error("ShearWave needs shearing box conditions along x (boundary_xmin=boundary_xmax=4)");
+  const double TwoPi = 4.0 * std::asin(1.0);
+  const double d0 = 1.0;
+  const double Lx = p.dx * p.nx, Ly = p.dy * p.ny;
+  const double energy = cfg.get_float("ShearWave", "energy", 1.0f);
+  const double delta_vx = (-4.0e-4) * p.cIso, delta_vy = (1.0e-4) * p.cIso;
+  const double kx0 = -4 * TwoPi / Lx, ky0 = TwoPi / Ly;
+  const double xi0 = 0.5 * p.Omega0 / d0;
+  const double delta_rho = (kx0 * delta_vy - ky0 * delta_vx) / xi0;
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j) {
+      const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = 0; i < g.isize; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        const double d = d0 * (1.0 - delta_rho * std::sin(kx0 * xPos + ky0 * yPos));
+        g.at(i, j, k, RGPU_ID) = d;
+        g.at(i, j, k, RGPU_IP) = energy;
+        g.at(i, j, k, RGPU_IU) = d * delta_vx * std::cos(kx0 * xPos + ky0 * yPos);
+        g.at(i, j, k, RGPU_IV) = d * delta_vy * std::cos(kx0 * xPos + ky0 * yPos);
+      }
+    }
+}
+
 // ---- MHD: jet medium with an optional static field (MHDRunBase.cpp:1747-1798) and Sod tube (:1806-1862) ----------
 void init_mhd_jet(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   const double Bx = cfg.get_float("jet", "BStatic_x", 0.0f), By = cfg.get_float("jet", "BStatic_y", 0.0f);
@@ -698,6 +782,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "Rotor" || problem == "rotor") init_mhd_rotor(cfg, p, g);
     else if (problem == "FieldLoop" || problem == "fieldloop" || problem == "Fieldloop" || problem == "field-loop" || problem == "Field-Loop") init_mhd_field_loop(cfg, p, g);
     else if (problem == "CurrentSheet" || problem == "currentsheet" || problem == "Currentsheet" || problem == "current-sheet" || problem == "Current-Sheet") init_mhd_current_sheet(cfg, p, g);
+    else if (problem == "ShearWave" || problem == "shearwave" || problem == "Shear-Wave" || problem == "shear-wave" || problem == "Shearwave") init_mhd_shear_wave(cfg, p, g);
     else throw std::runtime_error("MHD problem '" + problem + "' is outside the implemented scope");
   } else {
     if (problem == "jet") init_hydro_jet(p, g);
@@ -706,6 +791,8 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "Kelvin-Helmholtz") init_hydro_kelvin_helmholtz(cfg, p, g);
     else if (problem == "Rayleigh-Taylor") init_rayleigh_taylor(cfg, p, g);
     else if (problem == "blast") init_hydro_blast(cfg, p, g);
+    else if (problem == "Gresho-vortex") init_hydro_gresho(cfg, p, g);
+    else if (problem == "falling-bubble") init_hydro_falling_bubble(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
 }
