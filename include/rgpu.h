@@ -78,8 +78,8 @@ typedef struct rgpu_params {
   int32_t niter_riemann, iorder;
   int32_t riemannSolver;        /* RGPU_RS_*  (HydroParameters.h:353-381) */
   int32_t magRiemannSolver;     /* RGPU_MAG_* (HydroParameters.h:388-417) */
-  int32_t implementationVersion;/* [MHD] implementationVersion: 2D must be 1; 3D 3/4 (Omega0>0 forces 1/4, MHDRunGodunov.cpp:119-126) */
-  int32_t unsplitVersion;       /* [hydro] unsplitVersion: only 1 is implemented (HydroRunGodunov.cpp:1858-1860) */
+  int32_t implementationVersion;/* [MHD] implementationVersion: 2D 0 or 1; 3D 3/4 (Omega0>0 forces 1/4, MHDRunGodunov.cpp:119-126) */
+  int32_t unsplitVersion;       /* [hydro] unsplitVersion: 1 or 2 (HydroRunGodunov.cpp:1852-1866; 2 = direction-wise sweeps) */
   int32_t shearingBoxEnabled;   /* bc xmin==xmax==4 and Omega0>0 (MHDRunGodunov.cpp:97-103) */
   int32_t enableJet, ijet, offsetJet;  /* HydroParameters.h:435-444 */
   double  djet, ujet, pjet, cjet;

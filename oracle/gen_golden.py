@@ -98,6 +98,17 @@ CASES = {
     "gresho3d_16x16x6": ("Gresho_vortex2d", "mesh.nx=16;mesh.ny=16;mesh.nz=6;hydro.unsplitVersion=1;Gresho_vortex.v_bulk_z=0.25;run.nstepmax=5;run.noutput=100", [0, 5]),
     "bubble2d_24": ("falling_bubble_gpu_2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=10;run.noutput=100", [0, 10]),
     "shearwave_16x8x4": ("mhd_shearWave_3d", "mesh.nx=16;mesh.ny=8;mesh.nz=4;output.outputVtkAscii=no;run.nstepmax=8;run.noutput=100", [0, 8]),
+    # --- hydro unsplitVersion=2 (direction-wise sweeps: same fluxes, other accumulation order) ---------------------
+    "gresho2d_32_v2": ("Gresho_vortex2d", "mesh.nx=32;mesh.ny=32;run.nstepmax=10;run.noutput=100", [10]),
+    "kh2d_robertson_32x24_v2": ("kelvin_helmholtz_gpu_2d", "mesh.nx=32;mesh.ny=24;run.nstepmax=10;run.noutput=100", [10]),
+    "implode3d_12_v2": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.unsplitVersion=2;hydro.riemannSolver=hllc;run.nstepmax=6;run.noutput=100", [6]),
+    "rt2d_16x48_v2": ("rayleigh_taylor_gpu_2d", "mesh.nx=16;mesh.ny=48;hydro.unsplitVersion=2;run.nstepmax=8;run.noutput=100", [8]),
+    # --- 2D MHD implementationVersion=0 (same numbers as version 1, plus the gravity terms) ----------------------------
+    "rt2d_mhd_12x36_v0": ("rayleigh_taylor_cpu_2d_mhd", "mesh.nx=12;mesh.ny=36;run.nstepmax=8;run.noutput=100", [8]),
+    "briowu_x_32_v0": ("mhd_BrioWu", "mesh.nx=32;mesh.ny=16;BrioWu.direction=0;MHD.implementationVersion=0;run.nstepmax=12;run.noutput=100", [12]),
+    "ot2d_24_v0": ("orszag-tang", "mesh.nx=24;mesh.ny=24;MHD.implementationVersion=0;run.nstepmax=12;run.noutput=100", [12]),
+    "implode3d_12_rand": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;implode.amplitude=0.02;implode.seed=7;hydro.riemannSolver=hllc;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "implode2d_16_rand": ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=1;implode.amplitude=0.05;run.nstepmax=5;run.noutput=100", [0, 5]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 

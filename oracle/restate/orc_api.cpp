@@ -48,11 +48,11 @@ static int check_scope(const rgpu_params* p) {
     const bool three_d = p->nz_global != 1;
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLA && p->magRiemannSolver != RGPU_MAG_HLLF &&
         p->magRiemannSolver != RGPU_MAG_LLF) return RGPU_EUNSUPPORTED;
-    if (!three_d && p->implementationVersion != 1) return RGPU_EUNSUPPORTED;
+    if (!three_d && p->implementationVersion != 1 && p->implementationVersion != 0) return RGPU_EUNSUPPORTED;
     if (!three_d && p->Omega0 > 0) return RGPU_EUNSUPPORTED;
     if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) return RGPU_EUNSUPPORTED;
   } else {
-    if (p->unsplitVersion != 1) return RGPU_EUNSUPPORTED;
+    if (p->unsplitVersion != 1 && p->unsplitVersion != 2) return RGPU_EUNSUPPORTED;
   }
   return 0;
 }

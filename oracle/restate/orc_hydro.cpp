@@ -61,8 +61,14 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
           for (int v = 0; v < NV; ++v) { qm[d].d[o + v * N] = tqm[d][v]; qp[d].d[o + v * N] = tqp[d][v]; }
       }
 
-  // Riemann problems at the low faces of every cell of [gw, size-gw] + scatter update
+  // Riemann problems at the low faces of every cell of [gw, size-gw] + scatter update.
+  // unsplitVersion 1 (godunov_unsplit_cpu_v1, HydroRunGodunov.cpp:2437-2949): one sweep, the x, y, z fluxes of a cell
+  // applied together.  unsplitVersion 2 (godunov_unsplit_cpu_v2, :2955-3849): one sweep per direction -- the same
+  // fluxes (its direction-wise trace evaluates the same expressions), but a cell receives them in the order
+  // +Fx, -Fx', +Fy, -Fy', +Fz, -Fz' instead of +Fx, +Fy, +Fz, -Fx', -Fy', -Fz'.
   const int kb0 = (NDIM == 3) ? gw : 0, kb1 = (NDIM == 3) ? ksize - gw + 1 : 1;
+  const int nsweep = (p.unsplitVersion == 2) ? NDIM : 1;
+  for (int sweep = 0; sweep < nsweep; ++sweep)
   for (int k = kb0; k < kb1; k++)
     for (int j = gw; j < jsize - gw + 1; j++)
       for (int i = gw; i < isize - gw + 1; i++) {
@@ -70,6 +76,7 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
         double ql[NV], qr[NV], flux[3][NV];
         // face-normal frame: swap IU with the normal velocity
         for (int d = 0; d < NDIM; ++d) {
+          if (nsweep > 1 && d != sweep) continue;
           const int swp = (d == 0) ? IU : (d == 1) ? IV : IW;
           for (int v = 0; v < NV; ++v) {
             int vs = v;
@@ -81,23 +88,24 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
           hydro_riemann<NV>(p, ql, qr, flux[d]);
         }
         const bool in_i = i < isize - gw, in_j = j < jsize - gw, in_k = (NDIM == 3) ? (k < ksize - gw) : true;
+        const bool do_x = nsweep == 1 || sweep == 0, do_y = nsweep == 1 || sweep == 1, do_z = NDIM == 3 && (nsweep == 1 || sweep == 2);
         // x
-        if (i > gw && in_j && in_k)
+        if (do_x && i > gw && in_j && in_k)
           for (int v = 0; v < NV; ++v) Unew.d[o - 1 + v * N] -= flux[0][v] * dtdx;
-        if (in_i && in_j && in_k)
+        if (do_x && in_i && in_j && in_k)
           for (int v = 0; v < NV; ++v) Unew.d[o + v * N] += flux[0][v] * dtdx;
         // y (IU <-> IV swapped back)
-        if (in_i && j > gw && in_k)
+        if (do_y && in_i && j > gw && in_k)
           for (int v = 0; v < NV; ++v) {
             const int vs = (v == IU) ? IV : (v == IV) ? IU : v;
             Unew.d[o - stride[1] + v * N] -= flux[1][vs] * dtdy;
           }
-        if (in_i && in_j && in_k)
+        if (do_y && in_i && in_j && in_k)
           for (int v = 0; v < NV; ++v) {
             const int vs = (v == IU) ? IV : (v == IV) ? IU : v;
             Unew.d[o + v * N] += flux[1][vs] * dtdy;
           }
-        if (NDIM == 3) {
+        if (do_z) {
           if (in_i && in_j && k > gw)
             for (int v = 0; v < NV; ++v) {
               const int vs = (v == IU) ? IW : (v == IW) ? IU : v;

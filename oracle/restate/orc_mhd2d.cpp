@@ -110,10 +110,13 @@ void trace_mhd_2d(const rgpu_params& g, double qNb[3][3][8], double bfNb[4][4][3
 }  // namespace
 
 void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
+  // Implementation versions 0 and 1 of the 2D step compute the same numbers (version 0 recomputes what version 1
+  // stores); only version 0 has the static-gravity terms.
   const rgpu_params& p = c.p;
   const int gw = c.gw, isize = c.isize, jsize = c.jsize;
   const double dtdx = dt / c.dx, dtdy = dt / c.dy;
   const size_t N = c.ncell;
+  const bool grav = p.gravityEnabled && p.implementationVersion == 0;
 
   make_all_boundaries(c, Uold_d, 0.0, 0.0);
   std::memcpy(Unew_d, Uold_d, sizeof(double) * N * 8);
@@ -150,6 +153,14 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
           bfNb[di][dj][IX] = U(ii, jj, IA); bfNb[di][dj][IY] = U(ii, jj, IB); bfNb[di][dj][IZ] = U(ii, jj, IC);
         }
       trace_mhd_2d(p, qNb, bfNb, dtdx, dtdy, xPos, qm, qp, qEdge);
+      if (grav) {   // implementation version 0 only (mhd_godunov_unsplit_cpu_v0.cpp:495-525): predictor on all 8 states
+        const double gx = 0.5 * dt * p.gravity_x, gy = 0.5 * dt * p.gravity_y;
+        // the y states are already in the swapped (y-normal) frame when the reference adds the predictor
+        // (swap at :177-179, :388-390, predictor at :500-512): g_x lands on v and g_y on u there
+        qm[0][IU] += gx; qm[0][IV] += gy; qp[0][IU] += gx; qp[0][IV] += gy;
+        qm[1][IV] += gx; qm[1][IU] += gy; qp[1][IV] += gx; qp[1][IU] += gy;
+        for (int e = 0; e < 4; ++e) { qEdge[e][IU] += gx; qEdge[e][IV] += gy; }
+      }
       for (int v = 0; v < 8; ++v) {
         qm_x(i, j, v) = qm[0][v]; qp_x(i, j, v) = qp[0][v]; qm_y(i, j, v) = qm[1][v]; qp_y(i, j, v) = qp[1][v];
         eRT(i, j, v) = qEdge[0][v]; eRB(i, j, v) = qEdge[1][v]; eLT(i, j, v) = qEdge[2][v]; eLB(i, j, v) = qEdge[3][v];
@@ -182,6 +193,15 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
       }
       emf(i, j, 0) = compute_emf<2>(p, qe);
     }
+
+  // gravity source term on the momenta (version 0: mhd_godunov_unsplit_cpu_v0.cpp:616-618, HydroRunBase.cpp:1925-1950)
+  if (grav)
+    for (int j = gw; j < jsize - gw; j++)
+      for (int i = gw; i < isize - gw; i++) {
+        const double rhoOld = U(i, j, ID), rhoNew = Unew(i, j, ID);
+        Unew(i, j, IU) += 0.5 * dt * p.gravity_x * (rhoOld + rhoNew);
+        Unew(i, j, IV) += 0.5 * dt * p.gravity_y * (rhoOld + rhoNew);
+      }
 
   // constrained transport
   for (int j = gw; j < jsize - gw + 1; j++)

@@ -24,6 +24,7 @@ enum { XD = 0, YD = 1, ZD = 2 };
 struct DevParams {
   int isize, jsize, ksize, gw, nx, ny, nz, nvar;
   int three_d, mhd, rot, shearbox;
+  int dirwise_update, pad1;    // hydro unsplitVersion 2: fluxes applied direction by direction
   unsigned sj, sk;             // flat strides of +1 in j and k
   unsigned long long ncell;    // component stride
   double dx, dy, dz, xMin, deltaX;   // deltaX = xMax - xMin

@@ -92,9 +92,10 @@ void init_hydro_jet(const rgpu_params& p, const Grid& g) {
 
 // ---- hydro: implode (HydroRunBase.cpp:5449-5536) -------------------------------------------------------------
 void init_hydro_implode(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
-  const float amplitude = cfg.get_float("implode", "amplitude", 0.0f);
-  if (amplitude != 0.0f)
-    throw std::runtime_error("implode.amplitude != 0 needs the libc rand() stream: outside the implemented scope");
+  // density perturbation: one libc rand() draw per interior cell in k,j,i order (HydroRunBase.cpp:5455-5466)
+  const double amplitude = cfg.get_float("implode", "amplitude", 0.0f);
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer("implode", "seed", 1)));
+  if (g.three_d) for (long n = 0; n < (long)g.k_shift * g.ny * g.nx; ++n) rng.next();   // cells of the slabs below
   const int k0 = g.three_d ? g.gw : 0, k1 = g.three_d ? g.ksize - g.gw : 1;
   for (int k = k0; k < k1; ++k)
     for (int j = g.gw; j < g.jsize - g.gw; ++j)
@@ -105,11 +106,12 @@ void init_hydro_implode(const IniConfig& cfg, const rgpu_params& p, const Grid& 
           heavy = ((float)i / g.nx + (float)j / g.ny + (float)(k + g.k_shift) / g.nz_glob) > 0.5;
         else
           heavy = ((float)i / g.nx + (float)j / g.ny) > 0.5;
+        const double pert = amplitude * (1.0 * rng.next() / GlibcRand::kRandMax - 0.5);
         if (heavy) {
-          g.at(i, j, k, RGPU_ID) = 1.0f;
+          g.at(i, j, k, RGPU_ID) = 1.0f + pert;
           g.at(i, j, k, RGPU_IP) = 1.0f / (p.gamma0 - 1.0f);
         } else {
-          g.at(i, j, k, RGPU_ID) = 0.125f;
+          g.at(i, j, k, RGPU_ID) = 0.125f + pert;
           g.at(i, j, k, RGPU_IP) = 0.14f / (p.gamma0 - 1.0f);
         }
         g.at(i, j, k, RGPU_IU) = 0.0f;

@@ -1,4 +1,5 @@
-// kernels_hydro.h -- per-cell bodies of the hydro unsplit step ("unsplitVersion 1"), 2D (NV=4) and 3D (NV=5).
+// kernels_hydro.h -- per-cell bodies of the hydro unsplit step ("unsplitVersion 1" and, through the order of the
+// update, "unsplitVersion 2"), 2D (NV=4) and 3D (NV=5).
 //   hydro_prim_cell    U         -> Q  (NV)          convertToPrimitives   HydroRunGodunov.cpp:4133-4262
 //   hydro_trace_cell   Q         -> TH (NV*(1+ND))   slopes + trace        HydroRunGodunov.cpp:2454-2509, 2666-2748
 //   hydro_flux_cell    TH        -> FH (NV*ND)       Riemann at low faces  HydroRunGodunov.cpp:2525-2565, 2757-2822
@@ -146,20 +147,29 @@ RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ U
   if (inner) {
     const unsigned strd[3] = {1u, g.sj, g.sk};
     const double dtd[3] = {dtdx, dtdy, dtdz};
-    // own low faces first (+), in x,y,z order; then the high faces (-), in x,y,z order
+    // unsplitVersion 1: own low faces first (+), in x,y,z order; then the high faces (-), in x,y,z order.
+    // unsplitVersion 2 (direction-wise sweeps of the reference, HydroRunGodunov.cpp:2955-3849): +x, -x, +y, -y, +z, -z.
+    auto apply = [&](int d, int pass) {
+      const unsigned o = idx + (pass ? strd[d] : 0u);
+      const int swp = (d == 0) ? IU : (d == 1) ? IV : IW;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-      for (int d = 0; d < ND; ++d) {
-        const unsigned o = idx + (pass ? strd[d] : 0u);
-        const int swp = (d == 0) ? IU : (d == 1) ? IV : IW;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int vs = (v == IU) ? swp : (v == swp) ? IU : v;   // back from the face-normal frame
-          const double f = F[o + (size_t)(d * NV + vs) * N] * dtd[d];
-          if (pass == 0) u[v] += f; else u[v] -= f;
-        }
+      for (int v = 0; v < NV; ++v) {
+        const int vs = (v == IU) ? swp : (v == swp) ? IU : v;   // back from the face-normal frame
+        const double f = F[o + (size_t)(d * NV + vs) * N] * dtd[d];
+        if (pass == 0) u[v] += f; else u[v] -= f;
       }
+    };
+    if (!g.dirwise_update) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int d = 0; d < ND; ++d) apply(d, pass);
+    } else {
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) apply(d, pass);
+    }
     if (g.grav_on) {  // momentum source (compute_gravity_source_term, HydroRunBase.cpp:1925-1985); energy untouched
       const double rho_sum = Uold[idx + ID * N] + u[ID];
       u[IU] += g.hgx * rho_sum;

@@ -127,14 +127,17 @@ RG_DEVFN Prim8 face_state2d(const DevParams& g, const double* __restrict__ T, un
   Prim8 o;
   o.r = t[T2_R * N] + s * t[(S + 0) * N];
   o.p = t[T2_P * N] + s * t[(S + 1) * N];
-  const double u = t[T2_U * N] + s * t[(S + 2) * N];
-  const double v = t[T2_V * N] + s * t[(S + 3) * N];
+  double u = t[T2_U * N] + s * t[(S + 2) * N];
+  double v = t[T2_V * N] + s * t[(S + 3) * N];
   o.w = t[T2_W * N] + s * t[(S + 4) * N];
   const int TF = (D == XD) ? T2_AL : T2_BL;
   const double bn = (SIDE > 0) ? T[(m + sD) + (size_t)TF * N] : t[TF * N];
   const double bt = ((D == XD) ? t[T2_B * N] : t[T2_A * N]) + s * t[(S + 5) * N];
   o.c = t[T2_C * N] + s * t[(S + 6) * N];
   if (D == XD) { o.u = u; o.v = v; } else { o.u = v; o.v = u; }
+  // implementation version 0: the reference adds the gravity predictor AFTER the swap into the face-normal frame
+  // (mhd_godunov_unsplit_cpu_v0.cpp:177-179, 388-390, then 500-512), so on y faces g_x lands on v and g_y on u
+  if (g.grav_on) { o.u += g.hgx; o.v += g.hgy; }
   o.a = bn; o.b = bt;
   floor2d(g, o);
   return o;
@@ -151,6 +154,7 @@ RG_DEVFN Prim8 edge_state2d(const DevParams& g, const double* __restrict__ T, un
   o.p = t[T2_P * N] + (sx * t[(T2_DX + 1) * N] + sy * t[(T2_DY + 1) * N]);
   o.u = t[T2_U * N] + (sx * t[(T2_DX + 2) * N] + sy * t[(T2_DY + 2) * N]);
   o.v = t[T2_V * N] + (sx * t[(T2_DX + 3) * N] + sy * t[(T2_DY + 3) * N]);
+  if (g.grav_on) { o.u += g.hgx; o.v += g.hgy; }   // (mhd_godunov_unsplit_cpu_v0.cpp:514-524)
   o.w = t[T2_W * N] + (sx * t[(T2_DX + 4) * N] + sy * t[(T2_DY + 4) * N]);
   o.c = t[T2_C * N] + (sx * t[(T2_DX + 6) * N] + sy * t[(T2_DY + 6) * N]);
   const unsigned mx = (SX > 0) ? m + 1 : m;
@@ -214,6 +218,11 @@ RG_DEVFN void mhd_update2d_cell(const DevParams& g, const double* __restrict__ U
     RG_LOADF2(F2_Y, sj);
     u[ID] -= f[0] * dtdy; u[IP] -= f[1] * dtdy; u[IU] -= f[3] * dtdy; u[IV] -= f[2] * dtdy; u[IW] -= f[4] * dtdy; u[IC] -= f[5] * dtdy;
 #undef RG_LOADF2
+    if (g.grav_on) {  // momentum source (mhd_godunov_unsplit_cpu_v0.cpp:616-618)
+      const double rho_sum = Uold[idx + ID * N] + u[ID];
+      u[IU] += g.hgx * rho_sum;
+      u[IV] += g.hgy * rho_sum;
+    }
   }
   if (c.i >= gw && c.i <= g.isize - gw && c.j >= gw && c.j <= g.jsize - gw) {
     const double* e = F + (size_t)F2_EMF * N;

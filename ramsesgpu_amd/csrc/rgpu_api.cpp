@@ -82,14 +82,16 @@ int validate(const rgpu_params* p, std::string* why) {
   // 3D step call slope routines that leave dq unset for type 3 (slope.h:97-147,324-427; slope_mhd.h:436-502)
   if (p->slope_type == 3 && (!p->mhdEnabled || p->Omega0 > 0)) { *why = "slope_type 3 is defined for non-rotating MHD only (the reference leaves the slopes unset elsewhere)"; return RGPU_EUNSUPPORTED; }
   if (p->mhdEnabled) {
-    if (!three_d && p->implementationVersion != 1) { *why = "2D MHD: only implementationVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }
+    // 2D: versions 0 and 1 compute the same numbers (0 recomputes what 1 stores; 0 alone has the gravity terms); 2 is a
+    // superseded variant
+    if (!three_d && p->implementationVersion != 1 && p->implementationVersion != 0) { *why = "2D MHD: implementationVersion must be 0 or 1"; return RGPU_EUNSUPPORTED; }
     if (!three_d && p->Omega0 > 0) { *why = "2D rotating frame is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
     if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) { *why = "3D MHD: only implementationVersion 3/4 are implemented"; return RGPU_EUNSUPPORTED; }
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLF && p->magRiemannSolver != RGPU_MAG_HLLA &&
         p->magRiemannSolver != RGPU_MAG_LLF) { *why = "magRiemannSolver must be hlld, hllf, hlla or llf (roe / upwind do not exist in the reference either)"; return RGPU_EUNSUPPORTED; }
     if (p->shearingBoxEnabled && !three_d) { *why = "shearing box needs 3D"; return RGPU_EUNSUPPORTED; }
   } else {
-    if (p->unsplitVersion != 1) { *why = "hydro: only unsplitVersion=1 is implemented"; return RGPU_EUNSUPPORTED; }
+    if (p->unsplitVersion != 1 && p->unsplitVersion != 2) { *why = "hydro: unsplitVersion must be 1 or 2 (version 0 is a superseded variant)"; return RGPU_EUNSUPPORTED; }
     if (p->riemannSolver != RGPU_RS_APPROX && p->riemannSolver != RGPU_RS_HLL && p->riemannSolver != RGPU_RS_HLLC) { *why = "hydro riemannSolver must be approx, hll or hllc"; return RGPU_EINVAL; }
   }
   for (int f = 0; f < 6; ++f) {
@@ -124,6 +126,7 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   g->slope_type = p.slope_type;
   g->mag_slope_type = std::fmin(p.slope_type, 2.0);
   g->niter_riemann = p.niter_riemann; g->riemannSolver = p.riemannSolver; g->magRiemannSolver = p.magRiemannSolver;
+  g->dirwise_update = (!p.mhdEnabled && p.unsplitVersion == 2) ? 1 : 0; g->pad1 = 0;
   g->grav_on = 0; g->hgx = 0.0; g->hgy = 0.0; g->hgz = 0.0;   // per step: step_core_planes
 }
 
@@ -453,8 +456,9 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 }
 
 int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
-  // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; the 2D MHD step has none
-  c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d)) ? 1 : 0;
+  // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
+  // implementation version 0 has it
+  c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && c->p.implementationVersion != 0)) ? 1 : 0;
   c->g.hgx = 0.5 * dt * c->p.gravity_x;
   c->g.hgy = 0.5 * dt * c->p.gravity_y;
   c->g.hgz = 0.5 * dt * c->p.gravity_z;

@@ -66,7 +66,7 @@ def test_no_cpu_fallback_without_gpu(product_lib):
 
 def test_rejects_out_of_scope_configurations(emu_lib):
     L = emu_lib
-    for base, ov, frag in (("orszag-tang", "MHD.implementationVersion=0", "implementationVersion"),
+    for base, ov, frag in (("orszag-tang", "MHD.implementationVersion=2", "implementationVersion"),
                            ("orszag-tang", "MHD.magRiemannSolver=roe", "magRiemannSolver"),
                            ("implode3d", "mesh.nz=16;hydro.slope_type=3", "slope_type"),      # hydro: slopes left unset by the reference
                            ("mhd_mri_3d", "mesh.nz=16;hydro.slope_type=3", "slope_type")):    # rotating 3D step: same

@@ -29,6 +29,8 @@ CASES = [
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=27", 3, 3, 1),                         # three slabs, inner planes [6,9)
     ("kelvin_helmholtz_gpu_3d", "mesh.nx=8;mesh.ny=4;mesh.nz=16", 3, 2, 1),           # libc rand() stream continued across slabs
     ("mhd_fieldloop3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 3, 2, 1),                    # drand48 noise of the vector potential
+    ("rayleigh_taylor_gpu_3d_mhd", "mesh.nx=6;mesh.ny=6;mesh.nz=16;rayleigh-taylor.randomEnabled=yes", 3, 2, 1),   # gravity + rand() over ghosts too
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;implode.amplitude=0.02;hydro.unsplitVersion=2", 3, 2, 1),        # direction-wise update order
 ]
 
 
