@@ -109,6 +109,9 @@ CASES = {
     "ot2d_24_v0": ("orszag-tang", "mesh.nx=24;mesh.ny=24;MHD.implementationVersion=0;run.nstepmax=12;run.noutput=100", [12]),
     "implode3d_12_rand": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;implode.amplitude=0.02;implode.seed=7;hydro.riemannSolver=hllc;run.nstepmax=5;run.noutput=100", [0, 5]),
     "implode2d_16_rand": ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=1;implode.amplitude=0.05;run.nstepmax=5;run.noutput=100", [0, 5]),
+    "riemann2d_c3_24": ("riemann2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=8;run.noutput=100", [0, 8]),
+    "riemann2d_c12_24": ("riemann2d", "mesh.nx=24;mesh.ny=24;hydro.riemann_config_number=11;riemann2d.x=0.5;riemann2d.y=0.4;run.nstepmax=8;run.noutput=100", [0, 8]),
+    "riemann2d_c19_16": ("riemann2d", "mesh.nx=16;mesh.ny=16;hydro.riemann_config_number=25;run.nstepmax=4;run.noutput=100", [0, 4]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 

@@ -507,6 +507,53 @@ void init_rayleigh_taylor(const IniConfig& cfg, const rgpu_params& p, const Grid
   }
 }
 
+// ---- hydro: the 19 two-dimensional Riemann problems of Lax & Liu, SIAM J. Sci. Comput. 19 (1998) 319-340
+// (HydroRunBase.cpp:6798-6907; the state table is the paper's: {rho, u, v, p} of quadrants 1..4, single precision
+// like the reference's initRiemannConfig2d) --------------------------------------------------------------------------
+void init_hydro_riemann2d(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  static const float kLaxLiu[19][4][4] = {
+    {{1.0f, 0.0f, 0.0f, 1.0f}, {0.5197f, -0.7259f, 0.0f, 0.4f}, {0.1072f, -0.7259f, -1.4045f, 0.0439f}, {0.2579f, 0.0f, -1.4045f, 0.15f}},   // configuration 1
+    {{1.0f, 0.0f, 0.0f, 1.0f}, {0.5197f, -0.7259f, 0.0f, 0.4f}, {1.0f, -0.7259f, -0.7259f, 1.0f}, {0.5197f, 0.0f, -0.7259f, 0.4f}},   // configuration 2
+    {{1.5f, 0.0f, 0.0f, 1.5f}, {0.5323f, 1.206f, 0.0f, 0.3f}, {0.138f, 1.206f, 1.206f, 0.029f}, {0.5323f, 0.0f, 1.206f, 0.3f}},   // configuration 3
+    {{1.1f, 0.0f, 0.0f, 1.1f}, {0.5065f, 0.8939f, 0.0f, 0.35f}, {1.1f, 0.8939f, 0.8939f, 1.1f}, {0.5065f, 0.0f, 0.8939f, 0.35f}},   // configuration 4
+    {{1.0f, -0.75f, -0.5f, 1.0f}, {2.0f, -0.75f, 0.5f, 1.0f}, {1.0f, 0.75f, 0.5f, 1.0f}, {3.0f, 0.75f, -0.5f, 1.0f}},   // configuration 5
+    {{1.0f, 0.75f, -0.5f, 1.0f}, {2.0f, 0.75f, 0.5f, 0.5f}, {1.0f, -0.75f, 0.5f, 1.0f}, {3.0f, -0.75f, -0.5f, 1.0f}},   // configuration 6
+    {{1.0f, 0.1f, 0.1f, 1.0f}, {0.5197f, -0.6259f, 0.1f, 0.4f}, {0.8f, 0.1f, 0.1f, 0.4f}, {0.5197f, 0.1f, -0.6259f, 0.4f}},   // configuration 7
+    {{0.5197f, 0.1f, 0.1f, 0.4f}, {1.0f, -0.6259f, 0.1f, 1.0f}, {0.8f, 0.1f, 0.1f, 1.0f}, {1.0f, 0.1f, -0.6259f, 1.0f}},   // configuration 8
+    {{1.0f, 0.0f, 0.3f, 1.0f}, {2.0f, 0.0f, -0.3f, 1.0f}, {1.039f, 0.0f, -0.8133f, 0.4f}, {0.5197f, 0.0f, -0.4259f, 0.4f}},   // configuration 9
+    {{1.0f, 0.0f, 0.4297f, 1.0f}, {0.5f, 0.0f, 0.6076f, 1.0f}, {0.2281f, 0.0f, -0.6076f, 0.3333f}, {0.4562f, 0.0f, -0.4259f, 0.3333f}},   // configuration 10
+    {{1.0f, 0.1f, 0.0f, 1.0f}, {0.5313f, 0.8276f, 0.0f, 0.4f}, {0.8f, 0.1f, 0.0f, 0.4f}, {0.5313f, 0.1f, 0.7276f, 0.4f}},   // configuration 11
+    {{0.5313f, 0.0f, 0.0f, 0.4f}, {1.0f, 0.7276f, 0.0f, 1.0f}, {0.8f, 0.0f, 0.0f, 1.0f}, {1.0f, 0.0f, 0.7276f, 1.0f}},   // configuration 12
+    {{1.0f, 0.0f, -0.3f, 1.0f}, {2.0f, 0.0f, 0.3f, 1.0f}, {1.0625f, 0.0f, 0.8145f, 0.4f}, {0.5313f, 0.0f, 0.4276f, 0.4f}},   // configuration 13
+    {{2.0f, 0.0f, -0.5606f, 8.0f}, {1.0f, 0.0f, -1.2172f, 8.0f}, {0.4736f, 0.0f, 1.2172f, 2.6667f}, {0.9474f, 0.0f, 1.1606f, 2.6667f}},   // configuration 14
+    {{1.0f, 0.1f, -0.3f, 1.0f}, {0.5197f, -0.6259f, -0.3f, 0.4f}, {0.8f, 0.1f, -0.3f, 0.4f}, {0.5313f, 0.1f, 0.4276f, 0.4f}},   // configuration 15
+    {{0.5313f, 0.1f, 0.1f, 0.4f}, {1.0222f, -0.6179f, 0.1f, 1.0f}, {0.8f, 0.1f, 0.1f, 1.0f}, {1.0f, 0.1f, 0.8276f, 1.0f}},   // configuration 16
+    {{1.0f, 0.0f, -0.4f, 1.0f}, {2.0f, 0.0f, -0.3f, 1.0f}, {1.0625f, 0.0f, 0.2145f, 0.4f}, {0.5197f, 0.0f, -1.1259f, 0.4f}},   // configuration 17
+    {{1.0f, 0.0f, 1.0f, 1.0f}, {2.0f, 0.0f, -0.3f, 1.0f}, {1.0625f, 0.0f, 0.2145f, 0.4f}, {0.5197f, 0.0f, 0.2741f, 0.4f}},   // configuration 18
+    {{1.0f, 0.0f, 0.3f, 1.0f}, {2.0f, 0.0f, -0.3f, 1.0f}, {1.0625f, 0.0f, 0.2145f, 0.4f}, {0.5197f, 0.0f, -0.4259f, 0.4f}},   // configuration 19
+  };
+  if (g.three_d) throw std::runtime_error("riemann2d is a 2D problem");
+  int nb = static_cast<int>(cfg.get_integer("hydro", "riemann_config_number", 0));
+  if (nb < 0) nb = 0; else if (nb > 18) nb = 18;
+  const double xt = cfg.get_float("riemann2d", "x", 0.5f), yt = cfg.get_float("riemann2d", "y", 0.5f);
+  double q[4][4];   // conservative {rho, E, rho u, rho v} of quadrants 1..4 (primToCons_2D, constoprim.h:221-234)
+  for (int n = 0; n < 4; ++n) {
+    const double rho = kLaxLiu[nb][n][0], u = kLaxLiu[nb][n][1], v = kLaxLiu[nb][n][2], pr = kLaxLiu[nb][n][3];
+    q[n][RGPU_ID] = rho;
+    q[n][RGPU_IU] = u * rho;
+    q[n][RGPU_IV] = v * rho;
+    q[n][RGPU_IP] = pr / (p.gamma0 - 1.0f) + rho * (u * u + v * v) * 0.5f;
+  }
+  for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+    const double y = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+    for (int i = g.gw; i < g.isize - g.gw; ++i) {
+      const double x = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+      const int quad = (x < xt) ? ((y < yt) ? 2 : 1) : ((y < yt) ? 3 : 0);
+      for (int v = 0; v < 4; ++v) g.at(i, j, 0, v) = q[quad][v];
+    }
+  }
+}
+
 // ---- hydro: Gresho vortex (HydroRunBase.cpp:5688-5838) ------------------------------------------------------------
 void init_hydro_gresho(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   const char* S = "Gresho_vortex";
@@ -794,6 +841,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "Rayleigh-Taylor") init_rayleigh_taylor(cfg, p, g);
     else if (problem == "blast") init_hydro_blast(cfg, p, g);
     else if (problem == "Gresho-vortex") init_hydro_gresho(cfg, p, g);
+    else if (problem == "riemann2d") init_hydro_riemann2d(cfg, p, g);
     else if (problem == "falling-bubble") init_hydro_falling_bubble(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
