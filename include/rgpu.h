@@ -182,6 +182,19 @@ int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
 int rgpu_inv_dt_accumulate(rgpu_ctx* c, int parity, int k_lo, int k_hi, int reset);
 int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt);
 
+/* History diagnostics of the MHD runs, reduced on the device instead of copying the state to the host
+ * (MHDRunBase::history_mri, MHDRunBase.cpp:3476-3619; history_default, :3311-3407 is its mass / divB subset).
+ * rgpu_history_mri: out[8] = mass, maxwell stress, reynolds stress, magnetic pressure, mean Bx, By, Bz, sum of divB,
+ * normalised like the reference's history file (single domain).  Sums are accumulated in a fixed order that is not the
+ * reference's loop order: they agree with it to round-off.
+ * Slab runs combine the two lower-level calls: rgpu_history_columns gives cols[9][isize] = sums over the interior y,z
+ * extent of this domain of {rho, mx/rho, my/rho (every i), magp terms, maxwell term, Bx, By, Bz, divB (interior i)};
+ * after an all-reduce, mean_vx/vy[i] = cols[1..2][i] / (ny * nz_global) feed rgpu_history_reynolds, which returns
+ * cols[isize] = sum_jk rho * dTau * (vx - mean_vx)(vy - mean_vy). */
+int rgpu_history_columns(rgpu_ctx* c, int parity, double* cols);
+int rgpu_history_reynolds(rgpu_ctx* c, int parity, const double* mean_vx, const double* mean_vy, double dTau, double* cols);
+int rgpu_history_mri(rgpu_ctx* c, int parity, double* out);
+
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
 

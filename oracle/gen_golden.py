@@ -112,6 +112,9 @@ CASES = {
     "riemann2d_c3_24": ("riemann2d", "mesh.nx=24;mesh.ny=24;run.nstepmax=8;run.noutput=100", [0, 8]),
     "riemann2d_c12_24": ("riemann2d", "mesh.nx=24;mesh.ny=24;hydro.riemann_config_number=11;riemann2d.x=0.5;riemann2d.y=0.4;run.nstepmax=8;run.noutput=100", [0, 8]),
     "riemann2d_c19_16": ("riemann2d", "mesh.nx=16;mesh.ny=16;hydro.riemann_config_number=25;run.nstepmax=4;run.noutput=100", [0, 4]),
+    # --- history diagnostics: the run also writes <prefix>_history.txt (one row per step with dtHist=0) ------------------
+    "mri_8x16x8_history": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MRI.amp=0.2;history.enabled=yes;history.dtHist=0.0;run.nstepmax=10;run.noutput=1000", [10]),
+    "ot3d_12_history": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;history.enabled=yes;history.dtHist=0.0;run.nstepmax=5;run.noutput=1000", [5]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 
@@ -187,6 +190,12 @@ def run_case(name):
             fields, dims = read_vti(os.path.join(td, "%s_%07d.vti" % (prefix, s)))
             names = VAR_NAMES[len(fields)]
             arrays["step_%d" % s] = np.stack([fields[n] for n in names])
+        # history file of the run, if it wrote one ([history] enabled=yes): rows of
+        # totalTime dt mass maxwell reynolds maxwell+reynolds magp mean_Bx mean_By mean_Bz divB (6 significant digits)
+        hist = os.path.join(td, prefix + "_history.txt")
+        if os.path.exists(hist):
+            rows = [[float(x) for x in ln.split()] for ln in open(hist) if ln.strip() and not ln.startswith("#")]
+            arrays["history"] = np.array(rows)
     # dt log: "step=  N t=  T dt=  D" lines; with nlog=1 the line printed at step N carries the dt of step N-1
     # (the first one carries the initial compute_dt).  Duplicated lines (output + log) are collapsed on N.
     dts = {}

@@ -2,6 +2,8 @@
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The product never links this.
 #include <cstdio>
 
+#include <vector>
+
 #include "orc_common.h"
 
 using namespace orc;
@@ -37,6 +39,57 @@ double orc_compute_inv_dt(const rgpu_params* p, const double* U) {
 double orc_compute_dt(const rgpu_params* p, const double* U) {
   Ctx c(*p);
   return p->cfl / compute_inv_dt(c, U);
+}
+
+// history_mri (MHDRunBase.cpp:3476-3619; history_default :3311-3407 prints its mass and divB): the reference's loops,
+// in its order.  out[8] = mass, maxwell, reynolds, magp, mean_Bx, mean_By, mean_Bz, divB
+void orc_history_mri(const rgpu_params* p, const double* U, double* out) {
+  Ctx c(*p);
+  const int gw = c.gw, isize = c.isize, jsize = c.jsize, ksize = c.ksize;
+  const size_t N = c.ncell;
+  const bool three_d = c.three_d;
+  const int k0 = three_d ? gw : 0, k1 = three_d ? ksize - gw : 1;
+  const size_t sj = (size_t)isize, sk = three_d ? (size_t)isize * jsize : 0;
+  const double dx = c.dx, dy = c.dy, dz = c.dz;
+  double mass = 0.0, magp = 0.0, maxwell = 0.0, mean_Bx = 0.0, mean_By = 0.0, mean_Bz = 0.0;
+  for (int k = k0; k < k1; k++)
+    for (int j = gw; j < jsize - gw; j++)
+      for (int i = gw; i < isize - gw; i++) {
+        const size_t o = c.idx(i, j, k);
+        mass += U[o + ID * N];
+        magp += 0.25 * ((U[o + IA * N] + U[o + 1 + IA * N]) * (U[o + IA * N] + U[o + 1 + IA * N]));
+        magp += 0.25 * ((U[o + IB * N] + U[o + sj + IB * N]) * (U[o + IB * N] + U[o + sj + IB * N]));
+        if (three_d) magp += 0.25 * ((U[o + IC * N] + U[o + sk + IC * N]) * (U[o + IC * N] + U[o + sk + IC * N]));
+        maxwell -= 0.25 * (U[o + IA * N] + U[o + 1 + IA * N]) * (U[o + IB * N] + U[o + sj + IB * N]);
+        mean_Bx += U[o + IA * N]; mean_By += U[o + IB * N]; mean_Bz += U[o + IC * N];
+      }
+  double dTau;
+  if (three_d) dTau = dx * dy * dz / (p->xMax - p->xMin) / (p->yMax - p->yMin) / (p->zMax - p->zMin);
+  else dTau = dx * dy / (p->xMax - p->xMin) / (p->yMax - p->yMin);
+  magp = magp * dTau / 2.; mass = mass * dTau; maxwell = maxwell * dTau;
+  mean_Bx = mean_Bx * dTau; mean_By = mean_By * dTau; mean_Bz = mean_Bz * dTau;
+  std::vector<double> lm((size_t)isize * 3, 0.0);
+  for (int k = k0; k < k1; k++)
+    for (int j = gw; j < jsize - gw; j++)
+      for (int i = 0; i < isize; i++) {
+        const size_t o = c.idx(i, j, k);
+        lm[i] += U[o + ID * N];
+        lm[isize + i] += U[o + IU * N] / U[o + ID * N];
+        lm[2 * isize + i] += U[o + IV * N] / U[o + ID * N];
+      }
+  const int nyz = p->ny * (three_d ? p->nz : 1);
+  for (int i = 0; i < 3 * isize; i++) lm[i] /= nyz;
+  double reynolds = 0.0, divB = 0.0;
+  for (int k = k0; k < k1; k++)
+    for (int j = gw; j < jsize - gw; j++)
+      for (int i = gw; i < isize - gw; i++) {
+        const size_t o = c.idx(i, j, k);
+        reynolds += U[o + ID * N] * dTau * (U[o + IU * N] / U[o + ID * N] - lm[isize + i]) * (U[o + IV * N] / U[o + ID * N] - lm[2 * isize + i]);
+        double dv = (U[o + 1 + IA * N] - U[o + IA * N]) / dx + (U[o + sj + IB * N] - U[o + IB * N]) / dy;
+        if (three_d) dv = dv + (U[o + sk + IC * N] - U[o + IC * N]) / dz;
+        divB += dv;
+      }
+  out[0] = mass; out[1] = maxwell; out[2] = reynolds; out[3] = magp; out[4] = mean_Bx; out[5] = mean_By; out[6] = mean_Bz; out[7] = divB;
 }
 
 static int check_scope(const rgpu_params* p) {

@@ -96,6 +96,34 @@ void GodunovRun::outputVtk(int nStep) {
 }
 
 // MHDRunGodunov.cpp:3801-4070 / HydroRunGodunov.cpp:3857-4080 (no restart, no history, VTI outputs only)
+// history(nStep, dt): the history file of the MHD runs (MHDRunBase.cpp:3285-3619), one row per call, same columns and
+// ostream formatting: MRI problems get history_mri's eleven columns, Orszag-Tang history_default's four, every other
+// problem none (history_empty; the inertial-wave and turbulence variants are outside the implemented scope).  The sums
+// come from the device (rgpu_history_mri) instead of a copy of the state to the host.
+void GodunovRun::history(int nStep, double dt) {
+  if (!p_.mhdEnabled) return;
+  const std::string problem = cfg_.get_string("hydro", "problem", "unknown");
+  const bool mri = problem == "MRI" || problem == "Mri" || problem == "mri";
+  const bool dflt = problem == "Orszag-Tang" || problem == "OrszagTang";
+  if (!mri && !dflt) return;
+  if (mri && p_.nz_global == 1) return;   // history_mri does nothing in 2D
+  double h[8];
+  check(rgpu_history_mri(ctx_, nStep % 2, h), "history");
+  const std::string fileName = cfg_.get_string("output", "outputDir", "./") + "/" + cfg_.get_string("output", "outputPrefix", "output") +
+                               "_" + cfg_.get_string("history", "filename", "history.txt");
+  std::ofstream histo(fileName.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+  if (totalTime_ <= 0) {
+    histo << "# history" << std::endl;
+    if (mri) histo << "# totalTime dt mass maxwell reynolds maxwell+reynolds magp mean_Bx mean_By mean_Bz divB\n";
+    else histo << "# totalTime dt mass divB\n";
+  }
+  if (mri)
+    histo << totalTime_ << "\t" << dt << "\t" << h[0] << "\t" << h[1] << "\t" << h[2] << "\t" << h[1] + h[2] << "\t" << h[3] << "\t"
+          << h[4] << "\t" << h[5] << "\t" << h[6] << "\t" << h[7] << "\n";
+  else
+    histo << totalTime_ << "\t" << dt << "\t" << h[0] << "\t" << h[7] << "\n";
+}
+
 int GodunovRun::start(double* mcell_per_s) {
   int nStep = init_simulation();
   make_all_boundaries(0);
@@ -106,6 +134,10 @@ int GodunovRun::start(double* mcell_per_s) {
   double dt = compute_dt(0);
   std::cout << "Initial dt : " << std::setprecision(8) << dt << std::endl;
   double io_seconds = 0.0;
+  // history cadence of MHDRunGodunov::start (MHDRunGodunov.cpp:3913-3916, 3975-3984)
+  const bool historyEnabled = p_.mhdEnabled && cfg_.get_bool("history", "enabled", false);
+  const double dtHist = cfg_.get_float("history", "dtHist", static_cast<float>(10 * dt));
+  double tHist = 0.0;
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
     if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0)
@@ -115,6 +147,10 @@ int GodunovRun::start(double* mcell_per_s) {
       if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
+    }
+    if (historyEnabled && (tHist == 0 || ((totalTime_ - dt <= tHist + dtHist) && (totalTime_ > tHist + dtHist)))) {
+      history(nStep, dt);
+      tHist += dtHist;
     }
     oneStepIntegration(nStep, totalTime_, dt);
   }

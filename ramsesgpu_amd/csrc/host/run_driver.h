@@ -30,6 +30,7 @@ class GodunovRun {
   // time loop of start(); returns the number of steps; *mcell = "cell updates per second" / 1e6
   int start(double* mcell_per_s);
   void outputVtk(int nStep);
+  void history(int nStep, double dt);                     // [history] enabled=yes: <outputDir>/<outputPrefix>_history.txt
 
   const rgpu_params& params() const { return p_; }
   double totalTime() const { return totalTime_; }

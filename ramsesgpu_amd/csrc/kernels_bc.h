@@ -184,4 +184,82 @@ RG_DEVFN double mhd_invdt_cell(const DevParams& g, const double* __restrict__ U,
   return sx / g.dx + sy / g.dy + sz / g.dz;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// history diagnostics of the MHD runs (MHDRunBase::history_mri / history_default, MHDRunBase.cpp:3311-3407,
+// 3476-3619).  The reference copies the whole state to the host and loops over it; here the y sums are done on the
+// device, one thread per (i,k) row in increasing j (coalesced along i), a second kernel adds the rows of a column in
+// increasing k, and the host adds the isize column values: a fixed summation order, reproducible run to run (it is
+// not the reference's k,j,i order, so sums agree to round-off, not bit for bit).
+//   q = 0 rho, 1 vx = mx/rho, 2 vy = my/rho            (all i, ghosts included: the y-z means of history_mri)
+//       3 magp terms, 4 maxwell term, 5 Bx, 6 By, 7 Bz, 8 divB   (interior i only)
+enum { HIST_NQ = 9 };
+RG_DEVFN void hist_row_cell(const DevParams& g, const double* __restrict__ U, double* __restrict__ rows, unsigned idx) {
+  const int nk = g.three_d ? g.nz : 1;
+  const int i = (int)(idx % (unsigned)g.isize), kk = (int)(idx / (unsigned)g.isize);
+  if (kk >= nk) return;
+  const int k = g.three_d ? kk + g.gw : 0;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.three_d ? g.sk : 0u;
+  const bool inner = i >= g.gw && i < g.isize - g.gw;
+  double acc[HIST_NQ];
+#pragma unroll
+  for (int q = 0; q < HIST_NQ; ++q) acc[q] = 0.0;
+  for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+    const unsigned o = (unsigned)i + sj * (unsigned)j + g.sk * (unsigned)k;
+    const double rho = U[o + ID * N];
+    acc[0] += rho;
+    acc[1] += U[o + IU * N] / rho;
+    acc[2] += U[o + IV * N] / rho;
+    if (inner) {
+      const double bx = U[o + IA * N], by = U[o + IB * N], bz = U[o + IC * N];
+      const double sx = bx + U[o + 1 + IA * N], sy = by + U[o + sj + IB * N];
+      acc[3] += 0.25 * (sx * sx);
+      acc[3] += 0.25 * (sy * sy);
+      double dv = (U[o + 1 + IA * N] - bx) / g.dx + (U[o + sj + IB * N] - by) / g.dy;
+      if (g.three_d) {
+        const double sz = bz + U[o + sk + IC * N];
+        acc[3] += 0.25 * (sz * sz);
+        dv = dv + (U[o + sk + IC * N] - bz) / g.dz;
+      }
+      acc[4] -= 0.25 * sx * sy;
+      acc[5] += bx; acc[6] += by; acc[7] += bz;
+      acc[8] += dv;
+    }
+  }
+  const size_t R = (size_t)g.isize * nk;
+#pragma unroll
+  for (int q = 0; q < HIST_NQ; ++q) rows[(size_t)q * R + idx] = acc[q];
+}
+
+// column sums: thread (i,q) adds rows[q][k][i] over k
+RG_DEVFN void hist_col_cell(const DevParams& g, const double* __restrict__ rows, double* __restrict__ cols, int nq, unsigned idx) {
+  const int nk = g.three_d ? g.nz : 1;
+  const int i = (int)(idx % (unsigned)g.isize), q = (int)(idx / (unsigned)g.isize);
+  if (q >= nq) return;
+  const size_t R = (size_t)g.isize * nk;
+  double a = 0.0;
+  for (int kk = 0; kk < nk; ++kk) a += rows[(size_t)q * R + (size_t)kk * g.isize + i];
+  cols[(size_t)q * g.isize + i] = a;
+}
+
+// Reynolds stress rows: sum_j rho * dTau * (vx - <vx>(i)) * (vy - <vy>(i)) for interior i (MHDRunBase.cpp:3589-3595)
+RG_DEVFN void hist_reynolds_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ mean_vx,
+                                 const double* __restrict__ mean_vy, double dTau, double* __restrict__ rows, unsigned idx) {
+  const int nk = g.three_d ? g.nz : 1;
+  const int i = (int)(idx % (unsigned)g.isize), kk = (int)(idx / (unsigned)g.isize);
+  if (kk >= nk) return;
+  const int k = g.three_d ? kk + g.gw : 0;
+  const size_t N = g.ncell;
+  double a = 0.0;
+  if (i >= g.gw && i < g.isize - g.gw) {
+    const double m1 = mean_vx[i], m2 = mean_vy[i];
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const unsigned o = (unsigned)i + g.sj * (unsigned)j + g.sk * (unsigned)k;
+      const double rho = U[o + ID * N];
+      a += rho * dTau * (U[o + IU * N] / rho - m1) * (U[o + IV * N] / rho - m2);
+    }
+  }
+  rows[idx] = a;
+}
+
 }  // namespace rgpu_dev

@@ -44,6 +44,18 @@ struct K_mhd_invdt {
   DevParams g; const double* U;
   RG_DEVFN double operator()(unsigned idx) const { return mhd_invdt_cell(g, U, idx); }
 };
+struct K_hist_rows {
+  DevParams g; const double* U; double* rows;
+  RG_DEVFN void operator()(unsigned idx) const { hist_row_cell(g, U, rows, idx); }
+};
+struct K_hist_cols {
+  DevParams g; const double* rows; double* cols; int nq;
+  RG_DEVFN void operator()(unsigned idx) const { hist_col_cell(g, rows, cols, nq, idx); }
+};
+struct K_hist_reynolds {
+  DevParams g; const double* U; const double* mean_vx; const double* mean_vy; double dTau; double* rows;
+  RG_DEVFN void operator()(unsigned idx) const { hist_reynolds_cell(g, U, mean_vx, mean_vy, dTau, rows, idx); }
+};
 struct K_mhd_trace2d {
   DevParams g; const double* U; const double* Q; double* T; double dtdx, dtdy;
   RG_DEVFN void operator()(unsigned idx) const { mhd_trace2d_cell(g, U, Q, T, dtdx, dtdy, idx); }

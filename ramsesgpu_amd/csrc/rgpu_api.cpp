@@ -12,6 +12,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "launchers.h"
 
@@ -505,6 +506,40 @@ int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
   return inv_dt_scan(c, parity, 0, c->n32, true) || inv_dt_fetch(c, invDt);
 }
 
+// ---- history diagnostics ------------------------------------------------------------------------------------------
+// Scratch lives in the flux array F, which is dead between steps: rows [HIST_NQ][nk][isize], then the column sums
+// [HIST_NQ][isize], then the two mean-velocity columns.
+struct HistScratch { double* rows; double* cols; double* mean; size_t R; };
+HistScratch hist_scratch(rgpu_ctx* c) {
+  HistScratch h;
+  const int nk = c->g.three_d ? c->g.nz : 1;
+  h.R = (size_t)c->g.isize * nk;
+  h.rows = c->F;
+  h.cols = c->F + (size_t)HIST_NQ * h.R;
+  h.mean = h.cols + (size_t)HIST_NQ * c->g.isize;
+  return h;
+}
+
+int history_columns(rgpu_ctx* c, int parity, double* h_cols) {
+  const HistScratch h = hist_scratch(c);
+  K_hist_rows kr = {c->g, c->U[parity & 1], h.rows};
+  K_hist_cols kc = {c->g, h.rows, h.cols, HIST_NQ};
+  if (rg_launch<kBlock>(c->stream, (unsigned)h.R, kr) || rg_launch<kBlock>(c->stream, (unsigned)(HIST_NQ * c->g.isize), kc)) return -1;
+  if (rg_copy_d2h(h_cols, h.cols, sizeof(double) * HIST_NQ * c->g.isize, c->stream) || rg_stream_sync(c->stream)) return -1;
+  return 0;
+}
+
+int history_reynolds(rgpu_ctx* c, int parity, const double* h_mean_vx, const double* h_mean_vy, double dTau, double* h_cols) {
+  const HistScratch h = hist_scratch(c);
+  const size_t is = (size_t)c->g.isize;
+  if (rg_copy_h2d(h.mean, h_mean_vx, sizeof(double) * is, c->stream) || rg_copy_h2d(h.mean + is, h_mean_vy, sizeof(double) * is, c->stream)) return -1;
+  K_hist_reynolds kr = {c->g, c->U[parity & 1], h.mean, h.mean + is, dTau, h.rows};
+  K_hist_cols kc = {c->g, h.rows, h.cols, 1};
+  if (rg_launch<kBlock>(c->stream, (unsigned)h.R, kr) || rg_launch<kBlock>(c->stream, (unsigned)is, kc)) return -1;
+  if (rg_copy_d2h(h_cols, h.cols, sizeof(double) * is, c->stream) || rg_stream_sync(c->stream)) return -1;
+  return 0;
+}
+
 #define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; } while (0)
 #define RG_HIPFAIL(c, what) fail((c), RGPU_EHIP, std::string(what) + ": " + rg_last_error_string())
 
@@ -623,6 +658,49 @@ int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt) {
   RG_CHECK_CTX(c);
   if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "inv_dt_result: null pointer / context without state");
   if (inv_dt_fetch(c, invDt)) return RG_HIPFAIL(c, "inv_dt_result");
+  return RGPU_OK;
+}
+
+int rgpu_history_columns(rgpu_ctx* c, int parity, double* cols) {
+  RG_CHECK_CTX(c);
+  if (!cols || !c->U[0]) return fail(c, RGPU_EINVAL, "history_columns: null pointer / context without state");
+  if (!c->p.mhdEnabled) return fail(c, RGPU_EUNSUPPORTED, "history diagnostics are defined for MHD runs");
+  if (history_columns(c, parity, cols)) return RG_HIPFAIL(c, "history_columns");
+  return RGPU_OK;
+}
+
+int rgpu_history_reynolds(rgpu_ctx* c, int parity, const double* mean_vx, const double* mean_vy, double dTau, double* cols) {
+  RG_CHECK_CTX(c);
+  if (!cols || !mean_vx || !mean_vy || !c->U[0]) return fail(c, RGPU_EINVAL, "history_reynolds: null pointer / context without state");
+  if (!c->p.mhdEnabled) return fail(c, RGPU_EUNSUPPORTED, "history diagnostics are defined for MHD runs");
+  if (history_reynolds(c, parity, mean_vx, mean_vy, dTau, cols)) return RG_HIPFAIL(c, "history_reynolds");
+  return RGPU_OK;
+}
+
+int rgpu_history_mri(rgpu_ctx* c, int parity, double* out) {
+  RG_CHECK_CTX(c);
+  if (!out || !c->U[0]) return fail(c, RGPU_EINVAL, "history_mri: null pointer / context without state");
+  if (!c->p.mhdEnabled) return fail(c, RGPU_EUNSUPPORTED, "history diagnostics are defined for MHD runs");
+  if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "slab contexts: combine rgpu_history_columns / _reynolds across ranks");
+  const rgpu_params& p = c->p;
+  const int is = c->g.isize, gw = c->g.gw;
+  std::vector<double> cols((size_t)HIST_NQ * is), rcol(is), mvx(is), mvy(is);
+  if (history_columns(c, parity, cols.data())) return RG_HIPFAIL(c, "history_mri");
+  double dTau = p.dx * p.dy;
+  if (c->g.three_d) dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin);   // MHDRunBase.cpp:3533-3536
+  else dTau = p.dx * p.dy / (p.xMax - p.xMin) / (p.yMax - p.yMin);                                         // :3351-3353
+  const int nyz = p.ny * (c->g.three_d ? p.nz : 1);
+  for (int i = 0; i < is; ++i) { mvx[i] = cols[(size_t)1 * is + i] / nyz; mvy[i] = cols[(size_t)2 * is + i] / nyz; }
+  if (history_reynolds(c, parity, mvx.data(), mvy.data(), dTau, rcol.data())) return RG_HIPFAIL(c, "history_mri");
+  double sum[HIST_NQ], reyn = 0.0;
+  for (int q = 0; q < HIST_NQ; ++q) { sum[q] = 0.0; for (int i = gw; i < is - gw; ++i) sum[q] += cols[(size_t)q * is + i]; }
+  for (int i = gw; i < is - gw; ++i) reyn += rcol[i];
+  out[0] = sum[0] * dTau;         // mass
+  out[1] = sum[4] * dTau;         // maxwell
+  out[2] = reyn;                  // reynolds (dTau is inside the sum, as in the reference)
+  out[3] = sum[3] * dTau / 2.;    // magp
+  out[4] = sum[5] * dTau; out[5] = sum[6] * dTau; out[6] = sum[7] * dTau;   // mean B
+  out[7] = sum[8];                // divB
   return RGPU_OK;
 }
 

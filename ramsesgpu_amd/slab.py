@@ -211,6 +211,35 @@ class SlabRun:
         self.totalTime += self.dt
         return self.dt
 
+    # ---- history diagnostics -----------------------------------------------------------------------------------
+    def history_mri(self):
+        """MHDRunBase::history_mri over the whole box: per-slab column sums on the device, SUM all-reduce of the
+        isize-long columns (the y-z means need the global sums before the Reynolds stress can be formed).
+        The magnetic terms read the faces of the first high ghost layer.  The reference's history sees them as the
+        update left them on the plain path (ghosts refilled at the START of the next step) and refilled on the rotating
+        path; the overlapped schedule refills them at the end of every step, which is the same numbers for periodic /
+        shearing / slab-interface faces (the MRI box) but not for open or reflecting physical faces on the plain path:
+        use overlap=False when those boundary-face terms matter."""
+        import numpy as np
+        s, p = self.solver, self.p
+        parity = self.nStep % 2
+        gw = p.ghostWidth
+
+        def reduce(a):
+            if self.world == 1:
+                return a
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t.cpu().numpy()
+
+        cols = reduce(s.history_columns(parity))
+        dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin)
+        nyz = p.ny * p.nz_global
+        rcol = reduce(s.history_reynolds(parity, cols[1] / nyz, cols[2] / nyz, dTau))
+        sums = cols[:, gw:-gw].sum(axis=1)
+        return {"mass": sums[0] * dTau, "maxwell": sums[4] * dTau, "reynolds": rcol[gw:-gw].sum(), "magp": sums[3] * dTau / 2.0,
+                "mean_Bx": sums[5] * dTau, "mean_By": sums[6] * dTau, "mean_Bz": sums[7] * dTau, "divB": sums[8]}
+
     def local_interior(self):
         gw = self.p.ghostWidth
         return self.U[self.nStep % 2][:, gw:-gw, gw:-gw, gw:-gw]

@@ -165,6 +165,30 @@ class Solver:
             raise RgpuError("compute_dt: " + self.lib.rgpu_last_error(self.ctx).decode())
         return d
 
+    HISTORY_NAMES = ("mass", "maxwell", "reynolds", "magp", "mean_Bx", "mean_By", "mean_Bz", "divB")
+
+    def history_mri(self, nStep=None):
+        """history_mri / history_default (MHDRunBase.cpp:3311-3619) reduced on the device"""
+        parity = (self.nStep if nStep is None else nStep) % 2
+        out = (C.c_double * 8)()
+        self._chk(self.lib.rgpu_history_mri(self.ctx, parity, out), "history_mri")
+        return dict(zip(self.HISTORY_NAMES, [float(v) for v in out]))
+
+    def history_columns(self, parity):
+        isz = self.p.nx + 2 * self.p.ghostWidth
+        cols = np.zeros((9, isz), dtype=np.float64)
+        self._chk(self.lib.rgpu_history_columns(self.ctx, parity, cols.ctypes.data_as(C.POINTER(C.c_double))), "history_columns")
+        return cols
+
+    def history_reynolds(self, parity, mean_vx, mean_vy, dTau):
+        isz = self.p.nx + 2 * self.p.ghostWidth
+        mvx, mvy = np.ascontiguousarray(mean_vx, dtype=np.float64), np.ascontiguousarray(mean_vy, dtype=np.float64)
+        col = np.zeros(isz, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.rgpu_history_reynolds(self.ctx, parity, mvx.ctypes.data_as(dp), mvy.ctypes.data_as(dp), dTau,
+                                                 col.ctypes.data_as(dp)), "history_reynolds")
+        return col
+
     def godunov_unsplit(self, nStep, dt, totalTime=None):
         t = self.totalTime if totalTime is None else totalTime
         self._chk(self.lib.rgpu_godunov_unsplit(self.ctx, nStep, dt, t), "godunov_unsplit")

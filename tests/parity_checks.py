@@ -219,3 +219,34 @@ def check_core_plane_pieces(lib, base, ov):
         outs.append(sv.getDataHost(1))
         sv.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+HISTORY_CASES = [
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MRI.amp=0.2", 6),
+    ("orszag-tang3d", "mesh.nx=12;mesh.ny=10;mesh.nz=8", 3),
+    ("orszag-tang", "mesh.nx=24;mesh.ny=16", 4),                       # 2D: history_default's mass / divB
+    ("mhd_BrioWu", "mesh.nx=16;mesh.ny=12;mesh.nz=8;BrioWu.direction=0;MHD.implementationVersion=4", 3),
+]
+
+
+def check_history(lib, oracle, base, ov, nsteps):
+    """device-reduced history diagnostics (rgpu_history_mri) == the oracle's sequential restatement of
+    MHDRunBase::history_mri to round-off: the device adds in a different (fixed) order, so every sum is compared with
+    a tolerance of 1e-12 x the sum of the magnitudes of its terms"""
+    p = lib.params_from_ini(ini(base), ov)
+    sv = Solver(p, lib)
+    sv.start(lib.init_condition(ini(base), ov, p), nsteps)
+    U = sv.getDataHost()
+    got = sv.history_mri()
+    sv.close()
+    ref = dict(zip(Solver.HISTORY_NAMES, oracle.history_mri(p, U)))
+    I = interior(U, p)
+    cells = I[0].size
+    dtau = 1.0 / cells          # dx*dy*dz / box volume
+    b = np.abs(I[5:8]).sum() * dtau + 1e-300
+    b2 = (I[5:8] ** 2).sum() * dtau + 1e-300
+    mom = np.abs(I[2] * I[3] / I[0]).sum() * dtau + 1e-300
+    scale = {"mass": ref["mass"], "maxwell": b2, "reynolds": mom, "magp": b2, "mean_Bx": b, "mean_By": b, "mean_Bz": b,
+             "divB": np.abs(I[5:8]).sum() * 6.0 / min(p.dx, p.dy) + 1e-300}
+    for k in Solver.HISTORY_NAMES:
+        assert abs(got[k] - ref[k]) <= 1e-12 * scale[k], (k, got[k], ref[k], scale[k])

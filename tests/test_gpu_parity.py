@@ -194,3 +194,30 @@ def test_two_slab_processes_on_one_gpu(base, ov, nsteps, gpu_lib, oracle, tmp_pa
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
     assert open(out).read().strip() == "OK", open(out).read()
+
+
+@pytest.mark.parametrize("base,ov,nsteps", pc.HISTORY_CASES + [("mhd_mri_3d", "mesh.nx=64;mesh.ny=96;mesh.nz=48", 3)],
+                         ids=["%s[%s]" % (b, o) for b, o, _ in pc.HISTORY_CASES] + ["mri-64x96x48"])
+def test_history_diagnostics(base, ov, nsteps, gpu_lib, oracle):
+    pc.check_history(gpu_lib, oracle, base, ov, nsteps)
+
+
+def test_run_driver_writes_reference_history_file(gpu_lib, tmp_path):
+    """rgpuh_run with [history] enabled=yes writes <prefix>_history.txt like MHDRunGodunov::start + history_mri; the
+    physically meaningful columns equal the reference's file (tests/golden/mri_8x16x8_history.npz) digit for digit, the
+    round-off sized ones (mean field, divB: sums that cancel to ~1e-22) stay round-off sized"""
+    import ctypes as C
+    from conftest import golden_cases, load_golden
+    case = golden_cases()["mri_8x16x8_history"]
+    H = load_golden("mri_8x16x8_history")["history"]
+    ov = case["overrides"] + ";output.outputVtk=no;output.outputHdf5=no;output.outputDir=%s" % tmp_path
+    err = C.create_string_buffer(512)
+    mc = C.c_double(0)
+    n = gpu_lib.lib.rgpuh_run(ini(case["base"]).encode(), ov.encode(), C.byref(mc), err, 512)
+    assert n == 10, err.value
+    rows = np.array([[float(x) for x in ln.split()] for ln in open(tmp_path / "mhd_mri_3d_history.txt") if not ln.startswith("#")])
+    assert rows.shape == H.shape
+    for col in (0, 1, 2, 3, 4, 5, 6):          # totalTime dt mass maxwell reynolds maxwell+reynolds magp
+        assert np.allclose(rows[:, col], H[:, col], rtol=3e-6, atol=0), col
+    assert np.allclose(rows[:, 8], H[:, 8], rtol=1e-4, atol=1e-18)          # mean_By: small but physical
+    assert np.abs(rows[:, [7, 9, 10]]).max() <= 1e-15                        # mean_Bx, mean_Bz, divB: round-off

@@ -35,3 +35,8 @@ def test_boundaries_and_dt(base, ov, emu_lib, oracle):
                                      ("implode3d", "mesh.nx=10;mesh.ny=10;mesh.nz=20")], ids=["mri", "implode3d"])
 def test_step_core_in_plane_pieces(base, ov, emu_lib):
     pc.check_core_plane_pieces(emu_lib, base, ov)
+
+
+@pytest.mark.parametrize("base,ov,nsteps", pc.HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.HISTORY_CASES])
+def test_history_diagnostics(base, ov, nsteps, emu_lib, oracle):
+    pc.check_history(emu_lib, oracle, base, ov, nsteps)
