@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 2
+#define RGPU_ABI_VERSION 3
 
 /* component indexes -- constants.h:59-71 */
 enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
@@ -90,6 +90,9 @@ typedef struct rgpu_params {
   /* uniform static gravity field ([gravity] static_field_x/y/z, HydroParameters.h:322-324): the reference keeps it in a
    * per-cell array h_gravity that its problems fill with exactly this vector (HydroRunBase.cpp:6336-6337, 6403-6405) */
   double  gravity_x, gravity_y, gravity_z;
+  /* dissipative stage after the Godunov update (HydroParameters.h:327-328): kinematic viscosity [hydro] nu and
+   * resistivity [MHD] eta; 0 = off */
+  double  nu, eta;
 } rgpu_params;
 
 typedef struct rgpu_ctx rgpu_ctx;
@@ -208,7 +211,7 @@ int rgpu_synchronize(rgpu_ctx* c);
 
 enum {
   RGPU_T_BOUNDARIES = 0, RGPU_T_PRIM, RGPU_T_ELEC, RGPU_T_TRACE, RGPU_T_FLUX, RGPU_T_EMF, RGPU_T_UPDATE,
-  RGPU_T_SHEAR, RGPU_T_DT, RGPU_T_COUNT
+  RGPU_T_SHEAR, RGPU_T_DT, RGPU_T_DISSIPATIVE, RGPU_T_COUNT
 };
 /* RGPU_T_FLUX is the Riemann phase: face fluxes and edge EMFs are one kernel (RGPU_T_EMF stays 0).
  * enable!=0 brackets every phase with hipEvents (serialises the stream; off by default) */

@@ -115,6 +115,14 @@ CASES = {
     # --- history diagnostics: the run also writes <prefix>_history.txt (one row per step with dtHist=0) ------------------
     "mri_8x16x8_history": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MRI.amp=0.2;history.enabled=yes;history.dtHist=0.0;run.nstepmax=10;run.noutput=1000", [10]),
     "ot3d_12_history": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;history.enabled=yes;history.dtHist=0.0;run.nstepmax=5;run.noutput=1000", [5]),
+    # --- viscosity and resistivity (operator-split stage after the Godunov update) ----------------------
+    "ot2d_24_visc_res": ("orszag-tang", "mesh.nx=24;mesh.ny=24;hydro.nu=0.01;MHD.eta=0.02;run.nstepmax=10;run.noutput=100", [10]),
+    "briowu_x_32_res": ("mhd_BrioWu", "mesh.nx=32;mesh.ny=16;BrioWu.direction=0;MHD.eta=0.01;run.nstepmax=10;run.noutput=100", [10]),
+    "ot3d_12_visc_res": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.nu=0.005;MHD.eta=0.01;run.nstepmax=5;run.noutput=100", [5]),
+    "ot3d_12_iso_visc_res": ("orszag-tang3d", "mesh.nx=12;mesh.ny=10;mesh.nz=8;hydro.cIso=0.9;hydro.nu=0.005;MHD.eta=0.01;run.nstepmax=4;run.noutput=100", [4]),
+    "mri_8x16x8_visc_res": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MRI.amp=0.2;hydro.nu=1e-6;MHD.eta=2e-6;run.nstepmax=8;run.noutput=1000", [8]),
+    "implode3d_12_visc": ("implode3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.riemannSolver=hllc;hydro.nu=0.002;run.nstepmax=6;run.noutput=100", [6]),
+    "blast2d_24x36_visc": ("blast2d", "mesh.nx=24;mesh.ny=36;hydro.nu=0.001;run.nstepmax=8;run.noutput=100", [8]),
     "sod2d_32x8": ("hydro_sod2d", "mesh.nx=32;mesh.ny=8;run.nstepmax=10;run.noutput=100", [0, 10]),
 }
 

@@ -64,5 +64,6 @@ double compute_inv_dt(const Ctx& c, const double* U);                           
 void hydro_step(const Ctx& c, double* Uold, double* Unew, double dt);                  // orc_hydro.cpp
 void mhd_step_2d(const Ctx& c, double* Uold, double* Unew, double dt);                 // orc_mhd2d.cpp
 void mhd_step_3d(const Ctx& c, double* Uold, double* Unew, double dt, double totalTime);  // orc_mhd3d.cpp
+void dissipative_stage(const Ctx& c, double* U, double dt, double totalTime);          // orc_dissipative.cpp
 
 }  // namespace orc

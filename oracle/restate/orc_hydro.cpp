@@ -132,6 +132,7 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
           for (int e = 0; e < NDIM; ++e) Unew.d[o + (IU + e) * N] += 0.5 * dt * grav[e] * (rhoOld + rhoNew);
         }
   }
+  dissipative_stage(c, Unew_d, dt, 0.0);   // [hydro] nu > 0 (HydroRunGodunov.cpp:2620-2640, 2908-2925)
 }
 
 }  // namespace

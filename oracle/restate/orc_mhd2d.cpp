@@ -209,6 +209,7 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
       Unew(i, j, IA) += (emf(i, j + 1, 0) - emf(i, j, 0)) * dtdy;
       Unew(i, j, IB) -= (emf(i + 1, j, 0) - emf(i, j, 0)) * dtdx;
     }
+  dissipative_stage(c, Unew_d, dt, 0.0);   // nu / eta > 0 (mhd_godunov_unsplit_cpu_v1.cpp:244-272)
 }
 
 }  // namespace orc

@@ -1,13 +1,13 @@
 """ctypes view of include/rgpu.h (the C ABI) -- plain structs and prototypes, no compute here."""
 import ctypes as C
 
-RGPU_ABI_VERSION = 2
+RGPU_ABI_VERSION = 3
 
 ID, IP, IU, IV, IW, IA, IB, IC = range(8)
 BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
 RS_APPROX, RS_HLL, RS_HLLC, RS_HLLD, RS_LLF = range(5)
 XDIR, YDIR, ZDIR = 1, 2, 3
-T_NAMES = ["boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt"]
+T_NAMES = ["boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative"]
 
 
 class RgpuParams(C.Structure):
@@ -39,6 +39,7 @@ class RgpuParams(C.Structure):
         ("nz_global", C.c_int32),
         ("gravityEnabled", C.c_int32),
         ("gravity_x", C.c_double), ("gravity_y", C.c_double), ("gravity_z", C.c_double),
+        ("nu", C.c_double), ("eta", C.c_double),
     ]
 
     @property

@@ -89,8 +89,8 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
     p->gravity_y = filled ? cfg.get_float("gravity", "static_field_y", 0.0f) : 0.0f;
     p->gravity_z = filled ? cfg.get_float("gravity", "static_field_z", 0.0f) : 0.0f;
   }
-  if (cfg.get_float("hydro", "nu", 0.0f) > 0 || cfg.get_float("MHD", "eta", 0.0f) > 0)
-    throw std::runtime_error("viscosity / resistivity are outside the implemented scope");
+  p->nu = cfg.get_float("hydro", "nu", 0.0f);     // HydroParameters.h:327-328
+  p->eta = cfg.get_float("MHD", "eta", 0.0f);
   if (lower(cfg.get_string("hydro", "scheme", "muscl")) != "muscl")
     throw std::runtime_error("only scheme=muscl is implemented");
 

@@ -2,6 +2,7 @@
 // calling the per-cell body.  rg_kernel<BLOCK, K_xxx> is the __global__ entry the profiler sees.
 #pragma once
 #include "kernels_bc.h"
+#include "kernels_dissipative.h"
 #include "kernels_hydro.h"
 #include "kernels_mhd2d.h"
 #include "kernels_mhd3d.h"
@@ -43,6 +44,31 @@ struct K_mhd_prim {
 struct K_mhd_invdt {
   DevParams g; const double* U;
   RG_DEVFN double operator()(unsigned idx) const { return mhd_invdt_cell(g, U, idx); }
+};
+template <int ND>
+struct K_visc_flux {
+  DevParams g; const double* U; double* Fd; double nu, dt;
+  RG_DEVFN void operator()(unsigned idx) const { visc_flux_cell<ND>(g, U, Fd, nu, dt, idx); }
+};
+template <int ND>
+struct K_flux_update {
+  DevParams g; double* U; const double* Fd; int v0, v1;
+  RG_DEVFN void operator()(unsigned idx) const { flux_update_cell<ND>(g, U, Fd, v0, v1, idx); }
+};
+template <int ND>
+struct K_resist_emf {
+  DevParams g; const double* U; double* E; double eta;
+  RG_DEVFN void operator()(unsigned idx) const { resist_emf_cell<ND>(g, U, E, eta, idx); }
+};
+template <int ND>
+struct K_resist_ct {
+  DevParams g; double* U; const double* E; double dtdx, dtdy, dtdz;
+  RG_DEVFN void operator()(unsigned idx) const { resist_ct_cell<ND>(g, U, E, dtdx, dtdy, dtdz, idx); }
+};
+template <int ND>
+struct K_resist_eflux {
+  DevParams g; const double* U; double* Fd; double eta, dt;
+  RG_DEVFN void operator()(unsigned idx) const { resist_eflux_cell<ND>(g, U, Fd, eta, dt, idx); }
 };
 struct K_hist_rows {
   DevParams g; const double* U; double* rows;

@@ -95,6 +95,11 @@ int validate(const rgpu_params* p, std::string* why) {
     if (p->unsplitVersion != 1 && p->unsplitVersion != 2) { *why = "hydro: unsplitVersion must be 1 or 2 (version 0 is a superseded variant)"; return RGPU_EUNSUPPORTED; }
     if (p->riemannSolver != RGPU_RS_APPROX && p->riemannSolver != RGPU_RS_HLL && p->riemannSolver != RGPU_RS_HLLC) { *why = "hydro riemannSolver must be approx, hll or hllc"; return RGPU_EINVAL; }
   }
+  if (p->nu < 0 || p->eta < 0) { *why = "nu and eta must be >= 0"; return RGPU_EINVAL; }
+  if ((p->nu > 0 || (p->mhdEnabled && p->eta > 0)) && p->slab_count > 1) {
+    *why = "viscosity / resistivity need a ghost exchange of the updated state inside the step: not available for slab contexts";
+    return RGPU_EUNSUPPORTED;
+  }
   for (int f = 0; f < 6; ++f) {
     const int b = p->bc[f];
     const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
@@ -476,6 +481,47 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   return mhd3d_core(c, in, out, dt, totalTime, a, b);
 }
 
+// Dissipative stage ([hydro] nu, [MHD] eta) on the state the step has just written: refill its ghosts (plain or
+// shearing-box fill, as the call sites do), resistive emf + CT (+ energy flux unless isothermal), then viscous fluxes.
+// Scratch: fluxes in F, the resistive emf in T (both dead at this point of the step).
+template <int ND>
+int dissipative_nd(rgpu_ctx* c, double* U, double dt, double nu, double eta) {
+  const DevParams& g = c->g;
+  const unsigned n = c->n32;
+  if (eta > 0) {
+    K_resist_emf<ND> ke = {g, U, c->T, eta};
+    K_resist_ct<ND> kc = {g, U, c->T, dt / g.dx, dt / g.dy, dt / g.dz};
+    if (rg_launch<kBlock>(c->stream, n, ke) || rg_launch<kBlock>(c->stream, n, kc)) return -1;
+    if (g.cIso <= 0) {
+      K_resist_eflux<ND> kf = {g, U, c->F, eta, dt};
+      K_flux_update<ND> ku = {g, U, c->F, IP, IP + 1};
+      if (rg_launch<kBlock>(c->stream, n, kf) || rg_launch<kBlock>(c->stream, n, ku)) return -1;
+    }
+  }
+  if (nu > 0) {
+    K_visc_flux<ND> kv = {g, U, c->F, nu, dt};
+    K_flux_update<ND> ku = {g, U, c->F, 0, ND + 2};
+    if (rg_launch<kBlock>(c->stream, n, kv) || rg_launch<kBlock>(c->stream, n, ku)) return -1;
+  }
+  return 0;
+}
+
+int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  const double nu = c->p.nu, eta = c->p.mhdEnabled ? c->p.eta : 0.0;
+  if (!(nu > 0 || eta > 0)) return 0;
+  Phase ph(c, RGPU_T_DISSIPATIVE);
+  double* U = c->U[(nStep + 1) % 2];
+  int rc;
+  if (c->g.shearbox && c->g.three_d) {
+    rc = do_make_boundaries(c, U, RGPU_YDIR) || do_make_boundaries_shear(c, U, totalTime, dt) ||
+         do_make_boundaries(c, U, RGPU_ZDIR) || do_make_boundaries(c, U, RGPU_YDIR);
+  } else {
+    rc = do_make_boundaries(c, U, RGPU_XDIR) || do_make_boundaries(c, U, RGPU_YDIR) || (c->g.three_d && do_make_boundaries(c, U, RGPU_ZDIR));
+  }
+  if (rc) return -1;
+  return c->g.three_d ? dissipative_nd<3>(c, U, dt, nu, eta) : dissipative_nd<2>(c, U, dt, nu, eta);
+}
+
 int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   return step_core_planes(c, nStep, dt, totalTime, 0, c->g.ksize);
 }
@@ -757,7 +803,8 @@ int rgpu_godunov_unsplit(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "slab contexts must use rgpu_step_pre/core/post_a/post_b around the halo exchange");
-  if (step_pre(c, nStep) || step_core(c, nStep, dt, totalTime) || step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
+  if (step_pre(c, nStep) || step_core(c, nStep, dt, totalTime) || step_dissipative(c, nStep, dt, totalTime) ||
+      step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
     return RG_HIPFAIL(c, "godunov_unsplit");
   return RGPU_OK;
 }
@@ -794,7 +841,7 @@ int rgpu_reset_timers(rgpu_ctx* c) {
   return RGPU_OK;
 }
 const char* rgpu_timer_name(int which) {
-  static const char* names[RGPU_T_COUNT] = {"boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt"};
+  static const char* names[RGPU_T_COUNT] = {"boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative"};
   return (which >= 0 && which < RGPU_T_COUNT) ? names[which] : "?";
 }
 

@@ -74,6 +74,6 @@ def test_rejects_out_of_scope_configurations(emu_lib):
         with pytest.raises(RgpuError) as e:
             Solver(p, L)
         assert frag in str(e.value)
-    for ov in ("hydro.nu=0.1", "gravity.self=yes", "hydro.scheme=plmde"):
+    for ov in ("gravity.self=yes", "hydro.scheme=plmde"):
         with pytest.raises(RgpuError):
             L.params_from_ini(ini("orszag-tang"), ov)
