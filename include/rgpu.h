@@ -175,6 +175,11 @@ int rgpu_step_post_b(rgpu_ctx* c, int nStep, double dt, double totalTime);
  * X,Y faces (HydroRunBase.cpp:2333-2342) or, shearing box, Y + shear remap + Y (MHDRunGodunov.cpp:3779-3793 with
  * the z copy commuted out: all three act within one z plane). */
 int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
+/* The dissipative stage of the step ([hydro] nu / [MHD] eta > 0; no-op otherwise) on U[(nStep+1)%2], WITHOUT the ghost
+ * fill that precedes it in rgpu_godunov_unsplit: a slab driver calls it between rgpu_step_core and rgpu_step_post_a after
+ * it has filled the ghosts of the output itself (rgpu_make_boundaries / _shear + its z exchange), as the reference's MPI
+ * classes do with make_all_boundaries(h_UNew) (mhd_godunov_unsplit_cpu_v3.cpp:662-668). */
+int rgpu_step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime);
 int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
 
 /* rgpu_compute_inv_dt in pieces: accumulate the max over the cells of planes [k_lo,k_hi) into the context's device

@@ -25,6 +25,7 @@ struct DevParams {
   int isize, jsize, ksize, gw, nx, ny, nz, nvar;
   int three_d, mhd, rot, shearbox;
   int dirwise_update, pad1;    // hydro unsplitVersion 2: fluxes applied direction by direction
+  int zlo_copy, zhi_copy;      // z faces that are slab interfaces (RGPU_BC_COPY): the neighbour's cells continue there
   unsigned sj, sk;             // flat strides of +1 in j and k
   unsigned long long ncell;    // component stride
   double dx, dy, dz, xMin, deltaX;   // deltaX = xMax - xMin

@@ -14,6 +14,19 @@ namespace rgpu_dev {
 
 RG_DEVFN double cell_vel(const double* __restrict__ U, size_t N, unsigned o, int a) { return U[o + (size_t)(IU + a) * N] / U[o + (size_t)ID * N]; }
 
+// Range of the resistive emf and of its CT update.  At a slab interface the ghost planes are the neighbour's interior:
+// its plane next to the interface gets the same CT update there, and the energy flux of the cells on this side reads
+// that field, so the range is extended by one plane into the ghosts (the emf by one more) -- the slab run then equals
+// the single-domain run bit for bit.  At physical faces the reference's ranges are kept.
+RG_DEVFN bool in_resist_range(const DevParams& g, const IJK c, int ND, int extra) {
+  if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw) return false;
+  if (ND == 3) {
+    const int lo = g.gw - (g.zlo_copy ? 1 : 0), hi = g.ksize - g.gw + (g.zhi_copy ? extra : 0);
+    if (c.k < lo || c.k > hi) return false;
+  }
+  return true;
+}
+
 RG_DEVFN bool in_face_range(const DevParams& g, const IJK c, int ND) {
   if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw) return false;
   if (ND == 3 && (c.k < g.gw || c.k > g.ksize - g.gw)) return false;
@@ -102,7 +115,7 @@ RG_DEVFN void flux_update_cell(const DevParams& g, double* __restrict__ U, const
 template <int ND>
 RG_DEVFN void resist_emf_cell(const DevParams& g, const double* __restrict__ U, double* __restrict__ E, double eta, unsigned idx) {
   const IJK c = unflatten(g, idx);
-  if (!in_face_range(g, c, ND)) return;
+  if (!in_resist_range(g, c, ND, 1)) return;
   const size_t N = g.ncell;
   const unsigned sj = g.sj, sk = g.sk;
   const double* A = U + IA * N; const double* B = U + IB * N; const double* C = U + IC * N;
@@ -123,7 +136,7 @@ template <int ND>
 RG_DEVFN void resist_ct_cell(const DevParams& g, double* __restrict__ U, const double* __restrict__ E, double dtdx, double dtdy,
                              double dtdz, unsigned idx) {
   const IJK c = unflatten(g, idx);
-  if (!in_face_range(g, c, ND)) return;
+  if (!in_resist_range(g, c, ND, 0)) return;
   const size_t N = g.ncell;
   const unsigned sj = g.sj, sk = g.sk;
   const double* eZ = E + (size_t)EMF_Z * N; const double* eY = E + (size_t)EMF_Y * N; const double* eX = E + (size_t)EMF_X * N;
@@ -133,7 +146,7 @@ RG_DEVFN void resist_ct_cell(const DevParams& g, double* __restrict__ U, const d
     b -= (eZ[idx + 1] - eZ[idx]) * dtdx;
   } else {
     double cc = U[idx + IC * N];
-    if (c.k < g.ksize - g.gw) {
+    if (c.k < g.ksize - g.gw || g.zhi_copy) {
       a += (eZ[idx + sj] - eZ[idx]) * dtdy;
       b -= (eZ[idx + 1] - eZ[idx]) * dtdx;
     }

@@ -96,10 +96,6 @@ int validate(const rgpu_params* p, std::string* why) {
     if (p->riemannSolver != RGPU_RS_APPROX && p->riemannSolver != RGPU_RS_HLL && p->riemannSolver != RGPU_RS_HLLC) { *why = "hydro riemannSolver must be approx, hll or hllc"; return RGPU_EINVAL; }
   }
   if (p->nu < 0 || p->eta < 0) { *why = "nu and eta must be >= 0"; return RGPU_EINVAL; }
-  if ((p->nu > 0 || (p->mhdEnabled && p->eta > 0)) && p->slab_count > 1) {
-    *why = "viscosity / resistivity need a ghost exchange of the updated state inside the step: not available for slab contexts";
-    return RGPU_EUNSUPPORTED;
-  }
   for (int f = 0; f < 6; ++f) {
     const int b = p->bc[f];
     const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
@@ -133,6 +129,10 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   g->mag_slope_type = std::fmin(p.slope_type, 2.0);
   g->niter_riemann = p.niter_riemann; g->riemannSolver = p.riemannSolver; g->magRiemannSolver = p.magRiemannSolver;
   g->dirwise_update = (!p.mhdEnabled && p.unsplitVersion == 2) ? 1 : 0; g->pad1 = 0;
+  // interfaces INSIDE the global box only: the periodic wrap between the last and the first slab is a boundary of the
+  // reference's single domain and keeps its ranges
+  g->zlo_copy = (p.bc[4] == RGPU_BC_COPY && p.slab_rank > 0) ? 1 : 0;
+  g->zhi_copy = (p.bc[5] == RGPU_BC_COPY && p.slab_rank < p.slab_count - 1) ? 1 : 0;
   g->grav_on = 0; g->hgx = 0.0; g->hgy = 0.0; g->hgz = 0.0;   // per step: step_core_planes
 }
 
@@ -506,13 +506,15 @@ int dissipative_nd(rgpu_ctx* c, double* U, double dt, double nu, double eta) {
   return 0;
 }
 
-int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime, bool fill_ghosts = true) {
   const double nu = c->p.nu, eta = c->p.mhdEnabled ? c->p.eta : 0.0;
   if (!(nu > 0 || eta > 0)) return 0;
   Phase ph(c, RGPU_T_DISSIPATIVE);
   double* U = c->U[(nStep + 1) % 2];
-  int rc;
-  if (c->g.shearbox && c->g.three_d) {
+  int rc = 0;
+  if (!fill_ghosts) {
+    // slab driver: it has filled the ghosts itself (in-plane fills + z exchange)
+  } else if (c->g.shearbox && c->g.three_d) {
     rc = do_make_boundaries(c, U, RGPU_YDIR) || do_make_boundaries_shear(c, U, totalTime, dt) ||
          do_make_boundaries(c, U, RGPU_ZDIR) || do_make_boundaries(c, U, RGPU_YDIR);
   } else {
@@ -773,6 +775,12 @@ int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi)) return RG_HIPFAIL(c, "step_core_planes");
+  return RGPU_OK;
+}
+int rgpu_step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (step_dissipative(c, nStep, dt, totalTime, false)) return RG_HIPFAIL(c, "step_dissipative");
   return RGPU_OK;
 }
 int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi) {

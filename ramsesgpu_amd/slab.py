@@ -158,6 +158,11 @@ class SlabRun:
         if not self._rotating:
             self.exchange_z(nStep % 2)          # plain path: ghosts of the INPUT
         s.step_core(nStep, dt, t)
+        if self._dissipative:
+            # viscosity / resistivity work on the updated state with ALL its ghosts: one more fill + exchange
+            # (make_all_boundaries(h_UNew) of the reference, mhd_godunov_unsplit_cpu_v3.cpp:662-668)
+            self.make_all_boundaries((nStep + 1) % 2, t, dt)
+            s.step_dissipative(nStep, dt, t)
         s.step_post_a(nStep, dt, t)
         if self._rotating:
             self.exchange_z((nStep + 1) % 2)    # rotating path: ghosts of the OUTPUT
@@ -173,8 +178,12 @@ class SlabRun:
             return [(0, ks)], [(gw, nz + gw)], None
         return [(0, 2 * gw), (nz, ks)], [(gw, 2 * gw), (nz, nz + gw)], (2 * gw, nz)
 
+    @property
+    def _dissipative(self):
+        return bool(self.p.nu > 0 or (self.p.mhdEnabled and self.p.eta > 0))
+
     def godunov_unsplit(self, nStep, dt):
-        if not self.overlap:
+        if not self.overlap or self._dissipative:     # the dissipative stage needs a second exchange inside the step
             return self.godunov_unsplit_serial(nStep, dt)
         s, t = self.solver, self.totalTime
         pin, pout = nStep % 2, (nStep + 1) % 2

@@ -232,6 +232,9 @@ class Solver:
         self._chk(self.lib.rgpu_inv_dt_result(self.ctx, C.byref(v)), "inv_dt_result")
         return v.value
 
+    def step_dissipative(self, nStep, dt, t):
+        self._chk(self.lib.rgpu_step_dissipative(self.ctx, nStep, dt, t), "step_dissipative")
+
     def step_post_a(self, nStep, dt, t):
         self._chk(self.lib.rgpu_step_post_a(self.ctx, nStep, dt, t), "step_post_a")
 

@@ -31,6 +31,11 @@ CASES = [
     ("mhd_fieldloop3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 3, 2, 1),                    # drand48 noise of the vector potential
     ("rayleigh_taylor_gpu_3d_mhd", "mesh.nx=6;mesh.ny=6;mesh.nz=16;rayleigh-taylor.randomEnabled=yes", 3, 2, 1),   # gravity + rand() over ghosts too
     ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;implode.amplitude=0.02;hydro.unsplitVersion=2", 3, 2, 1),        # direction-wise update order
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;hydro.nu=0.005;MHD.eta=0.01", 3, 2, 1),                      # dissipative stage: second exchange
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MRI.amp=0.2;hydro.nu=1e-6;MHD.eta=2e-6", 3, 2, 1),             # ... on the rotating path
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12;hydro.nu=0.002", 3, 3, 1),                                       # hydro viscosity, three slabs
+    ("orszag-tang3d", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.nu=0.005;MHD.eta=0.01", 3, 3, 1),                      # middle slab: internal interfaces on both sides
+    ("mhd_BrioWu", "mesh.nx=8;mesh.ny=6;mesh.nz=16;BrioWu.direction=2;MHD.implementationVersion=4;MHD.eta=0.02;mesh.boundary_zmin=2;mesh.boundary_zmax=2", 3, 2, 1),  # open z ends
 ]
 
 
