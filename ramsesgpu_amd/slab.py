@@ -106,6 +106,11 @@ class SlabRun:
         if self.world == 1:
             return []
         ops = self._p2p_ops(parity)
+        if ops and self.device.type == "cuda" and dist.get_backend(self.group) != "nccl":
+            # RCCL orders its transfers after the kernels already queued on the current stream.  The gloo backend (used
+            # by the tests that put two ranks on one GPU) reads the device buffers from host threads as soon as it is
+            # called, so the queued kernels have to be finished first.
+            torch.cuda.current_stream(self.device).synchronize()
         return dist.batch_isend_irecv(ops) if ops else []
 
     @staticmethod

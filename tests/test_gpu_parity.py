@@ -176,8 +176,10 @@ def test_step_core_in_plane_pieces(base, ov, gpu_lib):
 
 @pytest.mark.parametrize("base,ov,nsteps", [("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=40", 4),
                                             ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=32", 3),
-                                            ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=24;hydro.riemannSolver=hllc", 4)],
-                         ids=["mri", "ot3d", "implode3d"])
+                                            ("implode3d", "mesh.nx=16;mesh.ny=16;mesh.nz=24;hydro.riemannSolver=hllc", 4),
+                                            ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=24;hydro.nu=0.005;MHD.eta=0.01", 3),
+                                            ("rayleigh_taylor_gpu_3d_mhd", "mesh.nx=8;mesh.ny=8;mesh.nz=32", 3)],
+                         ids=["mri", "ot3d", "implode3d", "ot3d-visc-res", "rt3d-mhd-gravity"])
 def test_two_slab_processes_on_one_gpu(base, ov, nsteps, gpu_lib, oracle, tmp_path):
     """world_size 2, both ranks on cuda:0 with the HIP library, ghost planes moved by gloo (RCCL needs one device per
     rank): the slab driver's overlapped schedule with a real exchange in flight == single-domain oracle."""
