@@ -161,10 +161,18 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU fallback\n")
         sys.exit(3)
+    # test hooks (not used by the driver): RGPU_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and RGPU_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device -- lets the N>1 code path be exercised on a 1-GPU box
+    if os.environ.get("RGPU_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RGPU_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     L = load_library()
     ini = os.path.join(ROOT, "configs", BASE + ".ini")
