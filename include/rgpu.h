@@ -202,6 +202,10 @@ int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt);
 int rgpu_history_columns(rgpu_ctx* c, int parity, double* cols);
 int rgpu_history_reynolds(rgpu_ctx* c, int parity, const double* mean_vx, const double* mean_vy, double dTau, double* cols);
 int rgpu_history_mri(rgpu_ctx* c, int parity, double* out);
+/* One cell of the state, out[nbVar] = U(i,j,k,:) with ghost-inclusive local indices: what history_inertial_wave
+ * (MHDRunBase.cpp:3414-3469) probes -- U(ghostWidth + nx/2, ghostWidth) in 2D, U(ghostWidth + nx/2, 1, ghostWidth) in 3D --
+ * without copying the whole array back (the reference calls copyGpuToCpu first). */
+int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out);
 
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);

@@ -69,6 +69,12 @@ CASES = {
     "briowu_x_64_slope3": ("mhd_BrioWu", "mesh.nx=64;mesh.ny=64;BrioWu.direction=0;hydro.slope_type=3.0;run.nstepmax=20;run.noutput=100", [20]),
     "ot3d_12_slope3": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;hydro.slope_type=3.0;run.nstepmax=4;run.noutput=100", [4]),
     # --- further shipped problems (initial conditions of the host side + the same step) -------------------------------
+    # --- 2D branch of the rotating-frame step (godunov_unsplit_rotating_cpu, MHDRunGodunov.cpp:2089-2434) ---------------
+    "inertialwave2d_32": ("mhd_inertialWave_2d", "run.nstepmax=30;run.noutput=1000;output.outputVtk=yes;output.outputHdf5=no;output.outputVtkAscii=no", [0, 30]),
+    "ot2d_32_rot": ("orszag-tang", "mesh.nx=32;mesh.ny=32;MHD.omega0=0.5;run.nstepmax=20;run.noutput=100", [20]),
+    "ot2d_24x40_rot_iso_hll": ("orszag-tang", "mesh.nx=24;mesh.ny=40;MHD.omega0=0.3;hydro.cIso=0.8;hydro.riemannSolver=hll;MHD.magRiemannSolver=hllf;run.nstepmax=12;run.noutput=100", [12]),
+    "briowu_x_48_rot_open": ("mhd_BrioWu", "mesh.nx=48;mesh.ny=16;BrioWu.direction=0;MHD.omega0=0.2;hydro.nu=0.002;MHD.eta=0.004;run.nstepmax=15;run.noutput=100", [15]),
+    "ot2d_20x16_rot_slope3": ("orszag-tang", "mesh.nx=20;mesh.ny=16;MHD.omega0=0.4;hydro.slope_type=3.0;MHD.magRiemannSolver=hlla;run.nstepmax=10;run.noutput=100", [10]),
     "rotor_32_ic": ("mhd_rotor", "mesh.nx=32;mesh.ny=32;run.nstepmax=0;run.noutput=100", [0]),   # IC only: with implementationVersion=1 the reference itself turns this problem into NaN within a few steps
     "fieldloop2d_32x20": ("mhd_fieldloop2d", "mesh.nx=32;mesh.ny=20;run.nstepmax=10;run.noutput=100", [0, 10]),
     "fieldloop3d_16x8x8": ("mhd_fieldloop3d", "mesh.nx=16;mesh.ny=8;mesh.nz=8;run.nstepmax=5;run.noutput=100", [0, 5]),
@@ -114,6 +120,7 @@ CASES = {
     "riemann2d_c19_16": ("riemann2d", "mesh.nx=16;mesh.ny=16;hydro.riemann_config_number=25;run.nstepmax=4;run.noutput=100", [0, 4]),
     # --- history diagnostics: the run also writes <prefix>_history.txt (one row per step with dtHist=0) ------------------
     "mri_8x16x8_history": ("mhd_mri_3d", "mesh.nx=8;mesh.ny=16;mesh.nz=8;MRI.amp=0.2;history.enabled=yes;history.dtHist=0.0;run.nstepmax=10;run.noutput=1000", [10]),
+    "inertialwave2d_16_history": ("mhd_inertialWave_2d", "mesh.nx=16;mesh.ny=16;history.enabled=yes;history.dtHist=0.0;run.nstepmax=8;run.noutput=1000;output.outputVtk=yes;output.outputHdf5=no;output.outputVtkAscii=no", [8]),
     "ot3d_12_history": ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=12;history.enabled=yes;history.dtHist=0.0;run.nstepmax=5;run.noutput=1000", [5]),
     # --- viscosity and resistivity (operator-split stage after the Godunov update) ----------------------
     "ot2d_24_visc_res": ("orszag-tang", "mesh.nx=24;mesh.ny=24;hydro.nu=0.01;MHD.eta=0.02;run.nstepmax=10;run.noutput=100", [10]),
@@ -202,8 +209,12 @@ def run_case(name):
         # totalTime dt mass maxwell reynolds maxwell+reynolds magp mean_Bx mean_By mean_Bz divB (6 significant digits)
         hist = os.path.join(td, prefix + "_history.txt")
         if os.path.exists(hist):
-            rows = [[float(x) for x in ln.split()] for ln in open(hist) if ln.strip() and not ln.startswith("#")]
-            arrays["history"] = np.array(rows)
+            lines = [ln.rstrip("\n") for ln in open(hist) if ln.strip() and not ln.startswith("#")]
+            try:
+                arrays["history"] = np.array([[float(x) for x in ln.split()] for ln in lines])
+            except ValueError:
+                # history_inertial_wave prints totalTime and dt without a separator: keep the rows as text
+                arrays["history_text"] = np.array(lines)
     # dt log: "step=  N t=  T dt=  D" lines; with nlog=1 the line printed at step N carries the dt of step N-1
     # (the first one carries the initial compute_dt).  Duplicated lines (output + log) are collapsed on N.
     dts = {}

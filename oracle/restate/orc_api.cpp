@@ -96,13 +96,13 @@ static int check_scope(const rgpu_params* p) {
   if (p->slope_type != 0 && p->slope_type != 1 && p->slope_type != 2 && p->slope_type != 3) return RGPU_EUNSUPPORTED;
   // slope_type 3 (positivity preserving) exists in the 2D MHD and the plain 3D MHD steps only; the hydro steps and
   // the rotating 3D step call slope routines that leave dq unset for it (slope.h:97-147,324-427; slope_mhd.h:436-502)
-  if (p->slope_type == 3 && (!p->mhdEnabled || p->Omega0 > 0)) return RGPU_EUNSUPPORTED;
+  if (p->slope_type == 3 && (!p->mhdEnabled || (p->Omega0 > 0 && p->nz_global != 1))) return RGPU_EUNSUPPORTED;
   if (p->mhdEnabled) {
     const bool three_d = p->nz_global != 1;
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLA && p->magRiemannSolver != RGPU_MAG_HLLF &&
         p->magRiemannSolver != RGPU_MAG_LLF) return RGPU_EUNSUPPORTED;
     if (!three_d && p->implementationVersion != 1 && p->implementationVersion != 0) return RGPU_EUNSUPPORTED;
-    if (!three_d && p->Omega0 > 0) return RGPU_EUNSUPPORTED;
+    if (!three_d && p->Omega0 > 0 && p->shearingBoxEnabled) return RGPU_EUNSUPPORTED;   // "not fully implemented" in the reference
     if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) return RGPU_EUNSUPPORTED;
   } else {
     if (p->unsplitVersion != 1 && p->unsplitVersion != 2) return RGPU_EUNSUPPORTED;

@@ -3,7 +3,8 @@
 //   convertToPrimitives (2D)          MHDRunGodunov.cpp:479-517   (i<isize-1, j<jsize-1; Bz_cell = Bz/2)
 //   godunov_unsplit_cpu_v1 (2D)       mhd_godunov_unsplit_cpu_v1.cpp:35-241
 //   trace_unsplit_mhd_2d              trace_mhd.h:38-339
-// Omega0>0 in 2D (godunov_unsplit_rotating_cpu 2D branch) is outside the implemented scope.
+//   godunov_unsplit_rotating_cpu (2D) MHDRunGodunov.cpp:2031-2434, 3420-3436 (Omega0 > 0: Coriolis + alpha mixing in
+//                                     the update, shear terms on the Bz fluxes and emfZ, ghost fill at the END of the step)
 #include "orc_pointwise.h"
 
 namespace orc {
@@ -116,9 +117,18 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
   const int gw = c.gw, isize = c.isize, jsize = c.jsize;
   const double dtdx = dt / c.dx, dtdy = dt / c.dy;
   const size_t N = c.ncell;
-  const bool grav = p.gravityEnabled && p.implementationVersion == 0;
+  const bool rot = p.Omega0 > 0;   // the 2D branch of the rotating step has no gravity terms
+  const bool grav = p.gravityEnabled && p.implementationVersion == 0 && !rot;
+  double lambda = 0, ratio = 1, alpha1 = 1, alpha2 = 0;
+  if (rot) {   // MHDRunGodunov.cpp:2039-2053
+    lambda = p.Omega0 * dt;
+    lambda = 0.25 * lambda * lambda;
+    ratio = (1.0 - lambda) / (1.0 + lambda);
+    alpha1 = 1.0 / (1.0 + lambda);
+    alpha2 = p.Omega0 * dt / (1.0 + lambda);
+  }
 
-  make_all_boundaries(c, Uold_d, 0.0, 0.0);
+  if (!rot) make_all_boundaries(c, Uold_d, 0.0, 0.0);
   std::memcpy(Unew_d, Uold_d, sizeof(double) * N * 8);
 
   Field U, Unew, Q, qm_x, qm_y, qp_x, qp_y, eRT, eRB, eLT, eLB, emf;
@@ -174,10 +184,51 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
       for (int v = 0; v < 8; ++v) { flux_x[v] = 0.0; flux_y[v] = 0.0; }
       for (int v = 0; v < 8; ++v) { ql[v] = qm_x(i - 1, j, v); qr[v] = qp_x(i, j, v); }
       mhd_riemann(p, ql, qr, flux_x);
+      const double xPos = p.xMin + c.dx / 2 + (i - gw) * c.dx;
+      if (rot) {   // shear correction with the mean normal field left in the states by the solver (:2190-2197)
+        const double shear_x = -1.5 * p.Omega0 * (xPos + xPos - c.dx);
+        flux_x[IC] += shear_x * (ql[IA] + qr[IA]) / 2;
+      }
       static const int perm_y[8] = {ID, IP, IV, IU, IW, IB, IA, IC};
       for (int v = 0; v < 8; ++v) { ql[v] = qm_y(i, j - 1, perm_y[v]); qr[v] = qp_y(i, j, perm_y[v]); }
       mhd_riemann(p, ql, qr, flux_y);
+      if (rot) {   // :2224-2231
+        const double shear_y = -1.5 * p.Omega0 * xPos;
+        flux_y[IC] += shear_y * (ql[IA] + qr[IA]) / 2;
+      }
 
+      if (rot) {   // :2236-2290 (no shearing box in 2D)
+        if (i < isize - gw && j < jsize - gw) {
+          const double dsx = 2.0 * p.Omega0 * dt * Unew(i, j, IV) / (1.0 + lambda);
+          const double dsy = -0.5 * p.Omega0 * dt * Unew(i, j, IU) / (1.0 + lambda);
+          Unew(i, j, IU) = Unew(i, j, IU) * ratio + dsx;
+          Unew(i, j, IV) = Unew(i, j, IV) * ratio + dsy;
+        }
+        Unew(i - 1, j, ID) -= flux_x[ID] * dtdx;
+        Unew(i - 1, j, IP) -= flux_x[IP] * dtdx;
+        Unew(i - 1, j, IU) -= (alpha1 * flux_x[IU] + alpha2 * flux_x[IV]) * dtdx;
+        Unew(i - 1, j, IV) -= (alpha1 * flux_x[IV] - 0.25 * alpha2 * flux_x[IU]) * dtdx;
+        Unew(i - 1, j, IW) -= flux_x[IW] * dtdx;
+        Unew(i - 1, j, IC) -= flux_x[IC] * dtdx;
+        Unew(i, j, ID) += flux_x[ID] * dtdx;
+        Unew(i, j, IP) += flux_x[IP] * dtdx;
+        Unew(i, j, IU) += (alpha1 * flux_x[IU] + alpha2 * flux_x[IV]) * dtdx;
+        Unew(i, j, IV) += (alpha1 * flux_x[IV] - 0.25 * alpha2 * flux_x[IU]) * dtdx;
+        Unew(i, j, IW) += flux_x[IW] * dtdx;
+        Unew(i, j, IC) += flux_x[IC] * dtdx;
+        Unew(i, j - 1, ID) -= flux_y[ID] * dtdy;
+        Unew(i, j - 1, IP) -= flux_y[IP] * dtdy;
+        Unew(i, j - 1, IU) -= (alpha1 * flux_y[IV] + alpha2 * flux_y[IU]) * dtdy;
+        Unew(i, j - 1, IV) -= (alpha1 * flux_y[IU] - 0.25 * alpha2 * flux_y[IV]) * dtdy;
+        Unew(i, j - 1, IW) -= flux_y[IW] * dtdy;
+        Unew(i, j - 1, IC) -= flux_y[IC] * dtdy;
+        Unew(i, j, ID) += flux_y[ID] * dtdy;
+        Unew(i, j, IP) += flux_y[IP] * dtdy;
+        Unew(i, j, IU) += (alpha1 * flux_y[IV] + alpha2 * flux_y[IU]) * dtdy;
+        Unew(i, j, IV) += (alpha1 * flux_y[IU] - 0.25 * alpha2 * flux_y[IV]) * dtdy;
+        Unew(i, j, IW) += flux_y[IW] * dtdy;
+        Unew(i, j, IC) += flux_y[IC] * dtdy;
+      } else {
       Unew(i - 1, j, ID) -= flux_x[ID] * dtdx; Unew(i - 1, j, IP) -= flux_x[IP] * dtdx; Unew(i - 1, j, IU) -= flux_x[IU] * dtdx;
       Unew(i - 1, j, IV) -= flux_x[IV] * dtdx; Unew(i - 1, j, IW) -= flux_x[IW] * dtdx; Unew(i - 1, j, IC) -= flux_x[IC] * dtdx;
       Unew(i, j, ID) += flux_x[ID] * dtdx; Unew(i, j, IP) += flux_x[IP] * dtdx; Unew(i, j, IU) += flux_x[IU] * dtdx;
@@ -186,12 +237,13 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
       Unew(i, j - 1, IV) -= flux_y[IU] * dtdy; Unew(i, j - 1, IW) -= flux_y[IW] * dtdy; Unew(i, j - 1, IC) -= flux_y[IC] * dtdy;
       Unew(i, j, ID) += flux_y[ID] * dtdy; Unew(i, j, IP) += flux_y[IP] * dtdy; Unew(i, j, IU) += flux_y[IV] * dtdy;
       Unew(i, j, IV) += flux_y[IU] * dtdy; Unew(i, j, IW) += flux_y[IW] * dtdy; Unew(i, j, IC) += flux_y[IC] * dtdy;
+      }
 
       double qe[4][8];
       for (int v = 0; v < 8; ++v) {
         qe[0][v] = eRT(i - 1, j - 1, v); qe[1][v] = eRB(i - 1, j, v); qe[2][v] = eLT(i, j - 1, v); qe[3][v] = eLB(i, j, v);
       }
-      emf(i, j, 0) = compute_emf<2>(p, qe);
+      emf(i, j, 0) = compute_emf<2>(p, qe, xPos);
     }
 
   // gravity source term on the momenta (version 0: mhd_godunov_unsplit_cpu_v0.cpp:616-618, HydroRunBase.cpp:1925-1950)
@@ -210,6 +262,7 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
       Unew(i, j, IB) -= (emf(i + 1, j, 0) - emf(i, j, 0)) * dtdx;
     }
   dissipative_stage(c, Unew_d, dt, 0.0);   // nu / eta > 0 (mhd_godunov_unsplit_cpu_v1.cpp:244-272)
+  if (rot) make_all_boundaries(c, Unew_d, 0.0, 0.0);   // rotating path: ghosts of the OUTPUT (MHDRunGodunov.cpp:3424-3434)
 }
 
 }  // namespace orc

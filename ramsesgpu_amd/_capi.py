@@ -110,6 +110,8 @@ def declare_device_api(lib):
     lib.rgpu_history_reynolds.argtypes = [ctx, C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
     lib.rgpu_history_mri.restype = C.c_int
     lib.rgpu_history_mri.argtypes = [ctx, C.c_int, c_double_p]
+    lib.rgpu_read_cell.restype = C.c_int
+    lib.rgpu_read_cell.argtypes = [ctx, C.c_int, C.c_int, C.c_int, C.c_int, c_double_p]
     lib.rgpu_compute_dt.restype = C.c_double
     lib.rgpu_compute_dt.argtypes = [ctx, C.c_int]
     for name in ("rgpu_step_core_planes", "rgpu_step_fill_planes"):
@@ -147,7 +149,7 @@ def declare_device_api(lib):
 DECLARED_SYMBOLS = [
     "rgpu_create", "rgpu_create_external", "rgpu_destroy", "rgpu_state_elems", "rgpu_device_bytes", "rgpu_last_error",
     "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
-    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
+    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",

@@ -638,6 +638,21 @@ void init_mhd_shear_wave(const IniConfig& cfg, const rgpu_params& p, const Grid&
     }
 }
 
+// ---- MHD: inertial wave in the rotating frame (MHDRunBase.cpp:2503-2558): uniform state, every cell, zero field -----
+void init_mhd_inertial_wave(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const double density = cfg.get_float("InertialWave", "density", 1.0f);
+  const double energy = cfg.get_float("InertialWave", "energy", 1.0f);
+  double delta_vx = cfg.get_float("InertialWave", "delta_vx", 1.0f);
+  delta_vx *= p.cIso;
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j)
+      for (int i = 0; i < g.isize; ++i) {
+        g.at(i, j, k, RGPU_ID) = density;
+        g.at(i, j, k, RGPU_IP) = energy;
+        g.at(i, j, k, RGPU_IU) = density * delta_vx;
+      }
+}
+
 // ---- MHD: jet medium with an optional static field (MHDRunBase.cpp:1747-1798) and Sod tube (:1806-1862) ----------
 void init_mhd_jet(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   const double Bx = cfg.get_float("jet", "BStatic_x", 0.0f), By = cfg.get_float("jet", "BStatic_y", 0.0f);
@@ -832,6 +847,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "FieldLoop" || problem == "fieldloop" || problem == "Fieldloop" || problem == "field-loop" || problem == "Field-Loop") init_mhd_field_loop(cfg, p, g);
     else if (problem == "CurrentSheet" || problem == "currentsheet" || problem == "Currentsheet" || problem == "current-sheet" || problem == "Current-Sheet") init_mhd_current_sheet(cfg, p, g);
     else if (problem == "ShearWave" || problem == "shearwave" || problem == "Shear-Wave" || problem == "shear-wave" || problem == "Shearwave") init_mhd_shear_wave(cfg, p, g);
+    else if (problem == "InertialWave" || problem == "inertialwave" || problem == "Inertial-Wave" || problem == "inertial-wave" || problem == "Inertialwave") init_mhd_inertial_wave(cfg, p, g);
     else throw std::runtime_error("MHD problem '" + problem + "' is outside the implemented scope");
   } else {
     if (problem == "jet") init_hydro_jet(p, g);

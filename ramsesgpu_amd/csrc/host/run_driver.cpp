@@ -98,13 +98,37 @@ void GodunovRun::outputVtk(int nStep) {
 // MHDRunGodunov.cpp:3801-4070 / HydroRunGodunov.cpp:3857-4080 (no restart, no history, VTI outputs only)
 // history(nStep, dt): the history file of the MHD runs (MHDRunBase.cpp:3285-3619), one row per call, same columns and
 // ostream formatting: MRI problems get history_mri's eleven columns, Orszag-Tang history_default's four, every other
-// problem none (history_empty; the inertial-wave and turbulence variants are outside the implemented scope).  The sums
-// come from the device (rgpu_history_mri) instead of a copy of the state to the host.
+// problem none (history_empty; the turbulence variant is outside the implemented scope).  The sums come from the device
+// (rgpu_history_mri) instead of a copy of the state to the host.  The inertial-wave problem gets history_inertial_wave's
+// probe row (:3414-3469): the velocity of one cell in units of cIso, read with rgpu_read_cell.
 void GodunovRun::history(int nStep, double dt) {
   if (!p_.mhdEnabled) return;
   const std::string problem = cfg_.get_string("hydro", "problem", "unknown");
   const bool mri = problem == "MRI" || problem == "Mri" || problem == "mri";
   const bool dflt = problem == "Orszag-Tang" || problem == "OrszagTang";
+  const bool iwave = problem == "InertialWave" || problem == "inertialwave" || problem == "Inertial-Wave" ||
+                     problem == "inertial-wave" || problem == "Inertialwave";
+  if (iwave) {
+    double u[8];
+    const int iPos = p_.ghostWidth + p_.nx / 2, kPos = p_.ghostWidth;
+    if (p_.nz_global == 1) check(rgpu_read_cell(ctx_, nStep % 2, iPos, kPos, 0, u), "history");
+    else check(rgpu_read_cell(ctx_, nStep % 2, iPos, 1, kPos, u), "history");
+    const std::string fileName = cfg_.get_string("output", "outputDir", "./") + "/" + cfg_.get_string("output", "outputPrefix", "output") +
+                                 "_" + cfg_.get_string("history", "filename", "history.txt");
+    std::ofstream histo(fileName.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+    if (totalTime_ <= 0) histo << "# history" << std::endl;
+    const double rho = u[RGPU_ID], dvx = u[RGPU_IU] / rho, dvy = u[RGPU_IV] / rho;
+    // the reference's row, missing separator between totalTime and dt included; fmt() = " " + setw(12) fixed, 8 digits
+    histo << totalTime_ << "" << dt << " " << rho << " ";
+    const std::ios_base::fmtflags flags = histo.flags();
+    histo << " " << std::setw(12) << std::setprecision(8) << std::fixed << dvx / p_.cIso;
+    histo.flags(flags);
+    histo << " ";
+    histo << " " << std::setw(12) << std::setprecision(8) << std::fixed << dvy / p_.cIso;
+    histo.flags(flags);
+    histo << "\n";
+    return;
+  }
   if (!mri && !dflt) return;
   if (mri && p_.nz_global == 1) return;   // history_mri does nothing in 2D
   double h[8];

@@ -1,4 +1,5 @@
-// kernels_mhd2d.h -- per-cell bodies of the 2D MHD unsplit step ("implementationVersion 1").
+// kernels_mhd2d.h -- per-cell bodies of the 2D MHD unsplit step ("implementationVersion 1"), and of the 2D branch of
+// the rotating-frame step (Omega0 > 0, godunov_unsplit_rotating_cpu, MHDRunGodunov.cpp:2089-2434).
 //   mhd_prim_cell (kernels_mhd3d.h)  U     -> Q    (8)   MHDRunGodunov.cpp:479-517 (Bz_cell = Bz/2 in 2D)
 //   mhd_trace2d_cell                 U,Q   -> T2   (26)  mhd_godunov_unsplit_cpu_v1.cpp:43-94, trace_mhd.h:38-339
 //   mhd_flux2d_cell                  T2    -> F2   (13)  ..._cpu_v1.cpp:99-222  (2 HLLD + emfZ)
@@ -93,7 +94,13 @@ RG_DEVFN void mhd_trace2d_cell(const DevParams& g, const double* __restrict__ U,
   const double sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy;
   const double sA0 = (u * dBy + B * duy - v * dAy - A * dvy) * dtdy;
   const double sB0 = (-u * dBx - B * dux + v * dAx + A * dvx) * dtdx;
-  const double sC0 = (w * dAx + A * dwx - u * dCx - C * dux) * dtdx + (-v * dCy - C * dvy + w * dBy + B * dwy) * dtdy;
+  double sC0 = (w * dAx + A * dwx - u * dCx - C * dux) * dtdx + (-v * dCy - C * dvy + w * dBy + B * dwy) * dtdy;
+  if (g.Omega0 > 0) {  // rotating frame (trace_mhd.h:213-217)
+    const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+    const double shear = -1.5 * g.Omega0 * xPos;
+    sC0 += (shear * dAx - 1.5 * g.Omega0 * A) * dtdx;
+    sC0 += shear * dBy * dtdy;
+  }
   const double sAL0 = +(ELR - ELL) * 0.5 * dtdy;
   const double sBL0 = -(ERL - ELL) * 0.5 * dtdx;
 
@@ -171,11 +178,18 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
   const size_t N = g.ncell;
   const unsigned sj = g.sj;
   double fl[8];
+  // rotating frame (godunov_unsplit_rotating_cpu, 2D branch, MHDRunGodunov.cpp:2089-2434): the Bz fluxes get the
+  // shear advection of the mean normal field left in the states by the Riemann solver, emfZ its upwind term
+  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
   {
     Prim8 L = face_state2d<XD, +1>(g, T, idx - 1), R = face_state2d<XD, -1>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
+    if (g.rot) {
+      const double shear_x = -1.5 * g.Omega0 * (xPos + xPos - g.dx);
+      fl[IC] += shear_x * (L.a + R.a) / 2;
+    }
     F[idx + (size_t)(F2_X + 0) * N] = fl[ID]; F[idx + (size_t)(F2_X + 1) * N] = fl[IP]; F[idx + (size_t)(F2_X + 2) * N] = fl[IU];
     F[idx + (size_t)(F2_X + 3) * N] = fl[IV]; F[idx + (size_t)(F2_X + 4) * N] = fl[IW]; F[idx + (size_t)(F2_X + 5) * N] = fl[IC];
   }
@@ -184,20 +198,25 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
+    if (g.rot) {
+      const double shear_y = -1.5 * g.Omega0 * xPos;
+      fl[IC] += shear_y * (L.a + R.a) / 2;
+    }
     F[idx + (size_t)(F2_Y + 0) * N] = fl[ID]; F[idx + (size_t)(F2_Y + 1) * N] = fl[IP]; F[idx + (size_t)(F2_Y + 2) * N] = fl[IU];
     F[idx + (size_t)(F2_Y + 3) * N] = fl[IV]; F[idx + (size_t)(F2_Y + 4) * N] = fl[IW]; F[idx + (size_t)(F2_Y + 5) * N] = fl[IC];
   }
   {
     const Prim8 rt = edge_state2d<+1, +1>(g, T, idx - 1 - sj), rb = edge_state2d<+1, -1>(g, T, idx - 1);
     const Prim8 lt = edge_state2d<-1, +1>(g, T, idx - sj), lb = edge_state2d<-1, -1>(g, T, idx);
-    F[idx + (size_t)F2_EMF * N] = edge_emf<2>(g, rt, rb, lt, lb, 0.0);
+    F[idx + (size_t)F2_EMF * N] = edge_emf<2>(g, rt, rb, lt, lb, xPos);
   }
 }
 
 // The reference's 2D update has no guards (it also scribbles on ghost cells that the next ghost fill
 // overwrites); only interior cells and the CT range are reproduced, everything else is copied.
-RG_DEVFN void mhd_update2d_cell(const DevParams& g, const double* __restrict__ Uold, double* __restrict__ Unew,
-                                const double* __restrict__ F, double dtdx, double dtdy, unsigned idx) {
+RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
+                                double* __restrict__ Unew, const double* __restrict__ F, double dt, double dtdx, double dtdy,
+                                unsigned idx) {
   const IJK c = unflatten(g, idx);
   const size_t N = g.ncell;
   const unsigned sj = g.sj;
@@ -209,14 +228,41 @@ RG_DEVFN void mhd_update2d_cell(const DevParams& g, const double* __restrict__ U
   if (in_i && in_j) {
     double f[6];
 #define RG_LOADF2(base, off) _Pragma("unroll") for (int v = 0; v < 6; ++v) f[v] = F[(idx + (off)) + (size_t)((base) + v) * N]
-    RG_LOADF2(F2_X, 0);
-    u[ID] += f[0] * dtdx; u[IP] += f[1] * dtdx; u[IU] += f[2] * dtdx; u[IV] += f[3] * dtdx; u[IW] += f[4] * dtdx; u[IC] += f[5] * dtdx;
-    RG_LOADF2(F2_Y, 0);  // y-normal frame: f[2] = y momentum flux, f[3] = x momentum flux
-    u[ID] += f[0] * dtdy; u[IP] += f[1] * dtdy; u[IU] += f[3] * dtdy; u[IV] += f[2] * dtdy; u[IW] += f[4] * dtdy; u[IC] += f[5] * dtdy;
-    RG_LOADF2(F2_X, 1);
-    u[ID] -= f[0] * dtdx; u[IP] -= f[1] * dtdx; u[IU] -= f[2] * dtdx; u[IV] -= f[3] * dtdx; u[IW] -= f[4] * dtdx; u[IC] -= f[5] * dtdx;
-    RG_LOADF2(F2_Y, sj);
-    u[ID] -= f[0] * dtdy; u[IP] -= f[1] * dtdy; u[IU] -= f[3] * dtdy; u[IV] -= f[2] * dtdy; u[IW] -= f[4] * dtdy; u[IC] -= f[5] * dtdy;
+    if (!g.rot) {
+      RG_LOADF2(F2_X, 0);
+      u[ID] += f[0] * dtdx; u[IP] += f[1] * dtdx; u[IU] += f[2] * dtdx; u[IV] += f[3] * dtdx; u[IW] += f[4] * dtdx; u[IC] += f[5] * dtdx;
+      RG_LOADF2(F2_Y, 0);  // y-normal frame: f[2] = y momentum flux, f[3] = x momentum flux
+      u[ID] += f[0] * dtdy; u[IP] += f[1] * dtdy; u[IU] += f[3] * dtdy; u[IV] += f[2] * dtdy; u[IW] += f[4] * dtdy; u[IC] += f[5] * dtdy;
+      RG_LOADF2(F2_X, 1);
+      u[ID] -= f[0] * dtdx; u[IP] -= f[1] * dtdx; u[IU] -= f[2] * dtdx; u[IV] -= f[3] * dtdx; u[IW] -= f[4] * dtdx; u[IC] -= f[5] * dtdx;
+      RG_LOADF2(F2_Y, sj);
+      u[ID] -= f[0] * dtdy; u[IP] -= f[1] * dtdy; u[IU] -= f[3] * dtdy; u[IV] -= f[2] * dtdy; u[IW] -= f[4] * dtdy; u[IC] -= f[5] * dtdy;
+    } else {
+      // rotating frame (MHDRunGodunov.cpp:2253-2306): Coriolis on the old momenta before any flux reaches the cell,
+      // then the fluxes with the (alpha1, alpha2) mixing of the two in-plane momentum components
+      const rg_recip_t inv_l = rg_recip(1.0 + rc.lambda);
+      const double dsx = rg_div(2.0 * g.Omega0 * dt * u[IV], inv_l);
+      const double dsy = rg_div(-0.5 * g.Omega0 * dt * u[IU], inv_l);
+      u[IU] = u[IU] * rc.ratio + dsx;
+      u[IV] = u[IV] * rc.ratio + dsy;
+      const double a1 = rc.alpha1, a2 = rc.alpha2;
+      RG_LOADF2(F2_X, 0);
+      u[ID] += f[0] * dtdx; u[IP] += f[1] * dtdx;
+      u[IU] += (a1 * f[2] + a2 * f[3]) * dtdx; u[IV] += (a1 * f[3] - 0.25 * a2 * f[2]) * dtdx;
+      u[IW] += f[4] * dtdx; u[IC] += f[5] * dtdx;
+      RG_LOADF2(F2_Y, 0);
+      u[ID] += f[0] * dtdy; u[IP] += f[1] * dtdy;
+      u[IU] += (a1 * f[3] + a2 * f[2]) * dtdy; u[IV] += (a1 * f[2] - 0.25 * a2 * f[3]) * dtdy;
+      u[IW] += f[4] * dtdy; u[IC] += f[5] * dtdy;
+      RG_LOADF2(F2_X, 1);
+      u[ID] -= f[0] * dtdx; u[IP] -= f[1] * dtdx;
+      u[IU] -= (a1 * f[2] + a2 * f[3]) * dtdx; u[IV] -= (a1 * f[3] - 0.25 * a2 * f[2]) * dtdx;
+      u[IW] -= f[4] * dtdx; u[IC] -= f[5] * dtdx;
+      RG_LOADF2(F2_Y, sj);
+      u[ID] -= f[0] * dtdy; u[IP] -= f[1] * dtdy;
+      u[IU] -= (a1 * f[3] + a2 * f[2]) * dtdy; u[IV] -= (a1 * f[2] - 0.25 * a2 * f[3]) * dtdy;
+      u[IW] -= f[4] * dtdy; u[IC] -= f[5] * dtdy;
+    }
 #undef RG_LOADF2
     if (g.grav_on) {  // momentum source (mhd_godunov_unsplit_cpu_v0.cpp:616-618)
       const double rho_sum = Uold[idx + ID * N] + u[ID];

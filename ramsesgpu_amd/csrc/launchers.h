@@ -91,8 +91,8 @@ struct K_mhd_flux2d {
   RG_DEVFN void operator()(unsigned idx) const { mhd_flux2d_cell(g, T, F, idx); }
 };
 struct K_mhd_update2d {
-  DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell(g, Uold, Unew, F, dtdx, dtdy, idx); }
+  DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; double dt, dtdx, dtdy;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx); }
 };
 struct K_mhd_elec {
   DevParams g; const double* U; const double* Q; double* E;

@@ -81,12 +81,11 @@ int validate(const rgpu_params* p, std::string* why) {
   if (!(p->slope_type == 0 || p->slope_type == 1 || p->slope_type == 2 || p->slope_type == 3)) { *why = "slope_type must be 0, 1, 2 or 3"; return RGPU_EINVAL; }
   // positivity preserving slopes exist in the 2D MHD and the plain 3D MHD steps only: the hydro steps and the rotating
   // 3D step call slope routines that leave dq unset for type 3 (slope.h:97-147,324-427; slope_mhd.h:436-502)
-  if (p->slope_type == 3 && (!p->mhdEnabled || p->Omega0 > 0)) { *why = "slope_type 3 is defined for non-rotating MHD only (the reference leaves the slopes unset elsewhere)"; return RGPU_EUNSUPPORTED; }
+  if (p->slope_type == 3 && (!p->mhdEnabled || (p->Omega0 > 0 && p->nz_global != 1))) { *why = "slope_type 3 is defined for 2D MHD and non-rotating 3D MHD only (the reference leaves the slopes unset elsewhere)"; return RGPU_EUNSUPPORTED; }
   if (p->mhdEnabled) {
     // 2D: versions 0 and 1 compute the same numbers (0 recomputes what 1 stores; 0 alone has the gravity terms); 2 is a
     // superseded variant
     if (!three_d && p->implementationVersion != 1 && p->implementationVersion != 0) { *why = "2D MHD: implementationVersion must be 0 or 1"; return RGPU_EUNSUPPORTED; }
-    if (!three_d && p->Omega0 > 0) { *why = "2D rotating frame is outside the implemented scope"; return RGPU_EUNSUPPORTED; }
     if (three_d && !(p->Omega0 > 0) && p->implementationVersion != 3 && p->implementationVersion != 4) { *why = "3D MHD: only implementationVersion 3/4 are implemented"; return RGPU_EUNSUPPORTED; }
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLF && p->magRiemannSolver != RGPU_MAG_HLLA &&
         p->magRiemannSolver != RGPU_MAG_LLF) { *why = "magRiemannSolver must be hlld, hllf, hlla or llf (roe / upwind do not exist in the reference either)"; return RGPU_EUNSUPPORTED; }
@@ -355,13 +354,28 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   return 0;
 }
 
+// shearing-box / rotating-frame coefficients of the momentum update (MHDRunGodunov.cpp:2039-2053)
+RotCoef rot_coef(const rgpu_ctx* c, double dt) {
+  RotCoef rc = {0.0, 1.0, 1.0, 0.0};
+  if (c->g.rot) {
+    double lambda = c->p.Omega0 * dt;
+    lambda = 0.25 * lambda * lambda;
+    rc.lambda = lambda;
+    rc.ratio = (1.0 - lambda) / (1.0 + lambda);
+    rc.alpha1 = 1.0 / (1.0 + lambda);
+    rc.alpha2 = c->p.Omega0 * dt / (1.0 + lambda);
+  }
+  return rc;
+}
+
 int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
+  const RotCoef rc = rot_coef(c, dt);
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_FLUX); K_mhd_flux2d k = {g, c->T, c->F}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_UPDATE); K_mhd_update2d k = {g, in, out, c->F, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_UPDATE); K_mhd_update2d k = {g, rc, in, out, c->F, dt, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   return 0;
 }
 
@@ -374,15 +388,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   const rgpu_params& p = c->p;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
   const int ks = g.ksize;
-  RotCoef rc = {0.0, 1.0, 1.0, 0.0};
-  if (g.rot) {  // MHDRunGodunov.cpp:2047-2053
-    double lambda = p.Omega0 * dt;
-    lambda = 0.25 * lambda * lambda;
-    rc.lambda = lambda;
-    rc.ratio = (1.0 - lambda) / (1.0 + lambda);
-    rc.alpha1 = 1.0 / (1.0 + lambda);
-    rc.alpha2 = p.Omega0 * dt / (1.0 + lambda);
-  }
+  const RotCoef rc = rot_coef(c, dt);
   ShearRemap sr = {0, 0.0, 0.0};
   const bool shear = g.rot && g.shearbox;
   if (shear) {  // MHDRunGodunov.cpp:3213-3216 (flux / emf remap uses totalTime + dt/2)
@@ -464,7 +470,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
-  c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && c->p.implementationVersion != 0)) ? 1 : 0;
+  c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && (c->p.implementationVersion != 0 || c->g.rot))) ? 1 : 0;
   c->g.hgx = 0.5 * dt * c->p.gravity_x;
   c->g.hgy = 0.5 * dt * c->p.gravity_y;
   c->g.hgz = 0.5 * dt * c->p.gravity_z;
@@ -648,6 +654,18 @@ int rgpu_download(rgpu_ctx* c, double* hU, int parity) {
 }
 
 double* rgpu_device_state(rgpu_ctx* c, int parity) { return c ? c->U[parity & 1] : 0; }
+
+int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out) {
+  RG_CHECK_CTX(c);
+  if (!out || !c->U[0]) return fail(c, RGPU_EINVAL, "read_cell: null pointer / context without state");
+  const DevParams& g = c->g;
+  if (i < 0 || i >= g.isize || j < 0 || j >= g.jsize || k < 0 || k >= g.ksize) return fail(c, RGPU_EINVAL, "read_cell: index outside the array");
+  const size_t idx = (size_t)i + (size_t)g.isize * ((size_t)j + (size_t)g.jsize * (size_t)k);
+  for (int v = 0; v < c->p.nbVar; ++v)
+    if (rg_copy_d2h(out + v, c->U[parity & 1] + idx + (size_t)v * c->ncell, sizeof(double), c->stream)) return RG_HIPFAIL(c, "read_cell");
+  if (rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "read_cell");
+  return RGPU_OK;
+}
 
 int rgpu_make_boundaries(rgpu_ctx* c, int parity, int idim) {
   RG_CHECK_CTX(c);

@@ -167,6 +167,12 @@ class Solver:
 
     HISTORY_NAMES = ("mass", "maxwell", "reynolds", "magp", "mean_Bx", "mean_By", "mean_Bz", "divB")
 
+    def read_cell(self, parity, i, j, k=0):
+        """U(i, j, k, :) of one cell, ghost-inclusive local indices (the probe of history_inertial_wave)"""
+        out = np.zeros(int(self.p.nbVar))
+        self._chk(self.lib.rgpu_read_cell(self.ctx, parity, int(i), int(j), int(k), out.ctypes.data_as(_capi.c_double_p)), "read_cell")
+        return out
+
     def history_mri(self, nStep=None):
         """history_mri / history_default (MHDRunBase.cpp:3311-3619) reduced on the device"""
         parity = (self.nStep if nStep is None else nStep) % 2

@@ -172,12 +172,17 @@ ORACLE_RUNS = [
     ("mhd_BrioWu", "mesh.nx=16;mesh.ny=12;BrioWu.direction=1;MHD.magRiemannSolver=hllf;hydro.slope_type=3.0", 5),
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=6;mesh.nz=10;hydro.slope_type=3.0;MHD.magRiemannSolver=hllf;hydro.cIso=0.8", 3),
     ("mhd_BrioWu", "mesh.nx=10;mesh.ny=8;mesh.nz=8;BrioWu.direction=2;MHD.implementationVersion=3;hydro.slope_type=3.0", 4),
+    # 2D branch of the rotating-frame step: other solvers / slopes / boundaries, implementationVersion 0 + gravity knobs ignored
+    ("orszag-tang", "mesh.nx=16;mesh.ny=20;MHD.omega0=0.4;hydro.slope_type=3.0;MHD.magRiemannSolver=hlla", 5),
+    ("mhd_BrioWu", "mesh.nx=20;mesh.ny=12;BrioWu.direction=1;MHD.omega0=0.25;hydro.riemannSolver=llf;MHD.magRiemannSolver=llf;mesh.boundary_ymin=1;mesh.boundary_ymax=1", 5),
+    ("mhd_inertialWave_2d", "mesh.nx=8;mesh.ny=6;MHD.implementationVersion=0", 6),
 ]
 
 RANDOM_STEPS = [
     ("orszag-tang", "mesh.nx=20;mesh.ny=14", 1.5),
     ("orszag-tang", "mesh.nx=14;mesh.ny=20;hydro.riemannSolver=hll", 3.0),
     ("mhd_BrioWu", "mesh.nx=16;mesh.ny=16", 2.5),
+    ("orszag-tang", "mesh.nx=18;mesh.ny=14;MHD.omega0=0.6;hydro.cIso=0.7", 2.0),
     ("orszag-tang3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6", 1.5),
     ("orszag-tang3d", "mesh.nx=6;mesh.ny=10;mesh.nz=8;hydro.riemannSolver=llf", 3.0),
     ("mhd_mri_3d", "mesh.nx=8;mesh.ny=10;mesh.nz=6;hydro.cIso=0.8;MHD.omega0=0.3", 1.0),

@@ -223,3 +223,20 @@ def test_run_driver_writes_reference_history_file(gpu_lib, tmp_path):
         assert np.allclose(rows[:, col], H[:, col], rtol=3e-6, atol=0), col
     assert np.allclose(rows[:, 8], H[:, 8], rtol=1e-4, atol=1e-18)          # mean_By: small but physical
     assert np.abs(rows[:, [7, 9, 10]]).max() <= 1e-15                        # mean_Bx, mean_Bz, divB: round-off
+
+
+def test_run_driver_writes_inertial_wave_history_file(gpu_lib, tmp_path):
+    """2D rotating-frame run of the shipped inertial-wave problem through the run driver: the probe rows of
+    history_inertial_wave (one cell's velocity in units of cIso, 8 digits) equal the reference's file character for
+    character, the missing separator between totalTime and dt included"""
+    import ctypes as C
+    from conftest import golden_cases, load_golden
+    case = golden_cases()["inertialwave2d_16_history"]
+    want = [str(x) for x in load_golden("inertialwave2d_16_history")["history_text"]]
+    ov = case["overrides"] + ";output.outputVtk=no;output.outputHdf5=no;output.outputDir=%s" % tmp_path
+    err = C.create_string_buffer(512)
+    mc = C.c_double(0)
+    n = gpu_lib.lib.rgpuh_run(ini(case["base"]).encode(), ov.encode(), C.byref(mc), err, 512)
+    assert n == 8, err.value
+    got = [ln.rstrip("\n") for ln in open(tmp_path / "mhd_inertialWave_2d_history.txt") if ln.strip() and not ln.startswith("#")]
+    assert got == want

@@ -40,3 +40,21 @@ def test_step_core_in_plane_pieces(base, ov, emu_lib):
 @pytest.mark.parametrize("base,ov,nsteps", pc.HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.HISTORY_CASES])
 def test_history_diagnostics(base, ov, nsteps, emu_lib, oracle):
     pc.check_history(emu_lib, oracle, base, ov, nsteps)
+
+
+def test_run_driver_inertial_wave_history_file(emu_lib, tmp_path):
+    """host logic of the run driver (time loop, history cadence, the probe row of history_inertial_wave) on the 2D
+    rotating-frame step, through the emulation build: the file equals the reference's character for character"""
+    import ctypes as C
+    import os
+    from conftest import ROOT, load_golden
+    case = golden_cases()["inertialwave2d_16_history"]
+    want = [str(x) for x in load_golden("inertialwave2d_16_history")["history_text"]]
+    ov = case["overrides"] + ";output.outputVtk=no;output.outputHdf5=no;output.outputDir=%s" % tmp_path
+    err = C.create_string_buffer(512)
+    mc = C.c_double(0)
+    ini = os.path.join(ROOT, "configs", case["base"] + ".ini")
+    n = emu_lib.lib.rgpuh_run(ini.encode(), ov.encode(), C.byref(mc), err, 512)
+    assert n == 8, err.value
+    got = [ln.rstrip("\n") for ln in open(tmp_path / "mhd_inertialWave_2d_history.txt") if ln.strip() and not ln.startswith("#")]
+    assert got == want
