@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 3
+#define RGPU_ABI_VERSION 4
 
 /* component indexes -- constants.h:59-71 */
 enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
@@ -86,7 +86,8 @@ typedef struct rgpu_params {
   /* z-slab decomposition (replaces the reference's MPI cartesian topology, HydroMpiParameters.cpp:44-80) */
   int32_t slab_rank, slab_count;/* 0,1 for a single device */
   int32_t nz_global;            /* == nz when slab_count==1 */
-  int32_t gravityEnabled;       /* [gravity] static=yes, or forced by problem=Rayleigh-Taylor (HydroRunBase.cpp:250-260) */
+  int32_t gravityEnabled;       /* [gravity] static=yes, or forced by problem=Rayleigh-Taylor (HydroRunBase.cpp:250-260):
+                                 * 1 = the uniform vector below, 2 = a per-cell field given with rgpu_set_gravity_field */
   /* uniform static gravity field ([gravity] static_field_x/y/z, HydroParameters.h:322-324): the reference keeps it in a
    * per-cell array h_gravity that its problems fill with exactly this vector (HydroRunBase.cpp:6336-6337, 6403-6405) */
   double  gravity_x, gravity_y, gravity_z;
@@ -124,6 +125,11 @@ const char* rgpu_last_error(rgpu_ctx* c);
 int rgpu_upload(rgpu_ctx* c, const double* hU, int both);
 /* == copyGpuToCpu(nStep) + getDataHost(nStep) (HydroRunBase.cpp:7217-7229, 2442-2447); parity = nStep%2 */
 int rgpu_download(rgpu_ctx* c, double* hU, int parity);
+/* Static gravity field of a context created with gravityEnabled = 2: hG[3][ksize][jsize][isize] (ghost cells included,
+ * the z component ignored in 2D) = the reference's h_gravity / d_gravity (HydroRunBase.h, filled by the initial
+ * conditions of Keplerian-disk, HydroRunBase.cpp:6489-6500, and of the stratified MRI box, MHDRunBase.cpp:3163-3211).
+ * Until it is called the field is zero, like the reference's freshly allocated array. */
+int rgpu_set_gravity_field(rgpu_ctx* c, const double* hG);
 /* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */
 double* rgpu_device_state(rgpu_ctx* c, int parity);
 
@@ -250,6 +256,12 @@ int rgpuh_run_settings(const char* ini_path, const char* overrides, int* nStepma
  * (the MRI drand48 stream is skipped ahead so that every slab draws the numbers the single-domain run would). */
 int rgpuh_init_condition(const char* ini_path, const char* overrides, const rgpu_params* p, double* hU,
                          char* err, int err_len);
+
+/* Fill hG (3 * cells doubles: x, y, z component, ghost cells included; zeroed first) with the static gravity field the
+ * problem's init routine writes into h_gravity: Keplerian-disk (HydroRunBase.cpp:6489-6500, 6575-6597).  Returns 1 when the problem defines a field (params_from_ini then says gravityEnabled = 2), 0 when it does not,
+ * a negative RGPU_E* on error. */
+int rgpuh_init_gravity(const char* ini_path, const char* overrides, const rgpu_params* p, double* hG,
+                       char* err, int err_len);
 
 /* Run [run] nstepmax / tend like MHDRunGodunov::start / HydroRunGodunov::start on one GPU; writes .vti outputs
  * when [output] outputVtk=yes.  Returns steps done (>=0) or a negative error. Mcell-updates/s is printed like

@@ -75,6 +75,10 @@ CASES = {
     "ot2d_24x40_rot_iso_hll": ("orszag-tang", "mesh.nx=24;mesh.ny=40;MHD.omega0=0.3;hydro.cIso=0.8;hydro.riemannSolver=hll;MHD.magRiemannSolver=hllf;run.nstepmax=12;run.noutput=100", [12]),
     "briowu_x_48_rot_open": ("mhd_BrioWu", "mesh.nx=48;mesh.ny=16;BrioWu.direction=0;MHD.omega0=0.2;hydro.nu=0.002;MHD.eta=0.004;run.nstepmax=15;run.noutput=100", [15]),
     "ot2d_20x16_rot_slope3": ("orszag-tang", "mesh.nx=20;mesh.ny=16;MHD.omega0=0.4;hydro.slope_type=3.0;MHD.magRiemannSolver=hlla;run.nstepmax=10;run.noutput=100", [10]),
+    # --- per-cell static gravity field (h_gravity filled by the problem): Keplerian disk, 2D analytic / 3D differenced ----
+    "kepler2d_32": ("Keplerian_disk2d", "mesh.nx=32;mesh.ny=32;run.nstepmax=15;run.noutput=1000", [0, 15]),
+    "kepler2d_24x40_hll": ("Keplerian_disk2d", "mesh.nx=24;mesh.ny=40;hydro.riemannSolver=hll;hydro.unsplitVersion=2;run.nstepmax=10;run.noutput=1000", [10]),
+    "kepler3d_16x16x6": ("Keplerian_disk2d", "mesh.nx=16;mesh.ny=16;mesh.nz=6;run.nstepmax=8;run.noutput=1000", [0, 8]),
     "rotor_32_ic": ("mhd_rotor", "mesh.nx=32;mesh.ny=32;run.nstepmax=0;run.noutput=100", [0]),   # IC only: with implementationVersion=1 the reference itself turns this problem into NaN within a few steps
     "fieldloop2d_32x20": ("mhd_fieldloop2d", "mesh.nx=32;mesh.ny=20;run.nstepmax=10;run.noutput=100", [0, 10]),
     "fieldloop3d_16x8x8": ("mhd_fieldloop3d", "mesh.nx=16;mesh.ny=8;mesh.nz=8;run.nstepmax=5;run.noutput=100", [0, 5]),

@@ -110,6 +110,10 @@ static int check_scope(const rgpu_params* p) {
   return 0;
 }
 
+// h_gravity of the runs with gravityEnabled == 2: G[3][ksize][jsize][isize], caller-owned, used by every later call
+// (0 = forget it)
+void orc_set_gravity_field(const double* G) { Ctx::gravity_field() = G; }
+
 // godunov_unsplit(nStep, dt): Uold -> Unew (both ghost-inclusive, caller-owned)
 int orc_godunov_unsplit(const rgpu_params* p, double* Uold, double* Unew, double dt, double totalTime) {
   const int rc = check_scope(p);

@@ -39,6 +39,14 @@ struct Ctx {
     dx = p.dx; dy = p.dy; dz = p.dz;
   }
   size_t idx(int i, int j, int k) const { return (size_t)i + (size_t)isize * (j + (size_t)jsize * k); }
+  // static gravity at a cell: the uniform vector (gravityEnabled == 1) or the per-cell field h_gravity
+  // (gravityEnabled == 2, given with orc_set_gravity_field; zero until then, like the reference's allocation)
+  const double* G = gravity_field();
+  double grav(int i, int j, int k, int e) const {
+    if (p.gravityEnabled == 2) return G ? G[idx(i, j, k) + ncell * e] : 0.0;
+    return e == 0 ? p.gravity_x : e == 1 ? p.gravity_y : p.gravity_z;
+  }
+  static const double*& gravity_field() { static const double* g = 0; return g; }
 };
 
 // A component-major field with the reference's HostArray index map (Arrays.h:95-98).

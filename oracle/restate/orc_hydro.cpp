@@ -50,11 +50,10 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
           }
         hydro_trace<NDIM, NV>(p, q, dq, dtdx, dtdy, dtdz, tqm, tqp);
         if (p.gravityEnabled) {   // gravity predictor on every traced face state (HydroRunGodunov.cpp:2485-2497, 2705-2734)
-          const double grav[3] = {p.gravity_x, p.gravity_y, p.gravity_z};
           for (int d = 0; d < NDIM; ++d)
             for (int e = 0; e < NDIM; ++e) {
-              tqm[d][IU + e] += 0.5 * dt * grav[e];
-              tqp[d][IU + e] += 0.5 * dt * grav[e];
+              tqm[d][IU + e] += 0.5 * dt * c.grav(i, j, k, e);
+              tqp[d][IU + e] += 0.5 * dt * c.grav(i, j, k, e);
             }
         }
         for (int d = 0; d < NDIM; ++d)
@@ -122,14 +121,13 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
   // gravity source term on the momenta of the interior (compute_gravity_source_term, HydroRunBase.cpp:1925-1985);
   // the total energy is left alone, as in the reference
   if (p.gravityEnabled) {
-    const double grav[3] = {p.gravity_x, p.gravity_y, p.gravity_z};
     const int kg0 = (NDIM == 3) ? gw : 0, kg1 = (NDIM == 3) ? ksize - gw : 1;
     for (int k = kg0; k < kg1; k++)
       for (int j = gw; j < jsize - gw; j++)
         for (int i = gw; i < isize - gw; i++) {
           const size_t o = c.idx(i, j, k);
           const double rhoOld = Uold_d[o + ID * N], rhoNew = Unew.d[o + ID * N];
-          for (int e = 0; e < NDIM; ++e) Unew.d[o + (IU + e) * N] += 0.5 * dt * grav[e] * (rhoOld + rhoNew);
+          for (int e = 0; e < NDIM; ++e) Unew.d[o + (IU + e) * N] += 0.5 * dt * c.grav(i, j, k, e) * (rhoOld + rhoNew);
         }
   }
   dissipative_stage(c, Unew_d, dt, 0.0);   // [hydro] nu > 0 (HydroRunGodunov.cpp:2620-2640, 2908-2925)

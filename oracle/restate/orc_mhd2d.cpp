@@ -164,7 +164,7 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
         }
       trace_mhd_2d(p, qNb, bfNb, dtdx, dtdy, xPos, qm, qp, qEdge);
       if (grav) {   // implementation version 0 only (mhd_godunov_unsplit_cpu_v0.cpp:495-525): predictor on all 8 states
-        const double gx = 0.5 * dt * p.gravity_x, gy = 0.5 * dt * p.gravity_y;
+        const double gx = 0.5 * dt * c.grav(i, j, 0, 0), gy = 0.5 * dt * c.grav(i, j, 0, 1);
         // the y states are already in the swapped (y-normal) frame when the reference adds the predictor
         // (swap at :177-179, :388-390, predictor at :500-512): g_x lands on v and g_y on u there
         qm[0][IU] += gx; qm[0][IV] += gy; qp[0][IU] += gx; qp[0][IV] += gy;
@@ -251,8 +251,8 @@ void mhd_step_2d(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
     for (int j = gw; j < jsize - gw; j++)
       for (int i = gw; i < isize - gw; i++) {
         const double rhoOld = U(i, j, ID), rhoNew = Unew(i, j, ID);
-        Unew(i, j, IU) += 0.5 * dt * p.gravity_x * (rhoOld + rhoNew);
-        Unew(i, j, IV) += 0.5 * dt * p.gravity_y * (rhoOld + rhoNew);
+        Unew(i, j, IU) += 0.5 * dt * c.grav(i, j, 0, 0) * (rhoOld + rhoNew);
+        Unew(i, j, IV) += 0.5 * dt * c.grav(i, j, 0, 1) * (rhoOld + rhoNew);
       }
 
   // constrained transport

@@ -233,7 +233,7 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
         E[IZ][0][0] = elec(i, j, k, IZ); E[IZ][0][1] = elec(i, j + 1, k, IZ); E[IZ][1][0] = elec(i + 1, j, k, IZ); E[IZ][1][1] = elec(i + 1, j + 1, k, IZ);
         trace_mhd_3d(p, q, dq, bfNb, dbf, E, dtdx, dtdy, dtdz, xPos, tqm, tqp, tqe);
         if (p.gravityEnabled) {   // gravity predictor on all 18 traced states (..._cpu_v3.cpp:277-332, MHDRunGodunov.cpp:2684-2740)
-          const double grav_x = 0.5 * dt * p.gravity_x, grav_y = 0.5 * dt * p.gravity_y, grav_z = 0.5 * dt * p.gravity_z;
+          const double grav_x = 0.5 * dt * c.grav(i, j, k, 0), grav_y = 0.5 * dt * c.grav(i, j, k, 1), grav_z = 0.5 * dt * c.grav(i, j, k, 2);
           for (int d = 0; d < 3; ++d) {
             tqm[d][IU] += grav_x; tqm[d][IV] += grav_y; tqm[d][IW] += grav_z;
             tqp[d][IU] += grav_x; tqp[d][IV] += grav_y; tqp[d][IW] += grav_z;
@@ -372,9 +372,9 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
       for (int j = gw; j < jsize - gw; j++)
         for (int i = gw; i < isize - gw; i++) {
           const double rhoOld = U(i, j, k, ID), rhoNew = Unew(i, j, k, ID);
-          Unew(i, j, k, IU) += 0.5 * dt * p.gravity_x * (rhoOld + rhoNew);
-          Unew(i, j, k, IV) += 0.5 * dt * p.gravity_y * (rhoOld + rhoNew);
-          Unew(i, j, k, IW) += 0.5 * dt * p.gravity_z * (rhoOld + rhoNew);
+          Unew(i, j, k, IU) += 0.5 * dt * c.grav(i, j, k, 0) * (rhoOld + rhoNew);
+          Unew(i, j, k, IV) += 0.5 * dt * c.grav(i, j, k, 1) * (rhoOld + rhoNew);
+          Unew(i, j, k, IW) += 0.5 * dt * c.grav(i, j, k, 2) * (rhoOld + rhoNew);
         }
 
   if (rot && shearbox) {

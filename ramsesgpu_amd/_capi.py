@@ -1,7 +1,7 @@
 """ctypes view of include/rgpu.h (the C ABI) -- plain structs and prototypes, no compute here."""
 import ctypes as C
 
-RGPU_ABI_VERSION = 3
+RGPU_ABI_VERSION = 4
 
 ID, IP, IU, IV, IW, IA, IB, IC = range(8)
 BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
@@ -73,6 +73,8 @@ def declare_host_api(lib):
                                        C.c_char_p, C.c_int]
     lib.rgpuh_init_condition.restype = C.c_int
     lib.rgpuh_init_condition.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
+    lib.rgpuh_init_gravity.restype = C.c_int
+    lib.rgpuh_init_gravity.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
     return lib
 
 
@@ -108,6 +110,8 @@ def declare_device_api(lib):
     lib.rgpu_history_columns.argtypes = [ctx, C.c_int, c_double_p]
     lib.rgpu_history_reynolds.restype = C.c_int
     lib.rgpu_history_reynolds.argtypes = [ctx, C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
+    lib.rgpu_set_gravity_field.restype = C.c_int
+    lib.rgpu_set_gravity_field.argtypes = [ctx, C.c_void_p]
     lib.rgpu_history_mri.restype = C.c_int
     lib.rgpu_history_mri.argtypes = [ctx, C.c_int, c_double_p]
     lib.rgpu_read_cell.restype = C.c_int
@@ -153,5 +157,5 @@ DECLARED_SYMBOLS = [
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
-    "rgpu_backend_name", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_run",
+    "rgpu_backend_name", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_run",
 ]

@@ -35,7 +35,22 @@ struct DevParams {
   // static gravity: (0.5 * dt) * g of the CURRENT step, set by the step driver before it launches (the reference's
   // "HALF_F * dt * h_gravity(i,j,k,d)" with the uniform field its problems fill in)
   double hgx, hgy, hgz;
+  // grav_on == 2: per-cell field G[d * ncell + idx] (the reference's h_gravity / d_gravity, uploaded once with
+  // rgpu_set_gravity_field) and hdt = 0.5 * dt of the current step
+  const double* G;
+  double hdt;
 };
+
+// (0.5 * dt) * g at cell m: the uniform vector of the step, or the per-cell field
+RG_DEVFN void half_dt_gravity(const DevParams& g, unsigned m, double& gx, double& gy, double& gz) {
+  if (g.grav_on == 2) {
+    gx = g.hdt * g.G[m];
+    gy = g.hdt * g.G[m + g.ncell];
+    gz = g.three_d ? g.hdt * g.G[m + 2 * g.ncell] : 0.0;
+  } else {
+    gx = g.hgx; gy = g.hgy; gz = g.hgz;
+  }
+}
 
 struct Prim8 {  // primitive MHD state in some frame: density, pressure, 3 velocities, 3 field components
   double r, p, u, v, w, a, b, c;

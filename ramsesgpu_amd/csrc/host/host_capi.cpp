@@ -86,4 +86,17 @@ int rgpuh_init_condition(const char* ini_path, const char* overrides, const rgpu
   return RGPU_OK;
 }
 
+int rgpuh_init_gravity(const char* ini_path, const char* overrides, const rgpu_params* p, double* hG, char* err, int err_len) {
+  if (!p || !hG) return RGPU_EINVAL;
+  rgpu_host::IniConfig cfg;
+  const int rc = load(ini_path, overrides, &cfg, err, err_len);
+  if (rc) return rc;
+  try {
+    return rgpu_host::init_gravity_field(cfg, *p, hG) ? 1 : 0;
+  } catch (const std::exception& e) {
+    set_err(err, err_len, e.what());
+    return RGPU_EUNSUPPORTED;
+  }
+}
+
 }  // extern "C"

@@ -76,8 +76,9 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   if (cfg.get_bool("gravity", "self", false)) throw std::runtime_error("self gravity is outside the implemented scope");
   {
     const std::string prob = cfg.get_string("hydro", "problem", "unknown");
-    if (prob == "Keplerian-disk") throw std::runtime_error("problem Keplerian-disk (central point-mass gravity field) is outside the implemented scope");
     p->gravityEnabled = (cfg.get_bool("gravity", "static", false) || prob == "Rayleigh-Taylor") ? 1 : 0;   // falling-bubble is NOT forced
+    // problems whose initial condition fills h_gravity cell by cell (init_gravity_field): 2 = per-cell field
+    if (p->gravityEnabled && prob == "Keplerian-disk" && !p->mhdEnabled) p->gravityEnabled = 2;
     // The reference's steps read the per-cell array h_gravity, which only the Rayleigh-Taylor (and falling-bubble)
     // initial conditions fill with the [gravity] static_field vector; for every other problem it stays at its
     // zero-initialised allocation, i.e. "static=yes" switches the code path on with g = 0 (verified against the

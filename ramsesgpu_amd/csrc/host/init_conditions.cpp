@@ -612,6 +612,47 @@ void init_hydro_falling_bubble(const IniConfig& cfg, const rgpu_params& p, const
   }
 }
 
+// ---- hydro: Keplerian disk around a softened point mass (HydroRunBase.cpp:6445-6625), every cell ------------------
+// The gravity field of the same routine is produced by init_gravity_field below.
+struct KeplerDisk {
+  double epsilon, P0, xCenter, yCenter, grav;
+  KeplerDisk(const IniConfig& cfg, const rgpu_params& p) {
+    const double xMax = p.xMax, yMax = p.yMax;
+    epsilon = cfg.get_float("Keplerian-disk", "epsilon", 0.01f);
+    P0 = cfg.get_float("Keplerian-disk", "pressure", 1e-6f);
+    xCenter = cfg.get_float("Keplerian-disk", "xCenter", static_cast<float>((xMax + p.xMin) / 2.0));
+    yCenter = cfg.get_float("Keplerian-disk", "yCenter", static_cast<float>((yMax + p.yMin) / 2.0));
+    grav = cfg.get_float("gravity", "g", 1.0f);
+  }
+};
+
+void init_hydro_keplerian_disk(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const KeplerDisk kd(cfg, p);
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j) {
+      const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+      for (int i = 0; i < g.isize; ++i) {
+        const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+        const double theta = std::atan2(yPos - kd.yCenter, xPos - kd.xCenter);
+        const double r = std::sqrt((xPos - kd.xCenter) * (xPos - kd.xCenter) + (yPos - kd.yCenter) * (yPos - kd.yCenter));
+        const double velocity = r * std::pow(r * r + kd.epsilon * kd.epsilon, -3.0 / 4.0);
+        double d;
+        if (r < 0.5) d = 0.01 + std::pow(r / 0.5, 3.0);
+        else if (r <= 2) d = 0.01 + 1;
+        else d = 0.01 + std::pow(1 + (r - 2) / 0.1, -3.0);
+        g.at(i, j, k, RGPU_ID) = d;
+        // the reference binary (g++ -O2) evaluates sin(theta) and cos(theta) with ONE call of glibc's sincos(), whose
+        // sine differs from sin()'s in the last bit for some arguments: make the same call
+        double sin_t, cos_t;
+        ::sincos(theta, &sin_t, &cos_t);
+        g.at(i, j, k, RGPU_IU) = -sin_t * velocity * d;
+        g.at(i, j, k, RGPU_IV) = cos_t * velocity * d;
+        const double mu = g.at(i, j, k, RGPU_IU), mv = g.at(i, j, k, RGPU_IV);
+        g.at(i, j, k, RGPU_IP) = kd.P0 / (p.gamma0 - 1.0) + 0.5 * (mu * mu + mv * mv) / d;   // (+ 0*0 of the z momentum in 3D)
+      }
+    }
+}
+
 // ---- MHD: compressive shear wave in the shearing box (MHDRunBase.cpp:2574-2658), every cell, ghosts included --------
 void init_mhd_shear_wave(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   if (!(p.bc[0] == RGPU_BC_SHEARINGBOX && p.bc[1] == RGPU_BC_SHEARINGBOX))
@@ -830,6 +871,43 @@ void init_mhd_current_sheet(const IniConfig& cfg, const rgpu_params& p, const Gr
 
 }  // namespace
 
+// The per-cell static gravity field of the problems that define one (gravityEnabled == 2): hG[3][ksize][jsize][isize]
+bool init_gravity_field(const IniConfig& cfg, const rgpu_params& p, double* hG) {
+  Grid g = make_grid(p, hG);
+  g.nvar = 3;
+  std::memset(hG, 0, sizeof(double) * g.ncell * 3);
+  const std::string problem = cfg.get_string("hydro", "problem", "unknown");
+  if (!p.mhdEnabled && problem == "Keplerian-disk") {
+    // g = -grad(Phi), Phi = -(r^2 + epsilon^2)^(-1/2): analytic in 2D (with the reference's xPos, yPos measured from
+    // the origin, not from the disk centre), one-sided differences of Phi in 3D (HydroRunBase.cpp:6489-6500, 6575-6597)
+    const KeplerDisk kd(cfg, p);
+    for (int k = 0; k < g.ksize; ++k)
+      for (int j = 0; j < g.jsize; ++j) {
+        const double yPos = p.yMin + p.dy / 2 + (j - g.gw) * p.dy;
+        for (int i = 0; i < g.isize; ++i) {
+          const double xPos = p.xMin + p.dx / 2 + (i - g.gw) * p.dx;
+          const double r = std::sqrt((xPos - kd.xCenter) * (xPos - kd.xCenter) + (yPos - kd.yCenter) * (yPos - kd.yCenter));
+          if (!g.three_d) {
+            const double dphi_dx = xPos * std::pow(r * r + kd.epsilon * kd.epsilon, -3.0 / 2);
+            const double dphi_dy = yPos * std::pow(r * r + kd.epsilon * kd.epsilon, -3.0 / 2);
+            g.at(i, j, k, 0) = -kd.grav * dphi_dx;
+            g.at(i, j, k, 1) = -kd.grav * dphi_dy;
+          } else {
+            const double phi = -1.0 / std::sqrt(r * r + kd.epsilon * kd.epsilon);
+            const double r_x = std::sqrt((xPos + p.dx - kd.xCenter) * (xPos + p.dx - kd.xCenter) + (yPos - kd.yCenter) * (yPos - kd.yCenter));
+            const double phi_x = -1.0 / std::sqrt(r_x * r_x + kd.epsilon * kd.epsilon);
+            const double r_y = std::sqrt((xPos - kd.xCenter) * (xPos - kd.xCenter) + (yPos + p.dy - kd.yCenter) * (yPos + p.dy - kd.yCenter));
+            const double phi_y = -1.0 / std::sqrt(r_y * r_y + kd.epsilon * kd.epsilon);
+            g.at(i, j, k, 0) = -(phi - phi_x) / p.dx;
+            g.at(i, j, k, 1) = -(phi - phi_y) / p.dy;
+          }
+        }
+      }
+    return true;
+  }
+  return false;
+}
+
 void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
   const Grid g = make_grid(p, hU);
   std::memset(hU, 0, sizeof(double) * g.ncell * g.nvar);
@@ -859,6 +937,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "Gresho-vortex") init_hydro_gresho(cfg, p, g);
     else if (problem == "riemann2d") init_hydro_riemann2d(cfg, p, g);
     else if (problem == "falling-bubble") init_hydro_falling_bubble(cfg, p, g);
+    else if (problem == "Keplerian-disk") init_hydro_keplerian_disk(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
 }

@@ -18,6 +18,11 @@ namespace rgpu_host {
 // Throws std::runtime_error for unknown problems.
 void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU);
 
+// hG: 3 * ncell doubles (x, y, z component planes, ghost cells included), zero-filled first; returns false when the
+// problem defines no per-cell field.  The reference fills h_gravity inside its init routines (Keplerian-disk:
+// HydroRunBase.cpp:6489-6500, 6575-6597).
+bool init_gravity_field(const IniConfig& cfg, const rgpu_params& p, double* hG);
+
 // glibc-compatible drand48 stream (48-bit LCG X' = a X + c mod 2^48, a=0x5DEECE66D, c=0xB; srand48(s) sets
 // X = (s<<16)|0x330E) with O(log n) skip-ahead.
 class Rand48 {

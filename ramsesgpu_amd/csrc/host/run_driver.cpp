@@ -36,6 +36,10 @@ void GodunovRun::check(int rc, const char* what) {
 int GodunovRun::init_simulation() {
   init_condition(cfg_, p_, h_U_.data());
   check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
+  if (p_.gravityEnabled == 2) {   // h_gravity of the problem, copied to the device once (d_gravity.copyFromHost)
+    std::vector<double> hG(3 * (h_U_.size() / p_.nbVar));
+    if (init_gravity_field(cfg_, p_, hG.data())) check(rgpu_set_gravity_field(ctx_, hG.data()), "set_gravity_field");
+  }
   return 0;
 }
 

@@ -88,9 +88,11 @@ RG_DEVFN void hydro_face_state(const DevParams& g, const double* __restrict__ T,
   qv[ID] = fmax(g.smallr, qv[ID]);
   qv[IP] = fmax(g.smallp * qv[ID], qv[IP]);
   if (g.grav_on) {  // gravity predictor on the traced state (HydroRunGodunov.cpp:2485-2497, 2705-2734)
-    qv[IU] += g.hgx;
-    qv[IV] += g.hgy;
-    if (NV == 5) qv[NV - 1] += g.hgz;
+    double gx, gy, gz;
+    half_dt_gravity(g, m, gx, gy, gz);
+    qv[IU] += gx;
+    qv[IV] += gy;
+    if (NV == 5) qv[NV - 1] += gz;
   }
   const int swp = (D == 0) ? IU : (D == 1) ? IV : IW;  // swap IU with the normal velocity
 #pragma unroll
@@ -172,9 +174,11 @@ RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ U
     }
     if (g.grav_on) {  // momentum source (compute_gravity_source_term, HydroRunBase.cpp:1925-1985); energy untouched
       const double rho_sum = Uold[idx + ID * N] + u[ID];
-      u[IU] += g.hgx * rho_sum;
-      u[IV] += g.hgy * rho_sum;
-      if (NV == 5) u[NV - 1] += g.hgz * rho_sum;
+      double gx, gy, gz;
+      half_dt_gravity(g, idx, gx, gy, gz);
+      u[IU] += gx * rho_sum;
+      u[IV] += gy * rho_sum;
+      if (NV == 5) u[NV - 1] += gz * rho_sum;
     }
   }
 #pragma unroll

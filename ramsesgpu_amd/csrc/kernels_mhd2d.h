@@ -144,7 +144,11 @@ RG_DEVFN Prim8 face_state2d(const DevParams& g, const double* __restrict__ T, un
   if (D == XD) { o.u = u; o.v = v; } else { o.u = v; o.v = u; }
   // implementation version 0: the reference adds the gravity predictor AFTER the swap into the face-normal frame
   // (mhd_godunov_unsplit_cpu_v0.cpp:177-179, 388-390, then 500-512), so on y faces g_x lands on v and g_y on u
-  if (g.grav_on) { o.u += g.hgx; o.v += g.hgy; }
+  if (g.grav_on) {
+    double gx, gy, gz;
+    half_dt_gravity(g, m, gx, gy, gz);
+    o.u += gx; o.v += gy;
+  }
   o.a = bn; o.b = bt;
   floor2d(g, o);
   return o;
@@ -161,7 +165,11 @@ RG_DEVFN Prim8 edge_state2d(const DevParams& g, const double* __restrict__ T, un
   o.p = t[T2_P * N] + (sx * t[(T2_DX + 1) * N] + sy * t[(T2_DY + 1) * N]);
   o.u = t[T2_U * N] + (sx * t[(T2_DX + 2) * N] + sy * t[(T2_DY + 2) * N]);
   o.v = t[T2_V * N] + (sx * t[(T2_DX + 3) * N] + sy * t[(T2_DY + 3) * N]);
-  if (g.grav_on) { o.u += g.hgx; o.v += g.hgy; }   // (mhd_godunov_unsplit_cpu_v0.cpp:514-524)
+  if (g.grav_on) {   // (mhd_godunov_unsplit_cpu_v0.cpp:514-524)
+    double gx, gy, gz;
+    half_dt_gravity(g, m, gx, gy, gz);
+    o.u += gx; o.v += gy;
+  }
   o.w = t[T2_W * N] + (sx * t[(T2_DX + 4) * N] + sy * t[(T2_DY + 4) * N]);
   o.c = t[T2_C * N] + (sx * t[(T2_DX + 6) * N] + sy * t[(T2_DY + 6) * N]);
   const unsigned mx = (SX > 0) ? m + 1 : m;
@@ -266,8 +274,10 @@ RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const doub
 #undef RG_LOADF2
     if (g.grav_on) {  // momentum source (mhd_godunov_unsplit_cpu_v0.cpp:616-618)
       const double rho_sum = Uold[idx + ID * N] + u[ID];
-      u[IU] += g.hgx * rho_sum;
-      u[IV] += g.hgy * rho_sum;
+      double gx, gy, gz;
+      half_dt_gravity(g, idx, gx, gy, gz);
+      u[IU] += gx * rho_sum;
+      u[IV] += gy * rho_sum;
     }
   }
   if (c.i >= gw && c.i <= g.isize - gw && c.j >= gw && c.j <= g.jsize - gw) {

@@ -250,7 +250,11 @@ RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, un
   double u = t[T_U * N] + s * t[(S + 2) * N];
   double v = t[T_V * N] + s * t[(S + 3) * N];
   double w = t[T_W * N] + s * t[(S + 4) * N];
-  if (g.grav_on) { u += g.hgx; v += g.hgy; w += g.hgz; }   // gravity predictor (..._cpu_v3.cpp:277-290)
+  if (g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:277-290)
+    double gx, gy, gz;
+    half_dt_gravity(g, m, gx, gy, gz);
+    u += gx; v += gy; w += gz;
+  }
   // normal field: the advanced face value (own low face, or the +1 neighbour's low face for the high side)
   const int TF = (D == XD) ? T_AL : (D == YD) ? T_BL : T_CL;
   const double bn = (SIDE > 0) ? T[(m + sD) + (size_t)TF * N] : t[TF * N];
@@ -294,7 +298,11 @@ RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, un
   vel[0] = RG_EDGE_SUM(t[T_U * N], 2, 2);
   vel[1] = RG_EDGE_SUM(t[T_V * N], 3, 3);
   vel[2] = RG_EDGE_SUM(t[T_W * N], 4, 4);
-  if (g.grav_on) { vel[0] += g.hgx; vel[1] += g.hgy; vel[2] += g.hgz; }   // gravity predictor (..._cpu_v3.cpp:292-330)
+  if (g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:292-330)
+    double gx, gy, gz;
+    half_dt_gravity(g, m, gx, gy, gz);
+    vel[0] += gx; vel[1] += gy; vel[2] += gz;
+  }
   // the field component along the edge is cell centred; its slope slot inside a direction group:
   //   group X holds (B,C) at 5,6 ; group Y holds (A,C) at 5,6 ; group Z holds (A,B) at 5,6
   const int Te = (EDIR == XD) ? T_A : (EDIR == YD) ? T_B : T_C;
@@ -536,9 +544,11 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
 #undef RG_LOADF
     if (g.grav_on) {  // momentum source before the shear remap of the density (MHDRunGodunov.cpp:3190-3192)
       const double rho_sum = Uold[idx + ID * N] + u[ID];
-      u[IU] += g.hgx * rho_sum;
-      u[IV] += g.hgy * rho_sum;
-      u[IW] += g.hgz * rho_sum;
+      double gx, gy, gz;
+      half_dt_gravity(g, idx, gx, gy, gz);
+      u[IU] += gx * rho_sum;
+      u[IV] += gy * rho_sum;
+      u[IW] += gz * rho_sum;
     }
     if (shear) {  // remapped density flux at the two x borders, then the density floor (:3289-3300)
       const size_t P = (size_t)g.jsize * g.ksize;

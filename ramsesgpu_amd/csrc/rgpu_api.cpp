@@ -31,6 +31,7 @@ struct rgpu_ctx {
   bool own_state;
   double* U[2];
   double *Q, *E, *T, *F, *emf, *shear_save, *shear_remap;
+  double* G;   // per-cell static gravity field (gravityEnabled == 2), 3 components
   unsigned long long* d_red;
   unsigned long long* h_red;
   size_t ncell, scratch_bytes;
@@ -132,7 +133,7 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   // reference's single domain and keeps its ranges
   g->zlo_copy = (p.bc[4] == RGPU_BC_COPY && p.slab_rank > 0) ? 1 : 0;
   g->zhi_copy = (p.bc[5] == RGPU_BC_COPY && p.slab_rank < p.slab_count - 1) ? 1 : 0;
-  g->grav_on = 0; g->hgx = 0.0; g->hgy = 0.0; g->hgz = 0.0;   // per step: step_core_planes
+  g->grav_on = 0; g->hgx = 0.0; g->hgy = 0.0; g->hgz = 0.0; g->G = 0; g->hdt = 0.0;   // per step: step_core_planes
 }
 
 // number of scratch doubles per cell for each array of the active solver family
@@ -172,6 +173,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->own_state = !external;
   c->U[0] = c->U[1] = 0;
   c->Q = c->E = c->T = c->F = c->emf = c->shear_save = c->shear_remap = 0;
+  c->G = 0;
   c->d_red = 0; c->h_red = 0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
@@ -193,6 +195,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (alloc_zero(c, &c->U[0], n) || alloc_zero(c, &c->U[1], n)) return fail(c, RGPU_ENOMEM, "device allocation of the state arrays failed");
   }
   const ScratchPlan sp = plan_for(*p);
+  if (p->gravityEnabled == 2 && alloc_zero(c, &c->G, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the gravity field failed");
   if (alloc_zero(c, &c->Q, c->ncell * sp.q) || alloc_zero(c, &c->E, c->ncell * sp.e) || alloc_zero(c, &c->T, c->ncell * sp.t) ||
       alloc_zero(c, &c->F, c->ncell * sp.f) || alloc_zero(c, &c->emf, c->ncell * sp.emf))
     return fail(c, RGPU_ENOMEM, "device allocation of the scratch arrays failed");
@@ -471,6 +474,9 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
   c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && (c->p.implementationVersion != 0 || c->g.rot))) ? 1 : 0;
+  if (c->g.grav_on && c->p.gravityEnabled == 2) c->g.grav_on = 2;   // per-cell field (rgpu_set_gravity_field)
+  c->g.G = c->G;
+  c->g.hdt = 0.5 * dt;
   c->g.hgx = 0.5 * dt * c->p.gravity_x;
   c->g.hgy = 0.5 * dt * c->p.gravity_y;
   c->g.hgz = 0.5 * dt * c->p.gravity_z;
@@ -611,7 +617,7 @@ int rgpu_create_external(const rgpu_params* p, double* dU, double* dU2, void* hi
 void rgpu_destroy(rgpu_ctx* c) {
   if (!c) return;
   if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
-  rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap);
+  rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G);
   rg_free(c->d_red); rg_host_free(c->h_red);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
   if (c->nchunks > 1) {
@@ -630,6 +636,7 @@ size_t rgpu_device_bytes(const rgpu_params* p) {
   const ScratchPlan sp = plan_for(*p);
   size_t doubles = ncell * (size_t)(2 * p->nbVar + sp.q + sp.e + sp.t + sp.f + sp.emf);
   if (p->shearingBoxEnabled) doubles += 4 * jsize * ksize;
+  if (p->gravityEnabled == 2) doubles += 3 * ncell;
   return doubles * sizeof(double);
 }
 
@@ -642,6 +649,14 @@ int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
   if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");
   if (both && rg_copy_d2d(c->U[1], c->U[0], bytes, c->stream)) return RG_HIPFAIL(c, "upload (copy to U2)");
   if (rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "upload sync");
+  return RGPU_OK;
+}
+
+int rgpu_set_gravity_field(rgpu_ctx* c, const double* hG) {
+  RG_CHECK_CTX(c);
+  if (!hG) return fail(c, RGPU_EINVAL, "set_gravity_field: null pointer");
+  if (c->p.gravityEnabled != 2 || !c->G) return fail(c, RGPU_EINVAL, "set_gravity_field: the context was not created with gravityEnabled = 2");
+  if (rg_copy_h2d(c->G, hG, c->ncell * 3 * sizeof(double), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "set_gravity_field");
   return RGPU_OK;
 }
 

@@ -70,6 +70,9 @@ class SlabRun:
         import numpy as np
         hU = self.L.init_condition(self.ini_path, self.overrides, self.p)
         self.U[0].copy_(torch.from_numpy(np.ascontiguousarray(hU)))
+        G = self.L.init_gravity(self.ini_path, self.overrides, self.p)   # this slab's planes of h_gravity, if the problem has one
+        if G is not None:
+            self.solver.set_gravity_field(G)
         self.make_all_boundaries(0, 0.0, 0.0)
         self.U[1].copy_(self.U[0])
         self.nStep, self.totalTime = 0, 0.0

@@ -86,6 +86,18 @@ class Library:
             raise RgpuError("init_condition: %s" % err.value.decode())
         return U
 
+    def init_gravity(self, ini_path, overrides, params):
+        """static gravity field [3][ksize][jsize][isize] of the problems that define one (params.gravityEnabled == 2),
+        else None"""
+        if int(params.gravityEnabled) != 2:
+            return None
+        G = np.zeros((3,) + tuple(params.shape[1:]), dtype=np.float64)
+        err = C.create_string_buffer(512)
+        rc = self.lib.rgpuh_init_gravity(ini_path.encode(), (overrides or "").encode(), C.byref(params), G.ctypes.data, err, 512)
+        if rc < 0:
+            raise RgpuError("init_gravity: %s" % err.value.decode())
+        return G if rc == 1 else None
+
 
 _default = None
 
@@ -166,6 +178,12 @@ class Solver:
         return d
 
     HISTORY_NAMES = ("mass", "maxwell", "reynolds", "magp", "mean_Bx", "mean_By", "mean_Bz", "divB")
+
+    def set_gravity_field(self, G):
+        """upload h_gravity (gravityEnabled == 2): [3][ksize][jsize][isize] doubles"""
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        assert G.shape == (3,) + tuple(self.p.shape[1:]), G.shape
+        self._chk(self.lib.rgpu_set_gravity_field(self.ctx, G.ctypes.data), "set_gravity_field")
 
     def read_cell(self, parity, i, j, k=0):
         """U(i, j, k, :) of one cell, ghost-inclusive local indices (the probe of history_inertial_wave)"""

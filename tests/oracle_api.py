@@ -22,11 +22,19 @@ class Oracle:
         self.lib.orc_history_mri.argtypes = [P, C.c_void_p, c_double_p]
         self.lib.orc_godunov_unsplit.argtypes = [P, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
         self.lib.orc_run.argtypes = [P, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int), c_double_p, C.c_void_p]
+        self.lib.orc_set_gravity_field.restype = None
+        self.lib.orc_set_gravity_field.argtypes = [C.c_void_p]
+        self._G = None
 
     @staticmethod
     def _arr(U):
         assert U.dtype == np.float64 and U.flags["C_CONTIGUOUS"]
         return U.ctypes.data
+
+    def set_gravity_field(self, G):
+        """h_gravity of the following calls when p.gravityEnabled == 2 ([3][ksize][jsize][isize]); None forgets it"""
+        self._G = None if G is None else np.ascontiguousarray(G, dtype=np.float64)
+        self.lib.orc_set_gravity_field(None if self._G is None else self._G.ctypes.data)
 
     def make_boundaries(self, p, U, idim):
         assert self.lib.orc_make_boundaries(C.byref(p), self._arr(U), idim) == 0

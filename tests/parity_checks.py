@@ -29,6 +29,16 @@ def assert_same(got, ref, what):
     assert nbad == 0, "%s: %d of %d doubles differ (max abs %.3e, rel L2 %.3e)" % (what, nbad, ref.size, np.abs(got - ref).max(), err)
 
 
+def attach_gravity(lib, base, ov, p, sv=None, oracle=None):
+    """per-cell gravity field of the problem (params.gravityEnabled == 2), handed to the solver and / or the oracle"""
+    G = lib.init_gravity(ini(base), ov, p)
+    if sv is not None and G is not None:
+        sv.set_gravity_field(G)
+    if oracle is not None:
+        oracle.set_gravity_field(G)
+    return G
+
+
 # ---- 1. fixtures produced by the reference binary --------------------------------------------------------------
 def check_golden_case(lib, name):
     case = golden_cases()[name]
@@ -38,6 +48,7 @@ def check_golden_case(lib, name):
         U0 = lib.init_condition(ini(case["base"]), case["overrides"], p)
         sv = Solver(p, lib)
         try:
+            attach_gravity(lib, case["base"], case["overrides"], p, sv=sv)
             sv.start(U0, s)
             assert_same(interior(sv.getDataHost(), p), g["step_%d" % s], "%s step %d vs reference" % (name, s))
             if s == max(case["steps"]) and np.isfinite(g["total_time"]):
@@ -129,9 +140,11 @@ def check_single_step_random(lib, oracle, base, ov, seed=3, mach=1.5, t0=2.0):
 def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
     p = lib.params_from_ini(ini(base), ov)
     U0 = lib.init_condition(ini(base), ov, p)
+    attach_gravity(lib, base, ov, p, oracle=oracle)
     ref, dts_ref, t_ref = oracle.run(p, U0, nsteps)
     sv = Solver(p, lib)
     try:
+        attach_gravity(lib, base, ov, p, sv=sv)
         dts = sv.start(U0, nsteps)
         assert np.array_equal(np.array(dts), dts_ref), "%s: dt sequences differ" % base
         assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps))
@@ -172,6 +185,10 @@ ORACLE_RUNS = [
     ("mhd_BrioWu", "mesh.nx=16;mesh.ny=12;BrioWu.direction=1;MHD.magRiemannSolver=hllf;hydro.slope_type=3.0", 5),
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=6;mesh.nz=10;hydro.slope_type=3.0;MHD.magRiemannSolver=hllf;hydro.cIso=0.8", 3),
     ("mhd_BrioWu", "mesh.nx=10;mesh.ny=8;mesh.nz=8;BrioWu.direction=2;MHD.implementationVersion=3;hydro.slope_type=3.0", 4),
+    # per-cell gravity field (Keplerian disk): other solvers, direction-wise update, viscosity, 3D
+    ("Keplerian_disk2d", "mesh.nx=14;mesh.ny=10;hydro.riemannSolver=approx", 5),
+    ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=12;mesh.nz=6;hydro.riemannSolver=hll;hydro.unsplitVersion=2;hydro.nu=0.003", 4),
+    ("Keplerian_disk2d", "mesh.nx=12;mesh.ny=12;gravity.static=no", 3),
     # 2D branch of the rotating-frame step: other solvers / slopes / boundaries, implementationVersion 0 + gravity knobs ignored
     ("orszag-tang", "mesh.nx=16;mesh.ny=20;MHD.omega0=0.4;hydro.slope_type=3.0;MHD.magRiemannSolver=hlla", 5),
     ("mhd_BrioWu", "mesh.nx=20;mesh.ny=12;BrioWu.direction=1;MHD.omega0=0.25;hydro.riemannSolver=llf;MHD.magRiemannSolver=llf;mesh.boundary_ymin=1;mesh.boundary_ymax=1", 5),

@@ -44,6 +44,7 @@ def main():
         oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
         p = lib.params_from_ini(ini, ov)
         U0 = lib.init_condition(ini, ov, p)
+        oracle.set_gravity_field(lib.init_gravity(ini, ov, p))
         ref_full, dts_ref, _ = oracle.run(p, U0, nsteps)
         ref = interior(ref_full, p)
         nbad = int((got != ref).sum())

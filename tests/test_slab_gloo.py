@@ -36,6 +36,7 @@ CASES = [
     ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12;hydro.nu=0.002", 3, 3, 1),                                       # hydro viscosity, three slabs
     ("orszag-tang3d", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.nu=0.005;MHD.eta=0.01", 3, 3, 1),                      # middle slab: internal interfaces on both sides
     ("mhd_BrioWu", "mesh.nx=8;mesh.ny=6;mesh.nz=16;BrioWu.direction=2;MHD.implementationVersion=4;MHD.eta=0.02;mesh.boundary_zmin=2;mesh.boundary_zmax=2", 3, 2, 1),  # open z ends
+    ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=10;mesh.nz=12;hydro.riemannSolver=hll", 3, 2, 1),    # per-cell gravity field, slab by slab
 ]
 
 
