@@ -41,7 +41,8 @@ enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA 
 enum {
   RGPU_BC_UNDEFINED = 0, RGPU_BC_DIRICHLET = 1, RGPU_BC_NEUMANN = 2, RGPU_BC_PERIODIC = 3,
   RGPU_BC_SHEARINGBOX = 4, RGPU_BC_COPY = 5 /* ghost planes are supplied by a neighbour slab */,
-  RGPU_BC_Z_STRATIFIED = 6 /* not implemented: out of scope */
+  RGPU_BC_Z_STRATIFIED = 6 /* z faces of the vertically stratified MRI box (3D MHD, isothermal, Omega0 > 0):
+                            * make_boundary2_z_stratified, make_boundary_base.h:1356-1647 */
 };
 
 /* RiemannSolverType -- constants.h:140-146 */
@@ -94,6 +95,9 @@ typedef struct rgpu_params {
   /* dissipative stage after the Godunov update (HydroParameters.h:327-328): kinematic viscosity [hydro] nu and
    * resistivity [MHD] eta; 0 = off */
   double  nu, eta;
+  int32_t zStratifiedFloor;     /* [MRI] floor (HydroRunBase.cpp:2206): RGPU_BC_Z_STRATIFIED copies the density instead of
+                                 * extrapolating the hydrostatic profile */
+  int32_t pad_;
 } rgpu_params;
 
 typedef struct rgpu_ctx rgpu_ctx;

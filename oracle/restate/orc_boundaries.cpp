@@ -2,6 +2,7 @@
 //   make_boundary2<bct,loc> CPU version      make_boundary_base.h:1040-1332
 //   make_boundaries / make_all_boundaries    HydroRunBase.cpp:2276-2342
 //   make_jet                                 HydroRunBase.cpp:2374-2408
+//   make_boundary2_z_stratified_cpu          make_boundary_base.h:1356-1647 (dispatch HydroRunBase.cpp:2204-2216)
 //   make_boundaries_shear / _all_..._shear   MHDRunGodunov.cpp:3539-3793
 #include "orc_common.h"
 
@@ -43,6 +44,94 @@ void fill_face(const Ctx& c, double* U, int dir, int side, int bct) {
   }
 }
 
+// z faces of the vertically stratified MRI box, ghost width 3, the reference's two loops as written
+void fill_face_z_stratified(const Ctx& c, double* U, int side) {
+  const rgpu_params& p = c.p;
+  const double H = p.cIso / p.Omega0;
+  const double dx = c.dx, dy = c.dy, dz = c.dz, zMin = p.zMin, zMax = p.zMax;
+  const double factor = -dz / 2.0 / H / H;
+  const int imax = c.isize, jmax = c.jsize, kmax = c.ksize;
+  const size_t N = c.ncell;
+  double ratio_nyp1 = 1.0, ratio_nyp2 = 1.0, ratio_nyp3 = 1.0;
+  if (!p.zStratifiedFloor) {
+    if (side == 0) {
+      ratio_nyp1 = std::exp(factor * (-2 * (zMin + 0.5 * dz) + dz));
+      ratio_nyp2 = std::exp(factor * (-2 * (zMin + 0.5 * dz) + 3.0 * dz));
+      ratio_nyp3 = std::exp(factor * (-2 * (zMin + 0.5 * dz) + 5.0 * dz));
+    } else {
+      ratio_nyp1 = std::exp(factor * (2 * (zMax - 0.5 * dz) + dz));
+      ratio_nyp2 = std::exp(factor * (2 * (zMax - 0.5 * dz) + 3.0 * dz));
+      ratio_nyp3 = std::exp(factor * (2 * (zMax - 0.5 * dz) + 5.0 * dz));
+    }
+  }
+#define UU(i, j, k, v) U[c.idx((i), (j), (k)) + N * (v)]
+  if (side == 0) {
+    for (int j = 0; j < jmax; j++)
+      for (int i = 0; i < imax; i++) {
+        const double rho3 = UU(i, j, 3, ID);
+        const double rho2 = UU(i, j, 3, ID) * ratio_nyp1;
+        const double rho1 = UU(i, j, 3, ID) * ratio_nyp1 * ratio_nyp2;
+        const double rho0 = UU(i, j, 3, ID) * ratio_nyp1 * ratio_nyp2 * ratio_nyp3;
+        UU(i, j, 2, ID) = rho2; UU(i, j, 1, ID) = rho1; UU(i, j, 0, ID) = rho0;
+        for (int v = IU; v <= IV; ++v) {   // tangential velocities kept
+          UU(i, j, 0, v) = UU(i, j, 3, v) / rho3 * rho0;
+          UU(i, j, 1, v) = UU(i, j, 3, v) / rho3 * rho1;
+          UU(i, j, 2, v) = UU(i, j, 3, v) / rho3 * rho2;
+        }
+        const double w = std::fmin(UU(i, j, 3, IW), 0.0);
+        UU(i, j, 0, IW) = w; UU(i, j, 1, IW) = w; UU(i, j, 2, IW) = w;
+        for (int k = 0; k < 3; ++k) { UU(i, j, k, IA) = 0.0; UU(i, j, k, IB) = 0.0; }
+      }
+    for (int j = 0; j < jmax - 1; j++)
+      for (int i = 0; i < imax - 1; i++) {
+        double dbxdx = (UU(i + 1, j, 2, IA) - UU(i, j, 2, IA)) / dx;
+        double dbydy = (UU(i, j + 1, 2, IB) - UU(i, j, 2, IB)) / dy;
+        const double bz = UU(i, j, 3, IC);
+        const double dbz2 = dz * (dbxdx + dbydy);
+        UU(i, j, 2, IC) = bz + dbz2;
+        dbxdx = (UU(i + 1, j, 1, IA) - UU(i, j, 1, IA)) / dx;
+        dbydy = (UU(i, j + 1, 1, IB) - UU(i, j, 1, IB)) / dy;
+        const double dbz1 = dz * (dbxdx + dbydy);
+        UU(i, j, 1, IC) = bz + dbz2 + dbz1;
+        dbxdx = (UU(i + 1, j, 0, IA) - UU(i, j, 0, IA)) / dx;
+        dbydy = (UU(i, j + 1, 0, IB) - UU(i, j, 0, IB)) / dy;
+        const double dbz0 = dz * (dbxdx + dbydy);
+        UU(i, j, 0, IC) = bz + dbz2 + dbz1 + dbz0;
+      }
+  } else {
+    for (int j = 0; j < jmax; j++)
+      for (int i = 0; i < imax; i++) {
+        const double rho4 = UU(i, j, kmax - 4, ID);
+        const double rho3 = UU(i, j, kmax - 4, ID) * ratio_nyp1;
+        const double rho2 = UU(i, j, kmax - 4, ID) * ratio_nyp1 * ratio_nyp2;
+        const double rho1 = UU(i, j, kmax - 4, ID) * ratio_nyp1 * ratio_nyp2 * ratio_nyp3;
+        UU(i, j, kmax - 3, ID) = rho3; UU(i, j, kmax - 2, ID) = rho2; UU(i, j, kmax - 1, ID) = rho1;
+        for (int v = IU; v <= IV; ++v) {
+          UU(i, j, kmax - 3, v) = UU(i, j, kmax - 4, v) / rho4 * rho3;
+          UU(i, j, kmax - 2, v) = UU(i, j, kmax - 4, v) / rho4 * rho2;
+          UU(i, j, kmax - 1, v) = UU(i, j, kmax - 4, v) / rho4 * rho1;
+        }
+        const double w = std::fmax(UU(i, j, kmax - 4, IW), 0.0);
+        UU(i, j, kmax - 3, IW) = w; UU(i, j, kmax - 2, IW) = w; UU(i, j, kmax - 1, IW) = w;
+        for (int k = kmax - 3; k < kmax; ++k) { UU(i, j, k, IA) = 0.0; UU(i, j, k, IB) = 0.0; }
+      }
+    for (int j = 0; j < jmax - 1; j++)
+      for (int i = 0; i < imax - 1; i++) {
+        // (the reference differences By with itself here: U[offset] - U[offset])
+        double dbxdx = (UU(i + 1, j, kmax - 3, IA) - UU(i, j, kmax - 3, IA)) / dx;
+        double dbydy = (UU(i, j, kmax - 3, IB) - UU(i, j, kmax - 3, IB)) / dy;
+        const double bz = UU(i, j, kmax - 3, IC);
+        const double dbz1 = dz * (dbxdx + dbydy);
+        UU(i, j, kmax - 2, IC) = bz - dbz1;
+        dbxdx = (UU(i + 1, j, kmax - 2, IA) - UU(i, j, kmax - 2, IA)) / dx;
+        dbydy = (UU(i, j, kmax - 2, IB) - UU(i, j, kmax - 2, IB)) / dy;
+        const double dbz2 = dz * (dbxdx + dbydy);
+        UU(i, j, kmax - 1, IC) = bz - dbz1 - dbz2;
+      }
+  }
+#undef UU
+}
+
 void make_jet(const Ctx& c, double* U) {
   const rgpu_params& p = c.p;
   const int gw = c.gw;
@@ -74,6 +163,8 @@ void make_boundaries(const Ctx& c, double* U, int idim) {
   if (!c.three_d && dir == 2) return;
   fill_face(c, U, dir, 0, c.p.bc[2 * dir]);
   fill_face(c, U, dir, 1, c.p.bc[2 * dir + 1]);
+  if (dir == 2 && c.p.bc[4] == RGPU_BC_Z_STRATIFIED) fill_face_z_stratified(c, U, 0);
+  if (dir == 2 && c.p.bc[5] == RGPU_BC_Z_STRATIFIED) fill_face_z_stratified(c, U, 1);
   // the jet is re-imposed after the Y fill in 2D and after the Z fill in 3D
   if (c.p.enableJet && ((!c.three_d && dir == 1) || (c.three_d && dir == 2))) make_jet(c, U);
 }

@@ -40,6 +40,7 @@ class RgpuParams(C.Structure):
         ("gravityEnabled", C.c_int32),
         ("gravity_x", C.c_double), ("gravity_y", C.c_double), ("gravity_z", C.c_double),
         ("nu", C.c_double), ("eta", C.c_double),
+        ("zStratifiedFloor", C.c_int32), ("pad_", C.c_int32),
     ]
 
     @property

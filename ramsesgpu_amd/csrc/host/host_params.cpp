@@ -83,13 +83,14 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
     // initial conditions fill with the [gravity] static_field vector; for every other problem it stays at its
     // zero-initialised allocation, i.e. "static=yes" switches the code path on with g = 0 (verified against the
     // reference binary: tests/golden/*_gravity).
-    if (p->gravityEnabled && (prob == "MRI" || prob == "Mri" || prob == "mri"))
-      throw std::runtime_error("MRI with gravity (vertically stratified box, MHDRunBase.cpp:3163-3211) is outside the implemented scope");
+    // MRI with gravity = the vertically stratified box: init_mhd_mri_grav_field fills h_gravity (MHDRunBase.cpp:3163-3211)
+    if (p->gravityEnabled && p->mhdEnabled && (prob == "MRI" || prob == "Mri" || prob == "mri")) p->gravityEnabled = 2;
     const bool filled = (prob == "Rayleigh-Taylor" || prob == "falling-bubble");
     p->gravity_x = filled ? cfg.get_float("gravity", "static_field_x", 0.0f) : 0.0f;
     p->gravity_y = filled ? cfg.get_float("gravity", "static_field_y", 0.0f) : 0.0f;
     p->gravity_z = filled ? cfg.get_float("gravity", "static_field_z", 0.0f) : 0.0f;
   }
+  p->zStratifiedFloor = cfg.get_bool("MRI", "floor", false) ? 1 : 0;   // read by the z-stratified ghost fill (HydroRunBase.cpp:2206)
   p->nu = cfg.get_float("hydro", "nu", 0.0f);     // HydroParameters.h:327-328
   p->eta = cfg.get_float("MHD", "eta", 0.0f);
   if (lower(cfg.get_string("hydro", "scheme", "muscl")) != "muscl")

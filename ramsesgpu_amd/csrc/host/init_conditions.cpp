@@ -272,6 +272,23 @@ void init_mri(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
         else
           g.at(i, j, k, RGPU_IC) = 0.0;
       }
+  if (p.gravityEnabled) {
+    // vertically stratified box (MHDRunBase.cpp:2763-2796): isothermal hydrostatic density with a floor, purely
+    // azimuthal field within one scale height of the midplane; the momenta keep their d0-based perturbation
+    const double zFloor = cfg.get_float("MRI", "zFloor", 5.0f);
+    const double H = p.cIso / p.Omega0;
+    for (int k = 0; k < g.ksize; ++k) {
+      const double zPos = p.zMin + p.dz / 2 + (k + g.k_shift - g.gw) * p.dz;
+      for (int j = 0; j < g.jsize; ++j)
+        for (int i = 0; i < g.isize; ++i) {
+          g.at(i, j, k, RGPU_ID) = d0 * std::fmax(std::exp(-(zPos * zPos) / 2.0 / (H * H)), std::exp(-zFloor * zFloor / 2.0));
+          g.at(i, j, k, RGPU_IA) = 0.0;
+          g.at(i, j, k, RGPU_IB) = 0.0;
+          g.at(i, j, k, RGPU_IC) = 0.0;
+          if (zPos < H && zPos > -H) g.at(i, j, k, RGPU_IB) = B0;
+        }
+    }
+  }
 }
 
 // ---- hydro: Sod tube along x (HydroRunBase.cpp:5358-5438; the ghost-corner copies of the gw==2 case are dropped:
@@ -903,6 +920,28 @@ bool init_gravity_field(const IniConfig& cfg, const rgpu_params& p, double* hG) 
           }
         }
       }
+    return true;
+  }
+  if (p.mhdEnabled && (problem == "MRI" || problem == "Mri" || problem == "mri")) {
+    // init_mhd_mri_grav_field (MHDRunBase.cpp:3163-3211): g_z = -(Phi(z+dz) - Phi(z-dz)) / (2 dz), Phi = Omega0^2 z^2 / 2,
+    // optionally flattened above zFloor; x and y components zero
+    const bool smoothGravity = cfg.get_bool("MRI", "smoothGravity", false);
+    const double zFloor = cfg.get_float("MRI", "zFloor", 5.0f);
+    for (int k = 0; k < g.ksize; ++k) {
+      const double zPos = p.zMin + p.dz / 2 + (k + g.k_shift - g.gw) * p.dz;
+      double phi0 = 0.5 * p.Omega0 * p.Omega0 * (zPos - p.dz) * (zPos - p.dz);
+      double phi1 = 0.5 * p.Omega0 * p.Omega0 * (zPos + p.dz) * (zPos + p.dz);
+      if (smoothGravity) {
+        if ((zPos - p.dz) > zFloor) phi0 = 0.5 * p.Omega0 * p.Omega0 * zFloor * zFloor;
+        if ((zPos + p.dz) > zFloor) phi1 = 0.5 * p.Omega0 * p.Omega0 * zFloor * zFloor;
+      }
+      for (int j = 0; j < g.jsize; ++j)
+        for (int i = 0; i < g.isize; ++i) {
+          g.at(i, j, k, 0) = -0.5 * (0.0 - 0.0) / p.dx;
+          g.at(i, j, k, 1) = -0.5 * (0.0 - 0.0) / p.dy;
+          g.at(i, j, k, 2) = -0.5 * (phi1 - phi0) / p.dz;
+        }
+    }
     return true;
   }
   return false;

@@ -51,6 +51,57 @@ RG_DEVFN void bc_face_cell(const DevParams& g, double* __restrict__ U, int dir, 
   }
 }
 
+// BC_Z_STRATIFIED (make_boundary2_z_stratified_cpu, make_boundary_base.h:1356-1647), ghost width 3: one thread per
+// (i,j) column of one z face.  Density extrapolated along the isothermal hydrostatic profile (ratios r1..r3, computed on
+// the host with the C library's exp()), tangential velocities kept, normal momentum outflow-only, tangential field zero,
+// the energy left alone.  The reference's second loop derives the ghost Bz from div B = 0 with the tangential field it
+// has just set to zero on every column: the three corrections are (0 - 0)/dx terms, written out here as such.
+struct ZStrat { double r1, r2, r3; };
+
+RG_DEVFN void zstrat_column(const DevParams& g, const ZStrat zs, double* __restrict__ U, int side, unsigned ij) {
+  const size_t N = g.ncell;
+  const size_t sk = g.sk;
+  const int i = (int)(ij % (unsigned)g.isize), j = (int)(ij / (unsigned)g.isize);
+  // planes: src = the last interior plane, gh[0..2] = ghost planes going outwards
+  const int src = (side == 0) ? 3 : g.ksize - 4;
+  const int step = (side == 0) ? -1 : +1;
+  const size_t o_src = (size_t)ij + sk * (size_t)src;
+  size_t o_gh[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) o_gh[a] = (size_t)ij + sk * (size_t)(src + step * (a + 1));
+  const double rho_s = U[o_src + ID * N];
+  double rho[3];
+  rho[0] = rho_s * zs.r1;
+  rho[1] = rho_s * zs.r1 * zs.r2;
+  rho[2] = rho_s * zs.r1 * zs.r2 * zs.r3;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) U[o_gh[a] + ID * N] = rho[a];
+  const double mu = U[o_src + IU * N], mv = U[o_src + IV * N], mw = U[o_src + IW * N];
+  const double w = (side == 0) ? fmin(mw, 0.0) : fmax(mw, 0.0);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    U[o_gh[a] + IU * N] = mu / rho_s * rho[a];
+    U[o_gh[a] + IV * N] = mv / rho_s * rho[a];
+    U[o_gh[a] + IW * N] = w;
+    U[o_gh[a] + IA * N] = 0.0;
+    U[o_gh[a] + IB * N] = 0.0;
+  }
+  if (i < g.isize - 1 && j < g.jsize - 1) {
+    const double zero = 0.0;
+    const double dbz = g.dz * ((zero - zero) / g.dx + (zero - zero) / g.dy);
+    if (side == 0) {   // Bz lives on the low face: ghost planes 2,1,0 from the interior face 3
+      const double bz = U[o_src + IC * N];
+      U[o_gh[0] + IC * N] = bz + dbz;
+      U[o_gh[1] + IC * N] = bz + dbz + dbz;
+      U[o_gh[2] + IC * N] = bz + dbz + dbz + dbz;
+    } else {           // the face ksize-3 is evolved by the CT update; two faces beyond it
+      const double bz = U[o_gh[0] + IC * N];
+      U[o_gh[1] + IC * N] = bz - dbz;
+      U[o_gh[2] + IC * N] = bz - dbz - dbz;
+    }
+  }
+}
+
 struct JetParams { int ijet, offsetJet; double djet, ejet, mjet; };  // ejet = pjet/(gamma0-1)+0.5*djet*ujet^2, mjet = djet*ujet
 
 // one thread per injected ghost cell: 2D idx over ijet*gw (low-y rows), 3D over ijet*ijet*gw (low-z planes)

@@ -107,6 +107,10 @@ struct K_mhd_flux3d {
   DevParams g; const double* T; double* F; double* emf;
   RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK>(g, T, F, emf, idx); }
 };
+struct K_bc_zstrat {
+  DevParams g; ZStrat zs; double* U; int side;
+  RG_DEVFN void operator()(unsigned ij) const { zstrat_column(g, zs, U, side, ij); }
+};
 struct K_shear_save_emf {
   DevParams g; const double* emf; double* save;
   RG_DEVFN void operator()(unsigned idx) const { shear_save_emf_cell(g, emf, save, idx); }

@@ -99,8 +99,9 @@ int validate(const rgpu_params* p, std::string* why) {
   for (int f = 0; f < 6; ++f) {
     const int b = p->bc[f];
     const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
-                    (b == RGPU_BC_SHEARINGBOX && f < 2);
-    if (!ok && (three_d || f < 4)) { *why = "unsupported boundary condition type"; return RGPU_EUNSUPPORTED; }
+                    (b == RGPU_BC_SHEARINGBOX && f < 2) ||
+                    (b == RGPU_BC_Z_STRATIFIED && f >= 4 && three_d && p->mhdEnabled && p->ghostWidth == 3 && p->cIso > 0 && p->Omega0 > 0);
+    if (!ok && (three_d || f < 4)) { *why = "unsupported boundary condition type (z-stratified: z faces of an isothermal rotating 3D MHD box only)"; return RGPU_EUNSUPPORTED; }
   }
   const double cells = (double)(p->nx + 2 * p->ghostWidth) * (p->ny + 2 * p->ghostWidth) * (three_d ? p->nz + 2 * p->ghostWidth : 1);
   if (cells >= 4294967295.0) { *why = "more than 2^32 cells per device"; return RGPU_EUNSUPPORTED; }
@@ -232,6 +233,26 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
 // x and y faces are indexed with k slowest, so planes [k_lo,k_hi) of a face are one contiguous index range
 int launch_face(rgpu_ctx* c, double* U, int dir, int side, int k_lo, int k_hi) {
   const int bct = c->p.bc[2 * dir + side];
+  if (bct == RGPU_BC_Z_STRATIFIED && dir == 2) {
+    // hydrostatic density ratios of the three ghost planes (make_boundary_base.h:1366-1397), host exp() like the reference
+    const rgpu_params& p = c->p;
+    const double H = p.cIso / p.Omega0;
+    const double factor = -p.dz / 2.0 / H / H;
+    ZStrat zs = {1.0, 1.0, 1.0};
+    if (!p.zStratifiedFloor) {
+      if (side == 0) {
+        zs.r1 = std::exp(factor * (-2 * (p.zMin + 0.5 * p.dz) + p.dz));
+        zs.r2 = std::exp(factor * (-2 * (p.zMin + 0.5 * p.dz) + 3.0 * p.dz));
+        zs.r3 = std::exp(factor * (-2 * (p.zMin + 0.5 * p.dz) + 5.0 * p.dz));
+      } else {
+        zs.r1 = std::exp(factor * (2 * (p.zMax - 0.5 * p.dz) + p.dz));
+        zs.r2 = std::exp(factor * (2 * (p.zMax - 0.5 * p.dz) + 3.0 * p.dz));
+        zs.r3 = std::exp(factor * (2 * (p.zMax - 0.5 * p.dz) + 5.0 * p.dz));
+      }
+    }
+    K_bc_zstrat k = {c->g, zs, U, side};
+    return rg_launch<kBlock>(c->stream, (unsigned)c->g.isize * c->g.jsize, k);
+  }
   if (bct != RGPU_BC_DIRICHLET && bct != RGPU_BC_NEUMANN && bct != RGPU_BC_PERIODIC) return 0;  // shear / copy: untouched
   const DevParams& g = c->g;
   K_bc_face k = {g, U, dir, side, bct};

@@ -125,6 +125,7 @@ def check_single_step_random(lib, oracle, base, ov, seed=3, mach=1.5, t0=2.0):
     dt = 0.3 * oracle.compute_dt(p, U)
     sv = Solver(p, lib)
     try:
+        attach_gravity(lib, base, ov, p, sv=sv, oracle=oracle)
         sv.upload(U, both=True)
         sv.godunov_unsplit(0, dt, t0)
         got = sv.getDataHost(1)
@@ -189,6 +190,9 @@ ORACLE_RUNS = [
     ("Keplerian_disk2d", "mesh.nx=14;mesh.ny=10;hydro.riemannSolver=approx", 5),
     ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=12;mesh.nz=6;hydro.riemannSolver=hll;hydro.unsplitVersion=2;hydro.nu=0.003", 4),
     ("Keplerian_disk2d", "mesh.nx=12;mesh.ny=12;gravity.static=no", 3),
+    # stratified MRI box: other solvers, unsmoothed gravity, floor
+    ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=16;hydro.slope_type=2.0;MRI.amp=0.4;MHD.magRiemannSolver=hllf;hydro.riemannSolver=hll", 4),
+    ("mhd_mri_3d_stratified", "mesh.nx=8;mesh.ny=6;mesh.nz=12;hydro.slope_type=1.0;MRI.amp=0.4;MRI.smoothGravity=no;MRI.floor=yes;mesh.zmin=-1.5;mesh.zmax=1.5", 4),
     # 2D branch of the rotating-frame step: other solvers / slopes / boundaries, implementationVersion 0 + gravity knobs ignored
     ("orszag-tang", "mesh.nx=16;mesh.ny=20;MHD.omega0=0.4;hydro.slope_type=3.0;MHD.magRiemannSolver=hlla", 5),
     ("mhd_BrioWu", "mesh.nx=20;mesh.ny=12;BrioWu.direction=1;MHD.omega0=0.25;hydro.riemannSolver=llf;MHD.magRiemannSolver=llf;mesh.boundary_ymin=1;mesh.boundary_ymax=1", 5),
@@ -203,6 +207,7 @@ RANDOM_STEPS = [
     ("orszag-tang3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6", 1.5),
     ("orszag-tang3d", "mesh.nx=6;mesh.ny=10;mesh.nz=8;hydro.riemannSolver=llf", 3.0),
     ("mhd_mri_3d", "mesh.nx=8;mesh.ny=10;mesh.nz=6;hydro.cIso=0.8;MHD.omega0=0.3", 1.0),
+    ("mhd_mri_3d_stratified", "mesh.nx=8;mesh.ny=10;mesh.nz=8;hydro.slope_type=2.0;hydro.cIso=0.8;MHD.omega0=0.3", 1.0),
     ("mhd_mri_3d", "mesh.nx=8;mesh.ny=10;mesh.nz=6;hydro.cIso=0.8;MHD.omega0=0.3;mesh.boundary_xmin=3;mesh.boundary_xmax=3", 1.0),
     ("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6;hydro.riemannSolver=hllc", 3.0),
     ("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=6", 3.0),

@@ -37,6 +37,8 @@ CASES = [
     ("orszag-tang3d", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.nu=0.005;MHD.eta=0.01", 3, 3, 1),                      # middle slab: internal interfaces on both sides
     ("mhd_BrioWu", "mesh.nx=8;mesh.ny=6;mesh.nz=16;BrioWu.direction=2;MHD.implementationVersion=4;MHD.eta=0.02;mesh.boundary_zmin=2;mesh.boundary_zmax=2", 3, 2, 1),  # open z ends
     ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=10;mesh.nz=12;hydro.riemannSolver=hll", 3, 2, 1),    # per-cell gravity field, slab by slab
+    ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 2, 1),       # stratified box: g_z(z) planes per slab, z-stratified end faces
+    ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 3, 0),       # ... three slabs, serial schedule
 ]
 
 
