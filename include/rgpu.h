@@ -97,7 +97,10 @@ typedef struct rgpu_params {
   double  nu, eta;
   int32_t zStratifiedFloor;     /* [MRI] floor (HydroRunBase.cpp:2206): RGPU_BC_Z_STRATIFIED copies the density instead of
                                  * extrapolating the hydrostatic profile */
-  int32_t pad_;
+  int32_t randomForcingEnabled; /* problem "turbulence" (HydroRunBase.cpp:213-227): the static solenoidal driving field of
+                                 * rgpu_set_forcing_field is added to the momenta at the end of every step, scaled so that
+                                 * the kinetic energy input rate is randomForcingEdot (3D, no rotating frame) */
+  double  randomForcingEdot;    /* [turbulence] edot, or the Mac Low (1999) estimate when negative (HydroRunBase.cpp:7175-7194) */
 } rgpu_params;
 
 typedef struct rgpu_ctx rgpu_ctx;
@@ -134,6 +137,18 @@ int rgpu_download(rgpu_ctx* c, double* hU, int parity);
  * conditions of Keplerian-disk, HydroRunBase.cpp:6489-6500, and of the stratified MRI box, MHDRunBase.cpp:3163-3211).
  * Until it is called the field is zero, like the reference's freshly allocated array. */
 int rgpu_set_gravity_field(rgpu_ctx* c, const double* hG);
+/* Driving of the "turbulence" problem (randomForcingEnabled): hF[3][ksize][jsize][isize] = the reference's
+ * h_randomForcing / d_randomForcing (turbulenceInit.cpp, copied to the device at HydroRunBase.cpp:7206-7209).
+ * rgpu_godunov_unsplit applies it after the dissipative stage like the reference (HydroRunGodunov.cpp:2930-2938,
+ * mhd_godunov_unsplit_cpu_v3.cpp:696-704).  A z-slab driver does the same in pieces: rgpu_forcing_sums returns
+ * out[2] = { sum rho v.f , sum rho f.f } over the interior of this domain (compute_random_forcing_normalization,
+ * HydroRunBase.cpp:1201-1312; the other seven sums of the reference are debug output), the caller adds the slabs'
+ * values, computes norm = (sqrt(s0^2 + s1 dt edot 2 nbCells) - s0) / s1 and calls rgpu_add_forcing
+ * (add_random_forcing, HydroRunBase.cpp:1397-1428).  The sums are accumulated in a fixed order that is not the
+ * reference's loop order: results agree with the reference to round-off, not bit for bit. */
+int rgpu_set_forcing_field(rgpu_ctx* c, const double* hF);
+int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out);
+int rgpu_add_forcing(rgpu_ctx* c, int parity, double norm);
 /* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */
 double* rgpu_device_state(rgpu_ctx* c, int parity);
 
@@ -265,6 +280,11 @@ int rgpuh_init_condition(const char* ini_path, const char* overrides, const rgpu
  * problem's init routine writes into h_gravity: Keplerian-disk (HydroRunBase.cpp:6489-6500, 6575-6597).  Returns 1 when the problem defines a field (params_from_ini then says gravityEnabled = 2), 0 when it does not,
  * a negative RGPU_E* on error. */
 int rgpuh_init_gravity(const char* ini_path, const char* overrides, const rgpu_params* p, double* hG,
+                       char* err, int err_len);
+
+/* Same for the static driving field of the "turbulence" problem (turbulenceInit.cpp; params_from_ini then says
+ * randomForcingEnabled = 1): hF = 3 * cells doubles.  Returns 1 / 0 / negative like rgpuh_init_gravity. */
+int rgpuh_init_forcing(const char* ini_path, const char* overrides, const rgpu_params* p, double* hF,
                        char* err, int err_len);
 
 /* Run [run] nstepmax / tend like MHDRunGodunov::start / HydroRunGodunov::start on one GPU; writes .vti outputs

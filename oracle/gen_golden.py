@@ -83,6 +83,10 @@ CASES = {
     # (slope_type overridden: with the shipped 3.0 the reference's rotating step uses slopes it never sets)
     "mri_strat_8x16x32": ("mhd_mri_3d_stratified", "mesh.nx=8;mesh.ny=16;mesh.nz=32;hydro.slope_type=2.0;output.ghostIncluded=no;output.outputVtkAscii=no;run.nstepmax=12;run.noutput=6", [0, 6, 12]),
     "mri_strat_6x8x24_floor": ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=1.0;MRI.floor=yes;MRI.smoothGravity=no;MRI.amp=0.3;MRI.zFloor=2.5;hydro.nu=1e-5;MHD.eta=2e-5;output.ghostIncluded=no;output.outputVtkAscii=no;run.nstepmax=8;run.noutput=1000", [8]),
+    # --- driven turbulence: static driving field + normalisation sums (sequential in the reference: the device agrees to round-off) ---
+    "turb_hydro_16": ("turbulence_hydro", "mesh.nx=16;mesh.ny=16;mesh.nz=16;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=10;run.noutput=1000", [0, 10]),
+    "turb_hydro_12x12x18_hllc": ("turbulence_hydro", "mesh.nx=12;mesh.ny=12;mesh.nz=18;hydro.riemannSolver=hllc;hydro.unsplitVersion=2;turbulence.edot=-1.0;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [6]),
+    "turb_mhd_12": ("turbulence_mhd", "mesh.nx=12;mesh.ny=12;mesh.nz=12;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [0, 6]),
     "rotor_32_ic": ("mhd_rotor", "mesh.nx=32;mesh.ny=32;run.nstepmax=0;run.noutput=100", [0]),   # IC only: with implementationVersion=1 the reference itself turns this problem into NaN within a few steps
     "fieldloop2d_32x20": ("mhd_fieldloop2d", "mesh.nx=32;mesh.ny=20;run.nstepmax=10;run.noutput=100", [0, 10]),
     "fieldloop3d_16x8x8": ("mhd_fieldloop3d", "mesh.nx=16;mesh.ny=8;mesh.nz=8;run.nstepmax=5;run.noutput=100", [0, 5]),

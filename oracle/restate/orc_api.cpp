@@ -97,6 +97,7 @@ static int check_scope(const rgpu_params* p) {
   // slope_type 3 (positivity preserving) exists in the 2D MHD and the plain 3D MHD steps only; the hydro steps and
   // the rotating 3D step call slope routines that leave dq unset for it (slope.h:97-147,324-427; slope_mhd.h:436-502)
   if (p->slope_type == 3 && (!p->mhdEnabled || (p->Omega0 > 0 && p->nz_global != 1))) return RGPU_EUNSUPPORTED;
+  if (p->randomForcingEnabled && (p->nz_global == 1 || (p->mhdEnabled && p->Omega0 > 0))) return RGPU_EUNSUPPORTED;
   if (p->mhdEnabled) {
     const bool three_d = p->nz_global != 1;
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLA && p->magRiemannSolver != RGPU_MAG_HLLF &&
@@ -113,6 +114,8 @@ static int check_scope(const rgpu_params* p) {
 // h_gravity of the runs with gravityEnabled == 2: G[3][ksize][jsize][isize], caller-owned, used by every later call
 // (0 = forget it)
 void orc_set_gravity_field(const double* G) { Ctx::gravity_field() = G; }
+// h_randomForcing of the "turbulence" problem, same convention
+void orc_set_forcing_field(const double* F) { Ctx::forcing_field() = F; }
 
 // godunov_unsplit(nStep, dt): Uold -> Unew (both ghost-inclusive, caller-owned)
 int orc_godunov_unsplit(const rgpu_params* p, double* Uold, double* Unew, double dt, double totalTime) {

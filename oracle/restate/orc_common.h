@@ -47,7 +47,13 @@ struct Ctx {
     return e == 0 ? p.gravity_x : e == 1 ? p.gravity_y : p.gravity_z;
   }
   static const double*& gravity_field() { static const double* g = 0; return g; }
+  // h_randomForcing of the "turbulence" problem (orc_set_forcing_field)
+  const double* Frc = forcing_field();
+  static const double*& forcing_field() { static const double* f = 0; return f; }
 };
+
+// random forcing at the end of a 3D step (HydroRunBase.cpp:1201-1312, 1397-1428)
+void random_forcing(const Ctx& c, double* U, double dt);
 
 // A component-major field with the reference's HostArray index map (Arrays.h:95-98).
 struct Field {

@@ -209,4 +209,43 @@ void dissipative_stage(const Ctx& c, double* U, double dt, double totalTime) {
   }
 }
 
+// compute_random_forcing_normalization + add_random_forcing, the reference's sequential loops (k, j, i); of the nine
+// sums of the reference only the two that enter the normalisation are kept (the others are debug output)
+void random_forcing(const Ctx& c, double* U, double dt) {
+  const rgpu_params& p = c.p;
+  if (!p.randomForcingEnabled || !c.three_d || !c.Frc) return;
+  const int gw = c.gw;
+  const size_t N = c.ncell;
+  const double* F = c.Frc;
+  double r0 = 0.0, r1 = 0.0;
+  const long long nbCells = (long long)p.nx * p.ny * p.nz;
+  for (int k = gw; k < c.ksize - gw; k++)
+    for (int j = gw; j < c.jsize - gw; j++)
+      for (int i = gw; i < c.isize - gw; i++) {
+        const size_t o = c.idx(i, j, k);
+        const double rho = U[o + ID * N];
+        const double u = U[o + IU * N] / rho, v = U[o + IV * N] / rho, w = U[o + IW * N] / rho;
+        const double uu = F[o], vv = F[o + N], ww = F[o + 2 * N];
+        r0 += rho * (u * uu + v * vv + w * ww);
+        r1 += rho * uu * uu;
+        r1 += rho * vv * vv;
+        r1 += rho * ww * ww;
+      }
+  double norm;
+  if (p.randomForcingEdot == 0) norm = 0;
+  else norm = (std::sqrt(r0 * r0 + r1 * dt * p.randomForcingEdot * 2 * nbCells) - r0) / r1;
+  for (int k = gw; k < c.ksize - gw; k++)
+    for (int j = gw; j < c.jsize - gw; j++)
+      for (int i = gw; i < c.isize - gw; i++) {
+        const size_t o = c.idx(i, j, k);
+        const double rho = U[o + ID * N];
+        U[o + IP * N] += U[o + IU * N] / rho * F[o] * norm + 0.5 * ((F[o] * norm) * (F[o] * norm));
+        U[o + IP * N] += U[o + IV * N] / rho * F[o + N] * norm + 0.5 * ((F[o + N] * norm) * (F[o + N] * norm));
+        U[o + IP * N] += U[o + IW * N] / rho * F[o + 2 * N] * norm + 0.5 * ((F[o + 2 * N] * norm) * (F[o + 2 * N] * norm));
+        U[o + IU * N] += rho * F[o] * norm;
+        U[o + IV * N] += rho * F[o + N] * norm;
+        U[o + IW * N] += rho * F[o + 2 * N] * norm;
+      }
+}
+
 }  // namespace orc

@@ -40,7 +40,7 @@ class RgpuParams(C.Structure):
         ("gravityEnabled", C.c_int32),
         ("gravity_x", C.c_double), ("gravity_y", C.c_double), ("gravity_z", C.c_double),
         ("nu", C.c_double), ("eta", C.c_double),
-        ("zStratifiedFloor", C.c_int32), ("pad_", C.c_int32),
+        ("zStratifiedFloor", C.c_int32), ("randomForcingEnabled", C.c_int32), ("randomForcingEdot", C.c_double),
     ]
 
     @property
@@ -74,6 +74,8 @@ def declare_host_api(lib):
                                        C.c_char_p, C.c_int]
     lib.rgpuh_init_condition.restype = C.c_int
     lib.rgpuh_init_condition.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
+    lib.rgpuh_init_forcing.restype = C.c_int
+    lib.rgpuh_init_forcing.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
     lib.rgpuh_init_gravity.restype = C.c_int
     lib.rgpuh_init_gravity.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(RgpuParams), C.c_void_p, C.c_char_p, C.c_int]
     return lib
@@ -111,6 +113,12 @@ def declare_device_api(lib):
     lib.rgpu_history_columns.argtypes = [ctx, C.c_int, c_double_p]
     lib.rgpu_history_reynolds.restype = C.c_int
     lib.rgpu_history_reynolds.argtypes = [ctx, C.c_int, c_double_p, c_double_p, C.c_double, c_double_p]
+    lib.rgpu_set_forcing_field.restype = C.c_int
+    lib.rgpu_set_forcing_field.argtypes = [ctx, C.c_void_p]
+    lib.rgpu_forcing_sums.restype = C.c_int
+    lib.rgpu_forcing_sums.argtypes = [ctx, C.c_int, c_double_p]
+    lib.rgpu_add_forcing.restype = C.c_int
+    lib.rgpu_add_forcing.argtypes = [ctx, C.c_int, C.c_double]
     lib.rgpu_set_gravity_field.restype = C.c_int
     lib.rgpu_set_gravity_field.argtypes = [ctx, C.c_void_p]
     lib.rgpu_history_mri.restype = C.c_int
@@ -158,5 +166,5 @@ DECLARED_SYMBOLS = [
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
-    "rgpu_backend_name", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_run",
+    "rgpu_backend_name", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
 ]

@@ -99,4 +99,17 @@ int rgpuh_init_gravity(const char* ini_path, const char* overrides, const rgpu_p
   }
 }
 
+int rgpuh_init_forcing(const char* ini_path, const char* overrides, const rgpu_params* p, double* hF, char* err, int err_len) {
+  if (!p || !hF) return RGPU_EINVAL;
+  rgpu_host::IniConfig cfg;
+  const int rc = load(ini_path, overrides, &cfg, err, err_len);
+  if (rc) return rc;
+  try {
+    return rgpu_host::init_forcing_field(cfg, *p, hF) ? 1 : 0;
+  } catch (const std::exception& e) {
+    set_err(err, err_len, e.what());
+    return RGPU_EUNSUPPORTED;
+  }
+}
+
 }  // extern "C"

@@ -90,6 +90,23 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
     p->gravity_y = filled ? cfg.get_float("gravity", "static_field_y", 0.0f) : 0.0f;
     p->gravity_z = filled ? cfg.get_float("gravity", "static_field_z", 0.0f) : 0.0f;
   }
+  // problem "turbulence": static driving field + energy input rate (HydroRunBase.cpp:213-227, 7175-7194)
+  p->randomForcingEnabled = 0;
+  p->randomForcingEdot = -1.0;
+  if (cfg.get_string("hydro", "problem", "unknown") == "turbulence") {
+    p->randomForcingEnabled = 1;
+    const double d0 = cfg.get_float("turbulence", "density", 1.0f);
+    double eDot = cfg.get_float("turbulence", "edot", -1.0f);
+    const double mach = cfg.get_float("turbulence", "machNumber", 0.0f);
+    if (eDot < 0) {   // Mac Low (1999), as in Enzo; the sound speed is taken as one
+      const double boxSize = p->xMax - p->xMin;
+      const double boxMass = boxSize * boxSize * boxSize * d0;
+      const double vRms = mach / std::sqrt(1.0);
+      eDot = 0.81 / boxSize * boxMass * vRms * vRms * vRms;
+      eDot *= 0.8;
+    }
+    p->randomForcingEdot = eDot;
+  }
   p->zStratifiedFloor = cfg.get_bool("MRI", "floor", false) ? 1 : 0;   // read by the z-stratified ghost fill (HydroRunBase.cpp:2206)
   p->nu = cfg.get_float("hydro", "nu", 0.0f);     // HydroParameters.h:327-328
   p->eta = cfg.get_float("MHD", "eta", 0.0f);

@@ -670,6 +670,100 @@ void init_hydro_keplerian_disk(const IniConfig& cfg, const rgpu_params& p, const
     }
 }
 
+// ---- turbulence: static solenoidal driving field (turbulenceInit.cpp, after Enzo's turboinit.f) -----------------------
+// 16 Fourier modes with fixed amplitudes and phases (the tables below are the reference's data); the y and z phases of
+// the four diagonal modes are corrected so that the field is solenoidal.  F: 3 * ncell doubles, every cell.
+const int kTurbModes = 16;
+const int kTurbMode[kTurbModes][3] = {{1, 1, 1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}, {0, 1, 1},
+                                      {1, 0, 1}, {1, 1, 0}, {0, -1, 1}, {-1, 0, 1}, {-1, 1, 0}, {0, 0, 2}, {0, 2, 0}, {2, 0, 0}};
+const double kTurbPhaX[kTurbModes] = {4.88271710, 4.55016280, 3.68972560, 5.76067300, 2.02647730, 0.832007770, 1.93749010, 0.0141755510,
+                                      5.13556960, 2.77787590, 2.02909450, 0.663769130, 1.80512500, 3.31305960, 1.05063310, 1.75230850};
+const double kTurbPhaY[kTurbModes] = {1.40113130, 5.71809960, 3.82072880, 1.00265060, 2.26816680, 2.81446220, 0.990584490, 2.94580650,
+                                      3.92715640, 0.896237970, 1.85357800, 2.84606100, 1.63463330, 3.46619220, 5.58599570, 1.59481430};
+const double kTurbPhaZ[kTurbModes] = {5.60595510, 4.13909050, 6.22733640, 5.92633250, 3.51874880, 5.42229180, 5.77061890, 4.95180180,
+                                      4.46144340, 5.29367540, 5.50741860, 2.39496800, 4.59486870, 2.23851540, 3.19591550, 4.47066500};
+const double kTurbAmp[3][kTurbModes] = {
+    {0.0755957220, -1.35724380, 0.378455820, -0.383104000, 0.116980840, -1.16079680, 0.0, -0.0280965080,
+     0.0, 0.0, -0.232798780, 0.0, 0.0, -0.879534360, -0.604585950, 0.0},
+    {1.03223790, 0.530986910, -0.242943420, -0.832715270, -0.607103350, 0.0, -0.278135540, 0.0,
+     -1.18019080, 0.0, 0.0, 0.976678430, 0.0, -0.694509390, 0.0, -0.608007610},
+    {1.01825800, -0.966076610, 0.211956020, -0.605923650, 0.0, 0.314906060, 0.109417880, 0.0,
+     0.0, -1.53612340, 0.0, 0.0, 0.813212160, 0.0, -0.368619380, -0.371489380}};
+
+void turbulence_field(const rgpu_params& p, const Grid& g, double mach, double* F) {
+  static const double sign1[4] = {1.0, -1.0, -1.0, 1.0}, sign2[4] = {-1.0, -1.0, 1.0, 1.0};
+  const double pi = 2.0 * std::asin(1.0);
+  const double aa = 2.0 * pi / p.nx;   // "nbox" = nx (HydroRunBase.cpp:7199-7204)
+  double* u = F; double* v = F + g.ncell; double* w = F + 2 * g.ncell;
+  const int off = -g.gw;
+  for (int k = 0; k < g.ksize; ++k)
+    for (int j = 0; j < g.jsize; ++j)
+      for (int i = 0; i < g.isize; ++i) {
+        const size_t index = static_cast<size_t>(i) + static_cast<size_t>(g.isize) * (j + static_cast<size_t>(g.jsize) * k);
+        u[index] = 0.0; v[index] = 0.0; w[index] = 0.0;
+        for (int m = 0; m < kTurbModes; ++m) {
+          const double k1 = kTurbMode[m][0] * (i + off + 1) + kTurbMode[m][1] * (j + off + 1) + kTurbMode[m][2] * (k + g.k_shift + off + 1);
+          const double ax = kTurbAmp[0][m], ay = kTurbAmp[1][m], az = kTurbAmp[2][m];
+          u[index] = u[index] + ax * std::cos(aa * k1 + kTurbPhaX[m]);
+          if (m < 4) {
+            const double phayy = kTurbPhaX[m] + sign1[m] * std::acos((az * az - ax * ax - ay * ay) / 2.0 / ax / kTurbMode[m][0] / kTurbMode[m][1] / ay);
+            v[index] = v[index] + ay * std::cos(aa * k1 + phayy);
+            const double phazz = kTurbPhaX[m] + sign2[m] * std::acos((ay * ay - ax * ax - az * az) / 2.0 / ax / kTurbMode[m][0] / kTurbMode[m][2] / az);
+            w[index] = w[index] + az * std::cos(aa * k1 + phazz);
+          } else {
+            v[index] = v[index] + ay * std::cos(aa * k1 + kTurbPhaY[m]);
+            w[index] = w[index] + az * std::cos(aa * k1 + kTurbPhaZ[m]);
+          }
+        }
+        // normalisation to the requested rms Mach number
+        u[index] = u[index] / 2.848320 * mach;
+        v[index] = v[index] / 2.848320 * mach;
+        w[index] = w[index] / 2.848320 * mach;
+      }
+}
+
+// problem "turbulence" (HydroRunBase.cpp:6916-6964, MHDRunBase.cpp:3045-3098): perturbed density (libc rand()), the
+// driving field as initial velocity, uniform pressure; MHD adds a uniform field
+void init_turbulence(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  if (!g.three_d) throw std::runtime_error("the turbulence problem is not available in 2D");
+  const double d0 = cfg.get_float("turbulence", "density", 1.0f);
+  const double ampl = cfg.get_float("turbulence", "initialDensityPerturbationAmplitude", 0.0f);
+  const double P0 = cfg.get_float("turbulence", "pressure", 1.0f);
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer("turbulence", "random_seed", 33)));
+  for (long n = 0; n < (long)g.k_shift * g.ny * g.nx; ++n) rng.next();   // interior cells of the slabs below
+  std::vector<double> F(3 * g.ncell);
+  turbulence_field(p, g, cfg.get_float("turbulence", "machNumber", 0.0f), F.data());
+  double Bx0 = 0, By0 = 0, Bz0 = 0;
+  if (p.mhdEnabled) {
+    Bx0 = cfg.get_float("turbulence", "bx", 1e-8f);
+    By0 = cfg.get_float("turbulence", "by", 1e-8f);
+    Bz0 = cfg.get_float("turbulence", "bz", 1e-8f);
+    const double beta = cfg.get_float("turbulence", "beta", 0.0f);
+    if (beta > 0) {
+      const double cIso2 = p.cIso * p.cIso;
+      Bx0 = std::sqrt(2 * cIso2 * d0 / beta);
+      By0 = 0.0; Bz0 = 0.0;
+      if (cIso2 <= 0.0) Bx0 = cfg.get_float("turbulence", "Bx0", static_cast<float>(2.0 * d0 / beta));
+    }
+  }
+  for (int k = g.gw; k < g.ksize - g.gw; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j)
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        const size_t o = static_cast<size_t>(i) + static_cast<size_t>(g.isize) * (j + static_cast<size_t>(g.jsize) * k);
+        const double d = d0 * (1.0 + ampl * ((float)rng.next() / (float)(GlibcRand::kRandMax) - 0.5));
+        g.at(i, j, k, RGPU_ID) = d;
+        g.at(i, j, k, RGPU_IU) = d * F[o];
+        g.at(i, j, k, RGPU_IV) = d * F[o + g.ncell];
+        g.at(i, j, k, RGPU_IW) = d * F[o + 2 * g.ncell];
+        const double mu = g.at(i, j, k, RGPU_IU), mv = g.at(i, j, k, RGPU_IV), mw = g.at(i, j, k, RGPU_IW);
+        g.at(i, j, k, RGPU_IP) = P0 / (p.gamma0 - 1.0) + 0.5 * (mu * mu + mv * mv + mw * mw) / d;
+        if (p.mhdEnabled) {
+          g.at(i, j, k, RGPU_IA) = Bx0; g.at(i, j, k, RGPU_IB) = By0; g.at(i, j, k, RGPU_IC) = Bz0;
+          g.at(i, j, k, RGPU_IP) += 0.5 * (Bx0 * Bx0 + By0 * By0 + Bz0 * Bz0);
+        }
+      }
+}
+
 // ---- MHD: compressive shear wave in the shearing box (MHDRunBase.cpp:2574-2658), every cell, ghosts included --------
 void init_mhd_shear_wave(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   if (!(p.bc[0] == RGPU_BC_SHEARINGBOX && p.bc[1] == RGPU_BC_SHEARINGBOX))
@@ -947,6 +1041,14 @@ bool init_gravity_field(const IniConfig& cfg, const rgpu_params& p, double* hG) 
   return false;
 }
 
+// h_randomForcing of the "turbulence" problem: hF[3][ksize][jsize][isize]
+bool init_forcing_field(const IniConfig& cfg, const rgpu_params& p, double* hF) {
+  Grid g = make_grid(p, hF);
+  if (!p.randomForcingEnabled) return false;
+  turbulence_field(p, g, cfg.get_float("turbulence", "machNumber", 0.0f), hF);
+  return true;
+}
+
 void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
   const Grid g = make_grid(p, hU);
   std::memset(hU, 0, sizeof(double) * g.ncell * g.nvar);
@@ -964,6 +1066,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "FieldLoop" || problem == "fieldloop" || problem == "Fieldloop" || problem == "field-loop" || problem == "Field-Loop") init_mhd_field_loop(cfg, p, g);
     else if (problem == "CurrentSheet" || problem == "currentsheet" || problem == "Currentsheet" || problem == "current-sheet" || problem == "Current-Sheet") init_mhd_current_sheet(cfg, p, g);
     else if (problem == "ShearWave" || problem == "shearwave" || problem == "Shear-Wave" || problem == "shear-wave" || problem == "Shearwave") init_mhd_shear_wave(cfg, p, g);
+    else if (problem == "turbulence") init_turbulence(cfg, p, g);
     else if (problem == "InertialWave" || problem == "inertialwave" || problem == "Inertial-Wave" || problem == "inertial-wave" || problem == "Inertialwave") init_mhd_inertial_wave(cfg, p, g);
     else throw std::runtime_error("MHD problem '" + problem + "' is outside the implemented scope");
   } else {
@@ -977,6 +1080,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "riemann2d") init_hydro_riemann2d(cfg, p, g);
     else if (problem == "falling-bubble") init_hydro_falling_bubble(cfg, p, g);
     else if (problem == "Keplerian-disk") init_hydro_keplerian_disk(cfg, p, g);
+    else if (problem == "turbulence") init_turbulence(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
 }

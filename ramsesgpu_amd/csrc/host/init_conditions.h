@@ -23,6 +23,10 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU);
 // HydroRunBase.cpp:6489-6500, 6575-6597).
 bool init_gravity_field(const IniConfig& cfg, const rgpu_params& p, double* hG);
 
+// hF: 3 * ncell doubles, the static driving field of the "turbulence" problem (turbulenceInit.cpp); false for every other
+// problem.
+bool init_forcing_field(const IniConfig& cfg, const rgpu_params& p, double* hF);
+
 // glibc-compatible drand48 stream (48-bit LCG X' = a X + c mod 2^48, a=0x5DEECE66D, c=0xB; srand48(s) sets
 // X = (s<<16)|0x330E) with O(log n) skip-ahead.
 class Rand48 {

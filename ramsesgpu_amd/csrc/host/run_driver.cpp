@@ -40,6 +40,10 @@ int GodunovRun::init_simulation() {
     std::vector<double> hG(3 * (h_U_.size() / p_.nbVar));
     if (init_gravity_field(cfg_, p_, hG.data())) check(rgpu_set_gravity_field(ctx_, hG.data()), "set_gravity_field");
   }
+  if (p_.randomForcingEnabled) {   // h_randomForcing -> d_randomForcing (HydroRunBase.cpp:7199-7209)
+    std::vector<double> hF(3 * (h_U_.size() / p_.nbVar));
+    if (init_forcing_field(cfg_, p_, hF.data())) check(rgpu_set_forcing_field(ctx_, hF.data()), "set_forcing_field");
+  }
   return 0;
 }
 

@@ -282,6 +282,50 @@ RG_DEVFN void hist_row_cell(const DevParams& g, const double* __restrict__ U, do
   for (int q = 0; q < HIST_NQ; ++q) rows[(size_t)q * R + idx] = acc[q];
 }
 
+// random forcing (problem "turbulence"): row sums over the interior y of  rho v.f  and  rho f.f  (the two sums the
+// normalisation needs, HydroRunBase.cpp:1229-1243), same rows / columns layout as the history sums, interior i only
+RG_DEVFN void forcing_row_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Frc,
+                               double* __restrict__ rows, unsigned idx) {
+  const int nk = g.nz;
+  const int i = (int)(idx % (unsigned)g.isize), kk = (int)(idx / (unsigned)g.isize);
+  if (kk >= nk) return;
+  const int k = kk + g.gw;
+  const size_t N = g.ncell;
+  double a0 = 0.0, a1 = 0.0;
+  if (i >= g.gw && i < g.isize - g.gw)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const unsigned o = (unsigned)i + g.sj * (unsigned)j + g.sk * (unsigned)k;
+      const double rho = U[o + ID * N];
+      const double u = U[o + IU * N] / rho, v = U[o + IV * N] / rho, w = U[o + IW * N] / rho;
+      const double uu = Frc[o], vv = Frc[o + N], ww = Frc[o + 2 * N];
+      a0 += rho * (u * uu + v * vv + w * ww);
+      a1 += rho * uu * uu;
+      a1 += rho * vv * vv;
+      a1 += rho * ww * ww;
+    }
+  const size_t R = (size_t)g.isize * nk;
+  rows[idx] = a0;
+  rows[R + idx] = a1;
+}
+
+// add_random_forcing (HydroRunBase.cpp:1397-1428): energy first (with the momenta before the kick), then the momenta
+RG_DEVFN void add_forcing_cell(const DevParams& g, double* __restrict__ U, const double* __restrict__ Frc, double norm,
+                               unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (c.i < g.gw || c.i >= g.isize - g.gw || c.j < g.gw || c.j >= g.jsize - g.gw || c.k < g.gw || c.k >= g.ksize - g.gw) return;
+  const size_t N = g.ncell;
+  const double rho = U[idx + ID * N];
+  const double fx = Frc[idx], fy = Frc[idx + N], fz = Frc[idx + 2 * N];
+  double e = U[idx + IP * N];
+  e += U[idx + IU * N] / rho * fx * norm + 0.5 * ((fx * norm) * (fx * norm));
+  e += U[idx + IV * N] / rho * fy * norm + 0.5 * ((fy * norm) * (fy * norm));
+  e += U[idx + IW * N] / rho * fz * norm + 0.5 * ((fz * norm) * (fz * norm));
+  U[idx + IP * N] = e;
+  U[idx + IU * N] += rho * fx * norm;
+  U[idx + IV * N] += rho * fy * norm;
+  U[idx + IW * N] += rho * fz * norm;
+}
+
 // column sums: thread (i,q) adds rows[q][k][i] over k
 RG_DEVFN void hist_col_cell(const DevParams& g, const double* __restrict__ rows, double* __restrict__ cols, int nq, unsigned idx) {
   const int nk = g.three_d ? g.nz : 1;

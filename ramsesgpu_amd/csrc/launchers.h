@@ -107,6 +107,14 @@ struct K_mhd_flux3d {
   DevParams g; const double* T; double* F; double* emf;
   RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK>(g, T, F, emf, idx); }
 };
+struct K_forcing_rows {
+  DevParams g; const double* U; const double* Frc; double* rows;
+  RG_DEVFN void operator()(unsigned idx) const { forcing_row_cell(g, U, Frc, rows, idx); }
+};
+struct K_add_forcing {
+  DevParams g; double* U; const double* Frc; double norm;
+  RG_DEVFN void operator()(unsigned idx) const { add_forcing_cell(g, U, Frc, norm, idx); }
+};
 struct K_bc_zstrat {
   DevParams g; ZStrat zs; double* U; int side;
   RG_DEVFN void operator()(unsigned ij) const { zstrat_column(g, zs, U, side, ij); }

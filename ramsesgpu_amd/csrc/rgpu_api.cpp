@@ -32,6 +32,7 @@ struct rgpu_ctx {
   double* U[2];
   double *Q, *E, *T, *F, *emf, *shear_save, *shear_remap;
   double* G;   // per-cell static gravity field (gravityEnabled == 2), 3 components
+  double* Frc; // static driving field of the "turbulence" problem (randomForcingEnabled), 3 components
   unsigned long long* d_red;
   unsigned long long* h_red;
   size_t ncell, scratch_bytes;
@@ -96,6 +97,8 @@ int validate(const rgpu_params* p, std::string* why) {
     if (p->riemannSolver != RGPU_RS_APPROX && p->riemannSolver != RGPU_RS_HLL && p->riemannSolver != RGPU_RS_HLLC) { *why = "hydro riemannSolver must be approx, hll or hllc"; return RGPU_EINVAL; }
   }
   if (p->nu < 0 || p->eta < 0) { *why = "nu and eta must be >= 0"; return RGPU_EINVAL; }
+  if (p->gravityEnabled < 0 || p->gravityEnabled > 2) { *why = "gravityEnabled must be 0, 1 (uniform vector) or 2 (per-cell field)"; return RGPU_EINVAL; }
+  if (p->randomForcingEnabled && (!three_d || (p->mhdEnabled && p->Omega0 > 0))) { *why = "random forcing exists in the 3D non-rotating steps only (as in the reference)"; return RGPU_EUNSUPPORTED; }
   for (int f = 0; f < 6; ++f) {
     const int b = p->bc[f];
     const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
@@ -175,6 +178,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->U[0] = c->U[1] = 0;
   c->Q = c->E = c->T = c->F = c->emf = c->shear_save = c->shear_remap = 0;
   c->G = 0;
+  c->Frc = 0;
   c->d_red = 0; c->h_red = 0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
@@ -196,6 +200,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (alloc_zero(c, &c->U[0], n) || alloc_zero(c, &c->U[1], n)) return fail(c, RGPU_ENOMEM, "device allocation of the state arrays failed");
   }
   const ScratchPlan sp = plan_for(*p);
+  if (p->randomForcingEnabled && alloc_zero(c, &c->Frc, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the forcing field failed");
   if (p->gravityEnabled == 2 && alloc_zero(c, &c->G, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the gravity field failed");
   if (alloc_zero(c, &c->Q, c->ncell * sp.q) || alloc_zero(c, &c->E, c->ncell * sp.e) || alloc_zero(c, &c->T, c->ncell * sp.t) ||
       alloc_zero(c, &c->F, c->ncell * sp.f) || alloc_zero(c, &c->emf, c->ncell * sp.emf))
@@ -621,6 +626,40 @@ int history_reynolds(rgpu_ctx* c, int parity, const double* h_mean_vx, const dou
   return 0;
 }
 
+// random forcing: the two sums of compute_random_forcing_normalization over this domain's interior, reduced in the
+// rows (along y) / columns (along z) / host (along x) order of the history sums
+int forcing_sums(rgpu_ctx* c, int parity, double* out2) {
+  const HistScratch h = hist_scratch(c);
+  const size_t is = (size_t)c->g.isize;
+  K_forcing_rows kr = {c->g, c->U[parity & 1], c->Frc, h.rows};
+  K_hist_cols kc = {c->g, h.rows, h.cols, 2};
+  if (rg_launch<kBlock>(c->stream, (unsigned)h.R, kr) || rg_launch<kBlock>(c->stream, (unsigned)(2 * is), kc)) return -1;
+  std::vector<double> cols(2 * is);
+  if (rg_copy_d2h(cols.data(), h.cols, sizeof(double) * 2 * is, c->stream) || rg_stream_sync(c->stream)) return -1;
+  out2[0] = 0.0; out2[1] = 0.0;
+  for (size_t i = 0; i < is; ++i) { out2[0] += cols[i]; out2[1] += cols[is + i]; }
+  return 0;
+}
+
+double forcing_norm(const rgpu_params& p, const double* s, double dt) {   // HydroRunBase.cpp:1286-1293
+  if (p.randomForcingEdot == 0) return 0.0;
+  const long long nbCells = (long long)p.nx * p.ny * p.nz_global;
+  return (std::sqrt(s[0] * s[0] + s[1] * dt * p.randomForcingEdot * 2 * nbCells) - s[0]) / s[1];
+}
+
+int add_forcing(rgpu_ctx* c, int parity, double norm) {
+  K_add_forcing k = {c->g, c->U[parity & 1], c->Frc, norm};
+  return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
+}
+
+int step_forcing(rgpu_ctx* c, int nStep, double dt) {
+  if (!c->p.randomForcingEnabled) return 0;
+  Phase ph(c, RGPU_T_UPDATE);
+  double s[2];
+  if (forcing_sums(c, (nStep + 1) % 2, s)) return -1;
+  return add_forcing(c, (nStep + 1) % 2, forcing_norm(c->p, s, dt));
+}
+
 #define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; } while (0)
 #define RG_HIPFAIL(c, what) fail((c), RGPU_EHIP, std::string(what) + ": " + rg_last_error_string())
 
@@ -638,7 +677,7 @@ int rgpu_create_external(const rgpu_params* p, double* dU, double* dU2, void* hi
 void rgpu_destroy(rgpu_ctx* c) {
   if (!c) return;
   if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
-  rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G);
+  rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G); rg_free(c->Frc);
   rg_free(c->d_red); rg_host_free(c->h_red);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
   if (c->nchunks > 1) {
@@ -658,6 +697,7 @@ size_t rgpu_device_bytes(const rgpu_params* p) {
   size_t doubles = ncell * (size_t)(2 * p->nbVar + sp.q + sp.e + sp.t + sp.f + sp.emf);
   if (p->shearingBoxEnabled) doubles += 4 * jsize * ksize;
   if (p->gravityEnabled == 2) doubles += 3 * ncell;
+  if (p->randomForcingEnabled) doubles += 3 * ncell;
   return doubles * sizeof(double);
 }
 
@@ -678,6 +718,28 @@ int rgpu_set_gravity_field(rgpu_ctx* c, const double* hG) {
   if (!hG) return fail(c, RGPU_EINVAL, "set_gravity_field: null pointer");
   if (c->p.gravityEnabled != 2 || !c->G) return fail(c, RGPU_EINVAL, "set_gravity_field: the context was not created with gravityEnabled = 2");
   if (rg_copy_h2d(c->G, hG, c->ncell * 3 * sizeof(double), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "set_gravity_field");
+  return RGPU_OK;
+}
+
+int rgpu_set_forcing_field(rgpu_ctx* c, const double* hF) {
+  RG_CHECK_CTX(c);
+  if (!hF) return fail(c, RGPU_EINVAL, "set_forcing_field: null pointer");
+  if (!c->p.randomForcingEnabled || !c->Frc) return fail(c, RGPU_EINVAL, "set_forcing_field: the context was not created with randomForcingEnabled");
+  if (rg_copy_h2d(c->Frc, hF, c->ncell * 3 * sizeof(double), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "set_forcing_field");
+  return RGPU_OK;
+}
+
+int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out) {
+  RG_CHECK_CTX(c);
+  if (!out || !c->Frc) return fail(c, RGPU_EINVAL, "forcing_sums: null pointer / context without forcing field");
+  if (forcing_sums(c, parity, out)) return RG_HIPFAIL(c, "forcing_sums");
+  return RGPU_OK;
+}
+
+int rgpu_add_forcing(rgpu_ctx* c, int parity, double norm) {
+  RG_CHECK_CTX(c);
+  if (!c->Frc) return fail(c, RGPU_EINVAL, "add_forcing: context without forcing field");
+  if (add_forcing(c, parity, norm) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "add_forcing");
   return RGPU_OK;
 }
 
@@ -866,7 +928,7 @@ int rgpu_godunov_unsplit(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "slab contexts must use rgpu_step_pre/core/post_a/post_b around the halo exchange");
   if (step_pre(c, nStep) || step_core(c, nStep, dt, totalTime) || step_dissipative(c, nStep, dt, totalTime) ||
-      step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
+      step_forcing(c, nStep, dt) || step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
     return RG_HIPFAIL(c, "godunov_unsplit");
   return RGPU_OK;
 }

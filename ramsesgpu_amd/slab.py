@@ -73,6 +73,9 @@ class SlabRun:
         G = self.L.init_gravity(self.ini_path, self.overrides, self.p)   # this slab's planes of h_gravity, if the problem has one
         if G is not None:
             self.solver.set_gravity_field(G)
+        F = self.L.init_forcing(self.ini_path, self.overrides, self.p)   # ... and of h_randomForcing ("turbulence")
+        if F is not None:
+            self.solver.set_forcing_field(F)
         self.make_all_boundaries(0, 0.0, 0.0)
         self.U[1].copy_(self.U[0])
         self.nStep, self.totalTime = 0, 0.0
@@ -171,6 +174,8 @@ class SlabRun:
             # (make_all_boundaries(h_UNew) of the reference, mhd_godunov_unsplit_cpu_v3.cpp:662-668)
             self.make_all_boundaries((nStep + 1) % 2, t, dt)
             s.step_dissipative(nStep, dt, t)
+        if self.p.randomForcingEnabled:
+            self._random_forcing(nStep, dt)
         s.step_post_a(nStep, dt, t)
         if self._rotating:
             self.exchange_z((nStep + 1) % 2)    # rotating path: ghosts of the OUTPUT
@@ -190,8 +195,29 @@ class SlabRun:
     def _dissipative(self):
         return bool(self.p.nu > 0 or (self.p.mhdEnabled and self.p.eta > 0))
 
+    def _random_forcing(self, nStep, dt):
+        """random forcing of the "turbulence" problem on the updated state: the two normalisation sums of every slab are
+        added (SUM all-reduce), then every slab applies the same factor (compute_random_forcing_normalization +
+        add_random_forcing, HydroRunBase.cpp:1201-1428)"""
+        import math
+        s, p = self.solver, self.p
+        pout = (nStep + 1) % 2
+        s0, s1 = s.forcing_sums(pout)
+        if self.world > 1:
+            t = torch.tensor([s0, s1], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            s0, s1 = (float(v) for v in t.cpu())
+        if p.randomForcingEdot == 0:
+            norm = 0.0
+        else:
+            nb = p.nx * p.ny * p.nz_global
+            norm = (math.sqrt(s0 * s0 + s1 * dt * p.randomForcingEdot * 2 * nb) - s0) / s1
+        s.add_forcing(pout, norm)
+
     def godunov_unsplit(self, nStep, dt):
-        if not self.overlap or self._dissipative:     # the dissipative stage needs a second exchange inside the step
+        # the dissipative stage needs a second exchange inside the step; the random forcing changes the whole updated
+        # state after it (and needs a global sum first): both use the serial schedule
+        if not self.overlap or self._dissipative or self.p.randomForcingEnabled:
             return self.godunov_unsplit_serial(nStep, dt)
         s, t = self.solver, self.totalTime
         pin, pout = nStep % 2, (nStep + 1) % 2

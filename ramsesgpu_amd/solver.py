@@ -86,6 +86,17 @@ class Library:
             raise RgpuError("init_condition: %s" % err.value.decode())
         return U
 
+    def init_forcing(self, ini_path, overrides, params):
+        """static driving field [3][ksize][jsize][isize] of the "turbulence" problem (params.randomForcingEnabled), else None"""
+        if not int(params.randomForcingEnabled):
+            return None
+        F = np.zeros((3,) + tuple(params.shape[1:]), dtype=np.float64)
+        err = C.create_string_buffer(512)
+        rc = self.lib.rgpuh_init_forcing(ini_path.encode(), (overrides or "").encode(), C.byref(params), F.ctypes.data, err, 512)
+        if rc < 0:
+            raise RgpuError("init_forcing: %s" % err.value.decode())
+        return F if rc == 1 else None
+
     def init_gravity(self, ini_path, overrides, params):
         """static gravity field [3][ksize][jsize][isize] of the problems that define one (params.gravityEnabled == 2),
         else None"""
@@ -184,6 +195,20 @@ class Solver:
         G = np.ascontiguousarray(G, dtype=np.float64)
         assert G.shape == (3,) + tuple(self.p.shape[1:]), G.shape
         self._chk(self.lib.rgpu_set_gravity_field(self.ctx, G.ctypes.data), "set_gravity_field")
+
+    def set_forcing_field(self, F):
+        """upload h_randomForcing (randomForcingEnabled): [3][ksize][jsize][isize] doubles"""
+        F = np.ascontiguousarray(F, dtype=np.float64)
+        assert F.shape == (3,) + tuple(self.p.shape[1:]), F.shape
+        self._chk(self.lib.rgpu_set_forcing_field(self.ctx, F.ctypes.data), "set_forcing_field")
+
+    def forcing_sums(self, parity):
+        out = (C.c_double * 2)()
+        self._chk(self.lib.rgpu_forcing_sums(self.ctx, parity, out), "forcing_sums")
+        return float(out[0]), float(out[1])
+
+    def add_forcing(self, parity, norm):
+        self._chk(self.lib.rgpu_add_forcing(self.ctx, parity, float(norm)), "add_forcing")
 
     def read_cell(self, parity, i, j, k=0):
         """U(i, j, k, :) of one cell, ghost-inclusive local indices (the probe of history_inertial_wave)"""

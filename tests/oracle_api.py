@@ -25,6 +25,9 @@ class Oracle:
         self.lib.orc_set_gravity_field.restype = None
         self.lib.orc_set_gravity_field.argtypes = [C.c_void_p]
         self._G = None
+        self.lib.orc_set_forcing_field.restype = None
+        self.lib.orc_set_forcing_field.argtypes = [C.c_void_p]
+        self._F = None
 
     @staticmethod
     def _arr(U):
@@ -35,6 +38,11 @@ class Oracle:
         """h_gravity of the following calls when p.gravityEnabled == 2 ([3][ksize][jsize][isize]); None forgets it"""
         self._G = None if G is None else np.ascontiguousarray(G, dtype=np.float64)
         self.lib.orc_set_gravity_field(None if self._G is None else self._G.ctypes.data)
+
+    def set_forcing_field(self, F):
+        """h_randomForcing of the following calls when p.randomForcingEnabled; None forgets it"""
+        self._F = None if F is None else np.ascontiguousarray(F, dtype=np.float64)
+        self.lib.orc_set_forcing_field(None if self._F is None else self._F.ctypes.data)
 
     def make_boundaries(self, p, U, idim):
         assert self.lib.orc_make_boundaries(C.byref(p), self._arr(U), idim) == 0

@@ -20,11 +20,16 @@ def rel_l2(a, b):
     return num / den if den > 0 else num
 
 
-def assert_same(got, ref, what):
+def assert_same(got, ref, what, exact=True):
+    """bit-identical, except (exact=False) for runs with the random forcing of the "turbulence" problem: its
+    normalisation is a sum over the whole domain that the reference accumulates sequentially and the device in a
+    fixed parallel order, so those agree to round-off -- well inside the stated L2 tolerance -- not bit for bit"""
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert np.isfinite(got).all(), "%s: non-finite values" % what
     err = rel_l2(got, ref)
     assert err < L2_TOLERANCE, "%s: relative L2 %.3e exceeds the stated tolerance %.0e" % (what, err, L2_TOLERANCE)
+    if not exact:
+        return
     nbad = int((got != ref).sum())
     assert nbad == 0, "%s: %d of %d doubles differ (max abs %.3e, rel L2 %.3e)" % (what, nbad, ref.size, np.abs(got - ref).max(), err)
 
@@ -36,6 +41,11 @@ def attach_gravity(lib, base, ov, p, sv=None, oracle=None):
         sv.set_gravity_field(G)
     if oracle is not None:
         oracle.set_gravity_field(G)
+    F = lib.init_forcing(ini(base), ov, p)   # and the static driving field of the "turbulence" problem
+    if sv is not None and F is not None:
+        sv.set_forcing_field(F)
+    if oracle is not None:
+        oracle.set_forcing_field(F)
     return G
 
 
@@ -50,7 +60,8 @@ def check_golden_case(lib, name):
         try:
             attach_gravity(lib, case["base"], case["overrides"], p, sv=sv)
             sv.start(U0, s)
-            assert_same(interior(sv.getDataHost(), p), g["step_%d" % s], "%s step %d vs reference" % (name, s))
+            assert_same(interior(sv.getDataHost(), p), g["step_%d" % s], "%s step %d vs reference" % (name, s),
+                        exact=not p.randomForcingEnabled)
             if s == max(case["steps"]) and np.isfinite(g["total_time"]):
                 assert abs(sv.totalTime - float(g["total_time"])) <= 1e-11 * max(1.0, abs(sv.totalTime))
         finally:
@@ -147,6 +158,10 @@ def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
     try:
         attach_gravity(lib, base, ov, p, sv=sv)
         dts = sv.start(U0, nsteps)
+        if p.randomForcingEnabled:   # round-off level agreement only (see assert_same)
+            np.testing.assert_allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
+            assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps), exact=False)
+            return
         assert np.array_equal(np.array(dts), dts_ref), "%s: dt sequences differ" % base
         assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps))
         assert sv.totalTime == t_ref
@@ -190,6 +205,10 @@ ORACLE_RUNS = [
     ("Keplerian_disk2d", "mesh.nx=14;mesh.ny=10;hydro.riemannSolver=approx", 5),
     ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=12;mesh.nz=6;hydro.riemannSolver=hll;hydro.unsplitVersion=2;hydro.nu=0.003", 4),
     ("Keplerian_disk2d", "mesh.nx=12;mesh.ny=12;gravity.static=no", 3),
+    # driven turbulence (round-off agreement): other sizes / solvers, zero input rate, with viscosity
+    ("turbulence_hydro", "mesh.nx=10;mesh.ny=8;mesh.nz=12;hydro.riemannSolver=hll", 4),
+    ("turbulence_hydro", "mesh.nx=8;mesh.ny=8;mesh.nz=8;turbulence.edot=0.0;hydro.nu=0.001", 3),
+    ("turbulence_mhd", "mesh.nx=8;mesh.ny=10;mesh.nz=8;hydro.slope_type=2.0;turbulence.beta=2.0;MHD.eta=1e-4", 4),
     # stratified MRI box: other solvers, unsmoothed gravity, floor
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=16;hydro.slope_type=2.0;MRI.amp=0.4;MHD.magRiemannSolver=hllf;hydro.riemannSolver=hll", 4),
     ("mhd_mri_3d_stratified", "mesh.nx=8;mesh.ny=6;mesh.nz=12;hydro.slope_type=1.0;MRI.amp=0.4;MRI.smoothGravity=no;MRI.floor=yes;mesh.zmin=-1.5;mesh.zmax=1.5", 4),

@@ -18,6 +18,7 @@ def test_oracle_reproduces_reference_bit_for_bit(name, case, oracle, product_lib
     for s in case["steps"]:
         U0 = L.init_condition(ini(case["base"]), case["overrides"], p)
         oracle.set_gravity_field(L.init_gravity(ini(case["base"]), case["overrides"], p))   # h_gravity, where the problem has one
+        oracle.set_forcing_field(L.init_forcing(ini(case["base"]), case["overrides"], p))   # h_randomForcing, likewise
         U, dts, t = oracle.run(p, U0, s)
         ref = g["step_%d" % s]
         got = interior(U, p)

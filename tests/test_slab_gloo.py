@@ -39,6 +39,8 @@ CASES = [
     ("Keplerian_disk2d", "mesh.nx=10;mesh.ny=10;mesh.nz=12;hydro.riemannSolver=hll", 3, 2, 1),    # per-cell gravity field, slab by slab
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 2, 1),       # stratified box: g_z(z) planes per slab, z-stratified end faces
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 3, 0),       # ... three slabs, serial schedule
+    ("turbulence_hydro", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                                              # random forcing: all-reduced normalisation sums (round-off agreement)
+    ("turbulence_mhd", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.slope_type=2.0", 3, 3, 1),
 ]
 
 
