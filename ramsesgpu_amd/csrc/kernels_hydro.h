@@ -77,7 +77,7 @@ RG_DEVFN void hydro_trace_cell(const DevParams& g, const double* __restrict__ Q,
 }
 
 // qm[D] (SIDE=+1) / qp[D] (SIDE=-1) of cell m in the face-normal frame, with the floors of trace.h:388-389
-template <int D, int SIDE, int NV>
+template <int D, int SIDE, int NV, bool GF>
 RG_DEVFN void hydro_face_state(const DevParams& g, const double* __restrict__ T, unsigned m, double* o) {
   const size_t N = g.ncell;
   const double* t = T + m;
@@ -87,9 +87,9 @@ RG_DEVFN void hydro_face_state(const DevParams& g, const double* __restrict__ T,
   for (int n = 0; n < NV; ++n) qv[n] = t[(size_t)n * N] + s * t[(size_t)(NV * (1 + D) + n) * N];
   qv[ID] = fmax(g.smallr, qv[ID]);
   qv[IP] = fmax(g.smallp * qv[ID], qv[IP]);
-  if (g.grav_on) {  // gravity predictor on the traced state (HydroRunGodunov.cpp:2485-2497, 2705-2734)
+  if (GF || g.grav_on) {  // gravity predictor on the traced state (HydroRunGodunov.cpp:2485-2497, 2705-2734)
     double gx, gy, gz;
-    half_dt_gravity(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, m, gx, gy, gz);
     qv[IU] += gx;
     qv[IV] += gy;
     if (NV == 5) qv[NV - 1] += gz;
@@ -99,7 +99,7 @@ RG_DEVFN void hydro_face_state(const DevParams& g, const double* __restrict__ T,
   for (int n = 0; n < NV; ++n) o[n] = qv[(n == IU) ? swp : (n == swp) ? IU : n];
 }
 
-template <int ND, int NV>
+template <int ND, int NV, bool GF>
 RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F, unsigned idx) {
   const IJK c = unflatten(g, idx);
   if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw) return;
@@ -107,8 +107,8 @@ RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, 
   const size_t N = g.ncell;
   double ql[NV], qr[NV], fl[NV];
   {
-    hydro_face_state<0, +1, NV>(g, T, idx - 1, ql);
-    hydro_face_state<0, -1, NV>(g, T, idx, qr);
+    hydro_face_state<0, +1, NV, GF>(g, T, idx - 1, ql);
+    hydro_face_state<0, -1, NV, GF>(g, T, idx, qr);
 #pragma unroll
     for (int n = 0; n < NV; ++n) fl[n] = 0.0;
     hydro_riemann<NV>(g, ql, qr, fl);
@@ -116,8 +116,8 @@ RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, 
     for (int n = 0; n < NV; ++n) F[idx + (size_t)n * N] = fl[n];
   }
   {
-    hydro_face_state<1, +1, NV>(g, T, idx - g.sj, ql);
-    hydro_face_state<1, -1, NV>(g, T, idx, qr);
+    hydro_face_state<1, +1, NV, GF>(g, T, idx - g.sj, ql);
+    hydro_face_state<1, -1, NV, GF>(g, T, idx, qr);
 #pragma unroll
     for (int n = 0; n < NV; ++n) fl[n] = 0.0;
     hydro_riemann<NV>(g, ql, qr, fl);
@@ -125,8 +125,8 @@ RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, 
     for (int n = 0; n < NV; ++n) F[idx + (size_t)(NV + n) * N] = fl[n];
   }
   if (ND == 3) {
-    hydro_face_state<2, +1, NV>(g, T, idx - g.sk, ql);
-    hydro_face_state<2, -1, NV>(g, T, idx, qr);
+    hydro_face_state<2, +1, NV, GF>(g, T, idx - g.sk, ql);
+    hydro_face_state<2, -1, NV, GF>(g, T, idx, qr);
 #pragma unroll
     for (int n = 0; n < NV; ++n) fl[n] = 0.0;
     hydro_riemann<NV>(g, ql, qr, fl);
@@ -135,7 +135,7 @@ RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, 
   }
 }
 
-template <int ND, int NV>
+template <int ND, int NV, bool GF>
 RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ Uold, double* __restrict__ Unew,
                                 const double* __restrict__ F, double dtdx, double dtdy, double dtdz, unsigned idx) {
   const IJK c = unflatten(g, idx);
@@ -172,10 +172,10 @@ RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ U
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) apply(d, pass);
     }
-    if (g.grav_on) {  // momentum source (compute_gravity_source_term, HydroRunBase.cpp:1925-1985); energy untouched
+    if (GF || g.grav_on) {  // momentum source (compute_gravity_source_term, HydroRunBase.cpp:1925-1985); energy untouched
       const double rho_sum = Uold[idx + ID * N] + u[ID];
       double gx, gy, gz;
-      half_dt_gravity(g, idx, gx, gy, gz);
+      half_dt_gravity<GF>(g, idx, gx, gy, gz);
       u[IU] += gx * rho_sum;
       u[IV] += gy * rho_sum;
       if (NV == 5) u[NV - 1] += gz * rho_sum;

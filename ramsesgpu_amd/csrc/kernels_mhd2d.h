@@ -124,7 +124,7 @@ RG_DEVFN void floor2d(const DevParams& g, Prim8& s) {
 }
 
 // qm[D] (SIDE=+1) / qp[D] (SIDE=-1) of cell m, in the face-normal frame (trace_mhd.h:242-288)
-template <int D, int SIDE>
+template <int D, int SIDE, bool GF>
 RG_DEVFN Prim8 face_state2d(const DevParams& g, const double* __restrict__ T, unsigned m) {
   const size_t N = g.ncell;
   const unsigned sD = (D == XD) ? 1u : g.sj;
@@ -144,9 +144,9 @@ RG_DEVFN Prim8 face_state2d(const DevParams& g, const double* __restrict__ T, un
   if (D == XD) { o.u = u; o.v = v; } else { o.u = v; o.v = u; }
   // implementation version 0: the reference adds the gravity predictor AFTER the swap into the face-normal frame
   // (mhd_godunov_unsplit_cpu_v0.cpp:177-179, 388-390, then 500-512), so on y faces g_x lands on v and g_y on u
-  if (g.grav_on) {
+  if (GF || g.grav_on) {
     double gx, gy, gz;
-    half_dt_gravity(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, m, gx, gy, gz);
     o.u += gx; o.v += gy;
   }
   o.a = bn; o.b = bt;
@@ -155,7 +155,7 @@ RG_DEVFN Prim8 face_state2d(const DevParams& g, const double* __restrict__ T, un
 }
 
 // qEdge of cell m at corner (SX,SY) (trace_mhd.h:291-337), grid frame (= the edge frame of emfZ)
-template <int SX, int SY>
+template <int SX, int SY, bool GF>
 RG_DEVFN Prim8 edge_state2d(const DevParams& g, const double* __restrict__ T, unsigned m) {
   const size_t N = g.ncell;
   const double* t = T + m;
@@ -165,9 +165,9 @@ RG_DEVFN Prim8 edge_state2d(const DevParams& g, const double* __restrict__ T, un
   o.p = t[T2_P * N] + (sx * t[(T2_DX + 1) * N] + sy * t[(T2_DY + 1) * N]);
   o.u = t[T2_U * N] + (sx * t[(T2_DX + 2) * N] + sy * t[(T2_DY + 2) * N]);
   o.v = t[T2_V * N] + (sx * t[(T2_DX + 3) * N] + sy * t[(T2_DY + 3) * N]);
-  if (g.grav_on) {   // (mhd_godunov_unsplit_cpu_v0.cpp:514-524)
+  if (GF || g.grav_on) {   // (mhd_godunov_unsplit_cpu_v0.cpp:514-524)
     double gx, gy, gz;
-    half_dt_gravity(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, m, gx, gy, gz);
     o.u += gx; o.v += gy;
   }
   o.w = t[T2_W * N] + (sx * t[(T2_DX + 4) * N] + sy * t[(T2_DY + 4) * N]);
@@ -180,6 +180,7 @@ RG_DEVFN Prim8 edge_state2d(const DevParams& g, const double* __restrict__ T, un
   return o;
 }
 
+template <bool GF>
 RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F, unsigned idx) {
   const IJK c = unflatten(g, idx);
   if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw) return;
@@ -190,7 +191,7 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
   // shear advection of the mean normal field left in the states by the Riemann solver, emfZ its upwind term
   const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
   {
-    Prim8 L = face_state2d<XD, +1>(g, T, idx - 1), R = face_state2d<XD, -1>(g, T, idx);
+    Prim8 L = face_state2d<XD, +1, GF>(g, T, idx - 1), R = face_state2d<XD, -1, GF>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
@@ -202,7 +203,7 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
     F[idx + (size_t)(F2_X + 3) * N] = fl[IV]; F[idx + (size_t)(F2_X + 4) * N] = fl[IW]; F[idx + (size_t)(F2_X + 5) * N] = fl[IC];
   }
   {
-    Prim8 L = face_state2d<YD, +1>(g, T, idx - sj), R = face_state2d<YD, -1>(g, T, idx);
+    Prim8 L = face_state2d<YD, +1, GF>(g, T, idx - sj), R = face_state2d<YD, -1, GF>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
@@ -214,14 +215,15 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
     F[idx + (size_t)(F2_Y + 3) * N] = fl[IV]; F[idx + (size_t)(F2_Y + 4) * N] = fl[IW]; F[idx + (size_t)(F2_Y + 5) * N] = fl[IC];
   }
   {
-    const Prim8 rt = edge_state2d<+1, +1>(g, T, idx - 1 - sj), rb = edge_state2d<+1, -1>(g, T, idx - 1);
-    const Prim8 lt = edge_state2d<-1, +1>(g, T, idx - sj), lb = edge_state2d<-1, -1>(g, T, idx);
+    const Prim8 rt = edge_state2d<+1, +1, GF>(g, T, idx - 1 - sj), rb = edge_state2d<+1, -1, GF>(g, T, idx - 1);
+    const Prim8 lt = edge_state2d<-1, +1, GF>(g, T, idx - sj), lb = edge_state2d<-1, -1, GF>(g, T, idx);
     F[idx + (size_t)F2_EMF * N] = edge_emf<2>(g, rt, rb, lt, lb, xPos);
   }
 }
 
 // The reference's 2D update has no guards (it also scribbles on ghost cells that the next ghost fill
 // overwrites); only interior cells and the CT range are reproduced, everything else is copied.
+template <bool GF>
 RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
                                 double* __restrict__ Unew, const double* __restrict__ F, double dt, double dtdx, double dtdy,
                                 unsigned idx) {
@@ -272,10 +274,10 @@ RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const doub
       u[IW] -= f[4] * dtdy; u[IC] -= f[5] * dtdy;
     }
 #undef RG_LOADF2
-    if (g.grav_on) {  // momentum source (mhd_godunov_unsplit_cpu_v0.cpp:616-618)
+    if (GF || g.grav_on) {  // momentum source (mhd_godunov_unsplit_cpu_v0.cpp:616-618)
       const double rho_sum = Uold[idx + ID * N] + u[ID];
       double gx, gy, gz;
-      half_dt_gravity(g, idx, gx, gy, gz);
+      half_dt_gravity<GF>(g, idx, gx, gy, gz);
       u[IU] += gx * rho_sum;
       u[IV] += gy * rho_sum;
     }

@@ -238,7 +238,7 @@ RG_DEVFN void floor3d(const DevParams& g, Prim8& s) {
 
 // Face state of cell m in direction D, in the face-NORMAL frame.  SIDE=+1: the reference's qm[D] (state at the
 // HIGH face of m, the LEFT state of face m+1); SIDE=-1: qp[D] (state at the LOW face of m, the RIGHT state).
-template <int D, int SIDE>
+template <int D, int SIDE, bool GF>
 RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
   const size_t N = g.ncell;
   const unsigned sD = (D == XD) ? 1u : (D == YD) ? g.sj : g.sk;
@@ -250,9 +250,9 @@ RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, un
   double u = t[T_U * N] + s * t[(S + 2) * N];
   double v = t[T_V * N] + s * t[(S + 3) * N];
   double w = t[T_W * N] + s * t[(S + 4) * N];
-  if (g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:277-290)
+  if (GF || g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:277-290)
     double gx, gy, gz;
-    half_dt_gravity(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, m, gx, gy, gz);
     u += gx; v += gy; w += gz;
   }
   // normal field: the advanced face value (own low face, or the +1 neighbour's low face for the high side)
@@ -276,7 +276,7 @@ RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, un
 // Edge state of cell m for the edge along direction EDIR (0=x,1=y,2=z), at the corner given by the signs
 // (S1,S2) along the two transverse directions (t1,t2) = (y,z) | (z,x) | (x,y), returned in the EDGE frame
 // (u,v,w / a,b,c = components along t1, t2, e).  Reproduces qEdge of trace_mhd.h:2104-2246.
-template <int EDIR, int S1, int S2>
+template <int EDIR, int S1, int S2, bool GF>
 RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
   const size_t N = g.ncell;
   const int t1 = (EDIR + 1) % 3, t2 = (EDIR + 2) % 3;
@@ -298,9 +298,9 @@ RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, un
   vel[0] = RG_EDGE_SUM(t[T_U * N], 2, 2);
   vel[1] = RG_EDGE_SUM(t[T_V * N], 3, 3);
   vel[2] = RG_EDGE_SUM(t[T_W * N], 4, 4);
-  if (g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:292-330)
+  if (GF || g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:292-330)
     double gx, gy, gz;
-    half_dt_gravity(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, m, gx, gy, gz);
     vel[0] += gx; vel[1] += gy; vel[2] += gz;
   }
   // the field component along the edge is cell centred; its slope slot inside a direction group:
@@ -340,7 +340,7 @@ RG_DEVFN void store_flux(const DevParams& g, double* __restrict__ F, unsigned id
   for (int v = 0; v < 5; ++v) RG_STREAM_STORE(&F[idx + (size_t)(base + v) * N], fl[v]);
 }
 
-template <int MASK>
+template <int MASK, bool GF>
 RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F,
                               double* __restrict__ emf, unsigned idx) {
   const IJK c = unflatten(g, idx);
@@ -350,14 +350,14 @@ RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, 
   const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
   double fl[8];
   if (MASK & DO_FLUX_X) {
-    Prim8 L = face_state3d<XD, +1>(g, T, idx - 1), R = face_state3d<XD, -1>(g, T, idx);
+    Prim8 L = face_state3d<XD, +1, GF>(g, T, idx - 1), R = face_state3d<XD, -1, GF>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
     store_flux<XD>(g, F, idx, fl);
   }
   if (MASK & DO_FLUX_Y) {
-    Prim8 L = face_state3d<YD, +1>(g, T, idx - sj), R = face_state3d<YD, -1>(g, T, idx);
+    Prim8 L = face_state3d<YD, +1, GF>(g, T, idx - sj), R = face_state3d<YD, -1, GF>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
@@ -379,7 +379,7 @@ RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, 
     store_flux<YD>(g, F, idx, fl);
   }
   if (MASK & DO_FLUX_Z) {
-    Prim8 L = face_state3d<ZD, +1>(g, T, idx - sk), R = face_state3d<ZD, -1>(g, T, idx);
+    Prim8 L = face_state3d<ZD, +1, GF>(g, T, idx - sk), R = face_state3d<ZD, -1, GF>(g, T, idx);
 #pragma unroll
     for (int v = 0; v < 8; ++v) fl[v] = 0.0;
     mhd_riemann(g, L, R, fl);
@@ -387,18 +387,18 @@ RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, 
   }
   // EMFs: slot order (RT, RB, LT, LB) = (+,+) from c-t1-t2, (+,-) from c-t1, (-,+) from c-t2, (-,-) from c
   if (MASK & DO_EMF_Z) {  // t1 = x, t2 = y
-    const Prim8 rt = edge_state3d<2, +1, +1>(g, T, idx - 1 - sj), rb = edge_state3d<2, +1, -1>(g, T, idx - 1);
-    const Prim8 lt = edge_state3d<2, -1, +1>(g, T, idx - sj), lb = edge_state3d<2, -1, -1>(g, T, idx);
+    const Prim8 rt = edge_state3d<2, +1, +1, GF>(g, T, idx - 1 - sj), rb = edge_state3d<2, +1, -1, GF>(g, T, idx - 1);
+    const Prim8 lt = edge_state3d<2, -1, +1, GF>(g, T, idx - sj), lb = edge_state3d<2, -1, -1, GF>(g, T, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_Y) {  // t1 = z, t2 = x
-    const Prim8 rt = edge_state3d<1, +1, +1>(g, T, idx - sk - 1), rb = edge_state3d<1, +1, -1>(g, T, idx - sk);
-    const Prim8 lt = edge_state3d<1, -1, +1>(g, T, idx - 1), lb = edge_state3d<1, -1, -1>(g, T, idx);
+    const Prim8 rt = edge_state3d<1, +1, +1, GF>(g, T, idx - sk - 1), rb = edge_state3d<1, +1, -1, GF>(g, T, idx - sk);
+    const Prim8 lt = edge_state3d<1, -1, +1, GF>(g, T, idx - 1), lb = edge_state3d<1, -1, -1, GF>(g, T, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_X) {  // t1 = y, t2 = z
-    const Prim8 rt = edge_state3d<0, +1, +1>(g, T, idx - sj - sk), rb = edge_state3d<0, +1, -1>(g, T, idx - sj);
-    const Prim8 lt = edge_state3d<0, -1, +1>(g, T, idx - sk), lb = edge_state3d<0, -1, -1>(g, T, idx);
+    const Prim8 rt = edge_state3d<0, +1, +1, GF>(g, T, idx - sj - sk), rb = edge_state3d<0, +1, -1, GF>(g, T, idx - sj);
+    const Prim8 lt = edge_state3d<0, -1, +1, GF>(g, T, idx - sk), lb = edge_state3d<0, -1, -1, GF>(g, T, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, rt, rb, lt, lb, xPos));
   }
 }
@@ -478,7 +478,7 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
 // ------------------------------------------------------------------------------------------------------------
 struct RotCoef { double lambda, ratio, alpha1, alpha2; };  // MHDRunGodunov.cpp:2039-2053
 
-template <bool ROT>
+template <bool ROT, bool GF>
 RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
                                 double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
                                 const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
@@ -542,10 +542,10 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
     else { u[IU] -= f[IW] * dtdz; u[IV] -= f[IV] * dtdz; }
     u[IW] -= f[IU] * dtdz;
 #undef RG_LOADF
-    if (g.grav_on) {  // momentum source before the shear remap of the density (MHDRunGodunov.cpp:3190-3192)
+    if (GF || g.grav_on) {  // momentum source before the shear remap of the density (MHDRunGodunov.cpp:3190-3192)
       const double rho_sum = Uold[idx + ID * N] + u[ID];
       double gx, gy, gz;
-      half_dt_gravity(g, idx, gx, gy, gz);
+      half_dt_gravity<GF>(g, idx, gx, gy, gz);
       u[IU] += gx * rho_sum;
       u[IV] += gy * rho_sum;
       u[IW] += gz * rho_sum;

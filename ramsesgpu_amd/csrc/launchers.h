@@ -20,15 +20,16 @@ struct K_hydro_trace {
   DevParams g; const double* Q; double* T; double dtdx, dtdy, dtdz;
   RG_DEVFN void operator()(unsigned idx) const { hydro_trace_cell<ND, NV>(g, Q, T, dtdx, dtdy, dtdz, idx); }
 };
-template <int ND, int NV>
+// GF: per-cell gravity field (DevParams::G) instead of the uniform vector, see half_dt_gravity
+template <int ND, int NV, bool GF = false>
 struct K_hydro_flux {
   DevParams g; const double* T; double* F;
-  RG_DEVFN void operator()(unsigned idx) const { hydro_flux_cell<ND, NV>(g, T, F, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { hydro_flux_cell<ND, NV, GF>(g, T, F, idx); }
 };
-template <int ND, int NV>
+template <int ND, int NV, bool GF = false>
 struct K_hydro_update {
   DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { hydro_update_cell<ND, NV>(g, Uold, Unew, F, dtdx, dtdy, dtdz, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { hydro_update_cell<ND, NV, GF>(g, Uold, Unew, F, dtdx, dtdy, dtdz, idx); }
 };
 template <int NV>
 struct K_hydro_invdt {
@@ -86,13 +87,15 @@ struct K_mhd_trace2d {
   DevParams g; const double* U; const double* Q; double* T; double dtdx, dtdy;
   RG_DEVFN void operator()(unsigned idx) const { mhd_trace2d_cell(g, U, Q, T, dtdx, dtdy, idx); }
 };
+template <bool GF = false>
 struct K_mhd_flux2d {
   DevParams g; const double* T; double* F;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_flux2d_cell(g, T, F, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { mhd_flux2d_cell<GF>(g, T, F, idx); }
 };
+template <bool GF = false>
 struct K_mhd_update2d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; double dt, dtdx, dtdy;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell<GF>(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx); }
 };
 struct K_mhd_elec {
   DevParams g; const double* U; const double* Q; double* E;
@@ -102,10 +105,10 @@ struct K_mhd_trace3d {
   DevParams g; const double* U; const double* Q; const double* E; double* T; double dtdx, dtdy, dtdz;
   RG_DEVFN void operator()(unsigned idx) const { mhd_trace3d_cell(g, U, Q, E, T, dtdx, dtdy, dtdz, idx); }
 };
-template <int MASK>
+template <int MASK, bool GF = false>
 struct K_mhd_flux3d {
   DevParams g; const double* T; double* F; double* emf;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK>(g, T, F, emf, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK, GF>(g, T, F, emf, idx); }
 };
 struct K_forcing_rows {
   DevParams g; const double* U; const double* Frc; double* rows;
@@ -127,11 +130,11 @@ struct K_shear_remap {
   DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx;
   RG_DEVFN void operator()(unsigned idx) const { shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx); }
 };
-template <bool ROT>
+template <bool ROT, bool GF = false>
 struct K_mhd_update3d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
   double dt, dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_update3d_cell<ROT>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------

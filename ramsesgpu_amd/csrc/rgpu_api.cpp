@@ -378,8 +378,19 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   const int ks = g.ksize;
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 1, b + 1, ks), k)) return -1; }
-  { Phase ph(c, RGPU_T_FLUX); K_hydro_flux<ND, NV> k = {g, c->T, c->F}; if (launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1; }
-  { Phase ph(c, RGPU_T_UPDATE); K_hydro_update<ND, NV> k = {g, in, out, c->F, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), k)) return -1; }
+  const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
+  {
+    Phase ph(c, RGPU_T_FLUX);
+    K_hydro_flux<ND, NV, false> k = {g, c->T, c->F};
+    K_hydro_flux<ND, NV, true> kg = {g, c->T, c->F};
+    if (gf ? launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), kg) : launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1;
+  }
+  {
+    Phase ph(c, RGPU_T_UPDATE);
+    K_hydro_update<ND, NV, false> k = {g, in, out, c->F, dtdx, dtdy, dtdz};
+    K_hydro_update<ND, NV, true> kg = {g, in, out, c->F, dtdx, dtdy, dtdz};
+    if (gf ? launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), kg) : launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), k)) return -1;
+  }
   return 0;
 }
 
@@ -403,8 +414,19 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   const RotCoef rc = rot_coef(c, dt);
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_FLUX); K_mhd_flux2d k = {g, c->T, c->F}; if (rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1; }
-  { Phase ph(c, RGPU_T_UPDATE); K_mhd_update2d k = {g, rc, in, out, c->F, dt, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  const bool gf = g.grav_on == 2;
+  {
+    Phase ph(c, RGPU_T_FLUX);
+    K_mhd_flux2d<false> k = {g, c->T, c->F};
+    K_mhd_flux2d<true> kg = {g, c->T, c->F};
+    if (gf ? rg_launch<kBlockHeavy>(c->stream, c->n32, kg) : rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1;
+  }
+  {
+    Phase ph(c, RGPU_T_UPDATE);
+    K_mhd_update2d<false> k = {g, rc, in, out, c->F, dt, dtdx, dtdy};
+    K_mhd_update2d<true> kg = {g, rc, in, out, c->F, dt, dtdx, dtdy};
+    if (gf ? rg_launch<kBlock>(c->stream, c->n32, kg) : rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
+  }
   return 0;
 }
 
@@ -435,17 +457,25 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // traced states T, and T is 60 % of the step's HBM traffic.  (Two launches -- 128 VGPRs / 4 waves per SIMD for the
   // faces, 205 / 2 for the edges -- were faster while the solvers were purely VALU bound; after the shared-reciprocal
   // rewrite and the XCD-aware order the second read of T costs more: 64.4 -> 60.9 ms/step at 512^3.)
-  K_mhd_flux3d<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z | DO_EMF_X | DO_EMF_Y | DO_EMF_Z> k_riemann = {g, c->T, c->F, c->emf};
+  K_mhd_flux3d<DO_ALL, false> k_riemann = {g, c->T, c->F, c->emf};
+  K_mhd_flux3d<DO_ALL, true> k_riemann_gf = {g, c->T, c->F, c->emf};   // per-cell gravity field (see half_dt_gravity)
+  const bool gf = g.grav_on == 2;
+  auto riemann_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+    return gf ? launch_planes<kBlockHeavy, 1>(s, g, r, k_riemann_gf) : launch_planes<kBlockHeavy, 1>(s, g, r, k_riemann);
+  };
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
-  K_mhd_update3d<true> k_upd_rot = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-  K_mhd_update3d<false> k_upd = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+  K_mhd_update3d<true, false> k_upd_rot = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+  K_mhd_update3d<false, false> k_upd = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+  K_mhd_update3d<true, true> k_upd_rot_gf = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
+  K_mhd_update3d<false, true> k_upd_gf = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
   auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
     if (!shear || r.hi <= r.lo) return 0;
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
     return rg_launch_range<kBlock>(s, j0, jn, k_ssave) || rg_launch_range<kBlock>(s, j0, jn, k_sremap);
   };
   auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+    if (gf) return g.rot ? launch_planes<kBlock, 1>(s, g, r, k_upd_rot_gf) : launch_planes<kBlock, 1>(s, g, r, k_upd_gf);
     return g.rot ? launch_planes<kBlock, 1>(s, g, r, k_upd_rot) : launch_planes<kBlock, 1>(s, g, r, k_upd);
   };
 
@@ -455,7 +485,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     { Phase ph(c, RGPU_T_PRIM); if (launch_planes<kBlock, 1>(s, g, clip(a - 2, b + 2, ks), k_prim)) return -1; }
     { Phase ph(c, RGPU_T_ELEC); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 2, ks), k_elec)) return -1; }
     { Phase ph(c, RGPU_T_TRACE); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 1, ks), k_trace)) return -1; }
-    { Phase ph(c, RGPU_T_FLUX); if (launch_planes<kBlockHeavy, 1>(s, g, clip(a, b + 1, ks), k_riemann)) return -1; }
+    { Phase ph(c, RGPU_T_FLUX); if (riemann_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
     return 0;
@@ -481,7 +511,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_trace = kb + 1;
       if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
       const PlaneRange rf = clip(d_flux, kb + 1, ks);
-      if (launch_planes<kBlockHeavy, 1>(sa, g, rf, k_riemann)) return -1;
+      if (riemann_planes(sa, rf)) return -1;
       if (shear_planes(sa, rf)) return -1;
       d_flux = kb + 1;
       if (rg_event_record(c->ev_flux[ci], sa)) return -1;

@@ -11,7 +11,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
 PHASE = [("K_mhd_invdt", "dt"), ("K_mhd_prim", "prim"), ("K_mhd_elec", "elec"), ("K_mhd_trace3d", "trace"),
-         ("K_mhd_flux3d<63>", "flux"), ("K_mhd_flux3d<7>", "flux"), ("K_mhd_flux3d<56>", "emf"), ("K_mhd_update3d", "update"),
+         ("K_mhd_flux3d<63", "flux"), ("K_mhd_flux3d<7>", "flux"), ("K_mhd_flux3d<56>", "emf"), ("K_mhd_update3d", "update"),
          ("K_shear_save_emf", "shear"), ("K_shear_remap", "shear"), ("K_shear_ghost", "boundaries"), ("K_bc_face", "boundaries")]
 
 
