@@ -10,6 +10,8 @@
 #include <string>
 
 #define RG_DEVFN __device__ __forceinline__
+// promise to the optimiser about a launch-uniform parameter (kernels specialised at launch, see launchers.h)
+#define RG_ASSUME(cond) __builtin_assume(cond)
 #define RG_BACKEND_NAME "hip-gfx950"
 // store of a value that is not read again before it has left the caches (T, F, emf, the new state): nontemporal,
 // so that it does not evict the stencil neighbourhood the same XCD re-reads from its L2

@@ -9,6 +9,42 @@
 
 namespace rgpu_dev {
 
+// Launch-time specialisation of the 3D MHD kernels (SPEC template parameter of the functors below).  Solver choice, equation of state, rotating frame and gravity are
+// the same for every cell of a launch; left as run-time tests they cut the solvers' straight-line code into ~85 basic
+// blocks and keep every variant's registers allocated.  SPEC tells the optimiser what the host has checked
+// (spec_matches), everything else still comes from DevParams: 35.9 -> 28.8 ms for the 512^3 MRI launch.
+enum {
+  SPEC_NONE = 0,
+  SPEC_HLLD = 1,        // riemannSolver = hlld and magRiemannSolver = hlld
+  SPEC_ISOTHERMAL = 2,  // cIso > 0
+  SPEC_ADIABATIC = 4,   // cIso <= 0
+  SPEC_ROTATING = 8,    // Omega0 > 0
+  SPEC_INERTIAL = 16,   // Omega0 <= 0
+  SPEC_NO_GRAVITY = 32,
+  SPEC_SLOPE2 = 64      // slope_type = 2 (and with it the capped face-field slope type)
+};
+template <int SPEC>
+RG_DEVFN void spec_assume(const DevParams& g) {
+  if (SPEC & SPEC_HLLD) { RG_ASSUME(g.riemannSolver == 3); RG_ASSUME(g.magRiemannSolver == 0); }
+  if (SPEC & SPEC_ISOTHERMAL) RG_ASSUME(g.cIso > 0);
+  if (SPEC & SPEC_ADIABATIC) RG_ASSUME(!(g.cIso > 0));
+  if (SPEC & SPEC_ROTATING) { RG_ASSUME(g.rot == 1); RG_ASSUME(g.Omega0 > 0); }
+  if (SPEC & SPEC_INERTIAL) { RG_ASSUME(g.rot == 0); RG_ASSUME(!(g.Omega0 > 0)); }
+  if (SPEC & SPEC_NO_GRAVITY) RG_ASSUME(g.grav_on == 0);
+  if (SPEC & SPEC_SLOPE2) { RG_ASSUME(g.slope_type == 2.0); RG_ASSUME(g.mag_slope_type == 2.0); }
+}
+inline bool spec_matches(int spec, const DevParams& g) {
+  if ((spec & SPEC_HLLD) && !(g.riemannSolver == 3 && g.magRiemannSolver == 0)) return false;
+  if ((spec & SPEC_ISOTHERMAL) && !(g.cIso > 0)) return false;
+  if ((spec & SPEC_ADIABATIC) && (g.cIso > 0)) return false;
+  if ((spec & SPEC_ROTATING) && !(g.rot == 1 && g.Omega0 > 0)) return false;
+  if ((spec & SPEC_INERTIAL) && !(g.rot == 0 && !(g.Omega0 > 0))) return false;
+  if ((spec & SPEC_NO_GRAVITY) && g.grav_on != 0) return false;
+  if ((spec & SPEC_SLOPE2) && !(g.slope_type == 2.0 && g.mag_slope_type == 2.0)) return false;
+  return true;
+}
+
+
 // ---- hydro -----------------------------------------------------------------------------------------------------
 template <int NV>
 struct K_hydro_prim {
@@ -38,13 +74,15 @@ struct K_hydro_invdt {
 };
 
 // ---- MHD -------------------------------------------------------------------------------------------------------
+template <int SPEC = SPEC_NONE>
 struct K_mhd_prim {
   DevParams g; const double* U; double* Q; double dt;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_prim_cell(g, U, Q, dt, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_prim_cell(g, U, Q, dt, idx); }
 };
+template <int SPEC = SPEC_NONE>
 struct K_mhd_invdt {
   DevParams g; const double* U;
-  RG_DEVFN double operator()(unsigned idx) const { return mhd_invdt_cell(g, U, idx); }
+  RG_DEVFN double operator()(unsigned idx) const { spec_assume<SPEC>(g); return mhd_invdt_cell(g, U, idx); }
 };
 template <int ND>
 struct K_visc_flux {
@@ -97,18 +135,23 @@ struct K_mhd_update2d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; double dt, dtdx, dtdy;
   RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell<GF>(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx); }
 };
+template <int SPEC = SPEC_NONE>
 struct K_mhd_elec {
   DevParams g; const double* U; const double* Q; double* E;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_elec_cell(g, U, Q, E, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_elec_cell(g, U, Q, E, idx); }
 };
+template <int SPEC = SPEC_NONE>
 struct K_mhd_trace3d {
   DevParams g; const double* U; const double* Q; const double* E; double* T; double dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_trace3d_cell(g, U, Q, E, T, dtdx, dtdy, dtdz, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_trace3d_cell(g, U, Q, E, T, dtdx, dtdy, dtdz, idx); }
 };
-template <int MASK, bool GF = false>
+template <int MASK, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_flux3d {
   DevParams g; const double* T; double* F; double* emf;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_flux3d_cell<MASK, GF>(g, T, F, emf, idx); }
+  RG_DEVFN void operator()(unsigned idx) const {
+    spec_assume<SPEC>(g);
+    mhd_flux3d_cell<MASK, GF>(g, T, F, emf, idx);
+  }
 };
 struct K_forcing_rows {
   DevParams g; const double* U; const double* Frc; double* rows;
@@ -130,11 +173,11 @@ struct K_shear_remap {
   DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx;
   RG_DEVFN void operator()(unsigned idx) const { shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx); }
 };
-template <bool ROT, bool GF = false>
+template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_update3d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
   double dt, dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------

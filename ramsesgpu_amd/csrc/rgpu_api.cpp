@@ -412,7 +412,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   const RotCoef rc = rot_coef(c, dt);
-  { Phase ph(c, RGPU_T_PRIM); K_mhd_prim k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
+  { Phase ph(c, RGPU_T_PRIM); K_mhd_prim<> k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   const bool gf = g.grav_on == 2;
   {
@@ -429,6 +429,25 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   }
   return 0;
 }
+
+// Launch-time specialisations of the 3D MHD kernels (launchers.h): the isothermal rotating box (MRI) and the adiabatic
+// inertial one, both with the HLLD pair, slope type 2 and no gravity; everything else runs the generic kernels.
+const int kSpecMri = SPEC_HLLD | SPEC_ISOTHERMAL | SPEC_ROTATING | SPEC_NO_GRAVITY | SPEC_SLOPE2;
+const int kSpecPlain = SPEC_HLLD | SPEC_ADIABATIC | SPEC_INERTIAL | SPEC_NO_GRAVITY | SPEC_SLOPE2;
+inline int pick_spec(const DevParams& g) {
+  static const bool off = std::getenv("RGPU_NO_SPEC") != 0;
+  return off ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
+}
+template <template <int> class K, int BLOCK, class... A>
+int launch_spec(int spec, rg_stream_t s, const DevParams& g, PlaneRange r, A... a) {
+  if (spec == 1) { K<kSpecMri> k = {g, a...}; return launch_planes<BLOCK, 1>(s, g, r, k); }
+  if (spec == 2) { K<kSpecPlain> k = {g, a...}; return launch_planes<BLOCK, 1>(s, g, r, k); }
+  K<SPEC_NONE> k = {g, a...};
+  return launch_planes<BLOCK, 1>(s, g, r, k);
+}
+template <int S> using K_riemann_t = K_mhd_flux3d<DO_ALL, false, S>;
+template <int S> using K_upd_rot_t = K_mhd_update3d<true, false, S>;
+template <int S> using K_upd_t = K_mhd_update3d<false, false, S>;
 
 // 3D MHD: complete the update of planes [a,b).  The range is swept in chunks of ~8 planes; the HBM-bound stages
 // (prim, elec, trace, update) go to the context stream, the fp64-VALU-bound Riemann stages (flux, emf) to a second
@@ -450,41 +469,44 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     sr.eps_min = 1.0 - epsi / p.dy;
     sr.eps_max = epsi / p.dy;
   }
-  K_mhd_prim k_prim = {g, in, c->Q, dt};
-  K_mhd_elec k_elec = {g, in, c->Q, c->E};
-  K_mhd_trace3d k_trace = {g, in, c->Q, c->E, c->T, dtdx, dtdy, dtdz};
-  // One launch for the three face (HLLD) and the three edge (2D HLLD) Riemann problems of a cell: they read the same
-  // traced states T, and T is 60 % of the step's HBM traffic.  (Two launches -- 128 VGPRs / 4 waves per SIMD for the
+  // (one launch for the three face (HLLD) and the three edge (2D HLLD) Riemann problems of a cell: they read the same
+  // traced states T, and T is 60 % of the step's HBM traffic.  Two launches -- 128 VGPRs / 4 waves per SIMD for the
   // faces, 205 / 2 for the edges -- were faster while the solvers were purely VALU bound; after the shared-reciprocal
   // rewrite and the XCD-aware order the second read of T costs more: 64.4 -> 60.9 ms/step at 512^3.)
-  K_mhd_flux3d<DO_ALL, false> k_riemann = {g, c->T, c->F, c->emf};
-  K_mhd_flux3d<DO_ALL, true> k_riemann_gf = {g, c->T, c->F, c->emf};   // per-cell gravity field (see half_dt_gravity)
-  const bool gf = g.grav_on == 2;
+  const bool gf = g.grav_on == 2;   // per-cell gravity field: its own instantiations (see half_dt_gravity)
+  const int spec = gf ? 0 : pick_spec(g);
+  const double* Q = c->Q; const double* E = c->E; const double* T = c->T; const double* F = c->F; const double* emf = c->emf;
+  const double* remap = c->shear_remap;
+  auto prim_planes = [&](rg_stream_t s, PlaneRange r) -> int { return launch_spec<K_mhd_prim, kBlock>(spec, s, g, r, in, c->Q, dt); };
+  auto elec_planes = [&](rg_stream_t s, PlaneRange r) -> int { return launch_spec<K_mhd_elec, kBlock>(spec, s, g, r, in, Q, c->E); };
+  auto trace_planes = [&](rg_stream_t s, PlaneRange r) -> int { return launch_spec<K_mhd_trace3d, kBlock>(spec, s, g, r, in, Q, E, c->T, dtdx, dtdy, dtdz); };
   auto riemann_planes = [&](rg_stream_t s, PlaneRange r) -> int {
-    return gf ? launch_planes<kBlockHeavy, 1>(s, g, r, k_riemann_gf) : launch_planes<kBlockHeavy, 1>(s, g, r, k_riemann);
+    if (gf) { K_mhd_flux3d<DO_ALL, true> k = {g, T, c->F, c->emf}; return launch_planes<kBlockHeavy, 1>(s, g, r, k); }
+    return launch_spec<K_riemann_t, kBlockHeavy>(spec, s, g, r, T, c->F, c->emf);
   };
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
-  K_mhd_update3d<true, false> k_upd_rot = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-  K_mhd_update3d<false, false> k_upd = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-  K_mhd_update3d<true, true> k_upd_rot_gf = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
-  K_mhd_update3d<false, true> k_upd_gf = {g, rc, in, out, c->F, c->emf, c->shear_remap, dt, dtdx, dtdy, dtdz};
   auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
     if (!shear || r.hi <= r.lo) return 0;
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
     return rg_launch_range<kBlock>(s, j0, jn, k_ssave) || rg_launch_range<kBlock>(s, j0, jn, k_sremap);
   };
   auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
-    if (gf) return g.rot ? launch_planes<kBlock, 1>(s, g, r, k_upd_rot_gf) : launch_planes<kBlock, 1>(s, g, r, k_upd_gf);
-    return g.rot ? launch_planes<kBlock, 1>(s, g, r, k_upd_rot) : launch_planes<kBlock, 1>(s, g, r, k_upd);
+    if (gf) {
+      K_mhd_update3d<true, true> kr = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz};
+      K_mhd_update3d<false, true> kp = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz};
+      return g.rot ? launch_planes<kBlock, 1>(s, g, r, kr) : launch_planes<kBlock, 1>(s, g, r, kp);
+    }
+    return g.rot ? launch_spec<K_upd_rot_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz)
+                 : launch_spec<K_upd_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz);
   };
 
   const bool serial = c->timers_on || c->nchunks <= 1 || (b - a) < 16;
   if (serial) {
     rg_stream_t s = c->stream;
-    { Phase ph(c, RGPU_T_PRIM); if (launch_planes<kBlock, 1>(s, g, clip(a - 2, b + 2, ks), k_prim)) return -1; }
-    { Phase ph(c, RGPU_T_ELEC); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 2, ks), k_elec)) return -1; }
-    { Phase ph(c, RGPU_T_TRACE); if (launch_planes<kBlock, 1>(s, g, clip(a - 1, b + 1, ks), k_trace)) return -1; }
+    { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
+    { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+    { Phase ph(c, RGPU_T_TRACE); if (trace_planes(s, clip(a - 1, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_FLUX); if (riemann_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
@@ -503,11 +525,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   for (int ci = 0; ci <= C; ++ci) {
     if (ci < C) {
       const int kb = (ci + 1 == C) ? b : a + (int)(((long long)span * (ci + 1)) / C);
-      if (launch_planes<kBlock, 1>(sm, g, clip(d_prim, kb + 2, ks), k_prim)) return -1;
+      if (prim_planes(sm, clip(d_prim, kb + 2, ks))) return -1;
       d_prim = kb + 2;
-      if (launch_planes<kBlock, 1>(sm, g, clip(d_elec, kb + 2, ks), k_elec)) return -1;
+      if (elec_planes(sm, clip(d_elec, kb + 2, ks))) return -1;
       d_elec = kb + 2;
-      if (launch_planes<kBlock, 1>(sm, g, clip(d_trace, kb + 1, ks), k_trace)) return -1;
+      if (trace_planes(sm, clip(d_trace, kb + 1, ks))) return -1;
       d_trace = kb + 1;
       if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
       const PlaneRange rf = clip(d_flux, kb + 1, ks);
@@ -600,7 +622,13 @@ int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
 int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) {
   Phase ph(c, RGPU_T_DT);
   const double* U = c->U[parity & 1];
-  if (c->p.mhdEnabled) { K_mhd_invdt k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
+  if (c->p.mhdEnabled) {
+    const int spec = c->g.three_d ? pick_spec(c->g) : 0;
+    if (spec == 1) { K_mhd_invdt<kSpecMri> k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
+    if (spec == 2) { K_mhd_invdt<kSpecPlain> k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
+    K_mhd_invdt<> k = {c->g, U};
+    return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset);
+  }
   if (c->g.three_d) { K_hydro_invdt<5> k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
   K_hydro_invdt<4> k = {c->g, U};
   return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset);

@@ -15,6 +15,7 @@
 #define RG_DEVFN inline
 #define RG_BACKEND_NAME "host-emulation(test-only)"
 #define RG_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#define RG_ASSUME(cond) ((void)0)
 
 namespace rgpu_dev {
 using std::signbit;
