@@ -2,6 +2,7 @@
 // Thin layer between the step driver (rgpu_api.cpp) and the HIP runtime: kernel launch of per-cell functors on a
 // flat 1D grid, a wave64 max-reduction for the CFL scan, device memory and event helpers.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -151,7 +152,8 @@ inline int rg_launch_planes(rg_stream_t s, unsigned idx0, unsigned plane_cells, 
   const unsigned nsub = (m.band + T - 1) / T;
   m.T = (m.band + nsub - 1) / nsub;   // equal sub-bands: at most nsub-1 idle workgroup slots per band
   const unsigned grid = 8u * nsub * nplanes * m.T;
-  hipLaunchKernelGGL((rg_kernel_planes<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, m, k);
+  static const unsigned lds_pad = std::getenv("RGPU_HEAVY_LDS") ? (unsigned)std::atoi(std::getenv("RGPU_HEAVY_LDS")) : 0u;   // experiment
+  hipLaunchKernelGGL((rg_kernel_planes<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), BLOCK == 64 ? lds_pad : 0u, s, m, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -9,8 +9,8 @@
 
 namespace rgpu_dev {
 
-// Launch-time specialisation of the 3D MHD kernels (SPEC template parameter of the functors below).  Solver choice, equation of state, rotating frame and gravity are
-// the same for every cell of a launch; left as run-time tests they cut the solvers' straight-line code into ~85 basic
+// Launch-time specialisation of the heavy kernels (SPEC template parameter of the functors below).  Solver choice,
+// equation of state, rotating frame and gravity are the same for every cell of a launch; left as run-time tests they cut the solvers' straight-line code into ~85 basic
 // blocks and keep every variant's registers allocated.  SPEC tells the optimiser what the host has checked
 // (spec_matches), everything else still comes from DevParams: 35.9 -> 28.8 ms for the 512^3 MRI launch.
 enum {
@@ -21,7 +21,9 @@ enum {
   SPEC_ROTATING = 8,    // Omega0 > 0
   SPEC_INERTIAL = 16,   // Omega0 <= 0
   SPEC_NO_GRAVITY = 32,
-  SPEC_SLOPE2 = 64      // slope_type = 2 (and with it the capped face-field slope type)
+  SPEC_SLOPE2 = 64,     // slope_type = 2 (and with it the capped face-field slope type)
+  SPEC_HYDRO_APPROX = 128, SPEC_HYDRO_HLL = 256, SPEC_HYDRO_HLLC = 512,   // hydro riemannSolver
+  SPEC_SLOPE1 = 1024    // slope_type = 1
 };
 template <int SPEC>
 RG_DEVFN void spec_assume(const DevParams& g) {
@@ -32,6 +34,10 @@ RG_DEVFN void spec_assume(const DevParams& g) {
   if (SPEC & SPEC_INERTIAL) { RG_ASSUME(g.rot == 0); RG_ASSUME(!(g.Omega0 > 0)); }
   if (SPEC & SPEC_NO_GRAVITY) RG_ASSUME(g.grav_on == 0);
   if (SPEC & SPEC_SLOPE2) { RG_ASSUME(g.slope_type == 2.0); RG_ASSUME(g.mag_slope_type == 2.0); }
+  if (SPEC & SPEC_HYDRO_APPROX) RG_ASSUME(g.riemannSolver == 0);
+  if (SPEC & SPEC_HYDRO_HLL) RG_ASSUME(g.riemannSolver == 1);
+  if (SPEC & SPEC_HYDRO_HLLC) RG_ASSUME(g.riemannSolver == 2);
+  if (SPEC & SPEC_SLOPE1) RG_ASSUME(g.slope_type == 1.0);
 }
 inline bool spec_matches(int spec, const DevParams& g) {
   if ((spec & SPEC_HLLD) && !(g.riemannSolver == 3 && g.magRiemannSolver == 0)) return false;
@@ -41,6 +47,10 @@ inline bool spec_matches(int spec, const DevParams& g) {
   if ((spec & SPEC_INERTIAL) && !(g.rot == 0 && !(g.Omega0 > 0))) return false;
   if ((spec & SPEC_NO_GRAVITY) && g.grav_on != 0) return false;
   if ((spec & SPEC_SLOPE2) && !(g.slope_type == 2.0 && g.mag_slope_type == 2.0)) return false;
+  if ((spec & SPEC_HYDRO_APPROX) && g.riemannSolver != 0) return false;
+  if ((spec & SPEC_HYDRO_HLL) && g.riemannSolver != 1) return false;
+  if ((spec & SPEC_HYDRO_HLLC) && g.riemannSolver != 2) return false;
+  if ((spec & SPEC_SLOPE1) && !(g.slope_type == 1.0)) return false;
   return true;
 }
 
@@ -51,16 +61,16 @@ struct K_hydro_prim {
   DevParams g; const double* U; double* Q;
   RG_DEVFN void operator()(unsigned idx) const { hydro_prim_cell<NV>(g, U, Q, idx); }
 };
-template <int ND, int NV>
+template <int ND, int NV, int SPEC = SPEC_NONE>
 struct K_hydro_trace {
   DevParams g; const double* Q; double* T; double dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { hydro_trace_cell<ND, NV>(g, Q, T, dtdx, dtdy, dtdz, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); hydro_trace_cell<ND, NV>(g, Q, T, dtdx, dtdy, dtdz, idx); }
 };
 // GF: per-cell gravity field (DevParams::G) instead of the uniform vector, see half_dt_gravity
-template <int ND, int NV, bool GF = false>
+template <int ND, int NV, bool GF = false, int SPEC = SPEC_NONE>
 struct K_hydro_flux {
   DevParams g; const double* T; double* F;
-  RG_DEVFN void operator()(unsigned idx) const { hydro_flux_cell<ND, NV, GF>(g, T, F, idx); }
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); hydro_flux_cell<ND, NV, GF>(g, T, F, idx); }
 };
 template <int ND, int NV, bool GF = false>
 struct K_hydro_update {

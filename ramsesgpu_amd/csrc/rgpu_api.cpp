@@ -371,15 +371,38 @@ int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
   return rg_launch_planes<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k);
 }
 
+// hydro: launch-time specialisation on the Riemann solver and the slope type (launchers.h); the no-gravity instantiations
+// only, everything else runs the generic kernels
+template <int ND, int NV, int SPEC>
+int hydro_flux_trace_spec(rgpu_ctx* c, double dtdx, double dtdy, double dtdz, int a, int b) {
+  const DevParams& g = c->g;
+  const int ks = g.ksize;
+  { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV, SPEC> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 1, b + 1, ks), k)) return -1; }
+  { Phase ph(c, RGPU_T_FLUX); K_hydro_flux<ND, NV, false, SPEC> k = {g, c->T, c->F}; if (launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1; }
+  return 0;
+}
+
 template <int ND, int NV>
 int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int b) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
   const int ks = g.ksize;
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
-  { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 1, b + 1, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
-  {
+  static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
+  int rc = 1;   // 1 = not handled by a specialisation
+  if (!no_spec && g.grav_on == 0) {
+    const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
+    if (spec_matches(SPEC_HYDRO_APPROX | SL1, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_APPROX | SL1>(c, dtdx, dtdy, dtdz, a, b);
+    else if (spec_matches(SPEC_HYDRO_APPROX | SL2, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_APPROX | SL2>(c, dtdx, dtdy, dtdz, a, b);
+    else if (spec_matches(SPEC_HYDRO_HLLC | SL1, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_HLLC | SL1>(c, dtdx, dtdy, dtdz, a, b);
+    else if (spec_matches(SPEC_HYDRO_HLLC | SL2, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_HLLC | SL2>(c, dtdx, dtdy, dtdz, a, b);
+    else if (spec_matches(SPEC_HYDRO_HLL | SL1, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_HLL | SL1>(c, dtdx, dtdy, dtdz, a, b);
+    else if (spec_matches(SPEC_HYDRO_HLL | SL2, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_HLL | SL2>(c, dtdx, dtdy, dtdz, a, b);
+  }
+  if (rc < 0) return -1;
+  if (rc == 1) {
+    { Phase ph(c, RGPU_T_TRACE); K_hydro_trace<ND, NV> k = {g, c->Q, c->T, dtdx, dtdy, dtdz}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 1, b + 1, ks), k)) return -1; }
     Phase ph(c, RGPU_T_FLUX);
     K_hydro_flux<ND, NV, false> k = {g, c->T, c->F};
     K_hydro_flux<ND, NV, true> kg = {g, c->T, c->F};
