@@ -152,8 +152,7 @@ inline int rg_launch_planes(rg_stream_t s, unsigned idx0, unsigned plane_cells, 
   const unsigned nsub = (m.band + T - 1) / T;
   m.T = (m.band + nsub - 1) / nsub;   // equal sub-bands: at most nsub-1 idle workgroup slots per band
   const unsigned grid = 8u * nsub * nplanes * m.T;
-  static const unsigned lds_pad = std::getenv("RGPU_HEAVY_LDS") ? (unsigned)std::atoi(std::getenv("RGPU_HEAVY_LDS")) : 0u;   // experiment
-  hipLaunchKernelGGL((rg_kernel_planes<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), BLOCK == 64 ? lds_pad : 0u, s, m, k);
+  hipLaunchKernelGGL((rg_kernel_planes<BLOCK, K, MINW>), dim3(grid), dim3(BLOCK), 0, s, m, k);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
