@@ -531,36 +531,24 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rstarLLy = rg_div(LL.r * (SB - LL.v), iSB);
   const double AstarLL = rg_div(LL.a * (SB - LL.v), iSB);
   const double rstarLL = rg_div(rstarLLx * (SB - LL.v), iSB);
-  const double EstarLLx = ustar * BstarLL - LL.v * LL.a;
-  const double EstarLLy = LL.u * LL.b - vstar * AstarLL;
-  const double EstarLL = ustar * BstarLL - vstar * AstarLL;
 
   const double rstarLRx = rg_div(LR.r * (SL - LR.u), iSL);
   const double BstarLR = rg_div(LR.b * (SL - LR.u), iSL);
   const double rstarLRy = rg_div(LR.r * (ST - LR.v), iST);
   const double AstarLR = rg_div(LR.a * (ST - LR.v), iST);
   const double rstarLR = rg_div(rstarLRx * (ST - LR.v), iST);
-  const double EstarLRx = ustar * BstarLR - LR.v * LR.a;
-  const double EstarLRy = LR.u * LR.b - vstar * AstarLR;
-  const double EstarLR = ustar * BstarLR - vstar * AstarLR;
 
   const double rstarRLx = rg_div(RL.r * (SR - RL.u), iSR);
   const double BstarRL = rg_div(RL.b * (SR - RL.u), iSR);
   const double rstarRLy = rg_div(RL.r * (SB - RL.v), iSB);
   const double AstarRL = rg_div(RL.a * (SB - RL.v), iSB);
   const double rstarRL = rg_div(rstarRLx * (SB - RL.v), iSB);
-  const double EstarRLx = ustar * BstarRL - RL.v * RL.a;
-  const double EstarRLy = RL.u * RL.b - vstar * AstarRL;
-  const double EstarRL = ustar * BstarRL - vstar * AstarRL;
 
   const double rstarRRx = rg_div(RR.r * (SR - RR.u), iSR);
   const double BstarRR = rg_div(RR.b * (SR - RR.u), iSR);
   const double rstarRRy = rg_div(RR.r * (ST - RR.v), iST);
   const double AstarRR = rg_div(RR.a * (ST - RR.v), iST);
   const double rstarRR = rg_div(rstarRRx * (ST - RR.v), iST);
-  const double EstarRRx = ustar * BstarRR - RR.v * RR.a;
-  const double EstarRRy = RR.u * RR.b - vstar * AstarRR;
-  const double EstarRR = ustar * BstarRR - vstar * AstarRR;
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
   const rg_recip_t iqLL = rg_recip(rg_sqrt_pos(rstarLL)), iqLR = rg_recip(rg_sqrt_pos(rstarLR));
@@ -578,31 +566,50 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double SAB = fmin(vstar - calfvenB, 0.0);
   const double SAT = fmax(vstar + calfvenT, 0.0);
   const rg_recip_t iSA = rg_recip(SAR - SAL), iSAy = rg_recip(SAT - SAB);
-  const double AstarT = rg_div(SAR * AstarRR - SAL * AstarLR, iSA);
-  const double AstarB = rg_div(SAR * AstarRL - SAL * AstarLL, iSA);
-  const double BstarR = rg_div(SAT * BstarRR - SAB * BstarRL, iSAy);
-  const double BstarL = rg_div(SAT * BstarLR - SAB * BstarLL, iSAy);
 
-  // region selection by sign bits, evaluated as the reference's branch-free integer masks times doubles
-  // (riemann_mhd.h:759-787); a mask of 0 still multiplies its term (0*x), so the sum is reproduced as written
+  // Region selection by sign bits.  The reference evaluates all five candidate values and adds each multiplied by its
+  // 0 / 1 integer mask (riemann_mhd.h:759-787).  A term with mask 0 adds (0 * finite value) = +-0, which leaves the sum
+  // unchanged, so only the terms whose mask is 1 are evaluated here -- in a wave whose lanes agree on the region (the
+  // usual case) the other four are never computed.  (Only difference: a non-finite value in an unselected candidate
+  // would turn the reference's sum into NaN.)
   const int SB_pos = signbit(SB) ? 0 : 1, SB_neg = 1 - SB_pos;
   const int ST_pos = signbit(ST) ? 0 : 1, ST_neg = 1 - ST_pos;
   const int SL_pos = signbit(SL) ? 0 : 1, SL_neg = 1 - SL_pos;
   const int SR_pos = signbit(SR) ? 0 : 1, SR_neg = 1 - SR_pos;
   double E = 0, tmpE;
-  tmpE = rg_div(rg_div(SAL * SAB * EstarRR - SAL * SAT * EstarRL - SAR * SAB * EstarLR + SAR * SAT * EstarLL, iSA), iSAy) -
-         rg_div(SAT * SAB, iSAy) * (AstarT - AstarB) + rg_div(SAR * SAL, iSA) * (BstarR - BstarL);
-  E += (double)(SB_neg * ST_pos * SL_neg * SR_pos) * tmpE;
-  tmpE = rg_div(SAR * EstarLLx - SAL * EstarRLx + SAR * SAL * (RL.b - LL.b), iSA);
-  tmpE = (double)SL_pos * ELL + (double)(SL_neg * SR_neg) * ERL + (double)(SL_neg * SR_pos) * tmpE;
-  E += (double)SB_pos * tmpE;
-  tmpE = rg_div(SAR * EstarLRx - SAL * EstarRRx + SAR * SAL * (RR.b - LR.b), iSA);
-  tmpE = (double)SL_pos * ELR + (double)(SL_neg * SR_neg) * ERR + (double)(SL_neg * SR_pos) * tmpE;
-  E += (double)(SB_neg * ST_neg) * tmpE;
-  tmpE = rg_div(SAT * EstarLLy - SAB * EstarLRy - SAT * SAB * (LR.a - LL.a), iSAy);
-  E += (double)(SB_neg * ST_pos * SL_pos) * tmpE;
-  tmpE = rg_div(SAT * EstarRLy - SAB * EstarRRy - SAT * SAB * (RR.a - RL.a), iSAy);
-  E += (double)(SB_neg * ST_pos * SL_neg * SR_neg) * tmpE;
+  if (SB_neg * ST_pos * SL_neg * SR_pos) {
+    const double AstarT = rg_div(SAR * AstarRR - SAL * AstarLR, iSA);
+    const double AstarB = rg_div(SAR * AstarRL - SAL * AstarLL, iSA);
+    const double BstarR = rg_div(SAT * BstarRR - SAB * BstarRL, iSAy);
+    const double BstarL = rg_div(SAT * BstarLR - SAB * BstarLL, iSAy);
+    const double EstarLL = ustar * BstarLL - vstar * AstarLL, EstarLR = ustar * BstarLR - vstar * AstarLR;
+    const double EstarRL = ustar * BstarRL - vstar * AstarRL, EstarRR = ustar * BstarRR - vstar * AstarRR;
+    tmpE = rg_div(rg_div(SAL * SAB * EstarRR - SAL * SAT * EstarRL - SAR * SAB * EstarLR + SAR * SAT * EstarLL, iSA), iSAy) -
+           rg_div(SAT * SAB, iSAy) * (AstarT - AstarB) + rg_div(SAR * SAL, iSA) * (BstarR - BstarL);
+    E += (double)(SB_neg * ST_pos * SL_neg * SR_pos) * tmpE;
+  }
+  if (SB_pos) {
+    const double EstarLLx = ustar * BstarLL - LL.v * LL.a, EstarRLx = ustar * BstarRL - RL.v * RL.a;
+    tmpE = rg_div(SAR * EstarLLx - SAL * EstarRLx + SAR * SAL * (RL.b - LL.b), iSA);
+    tmpE = (double)SL_pos * ELL + (double)(SL_neg * SR_neg) * ERL + (double)(SL_neg * SR_pos) * tmpE;
+    E += (double)SB_pos * tmpE;
+  }
+  if (SB_neg * ST_neg) {
+    const double EstarLRx = ustar * BstarLR - LR.v * LR.a, EstarRRx = ustar * BstarRR - RR.v * RR.a;
+    tmpE = rg_div(SAR * EstarLRx - SAL * EstarRRx + SAR * SAL * (RR.b - LR.b), iSA);
+    tmpE = (double)SL_pos * ELR + (double)(SL_neg * SR_neg) * ERR + (double)(SL_neg * SR_pos) * tmpE;
+    E += (double)(SB_neg * ST_neg) * tmpE;
+  }
+  if (SB_neg * ST_pos * SL_pos) {
+    const double EstarLLy = LL.u * LL.b - vstar * AstarLL, EstarLRy = LR.u * LR.b - vstar * AstarLR;
+    tmpE = rg_div(SAT * EstarLLy - SAB * EstarLRy - SAT * SAB * (LR.a - LL.a), iSAy);
+    E += (double)(SB_neg * ST_pos * SL_pos) * tmpE;
+  }
+  if (SB_neg * ST_pos * SL_neg * SR_neg) {
+    const double EstarRLy = RL.u * RL.b - vstar * AstarRL, EstarRRy = RR.u * RR.b - vstar * AstarRR;
+    tmpE = rg_div(SAT * EstarRLy - SAB * EstarRRy - SAT * SAB * (RR.a - RL.a), iSAy);
+    E += (double)(SB_neg * ST_pos * SL_neg * SR_neg) * tmpE;
+  }
   return E;
 }
 
