@@ -1,11 +1,13 @@
 """Parity of the HIP path (ramsesgpu_amd/librgpu.so, gfx950) -- the tests proper.  Everything goes through the
 C ABI.  Checker: the oracle (CPU restatement pinned to the reference binary) and the reference's golden fixtures.
 Bar: bit-identical doubles (stated tolerance of north_star: relative L2 < 1e-12, see parity_checks.assert_same)."""
+import os
+
 import numpy as np
 import pytest
 
 import parity_checks as pc
-from conftest import golden_cases, ini
+from conftest import ROOT, golden_cases, ini
 from ramsesgpu_amd.solver import Solver, interior
 
 pytestmark = pytest.mark.gpu
@@ -240,3 +242,26 @@ def test_run_driver_writes_inertial_wave_history_file(gpu_lib, tmp_path):
     assert n == 8, err.value
     got = [ln.rstrip("\n") for ln in open(tmp_path / "mhd_inertialWave_2d_history.txt") if ln.strip() and not ln.startswith("#")]
     assert got == want
+
+
+@pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=24;mesh.ny=32;mesh.nz=20;MRI.amp=0.3"),
+                                     ("orszag-tang3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16"),
+                                     ("implode3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16;hydro.riemannSolver=hllc")])
+def test_launch_specialised_kernels_equal_generic_ones(base, ov, tmp_path):
+    """the launch-time specialisations (SPEC template parameter, launchers.h) only tell the optimiser what the host has
+    checked: the same run with RGPU_NO_SPEC=1 (generic kernels) must give the same bits"""
+    import hashlib
+    import subprocess
+    import sys
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from ramsesgpu_amd.solver import Solver, load_library\n"
+            "L = load_library(); p = L.params_from_ini(%r, %r); U0 = L.init_condition(%r, %r, p)\n"
+            "sv = Solver(p, L); sv.start(U0, 6); print(hashlib.sha256(np.ascontiguousarray(sv.getDataHost()).tobytes()).hexdigest())\n"
+            % (ROOT, ini(base), ov, ini(base), ov))
+    digests = []
+    for env_extra in ({}, {"RGPU_NO_SPEC": "1"}):
+        env = dict(os.environ, **env_extra)
+        res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        digests.append(res.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
