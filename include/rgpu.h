@@ -245,9 +245,10 @@ int rgpu_synchronize(rgpu_ctx* c);
 
 enum {
   RGPU_T_BOUNDARIES = 0, RGPU_T_PRIM, RGPU_T_ELEC, RGPU_T_TRACE, RGPU_T_FLUX, RGPU_T_EMF, RGPU_T_UPDATE,
-  RGPU_T_SHEAR, RGPU_T_DT, RGPU_T_DISSIPATIVE, RGPU_T_COUNT
+  RGPU_T_SHEAR, RGPU_T_DT, RGPU_T_DISSIPATIVE, RGPU_T_SWEEP, RGPU_T_COUNT
 };
 /* RGPU_T_FLUX is the Riemann phase: face fluxes and edge EMFs are one kernel (RGPU_T_EMF stays 0).
+ * RGPU_T_SWEEP is the LDS-tiled, z-marching fused kernel (hydro 3D: the whole step; 3D MHD: trace + Riemann problems).
  * enable!=0 brackets every phase with hipEvents (serialises the stream; off by default) */
 int rgpu_enable_timers(rgpu_ctx* c, int enable);
 /* accumulated seconds per phase since creation / last reset; n <= RGPU_T_COUNT */

@@ -7,7 +7,7 @@ ID, IP, IU, IV, IW, IA, IB, IC = range(8)
 BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
 RS_APPROX, RS_HLL, RS_HLLC, RS_HLLD, RS_LLF = range(5)
 XDIR, YDIR, ZDIR = 1, 2, 3
-T_NAMES = ["boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative"]
+T_NAMES = ["boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative", "sweep"]
 
 
 class RgpuParams(C.Structure):

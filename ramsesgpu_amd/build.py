@@ -31,7 +31,7 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     exe = os.path.join(HERE, "euler_hip")
     srcs = [os.path.join(CSRC, "rgpu_api.cpp")] + [os.path.join(CSRC, "host", s) for s in HOST_SRC]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(CSRC, "hip", "rg_backend.h"), os.path.join(HERE, "..", "include", "rgpu.h")] + \
+        [os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "rgpu.h")] + \
         [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith(".h")]
     if force or _newer(out, deps):
         # one object per translation unit, then one link: mixing "-x hip" and "-x c++" inputs in a single hipcc

@@ -24,7 +24,8 @@ enum { XD = 0, YD = 1, ZD = 2 };
 struct DevParams {
   int isize, jsize, ksize, gw, nx, ny, nz, nvar;
   int three_d, mhd, rot, shearbox;
-  int dirwise_update, pad1;    // hydro unsplitVersion 2: fluxes applied direction by direction
+  int dirwise_update;          // hydro unsplitVersion 2: fluxes applied direction by direction
+  int xcd_sub;                 // host side only: sub-band size (cells) of the XCD-aware workgroup order, 0 = linear
   int zlo_copy, zhi_copy;      // z faces that are slab interfaces (RGPU_BC_COPY): the neighbour's cells continue there
   unsigned sj, sk;             // flat strides of +1 in j and k
   unsigned long long ncell;    // component stride

@@ -137,11 +137,10 @@ __global__ void __launch_bounds__(BLOCK, MINW) rg_kernel_planes(rg_plane_map m, 
   const unsigned off = (xcd * m.band + in_band) * (unsigned)BLOCK + threadIdx.x;
   if (in_band < m.band && off < m.plane_cells) k(m.idx0 + p * m.plane_cells + off);
 }
-inline unsigned& rg_xcd_sub_cells() { static unsigned v = 4096; return v; }   // 0: linear order
+// sub = sub-band size in cells (per context, rgpu_ctx::xcd_sub); 0: linear order
 template <int BLOCK, int MINW = 1, class K>
-inline int rg_launch_planes(rg_stream_t s, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k) {
+inline int rg_launch_planes(rg_stream_t s, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k, unsigned sub) {
   if (nplanes == 0 || plane_cells == 0) return 0;
-  const unsigned sub = rg_xcd_sub_cells();
   if (sub == 0) return rg_launch_range<BLOCK, MINW>(s, idx0, plane_cells * nplanes, k);
   rg_plane_map m;
   m.idx0 = idx0; m.plane_cells = plane_cells; m.nplanes = nplanes;
@@ -197,6 +196,13 @@ inline int rg_device_count() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+inline int rg_current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+inline void rg_set_device(int d) { (void)hipSetDevice(d); }
+inline int rg_pointer_device(const void* p) {   // device owning a device pointer, -1 if unknown
+  hipPointerAttribute_t a;
+  if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.type == hipMemoryTypeDevice ? a.device : -1;
 }
 inline int rg_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess ? 0 : -1; }
 inline void rg_free(void* p) { if (p) (void)hipFree(p); }

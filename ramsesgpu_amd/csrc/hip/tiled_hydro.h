@@ -1,0 +1,314 @@
+// tiled_hydro.h (HIP / gfx950 only) -- the 3D hydro unsplit step as ONE cooperative, LDS-tiled, z-marching kernel.
+//
+// The flat pipeline (kernels_hydro.h: prim -> trace -> flux -> update, one thread per cell, four launches) moves
+// ~760 B per cell update through HBM / L2 for 80 B of state.  Here a workgroup owns an x-y tile of TX x TY cell
+// columns and marches along z; everything between "read U" and "write Unew" lives in registers and LDS:
+//
+//   * a thread owns one (i,j) column.  Its z neighbourhood (primitives of planes kk-1, kk, kk+1, the conservative
+//     state of planes kk, kk+1, the z face state qm_z of plane kk-1, the partially updated cell of plane kk-1) rides
+//     in registers from one iteration to the next -- the z halo costs nothing;
+//   * the x / y neighbourhood goes through LDS: the primitives of plane kk (tile + a one-cell ring without corners,
+//     the ring recomputed from U by the first 2(TX+TY) threads), the x / y face states qm (the left states of the
+//     neighbours' low faces) and the x / y fluxes (the high-face fluxes of the neighbours);
+//   * per plane: prim(kk+2) | barrier | slopes + trace(kk) | barrier | 3 Riemann problems at the low faces of
+//     (i,j,kk) | finish cell (i,j,kk-1) with the z flux just computed and store it | barrier | gather the x / y
+//     fluxes into cell (i,j,kk).
+//
+// Thread tiles overlap by one cell on each side (the outermost threads only supply face states), so a TX x TY
+// workgroup updates (TX-2) x (TY-2) columns.  HBM traffic per cell update: 40 B read (+ the tile overlap, served by L2
+// when neighbouring tiles run on the same XCD) + 40 B written; nothing else leaves the CU.
+// (Reference idiom: the shared-memory tiles of godunov_unsplit.cuh:1829-1988, 3212-3488 -- z-marching with the
+// flux gathered through shared memory; this is the gfx950 counterpart: wave64, 160 KB LDS, register z-pipeline.)
+//
+// Arithmetic: exactly the expressions of kernels_hydro.h (hydro_trace_cell / hydro_face_state / hydro_update_cell)
+// on the same operands in the same order, hence the same bits as the flat kernels and as the reference.
+#pragma once
+#include <cstdlib>
+
+#include "launchers.h"
+
+namespace rgpu_tiled {
+
+using namespace rgpu_dev;
+using rgpu::rg_stream_t;
+
+inline bool tiled_enabled() {
+  static const bool on = !(std::getenv("RGPU_TILED") && std::atoi(std::getenv("RGPU_TILED")) == 0);
+  return on;
+}
+
+// copy of whole z planes (ghost planes inside a requested plane range: the flat update kernel copies them too)
+struct K_copy_cells {
+  const double* src; double* dst; unsigned long long ncell; int nvar;
+  RG_DEVFN void operator()(unsigned idx) const {
+    for (int v = 0; v < nvar; ++v) dst[idx + (size_t)v * ncell] = src[idx + (size_t)v * ncell];
+  }
+};
+
+template <int TX, int TY>
+struct HydroTile {
+  double q[5][TY + 2][TX + 2];   // primitives of plane kk: tile + ring
+  double qm[2][5][TY][TX];       // qm_x, qm_y: state at the HIGH x / y face of each cell (grid frame, floors applied)
+  double f[2][5][TY][TX];        // flux through the LOW x / y face of each cell (face-normal frame)
+};
+
+// map the flat block index to (tile x, tile y, z segment) so that each XCD (block b runs on XCD b % 8) owns a
+// contiguous run of tiles -- x fastest, then y, then z segment: overlapping tile edges are then re-read from that
+// XCD's own L2
+struct TileGrid {
+  int nbx, nby, nseg, per_xcd;
+};
+
+template <int TX, int TY, int SPEC>
+__global__ void __launch_bounds__(TX * TY) hydro3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ Uin,
+                                                              double* __restrict__ Uout, double dtdx, double dtdy,
+                                                              double dtdz, int za, int zb) {
+  spec_assume<SPEC>(g);
+  constexpr int NV = 5;
+  constexpr int NT = TX * TY;
+  constexpr int RING = 2 * TX + 2 * TY;
+  static_assert(RING <= NT, "ring cells are handled by the first RING threads");
+  __shared__ HydroTile<TX, TY> L;
+
+  const int b = (int)blockIdx.x;
+  const int lin = (b & 7) * tg.per_xcd + (b >> 3);
+  if ((b >> 3) >= tg.per_xcd || lin >= tg.nbx * tg.nby * tg.nseg) return;   // whole workgroup leaves: no barrier is skipped
+  const int bx = lin % tg.nbx;
+  const int by = (lin / tg.nbx) % tg.nby;
+  const int seg = lin / (tg.nbx * tg.nby);
+  // this workgroup's planes [sa, sb) of the update range [za, zb)
+  const int span = zb - za;
+  const int sa = za + (int)(((long long)span * seg) / tg.nseg);
+  const int sb = za + (int)(((long long)span * (seg + 1)) / tg.nseg);
+  if (sb <= sa) return;
+
+  const int t = (int)threadIdx.x;
+  const int ti = t % TX, tj = t / TX;
+  const int i = bx * (TX - 2) + ti, j = by * (TY - 2) + tj;
+  const bool ina = i < g.isize && j < g.jsize;
+  const size_t N = g.ncell;
+  const unsigned sk = g.sk;
+  const unsigned idx2 = ina ? (unsigned)i + (unsigned)j * g.sj : 0u;
+  const int gw = g.gw;
+  // cells this thread writes: the inner threads of the tile, plus array row / column 0 (never inside an inner range)
+  const bool own = ina && ((ti >= 1 && ti < TX - 1) || i == 0) && ((tj >= 1 && tj < TY - 1) || j == 0);
+  const bool inner2d = i >= gw && i < g.isize - gw && j >= gw && j < g.jsize - gw;
+  const bool tr2d = i >= 1 && i < g.isize - 1 && j >= 1 && j < g.jsize - 1 && ina;
+  const bool fl2d = i >= gw && i <= g.isize - gw && j >= gw && j <= g.jsize - gw && ina;
+
+  // ring cell of this thread (threads 0 .. RING-1): the one-cell frame around the tile, corners excluded
+  int rti, rtj;
+  if (t < TX) { rti = t; rtj = -1; }
+  else if (t < 2 * TX) { rti = t - TX; rtj = TY; }
+  else if (t < 2 * TX + TY) { rti = -1; rtj = t - 2 * TX; }
+  else { rti = TX; rtj = t - 2 * TX - TY; }
+  const int ri = bx * (TX - 2) + rti, rj = by * (TY - 2) + rtj;
+  const bool ring = t < RING && ri >= 0 && ri < g.isize && rj >= 0 && rj < g.jsize;
+  const unsigned ridx2 = ring ? (unsigned)ri + (unsigned)rj * g.sj : 0u;
+
+  const double st = g.slope_type;
+  const double gamma = g.gamma0;
+
+  double qA[NV], qB[NV], qC[NV];    // primitives of planes kk-1, kk, kk+1 of this column
+  double uB[NV], uC[NV], uN[NV];    // conservative state of planes kk, kk+1, kk+2
+  double qmz[NV];                    // state at the high z face of cell (i,j,kk-1), grid frame
+  double up[NV];                     // cell (i,j,kk-1) with every flux but the one through its high z face applied
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { qA[v] = 1.0; qB[v] = 1.0; qC[v] = 1.0; uB[v] = 1.0; uC[v] = 1.0; uN[v] = 1.0; qmz[v] = 1.0; up[v] = 0.0; }
+
+  // prologue: planes sa-2, sa-1, sa
+  {
+    const int k0 = sa - 1;
+    if (ina) {
+      double ua[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        ua[v] = Uin[idx2 + (size_t)(k0 - 1) * sk + v * N];
+        uB[v] = Uin[idx2 + (size_t)k0 * sk + v * N];
+        uC[v] = Uin[idx2 + (size_t)(k0 + 1) * sk + v * N];
+      }
+      hydro_prim<NV>(g, ua, qA);
+      hydro_prim<NV>(g, uB, qB);
+      hydro_prim<NV>(g, uC, qC);
+    }
+  }
+
+  for (int kk = sa - 1; kk <= sb; ++kk) {
+    // ---- A: issue the loads of plane kk+2 (consumed at the bottom of the iteration) and of the ring of plane kk ----
+    const bool more = (kk + 2 <= sb + 1) && ina;
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) uN[v] = Uin[idx2 + (size_t)(kk + 2) * sk + v * N];
+    }
+    if (ring) {
+      double ur[NV], rq[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) ur[v] = Uin[ridx2 + (size_t)kk * sk + v * N];
+      hydro_prim<NV>(g, ur, rq);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) L.q[v][rtj + 1][rti + 1] = rq[v];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) L.q[v][tj + 1][ti + 1] = qB[v];
+    __syncthreads();
+
+    // ---- B: slopes and trace of cell (i,j,kk)  (hydro_trace_cell) ----
+    double q[NV], h[3][NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      q[v] = qB[v];
+      const double nb[3][2] = {{L.q[v][tj + 1][ti], L.q[v][tj + 1][ti + 2]}, {L.q[v][tj][ti + 1], L.q[v][tj + 2][ti + 1]}, {qA[v], qC[v]}};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        double s;
+        if (st == 0) s = 0.0;
+        else if (st == 1) s = minmod_slope(nb[d][0], q[v], nb[d][1]);
+        else s = tvd_slope(st, nb[d][0], q[v], nb[d][1]);
+        h[d][v] = s * 0.5;
+      }
+    }
+    double qpx[NV], qpy[NV], qpz[NV], qmz_new[NV];
+    {
+      double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = q[IW];
+      const double drx = h[0][ID], dpx = h[0][IP], dux = h[0][IU], dvx = h[0][IV], dwx = h[0][IW];
+      const double dry = h[1][ID], dpy = h[1][IP], duy = h[1][IU], dvy = h[1][IV], dwy = h[1][IW];
+      const double drz = h[2][ID], dpz = h[2][IP], duz = h[2][IU], dvz = h[2][IV], dwz = h[2][IW];
+      const rg_recip_t inv_r = rg_recip(r);
+      const double sr0 = (-u * drx - dux * r) * dtdx + (-v * dry - dvy * r) * dtdy + (-w * drz - dwz * r) * dtdz;
+      const double su0 = (-u * dux - rg_div(dpx, inv_r)) * dtdx + (-v * duy) * dtdy + (-w * duz) * dtdz;
+      const double sv0 = (-u * dvx) * dtdx + (-v * dvy - rg_div(dpy, inv_r)) * dtdy + (-w * dvz) * dtdz;
+      const double sw0 = (-u * dwx) * dtdx + (-v * dwy) * dtdy + (-w * dwz - rg_div(dpz, inv_r)) * dtdz;
+      const double sp0 = (-u * dpx - dux * gamma * p) * dtdx + (-v * dpy - dvy * gamma * p) * dtdy + (-w * dpz - dwz * gamma * p) * dtdz;
+      double tq[NV];
+      tq[ID] = r + sr0; tq[IU] = u + su0; tq[IV] = v + sv0; tq[IW] = w + sw0; tq[IP] = p + sp0;
+      // face states with the floors of trace.h:388-389 (hydro_face_state), grid frame
+      double qmx[NV], qmy[NV];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) {
+        qmx[n] = tq[n] + h[0][n]; qpx[n] = tq[n] - h[0][n];
+        qmy[n] = tq[n] + h[1][n]; qpy[n] = tq[n] - h[1][n];
+        qmz_new[n] = tq[n] + h[2][n]; qpz[n] = tq[n] - h[2][n];
+      }
+#define RG_FLOOR(a) a[ID] = fmax(g.smallr, a[ID]); a[IP] = fmax(g.smallp * a[ID], a[IP])
+      RG_FLOOR(qmx); RG_FLOOR(qpx); RG_FLOOR(qmy); RG_FLOOR(qpy); RG_FLOOR(qmz_new); RG_FLOOR(qpz);
+#undef RG_FLOOR
+#pragma unroll
+      for (int n = 0; n < NV; ++n) { L.qm[0][n][tj][ti] = qmx[n]; L.qm[1][n][tj][ti] = qmy[n]; }
+    }
+    __syncthreads();
+
+    // ---- C: Riemann problems at the three low faces of cell (i,j,kk)  (hydro_flux_cell) ----
+    double fx[NV], fy[NV], fz[NV];
+    {
+      const int tim = ti > 0 ? ti - 1 : 0, tjm = tj > 0 ? tj - 1 : 0;
+      double ql[NV], qr[NV];
+      // x: normal frame = grid frame
+#pragma unroll
+      for (int n = 0; n < NV; ++n) { ql[n] = L.qm[0][n][tj][tim]; qr[n] = qpx[n]; fx[n] = 0.0; }
+      hydro_riemann<NV>(g, ql, qr, fx);
+      // y: IU <-> IV
+      ql[ID] = L.qm[1][ID][tjm][ti]; ql[IP] = L.qm[1][IP][tjm][ti]; ql[IU] = L.qm[1][IV][tjm][ti]; ql[IV] = L.qm[1][IU][tjm][ti]; ql[IW] = L.qm[1][IW][tjm][ti];
+      qr[ID] = qpy[ID]; qr[IP] = qpy[IP]; qr[IU] = qpy[IV]; qr[IV] = qpy[IU]; qr[IW] = qpy[IW];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) fy[n] = 0.0;
+      hydro_riemann<NV>(g, ql, qr, fy);
+      // z: IU <-> IW; the left state is this column's own qm_z of the previous plane
+      ql[ID] = qmz[ID]; ql[IP] = qmz[IP]; ql[IU] = qmz[IW]; ql[IV] = qmz[IV]; ql[IW] = qmz[IU];
+      qr[ID] = qpz[ID]; qr[IP] = qpz[IP]; qr[IU] = qpz[IW]; qr[IV] = qpz[IV]; qr[IW] = qpz[IU];
+#pragma unroll
+      for (int n = 0; n < NV; ++n) fz[n] = 0.0;
+      hydro_riemann<NV>(g, ql, qr, fz);
+#pragma unroll
+      for (int n = 0; n < NV; ++n) qmz[n] = qmz_new[n];
+    }
+
+    // ---- D: cell (i,j,kk-1) is complete once the flux through its high z face is known ----
+    if (own && kk - 1 >= sa) {
+      if (inner2d) {
+        up[ID] -= fz[ID] * dtdz; up[IP] -= fz[IP] * dtdz; up[IU] -= fz[IW] * dtdz; up[IV] -= fz[IV] * dtdz; up[IW] -= fz[IU] * dtdz;
+      }
+      double* o = Uout + idx2 + (size_t)(kk - 1) * sk;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) RG_STREAM_STORE(&o[v * N], up[v]);
+    }
+
+    // ---- E: gather the x / y fluxes of plane kk  (hydro_update_cell, unsplitVersion 1 order) ----
+#pragma unroll
+    for (int n = 0; n < NV; ++n) { L.f[0][n][tj][ti] = fx[n]; L.f[1][n][tj][ti] = fy[n]; }
+    __syncthreads();
+    if (kk < sb) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) up[v] = uB[v];
+      if (own && inner2d) {
+        const int tip = ti + 1 < TX ? ti + 1 : ti, tjp = tj + 1 < TY ? tj + 1 : tj;
+        up[ID] += fx[ID] * dtdx; up[IP] += fx[IP] * dtdx; up[IU] += fx[IU] * dtdx; up[IV] += fx[IV] * dtdx; up[IW] += fx[IW] * dtdx;
+        up[ID] += fy[ID] * dtdy; up[IP] += fy[IP] * dtdy; up[IU] += fy[IV] * dtdy; up[IV] += fy[IU] * dtdy; up[IW] += fy[IW] * dtdy;
+        up[ID] += fz[ID] * dtdz; up[IP] += fz[IP] * dtdz; up[IU] += fz[IW] * dtdz; up[IV] += fz[IV] * dtdz; up[IW] += fz[IU] * dtdz;
+        up[ID] -= L.f[0][ID][tj][tip] * dtdx; up[IP] -= L.f[0][IP][tj][tip] * dtdx; up[IU] -= L.f[0][IU][tj][tip] * dtdx;
+        up[IV] -= L.f[0][IV][tj][tip] * dtdx; up[IW] -= L.f[0][IW][tj][tip] * dtdx;
+        up[ID] -= L.f[1][ID][tjp][ti] * dtdy; up[IP] -= L.f[1][IP][tjp][ti] * dtdy; up[IU] -= L.f[1][IV][tjp][ti] * dtdy;
+        up[IV] -= L.f[1][IU][tjp][ti] * dtdy; up[IW] -= L.f[1][IW][tjp][ti] * dtdy;
+      }
+    }
+
+    // ---- F: rotate the z pipeline ----
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { qA[v] = qB[v]; qB[v] = qC[v]; uB[v] = uC[v]; uC[v] = uN[v]; }
+    if (more) hydro_prim<NV>(g, uN, qC);
+  }
+  (void)tr2d; (void)fl2d;
+}
+
+template <int TX, int TY, int SPEC>
+inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
+                                double dtdz, int za, int zb) {
+  TileGrid tg;
+  tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
+  tg.nby = (g.jsize - 1 + (TY - 2) - 1) / (TY - 2);
+  const int span = zb - za;
+  static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
+  int nseg;
+  if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
+  else {
+    // enough workgroups for >= two rounds over 256 CUs x 3 resident workgroups, segments of >= 16 planes
+    nseg = (1536 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
+    if (nseg > span / 16) nseg = span / 16;
+  }
+  if (nseg < 1) nseg = 1;
+  if (nseg > span) nseg = span;
+  tg.nseg = nseg;
+  const int total = tg.nbx * tg.nby * tg.nseg;
+  tg.per_xcd = (total + 7) / 8;
+  hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
+                     dtdx, dtdy, dtdz, za, zb);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Complete the update of planes [a,b) of a 3D hydro step.  Returns 0 = done, 1 = not applicable (the caller runs the
+// flat kernels), < 0 = launch error.
+inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
+                         double dtdz, int a, int b) {
+  if (!tiled_enabled() || !g.three_d || g.mhd || g.nvar != 5 || g.grav_on != 0 || g.dirwise_update) return 1;
+  const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
+  // ghost planes inside [a,b): plain copy, like the flat update kernel
+  const K_copy_cells kc = {in, out, g.ncell, 5};
+  if (a < g.gw && rgpu::rg_launch_range<256>(s, (unsigned)a * g.sk, (unsigned)((b < g.gw ? b : g.gw) - a) * g.sk, kc)) return -1;
+  if (b > g.ksize - g.gw) {
+    const int lo = a > g.ksize - g.gw ? a : g.ksize - g.gw;
+    if (rgpu::rg_launch_range<256>(s, (unsigned)lo * g.sk, (unsigned)(b - lo) * g.sk, kc)) return -1;
+  }
+  if (zb <= za) return 0;
+  constexpr int TX = 32, TY = 8;
+  static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
+  if (!no_spec) {
+    const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
+#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb)
+    RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
+    RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
+    RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
+#undef RG_TRY
+  }
+  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+}
+
+}  // namespace rgpu_tiled

@@ -174,7 +174,7 @@ int GodunovRun::start(double* mcell_per_s) {
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
     if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0)
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
-    if ((nStep % rs_.nOutput) == 0) {
+    if (rs_.nOutput > 0 && (nStep % rs_.nOutput) == 0) {   // noutput <= 0: no output (the reference divides by zero here)
       const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
       if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "launchers.h"
+#include "rg_tiled.h"   // LDS-tiled cooperative kernels of the backend (hip/rg_tiled.h)
 
 using namespace rgpu;
 using namespace rgpu_dev;
@@ -48,6 +49,10 @@ struct rgpu_ctx {
   int nchunks;
   rg_stream_t stream2;
   rg_event_t ev_fork, ev_trace[kMaxChunks], ev_flux[kMaxChunks];
+  int n_order_events;   // ev_trace / ev_flux pairs actually created (freed in rgpu_destroy whatever nchunks became)
+  bool fork_ok;
+  int device;           // HIP device the context was created on; every entry point makes it current
+  unsigned xcd_sub;     // sub-band size (cells) of the XCD-aware workgroup order of THIS context, 0 = linear
   std::string err;
 };
 
@@ -132,7 +137,7 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   g->slope_type = p.slope_type;
   g->mag_slope_type = std::fmin(p.slope_type, 2.0);
   g->niter_riemann = p.niter_riemann; g->riemannSolver = p.riemannSolver; g->magRiemannSolver = p.magRiemannSolver;
-  g->dirwise_update = (!p.mhdEnabled && p.unsplitVersion == 2) ? 1 : 0; g->pad1 = 0;
+  g->dirwise_update = (!p.mhdEnabled && p.unsplitVersion == 2) ? 1 : 0; g->xcd_sub = 0;
   // interfaces INSIDE the global box only: the periodic wrap between the last and the first slab is a boundary of the
   // reference's single domain and keeps its ranges
   g->zlo_copy = (p.bc[4] == RGPU_BC_COPY && p.slab_rank > 0) ? 1 : 0;
@@ -173,7 +178,8 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   rgpu_ctx* c = new (std::nothrow) rgpu_ctx();
   if (!c) return RGPU_ENOMEM;
   *out = c;  // returned even on failure so that rgpu_last_error can be read; caller destroys it
-  c->p = *p;
+  std::memset(&c->p, 0, sizeof(c->p));
+  if (p) c->p = *p;
   c->own_state = !external;
   c->U[0] = c->U[1] = 0;
   c->Q = c->E = c->T = c->F = c->emf = c->shear_save = c->shear_remap = 0;
@@ -186,8 +192,20 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->stream = (rg_stream_t)0;
   c->stream2 = (rg_stream_t)0;
   c->nchunks = 1;
+  c->n_order_events = 0; c->fork_ok = false;
+  c->device = -1;
+  c->xcd_sub = 4096;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
+  c->device = rg_current_device();
+  if (external) {   // adopted arrays must live on the device the context will launch on
+    const int d1 = rg_pointer_device(dU), d2 = rg_pointer_device(dU2);
+    if (dU && dU2 && d1 >= 0 && d2 >= 0) {
+      if (d1 != d2) return fail(c, RGPU_EINVAL, "external state arrays live on different devices");
+      c->device = d1;
+      rg_set_device(d1);
+    }
+  }
   fill_dev_params(*p, &c->g);
   c->ncell = (size_t)c->g.ncell;
   c->n32 = (unsigned)c->ncell;
@@ -215,7 +233,8 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
   // sub-band size (cells) of the XCD-aware workgroup order, 0 = linear order (rg_backend.h: rg_launch_planes)
-  if (std::getenv("RGPU_XCD_SUB")) rg_xcd_sub_cells() = (unsigned)std::atoi(std::getenv("RGPU_XCD_SUB"));
+  if (std::getenv("RGPU_XCD_SUB")) c->xcd_sub = (unsigned)std::atoi(std::getenv("RGPU_XCD_SUB"));
+  c->g.xcd_sub = (int)c->xcd_sub;
   if (p->mhdEnabled && c->g.three_d) {
     // default: chunks of ~8 planes (measured best at 512^3: 64 chunks 75.7 ms/step vs 82-84 ms serial; 128 chunks
     // 77.4, 256 chunks 82.6); RGPU_CHUNKS=1 selects the serial single-stream schedule.  Equal stream priorities
@@ -225,8 +244,12 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (want > rgpu_ctx::kMaxChunks) want = rgpu_ctx::kMaxChunks;
     const int alu_prio = std::getenv("RGPU_ALU_PRIO") ? std::atoi(std::getenv("RGPU_ALU_PRIO")) : 0;
     if (want > 1 && rg_stream_create(&c->stream2, alu_prio) == 0) {
-      bool ok = rg_order_event_create(&c->ev_fork) == 0;
-      for (int i = 0; i < want && ok; ++i) ok = rg_order_event_create(&c->ev_trace[i]) == 0 && rg_order_event_create(&c->ev_flux[i]) == 0;
+      bool ok = c->fork_ok = rg_order_event_create(&c->ev_fork) == 0;
+      for (int i = 0; i < want && ok; ++i) {
+        if (rg_order_event_create(&c->ev_trace[i])) { ok = false; break; }
+        if (rg_order_event_create(&c->ev_flux[i])) { rg_event_destroy(c->ev_trace[i]); ok = false; break; }
+        c->n_order_events = i + 1;
+      }
       if (ok) c->nchunks = want;
     }
   }
@@ -368,7 +391,7 @@ inline PlaneRange clip(int lo, int hi, int ksize) {
 template <int BLOCK, int MINW, class K>
 int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
   if (r.hi <= r.lo) return 0;
-  return rg_launch_planes<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k);
+  return rg_launch_planes<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k, (unsigned)g.xcd_sub);
 }
 
 // hydro: launch-time specialisation on the Riemann solver and the slope type (launchers.h); the no-gravity instantiations
@@ -387,6 +410,11 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
   const int ks = g.ksize;
+  if (ND == 3) {   // LDS-tiled z-marching sweep: the whole step in one kernel (hip/tiled_hydro.h)
+    Phase ph(c, RGPU_T_SWEEP);
+    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b);
+    if (rc <= 0) return rc;
+  }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
@@ -741,7 +769,9 @@ int step_forcing(rgpu_ctx* c, int nStep, double dt) {
   return add_forcing(c, (nStep + 1) % 2, forcing_norm(c->p, s, dt));
 }
 
-#define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; } while (0)
+// every entry point makes the context's device current: a multi-GPU process (or a thread whose current device differs)
+// would otherwise launch on the wrong device
+#define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; if ((c)->device >= 0) rg_set_device((c)->device); } while (0)
 #define RG_HIPFAIL(c, what) fail((c), RGPU_EHIP, std::string(what) + ": " + rg_last_error_string())
 
 }  // namespace
@@ -757,15 +787,14 @@ int rgpu_create_external(const rgpu_params* p, double* dU, double* dU2, void* hi
 
 void rgpu_destroy(rgpu_ctx* c) {
   if (!c) return;
+  if (c->device >= 0) rg_set_device(c->device);
   if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
   rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G); rg_free(c->Frc);
   rg_free(c->d_red); rg_host_free(c->h_red);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
-  if (c->nchunks > 1) {
-    rg_event_destroy(c->ev_fork);
-    for (int i = 0; i < c->nchunks; ++i) { rg_event_destroy(c->ev_trace[i]); rg_event_destroy(c->ev_flux[i]); }
-    rg_stream_destroy(c->stream2);
-  }
+  if (c->fork_ok) rg_event_destroy(c->ev_fork);
+  for (int i = 0; i < c->n_order_events; ++i) { rg_event_destroy(c->ev_trace[i]); rg_event_destroy(c->ev_flux[i]); }
+  if (c->stream2) rg_stream_destroy(c->stream2);
   delete c;
 }
 
@@ -1046,7 +1075,7 @@ int rgpu_reset_timers(rgpu_ctx* c) {
   return RGPU_OK;
 }
 const char* rgpu_timer_name(int which) {
-  static const char* names[RGPU_T_COUNT] = {"boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative"};
+  static const char* names[RGPU_T_COUNT] = {"boundaries", "prim", "elec", "trace", "flux", "emf", "update", "shear", "dt", "dissipative", "sweep"};
   return (which >= 0 && which < RGPU_T_COUNT) ? names[which] : "?";
 }
 

@@ -43,9 +43,8 @@ inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k) {
   for (unsigned off = 0; off < n; ++off) k(idx0 + off);
   return 0;
 }
-inline unsigned& rg_xcd_sub_cells() { static unsigned v = 0; return v; }
 template <int BLOCK, int MINW = 1, class K>
-inline int rg_launch_planes(rg_stream_t, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k) {
+inline int rg_launch_planes(rg_stream_t, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k, unsigned = 0) {
   for (unsigned off = 0; off < plane_cells * nplanes; ++off) k(idx0 + off);
   return 0;
 }
@@ -58,6 +57,9 @@ inline int rg_reduce_max(rg_stream_t, unsigned n, const K& k, unsigned long long
   return 0;
 }
 inline int rg_device_count() { return 1; }
+inline int rg_current_device() { return 0; }
+inline void rg_set_device(int) {}
+inline int rg_pointer_device(const void*) { return -1; }
 inline int rg_malloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 1); return *p ? 0 : -1; }
 inline void rg_free(void* p) { std::free(p); }
 inline int rg_host_alloc(void** p, size_t bytes) { return rg_malloc(p, bytes); }

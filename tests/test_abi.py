@@ -77,3 +77,15 @@ def test_rejects_out_of_scope_configurations(emu_lib):
     for ov in ("gravity.self=yes", "hydro.scheme=plmde"):
         with pytest.raises(RgpuError):
             L.params_from_ini(ini("orszag-tang"), ov)
+
+
+def test_create_with_null_params_returns_einval(product_lib, emu_lib):
+    """rgpu_create(NULL, &ctx) reports RGPU_EINVAL through the returned context instead of dereferencing NULL"""
+    for L in (product_lib, emu_lib):
+        ctx = C.c_void_p()
+        L.lib.rgpu_create.restype = C.c_int
+        rc = L.lib.rgpu_create(None, C.byref(ctx))
+        assert rc == -1 and ctx.value
+        L.lib.rgpu_last_error.restype = C.c_char_p
+        assert b"NULL" in L.lib.rgpu_last_error(ctx)
+        L.lib.rgpu_destroy(ctx)

@@ -52,6 +52,31 @@ def test_medium_sizes_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
     pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, nsteps)
 
 
+# The bench's launch geometry: planes of > 32768 cells, where the XCD-aware workgroup order splits each XCD's y band
+# into several sub-bands (rg_backend.h: rg_launch_planes, nsub > 1), with >= 2 chunks of the two-stream sweep and
+# the LDS-tiled kernels' full-width tile rows.  Few planes keep the oracle at seconds per step.
+BENCH_GEOMETRY = [
+    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=512;mesh.nz=16", 2),
+    ("orszag-tang3d", "mesh.nx=256;mesh.ny=256;mesh.nz=24", 2),
+    ("implode3d", "mesh.nx=512;mesh.ny=512;mesh.nz=8;hydro.riemannSolver=hllc", 2),
+]
+
+
+@pytest.mark.parametrize("base,ov,nsteps", BENCH_GEOMETRY, ids=["%s[%s]" % (b, o) for b, o, _ in BENCH_GEOMETRY])
+def test_bench_launch_geometry_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
+    pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, nsteps)
+
+
+@pytest.mark.parametrize("sub", ["0", "2048", "4096"])
+@pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=224;mesh.ny=208;mesh.nz=16"),
+                                     ("implode3d", "mesh.nx=208;mesh.ny=224;mesh.nz=8;hydro.riemannSolver=hllc")],
+                         ids=["mri-224x208x16", "implode-208x224x8"])
+def test_xcd_sub_band_sizes_vs_oracle(base, ov, sub, gpu_lib, oracle, monkeypatch):
+    """RGPU_XCD_SUB (read at rgpu_create, kept per context): linear order, 2048- and 4096-cell sub-bands on a >= 200^2 plane"""
+    monkeypatch.setenv("RGPU_XCD_SUB", sub)
+    pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, 2)
+
+
 def test_orszag_tang_gate_full_size(gpu_lib, oracle):
     """BASELINE config: data/orszag-tang.ini as shipped (512^2, nstepmax=50).  Gate of north_star:
     L2 error vs euler_cpu < 1e-12 per variable; here the reference's CPU arithmetic is reproduced exactly."""
