@@ -4,3 +4,4 @@
 // each returning 0 = done, 1 = configuration not covered (the driver runs the flat per-cell kernels), < 0 = error.
 #pragma once
 #include "tiled_hydro.h"
+#include "tiled_mhd.h"

@@ -43,6 +43,30 @@ enum {
 enum { F_X = 0, F_Y = 5, F_Z = 10, F_COUNT = 15 };
 enum { EMF_Z = 0, EMF_Y = 1, EMF_X = 2 };            // EmfIndex, constants.h:191-195
 
+// Accessors of the compact traced state.  The flat kernels keep T as a global SoA array (component stride ncell, cell
+// index = flat array index); the LDS-tiled sweep of the HIP backend (hip/tiled_mhd.h) keeps two planes of an x-y
+// tile in LDS.  The trace / face-state / edge-state code below is written once against this interface:
+//   get(slot, m)   component `slot` of cell m            stride(D)   distance of the +1 neighbour along D
+//   writer.put(slot, value)                              (m and strides are whatever the accessor's index space is)
+struct TGlobalRead {
+  const double* T; size_t N; unsigned sj, sk;
+  RG_DEVFN double get(int slot, unsigned m) const { return T[m + (size_t)slot * N]; }
+  RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? sj : sk; }
+};
+// Inputs of the trace around a cell: primitives q, face-centred field bf (U components IA, IB, IC) and edge electric
+// field e, addressed by an in-plane cell index m (neighbours: m +- 1, m +- sj()) and a plane offset dz in {-1, 0, +1}.
+struct TraceInGlobal {
+  const double* U; const double* Q; const double* E; size_t N; unsigned sj_, sk_;
+  RG_DEVFN double q(int v, int dz, unsigned m) const { return Q[(size_t)v * N + (m + (unsigned)(dz * (int)sk_))]; }
+  RG_DEVFN double bf(int comp, int dz, unsigned m) const { return U[(size_t)(IA + comp) * N + (m + (unsigned)(dz * (int)sk_))]; }
+  RG_DEVFN double e(int comp, int dz, unsigned m) const { return E[(size_t)comp * N + (m + (unsigned)(dz * (int)sk_))]; }
+  RG_DEVFN unsigned sj() const { return sj_; }
+};
+struct TGlobalWrite {   // bound to one cell
+  double* t; size_t N;
+  RG_DEVFN void put(int slot, double v) const { RG_STREAM_STORE(&t[(size_t)slot * N], v); }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // primitive variables (2D and 3D)
 // ------------------------------------------------------------------------------------------------------------
@@ -105,22 +129,21 @@ RG_DEVFN void mhd_elec_cell(const DevParams& g, const double* __restrict__ U, co
 // Second half of the trace: from the cell state q, its limited full slopes in
 // x,y,z and the 9 edge electric fields E9 = {Ex(j,k),Ex(j,k+1),Ex(j+1,k), Ey(i,k),Ey(i,k+1),Ey(i+1,k),
 // Ez(i,j),Ez(i,j+1),Ez(i+1,j)} to the compact traced state.
-RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const double* __restrict__ U, double* __restrict__ T, const IJK c,
-                                 unsigned idx, const double* q, const double* dx_, const double* dy_, const double* dz_,
+template <class TIN, class TW>
+RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const TIN& in, const TW& tw, const IJK c,
+                                 unsigned m, const double* q, const double* dx_, const double* dy_, const double* dz_,
                                  const double* E9, double dtdx, double dtdy, double dtdz) {
-  const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
-  const double* Ua = U + IA * N; const double* Ub = U + IB * N; const double* Uc = U + IC * N;
-  double AL = Ua[idx], BL = Ub[idx], CL = Uc[idx];
-  const double AR = Ua[idx + 1], BR = Ub[idx + sj], CR = Uc[idx + sk];
+  const unsigned sj = in.sj();
+  double AL = in.bf(0, 0, m), BL = in.bf(1, 0, m), CL = in.bf(2, 0, m);
+  const double AR = in.bf(0, 0, m + 1), BR = in.bf(1, 0, m + sj), CR = in.bf(2, +1, m);
   // transverse slopes of the low-face field (slope_unsplit_mhd_3d: slope type capped at 2)
   const double mst = g.mag_slope_type;
-  const double dALy = 0.5 * tvd_slope(mst, Ua[idx - sj], AL, Ua[idx + sj]);
-  const double dALz = 0.5 * tvd_slope(mst, Ua[idx - sk], AL, Ua[idx + sk]);
-  const double dBLx = 0.5 * tvd_slope(mst, Ub[idx - 1], BL, Ub[idx + 1]);
-  const double dBLz = 0.5 * tvd_slope(mst, Ub[idx - sk], BL, Ub[idx + sk]);
-  const double dCLx = 0.5 * tvd_slope(mst, Uc[idx - 1], CL, Uc[idx + 1]);
-  const double dCLy = 0.5 * tvd_slope(mst, Uc[idx - sj], CL, Uc[idx + sj]);
+  const double dALy = 0.5 * tvd_slope(mst, in.bf(0, 0, m - sj), AL, in.bf(0, 0, m + sj));
+  const double dALz = 0.5 * tvd_slope(mst, in.bf(0, -1, m), AL, in.bf(0, +1, m));
+  const double dBLx = 0.5 * tvd_slope(mst, in.bf(1, 0, m - 1), BL, in.bf(1, 0, m + 1));
+  const double dBLz = 0.5 * tvd_slope(mst, in.bf(1, -1, m), BL, in.bf(1, +1, m));
+  const double dCLx = 0.5 * tvd_slope(mst, in.bf(2, 0, m - 1), CL, in.bf(2, 0, m + 1));
+  const double dCLy = 0.5 * tvd_slope(mst, in.bf(2, 0, m - sj), CL, in.bf(2, 0, m + sj));
 
   // electric field at the edges bounding the three low faces
   const double ELL = E9[0], ELR = E9[1], ERL = E9[2];
@@ -165,16 +188,15 @@ RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const double* __restrict__ 
   r = r + sr0; u = u + su0; v = v + sv0; w = w + sw0; p = p + sp0; A = A + sA0; B = B + sB0; C = C + sC0;
   AL = AL + sAL0; BL = BL + sBL0; CL = CL + sCL0;
 
-  double* t = T + idx;
-  RG_STREAM_STORE(&t[T_R * N], r); RG_STREAM_STORE(&t[T_P * N], p); RG_STREAM_STORE(&t[T_U * N], u); RG_STREAM_STORE(&t[T_V * N], v); RG_STREAM_STORE(&t[T_W * N], w); RG_STREAM_STORE(&t[T_A * N], A); RG_STREAM_STORE(&t[T_B * N], B); RG_STREAM_STORE(&t[T_C * N], C);
-  RG_STREAM_STORE(&t[T_AL * N], AL); RG_STREAM_STORE(&t[T_BL * N], BL); RG_STREAM_STORE(&t[T_CL * N], CL);
-  RG_STREAM_STORE(&t[(T_DX + 0) * N], drx); RG_STREAM_STORE(&t[(T_DX + 1) * N], dpx); RG_STREAM_STORE(&t[(T_DX + 2) * N], dux); RG_STREAM_STORE(&t[(T_DX + 3) * N], dvx); RG_STREAM_STORE(&t[(T_DX + 4) * N], dwx);
-  RG_STREAM_STORE(&t[(T_DX + 5) * N], dBx); RG_STREAM_STORE(&t[(T_DX + 6) * N], dCx);
-  RG_STREAM_STORE(&t[(T_DY + 0) * N], dry); RG_STREAM_STORE(&t[(T_DY + 1) * N], dpy); RG_STREAM_STORE(&t[(T_DY + 2) * N], duy); RG_STREAM_STORE(&t[(T_DY + 3) * N], dvy); RG_STREAM_STORE(&t[(T_DY + 4) * N], dwy);
-  RG_STREAM_STORE(&t[(T_DY + 5) * N], dAy); RG_STREAM_STORE(&t[(T_DY + 6) * N], dCy);
-  RG_STREAM_STORE(&t[(T_DZ + 0) * N], drz); RG_STREAM_STORE(&t[(T_DZ + 1) * N], dpz); RG_STREAM_STORE(&t[(T_DZ + 2) * N], duz); RG_STREAM_STORE(&t[(T_DZ + 3) * N], dvz); RG_STREAM_STORE(&t[(T_DZ + 4) * N], dwz);
-  RG_STREAM_STORE(&t[(T_DZ + 5) * N], dAz); RG_STREAM_STORE(&t[(T_DZ + 6) * N], dBz);
-  RG_STREAM_STORE(&t[T_DALY * N], dALy); RG_STREAM_STORE(&t[T_DALZ * N], dALz); RG_STREAM_STORE(&t[T_DBLX * N], dBLx); RG_STREAM_STORE(&t[T_DBLZ * N], dBLz); RG_STREAM_STORE(&t[T_DCLX * N], dCLx); RG_STREAM_STORE(&t[T_DCLY * N], dCLy);
+  tw.put(T_R, r); tw.put(T_P, p); tw.put(T_U, u); tw.put(T_V, v); tw.put(T_W, w); tw.put(T_A, A); tw.put(T_B, B); tw.put(T_C, C);
+  tw.put(T_AL, AL); tw.put(T_BL, BL); tw.put(T_CL, CL);
+  tw.put(T_DX + 0, drx); tw.put(T_DX + 1, dpx); tw.put(T_DX + 2, dux); tw.put(T_DX + 3, dvx); tw.put(T_DX + 4, dwx);
+  tw.put(T_DX + 5, dBx); tw.put(T_DX + 6, dCx);
+  tw.put(T_DY + 0, dry); tw.put(T_DY + 1, dpy); tw.put(T_DY + 2, duy); tw.put(T_DY + 3, dvy); tw.put(T_DY + 4, dwy);
+  tw.put(T_DY + 5, dAy); tw.put(T_DY + 6, dCy);
+  tw.put(T_DZ + 0, drz); tw.put(T_DZ + 1, dpz); tw.put(T_DZ + 2, duz); tw.put(T_DZ + 3, dvz); tw.put(T_DZ + 4, dwz);
+  tw.put(T_DZ + 5, dAz); tw.put(T_DZ + 6, dBz);
+  tw.put(T_DALY, dALy); tw.put(T_DALZ, dALz); tw.put(T_DBLX, dBLx); tw.put(T_DBLZ, dBLz); tw.put(T_DCLX, dCLx); tw.put(T_DCLY, dCLy);
 }
 
 RG_DEVFN bool trace3d_in_range(const DevParams& g, const IJK c) {
@@ -185,45 +207,54 @@ RG_DEVFN bool trace3d_in_range(const DevParams& g, const IJK c) {
 // Front end: Q and E come from the arrays written by mhd_prim_cell and mhd_elec_cell.  (A variant that recomputes
 // them from U inside this kernel -- no Q/E round trip, no prim/elec launches -- was measured NOT faster: 240 VGPRs,
 // 77.6-78.3 vs 76.6-77.3 ms/step at 512^3; it was dropped.)
-RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
-                               const double* __restrict__ E, double* __restrict__ T, double dtdx, double dtdy,
-                               double dtdz, unsigned idx) {
-  const IJK c = unflatten(g, idx);
-  if (!trace3d_in_range(g, c)) return;
-  const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
+// mhd_trace3d_at: cell c (in-plane index m of the input accessor) is known to be inside the trace range; tw receives
+// the 38 components
+template <class TIN, class TW>
+RG_DEVFN void mhd_trace3d_at(const DevParams& g, const TIN& in, const TW& tw, double dtdx, double dtdy,
+                             double dtdz, const IJK c, unsigned m) {
+  const unsigned sj = in.sj();
   const double st = g.slope_type;
   double q[8], dx_[8], dy_[8], dz_[8];
 #pragma unroll
   for (int v = 0; v < 8; ++v) {
-    const double* Qv = Q + v * N;
-    q[v] = Qv[idx];
+    q[v] = in.q(v, 0, m);
     if (st == 0) { dx_[v] = 0.0; dy_[v] = 0.0; dz_[v] = 0.0; }
     else if (st == 3) {   // plain path only (mhd_godunov_unsplit_cpu_v3.cpp:196-211); rejected at create for Omega0 > 0
       double lo = q[v], hi = q[v];
+#pragma unroll
       for (int dk = -1; dk <= 1; ++dk)
         for (int dj = -1; dj <= 1; ++dj)
 #pragma unroll
           for (int di = -1; di <= 1; ++di) {
-            const double nb = Qv[(unsigned)((int)idx + di + dj * (int)sj + dk * (int)sk)];
+            const double nb = in.q(v, dk, (unsigned)((int)m + di + dj * (int)sj));
             lo = (nb < lo) ? nb : lo;
             hi = (nb > hi) ? nb : hi;
           }
-      const double dfx = 0.5 * (Qv[idx + 1] - Qv[idx - 1]), dfy = 0.5 * (Qv[idx + sj] - Qv[idx - sj]);
-      const double dfz = 0.5 * (Qv[idx + sk] - Qv[idx - sk]);
+      const double dfx = 0.5 * (in.q(v, 0, m + 1) - in.q(v, 0, m - 1)), dfy = 0.5 * (in.q(v, 0, m + sj) - in.q(v, 0, m - sj));
+      const double dfz = 0.5 * (in.q(v, +1, m) - in.q(v, -1, m));
       const double dlim = positivity_limiter(lo, hi, q[v], fabs(dfx) + fabs(dfy) + fabs(dfz));
       dx_[v] = dlim * dfx;
       dy_[v] = dlim * dfy;
       dz_[v] = dlim * dfz;
     } else {
-      dx_[v] = tvd_slope(st, Qv[idx - 1], q[v], Qv[idx + 1]);
-      dy_[v] = tvd_slope(st, Qv[idx - sj], q[v], Qv[idx + sj]);
-      dz_[v] = tvd_slope(st, Qv[idx - sk], q[v], Qv[idx + sk]);
+      dx_[v] = tvd_slope(st, in.q(v, 0, m - 1), q[v], in.q(v, 0, m + 1));
+      dy_[v] = tvd_slope(st, in.q(v, 0, m - sj), q[v], in.q(v, 0, m + sj));
+      dz_[v] = tvd_slope(st, in.q(v, -1, m), q[v], in.q(v, +1, m));
     }
   }
-  const double* Ex = E; const double* Ey = E + N; const double* Ez = E + 2 * N;
-  const double E9[9] = {Ex[idx], Ex[idx + sk], Ex[idx + sj], Ey[idx], Ey[idx + sk], Ey[idx + 1], Ez[idx], Ez[idx + sj], Ez[idx + 1]};
-  mhd_trace3d_finish(g, U, T, c, idx, q, dx_, dy_, dz_, E9, dtdx, dtdy, dtdz);
+  const double E9[9] = {in.e(0, 0, m), in.e(0, +1, m), in.e(0, 0, m + sj), in.e(1, 0, m), in.e(1, +1, m), in.e(1, 0, m + 1),
+                        in.e(2, 0, m), in.e(2, 0, m + sj), in.e(2, 0, m + 1)};
+  mhd_trace3d_finish(g, in, tw, c, m, q, dx_, dy_, dz_, E9, dtdx, dtdy, dtdz);
+}
+
+RG_DEVFN void mhd_trace3d_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
+                               const double* __restrict__ E, double* __restrict__ T, double dtdx, double dtdy,
+                               double dtdz, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (!trace3d_in_range(g, c)) return;
+  const TGlobalWrite tw = {T + idx, (size_t)g.ncell};
+  const TraceInGlobal in = {U, Q, E, (size_t)g.ncell, g.sj, g.sk};
+  mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -238,31 +269,30 @@ RG_DEVFN void floor3d(const DevParams& g, Prim8& s) {
 
 // Face state of cell m in direction D, in the face-NORMAL frame.  SIDE=+1: the reference's qm[D] (state at the
 // HIGH face of m, the LEFT state of face m+1); SIDE=-1: qp[D] (state at the LOW face of m, the RIGHT state).
-template <int D, int SIDE, bool GF>
-RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
-  const size_t N = g.ncell;
-  const unsigned sD = (D == XD) ? 1u : (D == YD) ? g.sj : g.sk;
-  const double* t = T + m;
+// gm = GLOBAL flat index of cell m (only the per-cell gravity field reads it)
+template <int D, int SIDE, bool GF, class TA>
+RG_DEVFN Prim8 face_state3d(const DevParams& g, const TA& T, unsigned m, unsigned gm) {
+  const unsigned sD = T.stride(D);
   const int S = (D == XD) ? T_DX : (D == YD) ? T_DY : T_DZ;
   const double s = (double)SIDE;
-  double r = t[T_R * N] + s * t[(S + 0) * N];
-  double p = t[T_P * N] + s * t[(S + 1) * N];
-  double u = t[T_U * N] + s * t[(S + 2) * N];
-  double v = t[T_V * N] + s * t[(S + 3) * N];
-  double w = t[T_W * N] + s * t[(S + 4) * N];
+  double r = T.get(T_R, m) + s * T.get(S + 0, m);
+  double p = T.get(T_P, m) + s * T.get(S + 1, m);
+  double u = T.get(T_U, m) + s * T.get(S + 2, m);
+  double v = T.get(T_V, m) + s * T.get(S + 3, m);
+  double w = T.get(T_W, m) + s * T.get(S + 4, m);
   if (GF || g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:277-290)
     double gx, gy, gz;
-    half_dt_gravity<GF>(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, gm, gx, gy, gz);
     u += gx; v += gy; w += gz;
   }
   // normal field: the advanced face value (own low face, or the +1 neighbour's low face for the high side)
   const int TF = (D == XD) ? T_AL : (D == YD) ? T_BL : T_CL;
-  const double bn = (SIDE > 0) ? T[(m + sD) + (size_t)TF * N] : t[TF * N];
+  const double bn = (SIDE > 0) ? T.get(TF, m + sD) : T.get(TF, m);
   // the two transverse cell-centred components with their slopes along D (slots 5,6 of the slope group)
   double b1, b2;  // in grid order: the two components other than D, ascending
-  if (D == XD) { b1 = t[T_B * N] + s * t[(S + 5) * N]; b2 = t[T_C * N] + s * t[(S + 6) * N]; }
-  else if (D == YD) { b1 = t[T_A * N] + s * t[(S + 5) * N]; b2 = t[T_C * N] + s * t[(S + 6) * N]; }
-  else { b1 = t[T_A * N] + s * t[(S + 5) * N]; b2 = t[T_B * N] + s * t[(S + 6) * N]; }
+  if (D == XD) { b1 = T.get(T_B, m) + s * T.get(S + 5, m); b2 = T.get(T_C, m) + s * T.get(S + 6, m); }
+  else if (D == YD) { b1 = T.get(T_A, m) + s * T.get(S + 5, m); b2 = T.get(T_C, m) + s * T.get(S + 6, m); }
+  else { b1 = T.get(T_A, m) + s * T.get(S + 5, m); b2 = T.get(T_B, m) + s * T.get(S + 6, m); }
   Prim8 o;
   o.r = r; o.p = p;
   // permutation into the normal frame: x: (u,v,w | A,B,C)  y: (v,u,w | B,A,C)  z: (w,v,u | C,B,A)
@@ -276,31 +306,29 @@ RG_DEVFN Prim8 face_state3d(const DevParams& g, const double* __restrict__ T, un
 // Edge state of cell m for the edge along direction EDIR (0=x,1=y,2=z), at the corner given by the signs
 // (S1,S2) along the two transverse directions (t1,t2) = (y,z) | (z,x) | (x,y), returned in the EDGE frame
 // (u,v,w / a,b,c = components along t1, t2, e).  Reproduces qEdge of trace_mhd.h:2104-2246.
-template <int EDIR, int S1, int S2, bool GF>
-RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, unsigned m) {
-  const size_t N = g.ncell;
+template <int EDIR, int S1, int S2, bool GF, class TA>
+RG_DEVFN Prim8 edge_state3d(const DevParams& g, const TA& T, unsigned m, unsigned gm) {
   const int t1 = (EDIR + 1) % 3, t2 = (EDIR + 2) % 3;
-  const unsigned st1 = (t1 == XD) ? 1u : (t1 == YD) ? g.sj : g.sk;
-  const unsigned st2 = (t2 == XD) ? 1u : (t2 == YD) ? g.sj : g.sk;
+  const unsigned st1 = T.stride(t1);
+  const unsigned st2 = T.stride(t2);
   const int G1 = (t1 == XD) ? T_DX : (t1 == YD) ? T_DY : T_DZ;
   const int G2 = (t2 == XD) ? T_DX : (t2 == YD) ? T_DY : T_DZ;
-  const double* t = T + m;
   const double s1 = (double)S1, s2 = (double)S2;
   // cell-centred quantities: q + (s1*d_t1 + s2*d_t2).  In the reference the x-direction slope always comes
   // first inside the parenthesis, then y, then z; keep that operand order.
   const bool t1_first = t1 < t2;
 #define RG_EDGE_SUM(base, k1, k2) \
-  ((base) + (t1_first ? (s1 * t[(G1 + (k1)) * N] + s2 * t[(G2 + (k2)) * N]) : (s2 * t[(G2 + (k2)) * N] + s1 * t[(G1 + (k1)) * N])))
+  (T.get((base), m) + (t1_first ? (s1 * T.get(G1 + (k1), m) + s2 * T.get(G2 + (k2), m)) : (s2 * T.get(G2 + (k2), m) + s1 * T.get(G1 + (k1), m))))
   double vel[3];
   Prim8 o;
-  o.r = RG_EDGE_SUM(t[T_R * N], 0, 0);
-  o.p = RG_EDGE_SUM(t[T_P * N], 1, 1);
-  vel[0] = RG_EDGE_SUM(t[T_U * N], 2, 2);
-  vel[1] = RG_EDGE_SUM(t[T_V * N], 3, 3);
-  vel[2] = RG_EDGE_SUM(t[T_W * N], 4, 4);
+  o.r = RG_EDGE_SUM(T_R, 0, 0);
+  o.p = RG_EDGE_SUM(T_P, 1, 1);
+  vel[0] = RG_EDGE_SUM(T_U, 2, 2);
+  vel[1] = RG_EDGE_SUM(T_V, 3, 3);
+  vel[2] = RG_EDGE_SUM(T_W, 4, 4);
   if (GF || g.grav_on) {   // gravity predictor (..._cpu_v3.cpp:292-330)
     double gx, gy, gz;
-    half_dt_gravity<GF>(g, m, gx, gy, gz);
+    half_dt_gravity<GF>(g, gm, gx, gy, gz);
     vel[0] += gx; vel[1] += gy; vel[2] += gz;
   }
   // the field component along the edge is cell centred; its slope slot inside a direction group:
@@ -308,7 +336,7 @@ RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, un
   const int Te = (EDIR == XD) ? T_A : (EDIR == YD) ? T_B : T_C;
   const int k_in_G1 = (t1 == XD) ? ((EDIR == YD) ? 5 : 6) : (t1 == YD) ? ((EDIR == XD) ? 5 : 6) : ((EDIR == XD) ? 5 : 6);
   const int k_in_G2 = (t2 == XD) ? ((EDIR == YD) ? 5 : 6) : (t2 == YD) ? ((EDIR == XD) ? 5 : 6) : ((EDIR == XD) ? 5 : 6);
-  const double be = RG_EDGE_SUM(t[Te * N], k_in_G1, k_in_G2);
+  const double be = RG_EDGE_SUM(Te, k_in_G1, k_in_G2);
 #undef RG_EDGE_SUM
   // the two in-plane components are face centred: take the face on the signed side and add the signed
   // transverse half slope of THAT face (stored with the cell owning the face)
@@ -319,8 +347,8 @@ RG_DEVFN Prim8 edge_state3d(const DevParams& g, const double* __restrict__ T, un
   const int TS2 = (t2 == XD) ? ((t1 == YD) ? T_DALY : T_DALZ) : (t2 == YD) ? ((t1 == XD) ? T_DBLX : T_DBLZ) : ((t1 == XD) ? T_DCLX : T_DCLY);
   const unsigned m1 = (S1 > 0) ? m + st1 : m;
   const unsigned m2 = (S2 > 0) ? m + st2 : m;
-  const double b1 = T[m1 + (size_t)TF1 * N] + s2 * T[m1 + (size_t)TS1 * N];
-  const double b2 = T[m2 + (size_t)TF2 * N] + s1 * T[m2 + (size_t)TS2 * N];
+  const double b1 = T.get(TF1, m1) + s2 * T.get(TS1, m1);
+  const double b2 = T.get(TF2, m2) + s1 * T.get(TS2, m2);
   o.u = vel[t1]; o.v = vel[t2]; o.w = vel[EDIR];
   o.a = b1; o.b = b2; o.c = be;
   floor3d(g, o);
@@ -340,67 +368,83 @@ RG_DEVFN void store_flux(const DevParams& g, double* __restrict__ F, unsigned id
   for (int v = 0; v < 5; ++v) RG_STREAM_STORE(&F[idx + (size_t)(base + v) * N], fl[v]);
 }
 
-template <int MASK, bool GF>
-RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F,
-                              double* __restrict__ emf, unsigned idx) {
-  const IJK c = unflatten(g, idx);
-  if (c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw || c.k < g.gw || c.k > g.ksize - g.gw) return;
+// 1D Riemann problem at a face normal to D between the states L, R (face-normal frame) -> fl[0..4] used by the callers;
+// in the rotating frame the y flux gets the shear advection of the upwind state as left by the Riemann solver
+// (MHDRunGodunov.cpp:2861-2899)
+template <int D>
+RG_DEVFN void mhd_face_flux(const DevParams& g, Prim8& L, Prim8& R, double xPos, double* fl) {
+#pragma unroll
+  for (int v = 0; v < 8; ++v) fl[v] = 0.0;
+  mhd_riemann(g, L, R, fl);
+  if (D == YD && g.rot) {
+    const double shear_y = -1.5 * g.Omega0 * xPos;
+    const double bn_mean = 0.5 * (L.a + R.a);
+    const Prim8& s = (shear_y > 0) ? L : R;
+    const double eMag = 0.5 * (s.a * s.a + s.b * s.b + s.c * s.c);
+    const double eKin = 0.5 * (s.u * s.u + s.v * s.v + s.w * s.w);
+    const double eTot = eKin + eMag + s.p / (g.gamma0 - 1.0);
+    fl[ID] = fl[ID] + shear_y * s.r;
+    fl[IP] = fl[IP] + shear_y * (eTot + eMag - bn_mean * bn_mean);
+    fl[IU] = fl[IU] + shear_y * s.r * s.u;
+    fl[IV] = fl[IV] + shear_y * s.r * s.v;
+    fl[IW] = fl[IW] + shear_y * s.r * s.w;
+  }
+}
+
+// The Riemann problems selected by MASK at the low faces / low edges of the cell whose traced state is T(m); idx is its
+// global flat index (output location, gravity field), xPos its x coordinate.  The cell is known to be in range.
+template <int MASK, bool GF, class TA>
+RG_DEVFN void mhd_flux3d_at(const DevParams& g, const TA& T, unsigned m, double xPos, double* __restrict__ F,
+                            double* __restrict__ emf, unsigned idx) {
   const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
-  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+  const unsigned sx = T.stride(XD), sj = T.stride(YD), sk = T.stride(ZD);
+  const unsigned gsj = g.sj, gsk = g.sk;
   double fl[8];
   if (MASK & DO_FLUX_X) {
-    Prim8 L = face_state3d<XD, +1, GF>(g, T, idx - 1), R = face_state3d<XD, -1, GF>(g, T, idx);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
-    mhd_riemann(g, L, R, fl);
+    Prim8 L = face_state3d<XD, +1, GF>(g, T, m - sx, idx - 1), R = face_state3d<XD, -1, GF>(g, T, m, idx);
+    mhd_face_flux<XD>(g, L, R, xPos, fl);
     store_flux<XD>(g, F, idx, fl);
   }
   if (MASK & DO_FLUX_Y) {
-    Prim8 L = face_state3d<YD, +1, GF>(g, T, idx - sj), R = face_state3d<YD, -1, GF>(g, T, idx);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
-    mhd_riemann(g, L, R, fl);
-    if (g.rot) {
-      // shear advection of the y flux with the upwind state as left by the Riemann solver
-      // (MHDRunGodunov.cpp:2861-2899); states are in the y-normal frame
-      const double shear_y = -1.5 * g.Omega0 * xPos;
-      const double bn_mean = 0.5 * (L.a + R.a);
-      const Prim8& s = (shear_y > 0) ? L : R;
-      const double eMag = 0.5 * (s.a * s.a + s.b * s.b + s.c * s.c);
-      const double eKin = 0.5 * (s.u * s.u + s.v * s.v + s.w * s.w);
-      const double eTot = eKin + eMag + s.p / (g.gamma0 - 1.0);
-      fl[ID] = fl[ID] + shear_y * s.r;
-      fl[IP] = fl[IP] + shear_y * (eTot + eMag - bn_mean * bn_mean);
-      fl[IU] = fl[IU] + shear_y * s.r * s.u;
-      fl[IV] = fl[IV] + shear_y * s.r * s.v;
-      fl[IW] = fl[IW] + shear_y * s.r * s.w;
-    }
+    Prim8 L = face_state3d<YD, +1, GF>(g, T, m - sj, idx - gsj), R = face_state3d<YD, -1, GF>(g, T, m, idx);
+    mhd_face_flux<YD>(g, L, R, xPos, fl);
     store_flux<YD>(g, F, idx, fl);
   }
   if (MASK & DO_FLUX_Z) {
-    Prim8 L = face_state3d<ZD, +1, GF>(g, T, idx - sk), R = face_state3d<ZD, -1, GF>(g, T, idx);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) fl[v] = 0.0;
-    mhd_riemann(g, L, R, fl);
+    Prim8 L = face_state3d<ZD, +1, GF>(g, T, m - sk, idx - gsk), R = face_state3d<ZD, -1, GF>(g, T, m, idx);
+    mhd_face_flux<ZD>(g, L, R, xPos, fl);
     store_flux<ZD>(g, F, idx, fl);
   }
   // EMFs: slot order (RT, RB, LT, LB) = (+,+) from c-t1-t2, (+,-) from c-t1, (-,+) from c-t2, (-,-) from c
   if (MASK & DO_EMF_Z) {  // t1 = x, t2 = y
-    const Prim8 rt = edge_state3d<2, +1, +1, GF>(g, T, idx - 1 - sj), rb = edge_state3d<2, +1, -1, GF>(g, T, idx - 1);
-    const Prim8 lt = edge_state3d<2, -1, +1, GF>(g, T, idx - sj), lb = edge_state3d<2, -1, -1, GF>(g, T, idx);
+    const Prim8 rt = edge_state3d<2, +1, +1, GF>(g, T, m - sx - sj, idx - 1 - gsj), rb = edge_state3d<2, +1, -1, GF>(g, T, m - sx, idx - 1);
+    const Prim8 lt = edge_state3d<2, -1, +1, GF>(g, T, m - sj, idx - gsj), lb = edge_state3d<2, -1, -1, GF>(g, T, m, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_Y) {  // t1 = z, t2 = x
-    const Prim8 rt = edge_state3d<1, +1, +1, GF>(g, T, idx - sk - 1), rb = edge_state3d<1, +1, -1, GF>(g, T, idx - sk);
-    const Prim8 lt = edge_state3d<1, -1, +1, GF>(g, T, idx - 1), lb = edge_state3d<1, -1, -1, GF>(g, T, idx);
+    const Prim8 rt = edge_state3d<1, +1, +1, GF>(g, T, m - sk - sx, idx - gsk - 1), rb = edge_state3d<1, +1, -1, GF>(g, T, m - sk, idx - gsk);
+    const Prim8 lt = edge_state3d<1, -1, +1, GF>(g, T, m - sx, idx - 1), lb = edge_state3d<1, -1, -1, GF>(g, T, m, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_X) {  // t1 = y, t2 = z
-    const Prim8 rt = edge_state3d<0, +1, +1, GF>(g, T, idx - sj - sk), rb = edge_state3d<0, +1, -1, GF>(g, T, idx - sj);
-    const Prim8 lt = edge_state3d<0, -1, +1, GF>(g, T, idx - sk), lb = edge_state3d<0, -1, -1, GF>(g, T, idx);
+    const Prim8 rt = edge_state3d<0, +1, +1, GF>(g, T, m - sj - sk, idx - gsj - gsk), rb = edge_state3d<0, +1, -1, GF>(g, T, m - sj, idx - gsj);
+    const Prim8 lt = edge_state3d<0, -1, +1, GF>(g, T, m - sk, idx - gsk), lb = edge_state3d<0, -1, -1, GF>(g, T, m, idx);
     RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, rt, rb, lt, lb, xPos));
   }
+}
+
+RG_DEVFN bool flux3d_in_range(const DevParams& g, const IJK c) {
+  return !(c.i < g.gw || c.i > g.isize - g.gw || c.j < g.gw || c.j > g.jsize - g.gw || c.k < g.gw || c.k > g.ksize - g.gw);
+}
+
+template <int MASK, bool GF>
+RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, double* __restrict__ F,
+                              double* __restrict__ emf, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (!flux3d_in_range(g, c)) return;
+  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+  const TGlobalRead ta = {T, (size_t)g.ncell, g.sj, g.sk};
+  mhd_flux3d_at<MASK, GF>(g, ta, idx, xPos, F, emf, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -535,6 +535,19 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     if (gf) { K_mhd_flux3d<DO_ALL, true> k = {g, T, c->F, c->emf}; return launch_planes<kBlockHeavy, 1>(s, g, r, k); }
     return launch_spec<K_riemann_t, kBlockHeavy>(spec, s, g, r, T, c->F, c->emf);
   };
+  // LDS-tiled fused trace + Riemann sweep over the Riemann planes r (hip/tiled_mhd.h); 1 = not covered
+  auto sweep_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+    const int lo = r.lo < g.gw ? g.gw : r.lo, hi = r.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r.hi;
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, Q, E, c->F, c->emf, dtdx, dtdy, dtdz, lo, hi);
+  };
+  // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
+  const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
+  auto trace_riemann = [&](rg_stream_t s, int t_lo, int t_hi, PlaneRange rf) -> int {
+    if (use_sweep) { Phase ph(c, RGPU_T_SWEEP); return sweep_planes(s, rf); }
+    { Phase ph(c, RGPU_T_TRACE); if (trace_planes(s, clip(t_lo, t_hi, ks))) return -1; }
+    { Phase ph(c, RGPU_T_FLUX); if (riemann_planes(s, rf)) return -1; }
+    return 0;
+  };
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
   auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
@@ -557,8 +570,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     rg_stream_t s = c->stream;
     { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
     { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
-    { Phase ph(c, RGPU_T_TRACE); if (trace_planes(s, clip(a - 1, b + 1, ks))) return -1; }
-    { Phase ph(c, RGPU_T_FLUX); if (riemann_planes(s, clip(a, b + 1, ks))) return -1; }
+    if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
     return 0;
@@ -580,11 +592,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_prim = kb + 2;
       if (elec_planes(sm, clip(d_elec, kb + 2, ks))) return -1;
       d_elec = kb + 2;
-      if (trace_planes(sm, clip(d_trace, kb + 1, ks))) return -1;
+      if (!use_sweep && trace_planes(sm, clip(d_trace, kb + 1, ks))) return -1;
       d_trace = kb + 1;
       if (rg_event_record(c->ev_trace[ci], sm) || rg_stream_wait_event(sa, c->ev_trace[ci])) return -1;
       const PlaneRange rf = clip(d_flux, kb + 1, ks);
-      if (riemann_planes(sa, rf)) return -1;
+      if (use_sweep ? sweep_planes(sa, rf) : riemann_planes(sa, rf)) return -1;
       if (shear_planes(sa, rf)) return -1;
       d_flux = kb + 1;
       if (rg_event_record(c->ev_flux[ci], sa)) return -1;
@@ -1092,5 +1104,9 @@ int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, 
 }
 
 const char* rgpu_backend_name(void) { return RG_BACKEND_NAME; }
+
+#ifdef RG_SWEEP_PROF
+void rgpu_prof_read(unsigned long long* out, int reset) { rgpu_tiled::rgpu_prof_read_impl(out, reset); }
+#endif
 
 }  // extern "C"

@@ -7,11 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ramsesgpu_amd.solver import Library, Solver, lib_path
 
-base = sys.argv[1]; n = int(sys.argv[2]); nst = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+base = args[0]; n = int(args[1]); nst = int(args[2]) if len(args) > 2 else 10
 ov = "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (n, n, n)
 if base == "implode3d":
     ov += ";hydro.riemannSolver=hllc"
-L = Library(lib_path())
+prof = "--prof" in sys.argv
+if prof:   # experiment build with per-wave phase cycle counters (RG_SWEEP_PROF)
+    from ramsesgpu_amd import build as rb
+    L = Library(rb.build(verbose=False, extra_flags=["-DRG_SWEEP_PROF"], out_name="librgpu_prof.so"))
+else:
+    L = Library(lib_path())
 ini = os.path.join(ROOT, "configs", base + ".ini")
 p = L.params_from_ini(ini, ov)
 U0 = L.init_condition(ini, ov, p)
@@ -25,6 +31,15 @@ for _ in range(nst): sv.oneStepIntegration()
 sv.synchronize(); dtw = time.time() - t0
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("RGPU_"))
 print("%-14s %4d^3 [%s] %8.1f Mcell/s  %.3f ms/step" % (base, n, tag, nst * n ** 3 / dtw / 1e6, dtw / nst * 1e3), flush=True)
+if prof:
+    import ctypes as C
+    buf = (C.c_ulonglong * 32)()
+    L.lib.rgpu_prof_read(buf, 1)
+    sv.oneStepIntegration(); sv.synchronize()
+    L.lib.rgpu_prof_read(buf, 1)
+    print("     per-wave cycles of one step [trace work, wait1, riemann work, wait2] (sums over workgroups, 1e9):")
+    for w in range(8):
+        print("       wave %d: " % w + "  ".join("%8.3f" % (buf[w * 4 + q] / 1e9) for q in range(4)))
 sv.enable_timers(True); sv.reset_timers()
 for _ in range(3): sv.oneStepIntegration()
 tm = sv.timers()
