@@ -63,15 +63,85 @@ __device__ unsigned long long rg_prof[8 * 4];
 #define RG_PROF_T(x)
 #endif
 
+// T accessor of ONE plane buffer: the +z neighbour of a cell is not in it.  stride(ZD) = 0 makes the one component of a
+// state that reads the plane above (the face field on the + side) read this plane instead; the caller replaces that
+// component when the plane above has been traced (see "carried states" below).
+struct TLdsPlane {
+  const double* base;
+  RG_DEVFN double get(int slot, unsigned m) const { return base[slot * MH_CELLS + m]; }
+  RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)MH_PX : 0u; }
+};
+
+// Riemann problems of one direction d at cell m of plane kk: the edge EMF along d and the flux through the low d face.
+// Tk = traced state of plane kk.  States that belong to plane kk-1 (the two upper edge states of the x / y edges, the
+// left state of the z face) were built one iteration earlier from T(kk-1) -- except their one component that lives on
+// plane kk, which is filled in here -- and are carried in registers (c0, c1): T(kk-1) need not stay in LDS.
+// After solving, the states plane kk contributes to iteration kk+1 are built into c0, c1.
+template <int DIR>
+RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve) {
+  const size_t N = g.ncell;
+  const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
+    if (solve) {
+      c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);        // b2 = CL(m2) + s1 * dCLy(m2), s1 = +1, m2 = the cell above
+      c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
+      const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
+      Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
+      double fl[8];
+      mhd_face_flux<XD>(g, L, R, xPos, fl);
+      store_flux<XD>(g, F, idx, fl);
+    }
+    c0 = edge_state3d<0, +1, +1, false>(g, Tk, m - sj, idx);
+    c1 = edge_state3d<0, -1, +1, false>(g, Tk, m, idx);
+  } else if (DIR == YD) {   // edge along y: t1 = z, t2 = x.  rt = (+,+) from c-z-x, rb = (+,-) from c-z, lt = (-,+) from c-x, lb from c
+    if (solve) {
+      c0.a = Tk.get(T_CL, m - sx) + Tk.get(T_DCLX, m - sx);        // b1 = CL(m1) + s2 * dCLx(m1), s2 = +1
+      c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
+      const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
+      Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
+      double fl[8];
+      mhd_face_flux<YD>(g, L, R, xPos, fl);
+      store_flux<YD>(g, F, idx, fl);
+    }
+    c0 = edge_state3d<1, +1, +1, false>(g, Tk, m - sx, idx);
+    c1 = edge_state3d<1, +1, -1, false>(g, Tk, m, idx);
+  } else {   // edge along z: all four states on plane kk; z face: left state from plane kk-1
+    if (solve) {
+      const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
+      const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
+      c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
+      Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
+      double fl[8];
+      mhd_face_flux<ZD>(g, c0, R, xPos, fl);
+      store_flux<ZD>(g, F, idx, fl);
+    }
+    c0 = face_state3d<ZD, +1, false>(g, Tk, m, idx);
+  }
+}
+
+// Wave roles (8 waves; waves w and w + 4 share a SIMD):
+//   waves 0,1,2 and 4,5,6   Riemann problems of direction d = w & 3 for the cells [64 * (w >> 2), +64) of the tile:
+//                           edge EMF along d (2D HLLD, ~1100 VALU instructions) + flux through the low d face (~470)
+//   wave 3                  trace of cells 0..63 of the (tile + halo) plane, then of cells 128..152
+//   wave 7                  trace of cells 64..127
+// so every SIMD carries ~3100 (Riemann) or ~2700 (trace) wave-instructions per plane, both of its waves busy.
+// Per iteration kk (ONE phase, then a short one):  all threads issue the loads of the inputs of plane kk+3;
+// trace waves: T(kk+1) -> buffer (kk+1) & 1 from the staged Q / B (kk .. kk+2), E (kk+1, kk+2);
+// Riemann waves: problems of plane kk from T(kk) (buffer kk & 1) and the carried states;  barrier;
+// the staged values go to the LDS slots plane kk (Q / B) and kk+1 (E) have just vacated;  barrier.
 template <int SPEC>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                const double* __restrict__ Q, const double* __restrict__ E,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dtdx, double dtdy, double dtdz, int ra, int rb) {
   spec_assume<SPEC>(g);
-  __shared__ double LT[2 * MH_BUF];          // T of planes kk-1, kk            (buffer = plane & 1)
-  __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk-1 .. kk+1    (slot = plane % 3)
-  __shared__ double LE[2 * MH_ESLOT];        // E of planes kk, kk+1            (slot = plane & 1)
+  __shared__ double LT[2 * MH_BUF];          // T of planes kk (read) and kk+1 (written)   (buffer = plane & 1)
+  __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk .. kk+2                  (slot = plane % 3)
+  __shared__ double LE[2 * MH_ESLOT];        // E of planes kk+1, kk+2                      (slot = plane & 1)
 
   const int b = (int)blockIdx.x;
   const int lin = (b & 7) * tg.per_xcd + (b >> 3);
@@ -117,64 +187,67 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     }
   };
 
-  // trace role: thread t < MH_CELLS owns traced cell (i0 - 1 + tx, j0 - 1 + ty)
-  const int ty = t / MH_PX, tx = t - ty * MH_PX;
-  const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
-  const bool tr_ok = t < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw;   // low bounds hold by construction
-  const int tm = ty * MH_PX + tx;
-  const unsigned tqm = (unsigned)((ty + 1) * MH_QX + tx + 1);
+  const int wave = t >> 6, lane = t & 63;
+  const bool tracer = (wave & 3) == 3;
 
-  // Riemann role: wave pair = problem group, the pair's 128 lanes = the tile's cells
-  const int group = t >> 7;
-  const int cl = t & 127;
+  // trace role
+  auto trace_cell = [&](int k, int cell) {
+    const int ty = cell / MH_PX, tx = cell - ty * MH_PX;
+    const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
+    if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
+      const IJK c = {ti, tj, k};
+      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
+      const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
+                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}};
+      mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
+    }
+  };
+
+  // Riemann role
+  const int dir = wave & 3;
+  const int cl = (wave >> 2) * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
-  const bool fl_ok = ci <= g.isize - gw && cj <= g.jsize - gw;
+  const bool fl_ok = !tracer && ci <= g.isize - gw && cj <= g.jsize - gw;
   const unsigned cidx2 = fl_ok ? (unsigned)ci + (unsigned)cj * g.sj : 0u;
   const unsigned cm = (unsigned)((oy + 1) * MH_PX + ox + 1);
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
-
-  auto trace_plane = [&](int k) {
-    if (tr_ok) {
-      const IJK c = {ti, tj, k};
-      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + tm};
-      const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
-                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}};
-      mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, tqm);
-    }
-  };
+  Prim8 c0, c1;
+  c0.r = c0.p = 1.0; c0.u = c0.v = c0.w = c0.a = c0.b = c0.c = 0.0;
+  c1 = c0;
 
 #ifdef RG_SWEEP_PROF
   long long acc[4] = {0, 0, 0, 0};
 #endif
-  // prologue: inputs of planes sa-2, sa-1, sa (E of plane sa-2 lands in the slot plane sa takes over: write order matters)
+  // prologue: inputs of planes sa-2, sa-1, sa (trace(sa-1) reads them)
   stage_load(sa - 2); stage_store(sa - 2);
-  __syncthreads();
   stage_load(sa - 1); stage_store(sa - 1);
-  stage_load(sa);
+  __syncthreads();   // E of plane sa-2 and of plane sa share a slot
+  stage_load(sa); stage_store(sa);
   __syncthreads();
-  stage_store(sa);
-  __syncthreads();
-  // iteration sa-1 only traces; iterations sa .. sb-1 trace plane kk and solve the Riemann problems of plane kk
-  for (int kk = sa - 1; kk < sb; ++kk) {
+  // iteration kk: trace(kk+1) next to the Riemann problems of plane kk.  kk = sa-2 only traces plane sa-1, kk = sa-1 traces
+  // plane sa and builds the carried states from T(sa-1); the last iteration kk = sb-1 has nothing left to trace.
+  for (int kk = sa - 2; kk < sb; ++kk) {
     RG_PROF_T(tA);
-    trace_plane(kk);
+    const bool more = kk + 3 <= sb;
+    if (more) stage_load(kk + 3);
+    if (tracer) {
+      if (kk + 1 < sb) {
+        if (wave == 3) { trace_cell(kk + 1, lane); trace_cell(kk + 1, 128 + lane); }
+        else trace_cell(kk + 1, 64 + lane);
+      }
+    } else if (fl_ok && kk >= sa - 1) {
+      const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
+      const unsigned idx = cidx2 + (unsigned)kk * sk;
+      const bool solve = kk >= sa;
+      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
+      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
+      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
+    }
     RG_PROF_T(tB);
     __syncthreads();
     RG_PROF_T(tC);
-    const bool more = kk + 2 <= sb;
-    if (more) stage_load(kk + 2);
-    if (fl_ok && kk >= sa) {
-      const int bk = kk & 1;
-      const TLdsRead ta = {LT, (unsigned)((2 * bk - 1) * MH_BUF)};   // buffer(kk) - buffer(kk-1)
-      const unsigned m = (unsigned)(bk * MH_BUF) + cm;
-      const unsigned idx = cidx2 + (unsigned)kk * sk;
-      if (group == 0) mhd_flux3d_at<DO_EMF_X, false>(g, ta, m, xPos, F, emf, idx);
-      else if (group == 1) mhd_flux3d_at<DO_EMF_Y, false>(g, ta, m, xPos, F, emf, idx);
-      else if (group == 2) mhd_flux3d_at<DO_EMF_Z, false>(g, ta, m, xPos, F, emf, idx);
-      else mhd_flux3d_at<DO_FLUX_X | DO_FLUX_Y | DO_FLUX_Z, false>(g, ta, m, xPos, F, emf, idx);
-    }
-    if (more) stage_store(kk + 2);   // slots of Q / B (kk-1) and E (kk): dead since trace(kk)
+    if (more) stage_store(kk + 3);   // Q / B slot of plane kk and E slot of plane kk+1: dead since trace(kk+1)
     RG_PROF_T(tD);
     __syncthreads();
 #ifdef RG_SWEEP_PROF
@@ -199,8 +272,12 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   int nseg;
   if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
   else {
-    // one workgroup per CU is resident: aim at >= 8 rounds over 256 CUs, segments of >= 8 planes (one extra trace each)
-    nseg = (2048 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
+    // one workgroup per CU is resident; a segment costs two extra iterations (pipeline fill).  Segments of ~64 planes
+    // measured best at 512^3 (35.1 ms against 36.2 for one 513-plane march and 35.6 for 32-plane segments): enough
+    // workgroups to even out the last round over the 256 CUs.  Small boxes: at least ~8 rounds, segments >= 8 planes.
+    nseg = (span + 63) / 64;
+    const int want = (2048 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
+    if (nseg < want) nseg = want;
     if (nseg > span / 8) nseg = span / 8;
   }
   if (nseg < 1) nseg = 1;
