@@ -1,28 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- headline metric of BASELINE.json: Mcell-updates/s of the 3D MHD unsplit step (fp64).
+"""bench.py -- headline metric of BASELINE.json: Mcell-updates/s of the unsplit Godunov step (fp64).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload mri|implode3d|orszag-tang] [--size S | --nx --ny --nz]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A "step" is one oneStepIntegration of the hot path = compute_dt_mhd + godunov_unsplit (rotating + shearing-box
-variant) incl. the ghost fill, on synthetic data: configs/mhd_mri_3d.ini (values of the reference's
-data/mhd_mri_3d.ini) scaled to 512^3, [MRI] seed=0 -- BASELINE.json configs[3].  The state is resident in HBM
-when the timed region starts.  With N>1 the SAME 512^3 box is cut into N z-slabs (strong scaling), one process per
-GPU, halo planes exchanged with RCCL point-to-point calls, 1/dt max-reduced with one all-reduce.
+A "step" is one oneStepIntegration of the hot path = compute_dt[_mhd] + godunov_unsplit incl. the ghost fill, on synthetic
+data; the state is resident in HBM when the timed region starts.  Workloads (BASELINE.json configs):
+  mri          (default; the headline line) configs/mhd_mri_3d.ini scaled to 512^3: 3D MHD shearing box, isothermal,
+               HLLD + MAG_HLLD + CT, [MRI] seed=0 -- configs[3]; --nx 512 --ny 1024 --nz 512 --gpus 8 is configs[4]
+  implode3d    configs/implode3d.ini at 256^3 with riemannSolver=hllc -- configs[1]
+  orszag-tang  configs/orszag-tang.ini as shipped (512^2, 2D MHD) -- configs[2]; its correctness gate is in tests/
+With N>1 the SAME 3D box is cut into N z-slabs (strong scaling), one process per GPU, halo planes exchanged with RCCL
+point-to-point calls, 1/dt max-reduced with one all-reduce.  2D boxes do not shard: N independent replicas (weak).
 
 value = K * nx*ny*nz / t / 1e6 with t = max over ranks of the wall time of the K steps, bracketed by
 barrier + torch.cuda.synchronize() on both sides: the reference's own "cell updates per second"
 (MHDRunGodunov.cpp:4064-4068).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel of the step (by accumulated time): algorithmic bytes per launch (128 B per cell
-                update: read U once + write U once) / its average duration measured with
-                HIP events on the kernel's stream, against the 8 TB/s HBM3E peak.  `traffic` comes from the
+  roofline      dominant kernel of the step (by accumulated time): algorithmic bytes per launch (read U once + write U
+                once: 128 B per MHD cell update, 80 B hydro 3D) / its average duration measured
+                with HIP events on the kernel's stream, against the 8 TB/s HBM3E peak.  `traffic` comes from the
                 rocprofv3 --pmc summary under profiles/ (null if absent).
   roofline_step the same accounting for the whole step (all kernels).
   cpu_baseline  N=1, rank 0 only: the reference binary oracle/_ref/euler_cpu ("reference") -- or the oracle's
-                restatement ("port") -- on ONE host core, on a bounded sample of the same workload.
+                restatement ("port") -- on ONE host core, on a bounded sample of the same workload (256^3 for the 3D
+                workloads when the host has the memory).
 """
 import argparse
 import json
@@ -36,24 +40,45 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BASE = "mhd_mri_3d"
 HBM_PEAK = 8.0e12                 # B/s, MI355X HBM3E (guide: MI355X_MICROARCH.md)
-ALGO_BYTES_PER_CELL = 128.0       # MHD: 8 stored variables, read once + written once, fp64
+
+WORKLOADS = {
+    # name: ini base, extra overrides, default (nx, ny, nz), algorithmic bytes per cell update, description, path
+    "mri": dict(base="mhd_mri_3d", extra="", size=(512, 512, 512), bytes=128.0,
+                desc="configs/mhd_mri_3d.ini (= reference data/mhd_mri_3d.ini) scaled to %s: 3D MHD MRI, isothermal, "
+                     "rotating frame + shearing box, HLLD + MAG_HLLD + CT, [MRI] seed=0",
+                path="compute_dt_mhd + godunov_unsplit (rotating) + shearing ghost fill",
+                ref_mb_per_cell=1.7e-3),
+    "implode3d": dict(base="implode3d", extra="hydro.riemannSolver=hllc", size=(256, 256, 256), bytes=80.0,
+                      desc="configs/implode3d.ini (= reference data/implode3d.ini) at %s: 3D hydro implosion, HLLC, "
+                           "reflecting walls",
+                      path="compute_dt + godunov_unsplit (hydro unsplit version 1) + ghost fill",
+                      ref_mb_per_cell=0.6e-3),
+    "orszag-tang": dict(base="orszag-tang", extra="", size=(512, 512, 1), bytes=128.0,
+                        desc="configs/orszag-tang.ini (= reference data/orszag-tang.ini) at %s: 2D MHD Orszag-Tang vortex, "
+                             "HLLD + MAG_HLLD + CT",
+                        path="compute_dt_mhd + godunov_unsplit (2D MHD implementation 1) + ghost fill",
+                        ref_mb_per_cell=0.8e-3),
+}
 
 
-def workload_overrides(n):
-    return "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (n, n, n)
+def overrides_for(w, nx, ny, nz):
+    ov = "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (nx, ny, nz)
+    return ov + (";" + w["extra"] if w["extra"] else "")
 
 
-def _ref_ini(size, steps):
-    ini_text = open(os.path.join(ROOT, "configs", BASE + ".ini")).read()
-    for k, v in (("nx", size), ("ny", size), ("nz", size), ("nstepmax", steps), ("noutput", 10 ** 6),
-                 ("outputVtk", "no"), ("outputHdf5", "no")):
+def _ref_ini(w, nx, ny, nz, steps):
+    ini_text = open(os.path.join(ROOT, "configs", w["base"] + ".ini")).read()
+    edits = [("nx", nx), ("ny", ny), ("nz", nz), ("nstepmax", steps), ("noutput", 10 ** 6), ("outputVtk", "no"), ("outputHdf5", "no")]
+    for kv in (w["extra"].split(";") if w["extra"] else []):
+        k, v = kv.split("=")
+        edits.append((k.split(".")[1], v))
+    for k, v in edits:
         ini_text = re.sub(r"(?m)^%s=.*$" % k, "%s=%s" % (k, v), ini_text)
     return ini_text
 
 
-def _ref_rates(ref_bin, size, steps, copies):
+def _ref_rates(ref_bin, w, dims, steps, copies):
     """run `copies` independent euler_cpu processes at once; returns their reported cell-update rates [1/s] and the wall time"""
     with tempfile.TemporaryDirectory() as td:
         procs = []
@@ -61,7 +86,7 @@ def _ref_rates(ref_bin, size, steps, copies):
         for c in range(copies):
             d = os.path.join(td, "r%d" % c)
             os.makedirs(d)
-            open(os.path.join(d, "b.ini"), "w").write(_ref_ini(size, steps))
+            open(os.path.join(d, "b.ini"), "w").write(_ref_ini(w, dims[0], dims[1], dims[2], steps))
             procs.append(subprocess.Popen([ref_bin, "--param", "b.ini"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                           universal_newlines=True))
         outs = [pr.communicate()[0] for pr in procs]
@@ -74,36 +99,40 @@ def _ref_rates(ref_bin, size, steps, copies):
     return rates, wall
 
 
-def cpu_baseline_all_cores(size, steps):
-    """the reference binary is single-threaded (its OpenMP build races, SURVEY.md 5.2): occupy the host with one
-    independent replica per core and add the rates up -- an upper bound for any domain-decomposed CPU run"""
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "euler_cpu")
-    if not os.path.exists(ref_bin):
-        return None
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def _avail_gb():
     try:
-        avail_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
+        return os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2.0 ** 30
     except (ValueError, OSError):
-        avail_gb = 16.0
-    per_copy_gb = 1.7e-6 * (size + 6) ** 3      # ~1.7 kB per cell in the reference's 3D MHD arrays
-    copies = int(max(1, min(cores, 64, 0.5 * avail_gb / per_copy_gb)))   # 64 replicas already saturate the host's memory system
-    rates, wall = _ref_rates(ref_bin, size, steps, copies)
-    if len(rates) != copies:
-        return None
-    return {"value": sum(rates) / 1e6, "unit": "Mcell-updates/s", "cores": copies, "kind": "reference",
-            "sample": "%d independent replicas of %s at %d^3, %d steps, one single-threaded euler_cpu per core, rates summed (%.1f s)"
-                      % (copies, BASE, size, steps, wall)}
+        return 16.0
 
 
-def cpu_baseline(size, steps):
+def cpu_sample(w, dims, budget_s=25.0):
+    """bounded sample of the workload for the 1-core CPU leg: 256^3 for the 3D boxes when the host has the memory for the
+    reference's arrays, else 128^3; the 2D workload as shipped.  Steps sized for ~budget_s at the
+    reference's ~0.7 (MHD) / ~1.7 (hydro) Mcell-updates/s."""
+    if dims[2] == 1:
+        n = (min(dims[0], 512), min(dims[1], 512), 1)
+        rate = 0.9e6
+    else:
+        e = 256 if _avail_gb() > 1.5 * w["ref_mb_per_cell"] * 262 ** 3 / 1024.0 else 128
+        e = min(e, max(dims))
+        n = (min(e, dims[0]), min(e, dims[1]), min(e, dims[2]))
+        rate = 0.7e6 if w["bytes"] == 128.0 else 1.7e6
+    cells = n[0] * n[1] * n[2]
+    steps = int(max(1, min(50, round(budget_s * rate / cells))))
+    return n, steps
+
+
+def cpu_baseline(w, dims):
     """time the CPU path on a bounded sample (same physics, smaller box; the metric is intensive)"""
+    n, steps = cpu_sample(w, dims)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "euler_cpu")
-    sample = "%s at %d^3, %d steps, 1 thread" % (BASE, size, steps)
+    sample = "%s at %dx%dx%d, %d steps, 1 thread" % (w["base"], n[0], n[1], n[2], steps)
     if os.path.exists(ref_bin):
-        rates, wall = _ref_rates(ref_bin, size, steps, 1)
+        rates, wall = _ref_rates(ref_bin, w, n, steps, 1)
         if rates:
             return {"value": rates[0] / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "reference",
-                    "sample": sample + " (oracle/_ref/euler_cpu, g++ -O2, %.1f s)" % wall}
+                    "sample": sample + " (oracle/_ref/euler_cpu, g++ -O2, %.1f s incl. initial condition)" % wall}
     # fall back to the oracle's restatement (bit-identical arithmetic, same loop structure)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_api import Oracle
@@ -112,23 +141,44 @@ def cpu_baseline(size, steps):
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     L = load_library()
-    ini = os.path.join(ROOT, "configs", BASE + ".ini")
-    p = L.params_from_ini(ini, workload_overrides(size))
-    U0 = L.init_condition(ini, workload_overrides(size), p)
+    ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+    ov = overrides_for(w, *n)
+    p = L.params_from_ini(ini, ov)
+    U0 = L.init_condition(ini, ov, p)
     t0 = time.time()
     Oracle(so).run(p, U0, steps)
     wall = time.time() - t0
-    return {"value": steps * size ** 3 / wall / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
+    return {"value": steps * n[0] * n[1] * n[2] / wall / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
             "sample": sample + " (oracle/liboracle.so, g++ -O2, %.1f s)" % wall}
 
 
-def pmc_traffic(kernel_phase):
+def cpu_baseline_all_cores(w, steps=10):
+    """the reference binary is single-threaded (its OpenMP build races, SURVEY.md 5.2): occupy the host with one
+    independent replica per core and add the rates up -- an upper bound for any domain-decomposed CPU run.  NOT a
+    decomposed run of one box: independent 64^3 replicas."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "euler_cpu")
+    if not os.path.exists(ref_bin) or w["base"] != "mhd_mri_3d":
+        return None
+    size = 64
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per_copy_gb = 1.7e-6 * (size + 6) ** 3      # ~1.7 kB per cell in the reference's 3D MHD arrays
+    copies = int(max(1, min(cores, 64, 0.5 * _avail_gb() / per_copy_gb)))   # 64 replicas already saturate the host's memory system
+    rates, wall = _ref_rates(ref_bin, w, (size, size, size), steps, copies)
+    if len(rates) != copies:
+        return None
+    return {"value": sum(rates) / 1e6, "unit": "Mcell-updates/s", "cores": copies, "kind": "reference",
+            "sample": "%d INDEPENDENT replicas of %s at %d^3, %d steps, one single-threaded euler_cpu per core, rates summed (%.1f s)"
+                      % (copies, w["base"], size, steps, wall)}
+
+
+def pmc_traffic(workload, kernel_phase):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary, or None"""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
         d = json.load(open(path))
+        d = d.get(workload, d)
         return d.get(kernel_phase, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
@@ -139,12 +189,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=512, help="box edge (default: the 512^3 headline workload)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="mri")
+    ap.add_argument("--size", type=int, default=0, help="box edge (cubic; default: the workload's BASELINE size)")
+    ap.add_argument("--nx", type=int, default=0)
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--nz", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timeline-only", action="store_true", help="stop after the timed region (for rocprofv3 --kernel-trace concurrency analysis)")
-    ap.add_argument("--cpu-size", type=int, default=96)
-    ap.add_argument("--cpu-steps", type=int, default=10)
     args = ap.parse_args()
+
+    w = WORKLOADS[args.workload]
+    nx, ny, nz = w["size"]
+    if args.size:
+        nx, ny, nz = args.size, args.size, (args.size if nz != 1 else 1)
+    nx, ny = args.nx or nx, args.ny or ny
+    if nz != 1:
+        nz = args.nz or nz
+    two_d = nz == 1
 
     import torch
     import torch.distributed as dist
@@ -175,11 +236,11 @@ def main():
             dist.init_process_group(backend)
 
     L = load_library()
-    ini = os.path.join(ROOT, "configs", BASE + ".ini")
-    ov = workload_overrides(args.size)
-    n = args.size
+    ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+    ov = overrides_for(w, nx, ny, nz)
+    replicas = two_d and world > 1      # 2D boxes do not shard: independent replicas
 
-    if world == 1:
+    if world == 1 or replicas:
         p = L.params_from_ini(ini, ov)
         U0 = L.init_condition(ini, ov, p)
         run = Solver(p, L)
@@ -232,11 +293,13 @@ def main():
     dom_name, dom_ms, dom_launches = timers_src.dominant_kernel()
     timers_src.enable_timers(False)
 
-    cells_global = float(n) ** 3
+    cells_box = float(nx) * ny * nz
+    cells_global = cells_box * (world if replicas else 1)
     cells_local = cells_global / world
     value = args.steps * cells_global / elapsed / 1e6
     if rank == 0:
-        step_bytes = ALGO_BYTES_PER_CELL * cells_local
+        dims = "%dx%d" % (nx, ny) if two_d else "%dx%dx%d" % (nx, ny, nz)
+        step_bytes = w["bytes"] * cells_local
         # per step: a slab run launches the kernel once per plane range (two boundary ranges + the inner one)
         dom_ms = dom_ms * dom_launches / nprof
         achieved = step_bytes / (dom_ms * 1e-3)
@@ -245,24 +308,25 @@ def main():
             "metric": "Mcell-updates/s", "value": value, "unit": "Mcell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs/mhd_mri_3d.ini (= reference data/mhd_mri_3d.ini) scaled to %d^3: 3D MHD MRI, "
-                                   "isothermal, rotating frame + shearing box, HLLD + MAG_HLLD + CT, [MRI] seed=0" % n,
-                       "nx": n, "ny": n, "nz": n, "decomposition": "z-slabs x%d" % world,
-                       "path": "compute_dt_mhd + godunov_unsplit (rotating) + shearing ghost fill",
+            "config": {"workload": w["desc"] % dims,
+                       "nx": nx, "ny": ny, "nz": nz,
+                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d" % world,
+                       "path": w["path"],
                        "parity": "bit-identical to euler_cpu on all golden fixtures (tests/)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(dom_name),
+                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(args.workload, dom_name),
                          "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
-                         "note": "ALU-bound kernel (fp64 div/sqrt heavy Riemann solvers): see DESIGN.md"},
+                         "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
+                                  "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md")},
             "roofline_step": {"bound": "hbm", "achieved": step_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": step_bytes / (elapsed / args.steps) / HBM_PEAK,
                               "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": step_ms_events},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps)
-            allc = cpu_baseline_all_cores(64, 10)
+            out["cpu_baseline"] = cpu_baseline(w, (nx, ny, nz))
+            allc = cpu_baseline_all_cores(w)
             if allc:
                 out["cpu_baseline_all_cores"] = allc
         print(json.dumps(out))
