@@ -250,8 +250,22 @@ def main():
         # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
         step = run.oneStepIntegration
         timers_src = run
-    else:
+    elif os.environ.get("RGPU_BENCH_DRIVER", "cpp") == "python" or os.environ.get("RGPU_BENCH_BACKEND", "nccl") != "nccl":
+        # legacy harness: the same schedule in Python over torch.distributed (the only way to put two ranks on ONE GPU,
+        # which RCCL refuses: the RGPU_BENCH_ONE_DEVICE / RGPU_BENCH_BACKEND=gloo test hook)
         srun = SlabRun(ini, ov, library=L, device="cuda:%d" % local_rank)
+        srun.init_simulation()
+        step = srun.oneStepIntegration
+        timers_src = srun.solver
+        p = srun.p
+    else:
+        # the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the device;
+        # torch.distributed only carries the 128-byte unique id and the barriers of the timing contract
+        from ramsesgpu_amd import comm as rcomm
+        CL = rcomm.load_comm_library()
+        ids = [rcomm.unique_id(CL) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        srun = rcomm.CommRun(ini, ov, rank, world, ids[0], library=L, comm_library=CL)
         srun.init_simulation()
         step = srun.oneStepIntegration
         timers_src = srun.solver
@@ -312,7 +326,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["desc"] % dims,
                        "nx": nx, "ny": ny, "nz": nz,
-                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d" % world,
+                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d%s" % (world, " (C++ RCCL driver, include/rgpu_comm.h)" if world > 1 else ""),
                        "path": w["path"],
                        "parity": "bit-identical to euler_cpu on all golden fixtures (tests/)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 4
+#define RGPU_ABI_VERSION 4   /* layout of rgpu_params; new entry points do not change it */
 
 /* component indexes -- constants.h:59-71 */
 enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
@@ -151,6 +151,13 @@ int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out);
 int rgpu_add_forcing(rgpu_ctx* c, int parity, double norm);
 /* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */
 double* rgpu_device_state(rgpu_ctx* c, int parity);
+/* What a communication layer (include/rgpu_comm.h) needs to work on a context without host round trips: the parameters
+ * the context was created with, the HIP stream its kernels are queued on (hipStream_t as void*), and the 8-byte device
+ * slot the CFL scan leaves its maximum in (a non-negative double; rgpu_inv_dt_result reads it back) -- the operand
+ * of the MAX all-reduce that replaces the reference's MPI allReduce of dt (HydroRunBaseMpi.cpp:509-513). */
+int rgpu_get_params(rgpu_ctx* c, rgpu_params* out);
+void* rgpu_stream_handle(rgpu_ctx* c);
+double* rgpu_inv_dt_device_slot(rgpu_ctx* c);
 
 /* ---- the path ------------------------------------------------------------------------------------------- */
 

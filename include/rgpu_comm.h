@@ -1,0 +1,88 @@
+/*
+ * rgpu_comm.h -- C ABI of the z-slab driver: one process per GPU, RCCL over xGMI (librgpu_comm.so, next to librgpu.so).
+ *
+ * Replaces, for the one decomposition the path needs (mx = my = 1, mz = nranks), the reference's
+ * MPI layer around the step:
+ *   cartesian topology + neighbour ranks        HydroMpiParameters.cpp:44-80, 196-201   -> rgpu_comm_create
+ *   make_boundaries ZDIR: host-staged border buffers + MPI_Sendrecv (blocking)
+ *                                               HydroRunBaseMpi.cpp:3529-3661            -> rgpu_comm_exchange_z_start / _wait
+ *   make_all_boundaries[_shear] of the Mpi classes (X,Y,Z | X-int,Y,Z,shear,Z,Y)
+ *                                               MHDRunGodunovMpi.cpp:4266-4307           -> rgpu_comm_make_all_boundaries
+ *   compute_dt + MPI allReduce(MIN)             HydroRunBaseMpi.cpp:509-513, 696-700     -> rgpu_comm_compute_dt
+ *   godunov_unsplit / oneStepIntegration of MHDRunGodunovMpi / HydroRunGodunovMpi        -> rgpu_comm_godunov_unsplit,
+ *                                                                                           rgpu_comm_one_step_integration
+ * k is the slowest index, so the ghostWidth planes of one variable are one contiguous chunk: they are sent from / received
+ * into the state arrays in place (no pack kernels, no host staging) with ONE grouped ncclSend / ncclRecv set per exchange on
+ * a dedicated halo stream, ordered against the context's compute stream by events only.  The 1/dt maximum is all-reduced
+ * in place in the context's device slot (ncclMax on the compute stream) and read back once per step.
+ *
+ * Step schedule (overlap, the default): update the planes the neighbours read -> finish their x / y ghosts -> start the
+ * exchange of the output state -> update the inner planes while it is in flight -> wait (device side) -> physical z faces.
+ * Results are bit-identical to the single-domain run (tests/test_comm_driver.py, world sizes 1, 2, 3).
+ *
+ * Bootstrap: rank 0 calls rgpu_comm_unique_id and hands the 128 bytes to the other ranks by any out-of-band channel
+ * (a file, an environment variable, torch.distributed's store: the library does not care).
+ * Error model of rgpu.h: 0 or a negative RGPU_E* code, message in rgpu_comm_last_error.
+ */
+#ifndef RGPU_COMM_H_
+#define RGPU_COMM_H_
+
+#include "rgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGPU_COMM_ID_BYTES 128
+
+typedef struct rgpu_comm rgpu_comm;
+
+/* == ncclGetUniqueId; call on ONE rank */
+int rgpu_comm_unique_id(char id[RGPU_COMM_ID_BYTES]);
+
+/* Binds a context created with slab_rank = rank, slab_count = nranks (rgpuh_params_from_ini with slab.rank / slab.count,
+ * z faces towards neighbour slabs = RGPU_BC_COPY) to a communicator of nranks processes.  Collective over all ranks.
+ * The context must outlive the communicator.  nranks = 1 is allowed (periodic z: the rank is its own neighbour). */
+int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COMM_ID_BYTES], rgpu_comm** out);
+void rgpu_comm_destroy(rgpu_comm* cm);
+const char* rgpu_comm_last_error(rgpu_comm* cm);
+
+/* Halo exchange of the z ghost planes of U[parity] that belong to a neighbour slab.  _start queues it on the halo stream
+ * behind everything queued on the context's stream so far and returns; _wait makes the context's stream wait for it
+ * (device-side dependency, the host does not block). */
+int rgpu_comm_exchange_z_start(rgpu_comm* cm, int parity);
+int rgpu_comm_exchange_z_wait(rgpu_comm* cm);
+
+/* Ghost fill of all faces of U[parity] across the slabs, in the reference's order (plain: X, Y, Z; shearing box:
+ * Y, shear remap, Z, Y).  Used once for the initial state; the step keeps the ghosts valid afterwards. */
+int rgpu_comm_make_all_boundaries(rgpu_comm* cm, int parity, double totalTime, double dt);
+
+/* dt = cfl / max over all slabs of the inverse time step of U[useU] */
+int rgpu_comm_compute_dt(rgpu_comm* cm, int useU, double* dt);
+
+/* One unsplit step U[nStep%2] -> U[(nStep+1)%2] over all slabs, halo exchange included (all ghosts of the output valid
+ * on return, in stream order). */
+int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalTime);
+
+/* == oneStepIntegration(nStep, t, dt) of the Mpi run classes */
+int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt);
+
+/* 0: serial schedule (exchange between the step pieces), 1: overlapped (default) */
+int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
+
+/* hipSetDevice for launchers without a HIP binding of their own: call before rgpu_create / rgpu_comm_create */
+int rgpu_comm_set_device(int device);
+
+/* name of the transport the library was built with ("rccl") */
+const char* rgpu_comm_transport_name(void);
+
+/* euler_hip --slabs: run [run] nstepmax / tend of an .ini on rank `rank` of `nranks`; this process drives HIP device
+ * `device` (-1: the current one).  id as above.  Returns the steps done or a negative error; *mcell_per_s = whole-box
+ * cell updates per second. */
+int rgpuh_run_slabs(const char* ini_path, const char* overrides, int rank, int nranks, int device,
+                    const char id[RGPU_COMM_ID_BYTES], double* mcell_per_s, char* err, int err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGPU_COMM_H_ */

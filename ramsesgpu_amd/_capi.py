@@ -101,6 +101,12 @@ def declare_device_api(lib):
     lib.rgpu_download.argtypes = [ctx, C.c_void_p, C.c_int]
     lib.rgpu_device_state.restype = C.c_void_p
     lib.rgpu_device_state.argtypes = [ctx, C.c_int]
+    lib.rgpu_get_params.restype = C.c_int
+    lib.rgpu_get_params.argtypes = [ctx, P]
+    lib.rgpu_stream_handle.restype = C.c_void_p
+    lib.rgpu_stream_handle.argtypes = [ctx]
+    lib.rgpu_inv_dt_device_slot.restype = C.c_void_p
+    lib.rgpu_inv_dt_device_slot.argtypes = [ctx]
     lib.rgpu_make_boundaries.restype = C.c_int
     lib.rgpu_make_boundaries.argtypes = [ctx, C.c_int, C.c_int]
     lib.rgpu_make_boundaries_shear.restype = C.c_int
@@ -161,7 +167,7 @@ def declare_device_api(lib):
 # every symbol include/rgpu.h declares (checked by tests/test_abi.py against the built library)
 DECLARED_SYMBOLS = [
     "rgpu_create", "rgpu_create_external", "rgpu_destroy", "rgpu_state_elems", "rgpu_device_bytes", "rgpu_last_error",
-    "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
+    "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_get_params", "rgpu_stream_handle", "rgpu_inv_dt_device_slot", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
     "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",

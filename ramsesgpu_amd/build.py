@@ -53,9 +53,20 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code only
+    comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
+    comm_out = os.path.join(HERE, "librgpu_comm.so")
+    comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(HERE, "..", "include", "rgpu_comm.h"),
+                 os.path.join(HERE, "..", "include", "rgpu.h"), out]
+    if out_name == "librgpu.so" and (force or _newer(comm_out, comm_deps)):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu",
+               "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", comm_out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     main_src = os.path.join(CSRC, "host", "euler_hip_main.cpp")
-    if out_name == "librgpu.so" and (force or _newer(exe, [main_src, out])):
-        cmd = [HIPCC, "-O2", "-std=c++17", main_src, "-L", HERE, "-lrgpu", "-Wl,-rpath,$ORIGIN", "-o", exe]
+    if out_name == "librgpu.so" and (force or _newer(exe, [main_src, out, comm_out])):
+        cmd = [HIPCC, "-O2", "-std=c++17", main_src, "-L", HERE, "-lrgpu_comm", "-lrgpu", "-Wl,-rpath,$ORIGIN", "-o", exe]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

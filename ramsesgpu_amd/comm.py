@@ -1,0 +1,133 @@
+"""ctypes binding of the C++ z-slab driver (include/rgpu_comm.h, librgpu_comm.so): one process per GPU, RCCL halo
+exchange on a side stream, 1/dt all-reduced in the context's device slot.  CommRun mirrors the method names of the
+reference's Mpi run classes (init_simulation, make_all_boundaries, compute_dt, godunov_unsplit, oneStepIntegration) like
+ramsesgpu_amd.slab.SlabRun does for the torch.distributed harness; here Python only launches -- the schedule, the
+exchange and the reduction are C++."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from .solver import RgpuError, Solver, load_library
+
+ID_BYTES = 128
+
+
+def comm_lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgpu_comm.so")
+
+
+def load_comm_library(path=None):
+    lib = C.CDLL(path or comm_lib_path(), mode=C.RTLD_GLOBAL)
+    cm = C.c_void_p
+    lib.rgpu_comm_unique_id.restype = C.c_int
+    lib.rgpu_comm_unique_id.argtypes = [C.c_char_p]
+    lib.rgpu_comm_create.restype = C.c_int
+    lib.rgpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(cm)]
+    lib.rgpu_comm_destroy.restype = None
+    lib.rgpu_comm_destroy.argtypes = [cm]
+    lib.rgpu_comm_last_error.restype = C.c_char_p
+    lib.rgpu_comm_last_error.argtypes = [cm]
+    lib.rgpu_comm_transport_name.restype = C.c_char_p
+    lib.rgpu_comm_set_device.restype = C.c_int
+    lib.rgpu_comm_set_device.argtypes = [C.c_int]
+    lib.rgpu_comm_set_overlap.restype = C.c_int
+    lib.rgpu_comm_set_overlap.argtypes = [cm, C.c_int]
+    for name in ("rgpu_comm_exchange_z_wait",):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [cm]
+    lib.rgpu_comm_exchange_z_start.restype = C.c_int
+    lib.rgpu_comm_exchange_z_start.argtypes = [cm, C.c_int]
+    lib.rgpu_comm_make_all_boundaries.restype = C.c_int
+    lib.rgpu_comm_make_all_boundaries.argtypes = [cm, C.c_int, C.c_double, C.c_double]
+    lib.rgpu_comm_compute_dt.restype = C.c_int
+    lib.rgpu_comm_compute_dt.argtypes = [cm, C.c_int, C.POINTER(C.c_double)]
+    lib.rgpu_comm_godunov_unsplit.restype = C.c_int
+    lib.rgpu_comm_godunov_unsplit.argtypes = [cm, C.c_int, C.c_double, C.c_double]
+    lib.rgpu_comm_one_step_integration.restype = C.c_int
+    lib.rgpu_comm_one_step_integration.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rgpuh_run_slabs.restype = C.c_int
+    lib.rgpuh_run_slabs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    return lib
+
+
+DECLARED_SYMBOLS = [
+    "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
+    "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
+    "rgpu_comm_one_step_integration", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+]
+
+
+def unique_id(comm_lib):
+    buf = C.create_string_buffer(ID_BYTES)
+    if comm_lib.rgpu_comm_unique_id(buf) != 0:
+        raise RgpuError("rgpu_comm_unique_id failed")
+    return buf.raw
+
+
+class CommRun:
+    """rank `rank` of `world` z-slabs.  comm_id: the 128 bytes of rgpu_comm_unique_id from rank 0 (any side channel)."""
+
+    def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=True):
+        self.L = library or load_library()
+        self.CL = comm_library or load_comm_library()
+        self.rank, self.world = rank, world
+        self.ini_path, self.overrides = ini_path, overrides
+        self.p = self.L.params_from_ini(ini_path, overrides, slab=(rank, world))
+        if not self.p.three_d:
+            raise ValueError("2D problems do not shard: run replicas")
+        self.solver = Solver(self.p, self.L)
+        self.cm = C.c_void_p()
+        rc = self.CL.rgpu_comm_create(self.solver.ctx, rank, world, comm_id, C.byref(self.cm))
+        if rc != 0:
+            msg = self.CL.rgpu_comm_last_error(self.cm).decode() if self.cm else "allocation"
+            raise RgpuError("rgpu_comm_create: %s (%d)" % (msg, rc))
+        self._chk(self.CL.rgpu_comm_set_overlap(self.cm, 1 if overlap else 0), "set_overlap")
+        self.nStep, self.totalTime, self.dt = 0, 0.0, 0.0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RgpuError("%s: %s (%d)" % (what, self.CL.rgpu_comm_last_error(self.cm).decode(), rc))
+
+    def init_simulation(self):
+        """each rank builds its own slab of the initial condition (no scatter from rank 0)"""
+        hU = self.L.init_condition(self.ini_path, self.overrides, self.p)
+        self.solver.upload(np.ascontiguousarray(hU), both=False)
+        G = self.L.init_gravity(self.ini_path, self.overrides, self.p)
+        if G is not None:
+            self.solver.set_gravity_field(G)
+        F = self.L.init_forcing(self.ini_path, self.overrides, self.p)
+        if F is not None:
+            self.solver.set_forcing_field(F)
+        self.make_all_boundaries(0, 0.0, 0.0)
+        self.nStep, self.totalTime = 0, 0.0
+
+    def make_all_boundaries(self, parity, totalTime, dt):
+        self._chk(self.CL.rgpu_comm_make_all_boundaries(self.cm, parity, totalTime, dt), "make_all_boundaries")
+
+    def compute_dt(self, useU):
+        dt = C.c_double(0)
+        self._chk(self.CL.rgpu_comm_compute_dt(self.cm, useU, C.byref(dt)), "compute_dt")
+        return dt.value
+
+    def godunov_unsplit(self, nStep, dt):
+        self._chk(self.CL.rgpu_comm_godunov_unsplit(self.cm, nStep, dt, self.totalTime), "godunov_unsplit")
+
+    def oneStepIntegration(self):
+        n, t, dt = C.c_int(self.nStep), C.c_double(self.totalTime), C.c_double(0)
+        self._chk(self.CL.rgpu_comm_one_step_integration(self.cm, C.byref(n), C.byref(t), C.byref(dt)), "oneStepIntegration")
+        self.nStep, self.totalTime, self.dt = n.value, t.value, dt.value
+        return self.dt
+
+    def local_interior(self):
+        """interior cells of this slab (host copy)"""
+        gw = self.p.ghostWidth
+        self.solver.synchronize()
+        return self.solver.getDataHost(self.nStep % 2)[:, gw:-gw, gw:-gw, gw:-gw]
+
+    def close(self):
+        if self.cm:
+            self.CL.rgpu_comm_destroy(self.cm)
+            self.cm = C.c_void_p()
+        self.solver.close()

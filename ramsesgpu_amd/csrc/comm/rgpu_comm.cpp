@@ -1,0 +1,301 @@
+// rgpu_comm.cpp -- the z-slab driver behind include/rgpu_comm.h: one process per GPU, each stepping its slab through the
+// plane-ranged entry points of include/rgpu.h, ghost planes exchanged in place by the transport (rg_transport.h, chosen
+// by include path: csrc/hip = RCCL; tests/emu = callbacks for the CPU tests).  Plain host C++: no kernels here.
+//
+// Schedule and its equivalence to the reference's fill order: see include/rgpu_comm.h and DESIGN.md section 6.
+// (The Python class ramsesgpu_amd/slab.py is the same schedule over torch.distributed; it stays as the test harness.)
+#include "../../../include/rgpu_comm.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rg_transport.h"
+
+using rgpu_transport::P2P;
+
+struct rgpu_comm {
+  rgpu_ctx* ctx;
+  rgpu_params p;
+  rgpu_transport::Comm* tc;
+  int rank, nranks;
+  bool overlap;
+  int primed;     // parity of the state whose ghosts are all valid, -1 = none
+  int scanned;    // parity of the state whose 1/dt sits in the context's device slot, -1 = none
+  std::vector<P2P> ops[2];
+  std::string err;
+};
+
+namespace {
+
+int fail(rgpu_comm* cm, int code, const std::string& m) { if (cm) cm->err = m; return code; }
+int ctx_fail(rgpu_comm* cm, int rc, const char* what) { return fail(cm, rc, std::string(what) + ": " + rgpu_last_error(cm->ctx)); }
+int tr_fail(rgpu_comm* cm, const char* what) { return fail(cm, RGPU_EHIP, std::string(what) + ": " + cm->tc->err); }
+
+#define RG_TRY(call, what) do { const int rc_ = (call); if (rc_) return ctx_fail(cm, rc_, what); } while (0)
+
+bool rotating(const rgpu_comm* cm) { return cm->p.mhdEnabled && cm->p.Omega0 > 0; }
+bool dissipative(const rgpu_comm* cm) { return cm->p.nu > 0 || (cm->p.mhdEnabled && cm->p.eta > 0); }
+
+// send / receive descriptors of one state array (the arrays never move): per variable one contiguous chunk per face.
+// Posting order = the order the peer's matching calls are posted in (grouped RCCL send / recv match in order per peer).
+void build_ops(rgpu_comm* cm, int parity) {
+  std::vector<P2P>& ops = cm->ops[parity];
+  ops.clear();
+  const rgpu_params& p = cm->p;
+  const int gw = p.ghostWidth;
+  const size_t plane = (size_t)(p.nx + 2 * gw) * (p.ny + 2 * gw);
+  const size_t ncell = plane * (size_t)(p.nz + 2 * gw);
+  const size_t chunk = plane * gw;
+  double* U = rgpu_device_state(cm->ctx, parity);
+  const int prev = (cm->rank - 1 + cm->nranks) % cm->nranks, next = (cm->rank + 1) % cm->nranks;
+  const bool has_prev = p.bc[4] == RGPU_BC_COPY, has_next = p.bc[5] == RGPU_BC_COPY;
+  for (int v = 0; v < p.nbVar; ++v) {
+    double* Uv = U + (size_t)v * ncell;
+    if (has_prev) { const P2P o = {Uv + plane * gw, chunk, prev, 1}; ops.push_back(o); }            // low interior planes
+    if (has_next) { const P2P o = {Uv + plane * p.nz, chunk, next, 1}; ops.push_back(o); }            // high interior planes
+  }
+  for (int v = 0; v < p.nbVar; ++v) {
+    double* Uv = U + (size_t)v * ncell;
+    if (has_next) { const P2P o = {Uv + plane * (p.nz + gw), chunk, next, 0}; ops.push_back(o); }     // high ghost planes
+    if (has_prev) { const P2P o = {Uv, chunk, prev, 0}; ops.push_back(o); }                           // low ghost planes
+  }
+}
+
+int exchange_start(rgpu_comm* cm, int parity) {
+  const std::vector<P2P>& ops = cm->ops[parity & 1];
+  if (ops.empty()) return 0;
+  if (rgpu_transport::exchange_start(cm->tc, rgpu_stream_handle(cm->ctx), ops.data(), (int)ops.size())) return tr_fail(cm, "exchange_z_start");
+  return 0;
+}
+int exchange_wait(rgpu_comm* cm) {
+  if (rgpu_transport::exchange_wait(cm->tc, rgpu_stream_handle(cm->ctx))) return tr_fail(cm, "exchange_z_wait");
+  return 0;
+}
+int exchange(rgpu_comm* cm, int parity) {
+  const int rc = exchange_start(cm, parity);
+  return rc ? rc : exchange_wait(cm);
+}
+
+int make_all_boundaries(rgpu_comm* cm, int parity, double t, double dt) {
+  rgpu_ctx* c = cm->ctx;
+  if (cm->p.shearingBoxEnabled) {
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_YDIR), "make_boundaries(Y)");
+    RG_TRY(rgpu_make_boundaries_shear(c, parity, t, dt), "make_boundaries_shear");
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_ZDIR), "make_boundaries(Z)");   // physical z faces only
+    if (int rc = exchange(cm, parity)) return rc;
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_YDIR), "make_boundaries(Y)");
+  } else {
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_XDIR), "make_boundaries(X)");
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_YDIR), "make_boundaries(Y)");
+    RG_TRY(rgpu_make_boundaries(c, parity, RGPU_ZDIR), "make_boundaries(Z)");
+    if (int rc = exchange(cm, parity)) return rc;
+  }
+  cm->primed = parity;
+  return 0;
+}
+
+// max over the slabs of the inverse time step: all-reduce of the device slot in place, ONE read-back
+int compute_dt(rgpu_comm* cm, int useU, double* dt) {
+  rgpu_ctx* c = cm->ctx;
+  if (cm->scanned != useU) {   // not accumulated plane range by plane range during the last step: full scan
+    const int ks = cm->p.nz + 2 * cm->p.ghostWidth;
+    RG_TRY(rgpu_inv_dt_accumulate(c, useU, 0, ks, 1), "inv_dt_accumulate");
+  }
+  cm->scanned = -1;
+  if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), 1, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
+  double inv = 0.0;
+  RG_TRY(rgpu_inv_dt_result(c, &inv), "inv_dt_result");
+  *dt = cm->p.cfl / inv;
+  return 0;
+}
+
+int random_forcing(rgpu_comm* cm, int nStep, double dt) {
+  const rgpu_params& p = cm->p;
+  const int pout = (nStep + 1) % 2;
+  double s[2];
+  RG_TRY(rgpu_forcing_sums(cm->ctx, pout, s), "forcing_sums");
+  if (cm->nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, s, 2, rgpu_stream_handle(cm->ctx))) return tr_fail(cm, "allreduce(forcing sums)");
+  double norm = 0.0;
+  if (p.randomForcingEdot != 0) {
+    const long long nb = (long long)p.nx * p.ny * p.nz_global;
+    norm = (std::sqrt(s[0] * s[0] + s[1] * dt * p.randomForcingEdot * 2 * nb) - s[0]) / s[1];
+  }
+  RG_TRY(rgpu_add_forcing(cm->ctx, pout, norm), "add_forcing");
+  return 0;
+}
+
+// exchange between the step pieces, nothing overlapped
+int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
+  rgpu_ctx* c = cm->ctx;
+  const bool rot = rotating(cm);
+  RG_TRY(rgpu_step_pre(c, nStep, dt, t), "step_pre");
+  if (!rot) { if (int rc = exchange(cm, nStep % 2)) return rc; }          // plain path: ghosts of the INPUT
+  RG_TRY(rgpu_step_core(c, nStep, dt, t), "step_core");
+  if (dissipative(cm)) {
+    // viscosity / resistivity work on the updated state with ALL its ghosts (mhd_godunov_unsplit_cpu_v3.cpp:662-668)
+    if (int rc = make_all_boundaries(cm, (nStep + 1) % 2, t, dt)) return rc;
+    RG_TRY(rgpu_step_dissipative(c, nStep, dt, t), "step_dissipative");
+  }
+  if (cm->p.randomForcingEnabled) { if (int rc = random_forcing(cm, nStep, dt)) return rc; }
+  RG_TRY(rgpu_step_post_a(c, nStep, dt, t), "step_post_a");
+  if (rot) { if (int rc = exchange(cm, (nStep + 1) % 2)) return rc; }     // rotating path: ghosts of the OUTPUT
+  RG_TRY(rgpu_step_post_b(c, nStep, dt, t), "step_post_b");
+  cm->primed = rot ? (nStep + 1) % 2 : -1;
+  cm->scanned = -1;
+  return 0;
+}
+
+int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
+  // the dissipative stage needs a second exchange inside the step, the random forcing a global sum and a change of the
+  // whole updated state: both use the serial schedule
+  if (!cm->overlap || dissipative(cm) || cm->p.randomForcingEnabled) return godunov_unsplit_serial(cm, nStep, dt, t);
+  rgpu_ctx* c = cm->ctx;
+  const int pin = nStep % 2, pout = (nStep + 1) % 2;
+  const bool rot = rotating(cm);
+  if (cm->primed != pin && !rot) {   // ghosts of the input not known to be valid (first step): fill them like the reference
+    RG_TRY(rgpu_step_pre(c, nStep, dt, t), "step_pre");
+    if (int rc = exchange(cm, pin)) return rc;
+  }
+  const int gw = cm->p.ghostWidth, nz = cm->p.nz, ks = nz + 2 * gw;
+  // (boundary update ranges, planes to finish and send, inner update range) in array plane indices
+  int bnd[2][2], snd[2][2], nb;
+  bool has_inner;
+  if (nz <= 2 * gw) { nb = 1; bnd[0][0] = 0; bnd[0][1] = ks; snd[0][0] = gw; snd[0][1] = nz + gw; has_inner = false; }
+  else {
+    nb = 2; bnd[0][0] = 0; bnd[0][1] = 2 * gw; bnd[1][0] = nz; bnd[1][1] = ks;
+    snd[0][0] = gw; snd[0][1] = 2 * gw; snd[1][0] = nz; snd[1][1] = nz + gw; has_inner = true;
+  }
+  const bool scan = !rot;   // rotating path: the reference's compute_dt sees the refilled ghosts -> full scan next step
+  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes(c, nStep, dt, t, bnd[n][0], bnd[n][1]), "step_core_planes");
+  if (scan) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
+  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
+  if (int rc = exchange_start(cm, pout)) return rc;
+  if (has_inner) {
+    RG_TRY(rgpu_step_core_planes(c, nStep, dt, t, 2 * gw, nz), "step_core_planes");
+    if (scan) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
+    RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, 2 * gw, nz), "step_fill_planes");
+  }
+  if (int rc = exchange_wait(cm)) return rc;
+  RG_TRY(rgpu_make_boundaries(c, pout, RGPU_ZDIR), "make_boundaries(Z)");   // physical z faces (+ 3D jet)
+  cm->primed = pout;
+  cm->scanned = scan ? pout : -1;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgpu_comm_unique_id(char id[RGPU_COMM_ID_BYTES]) { return (id && rgpu_transport::unique_id(id) == 0) ? RGPU_OK : RGPU_EHIP; }
+
+int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COMM_ID_BYTES], rgpu_comm** out) {
+  if (!out) return RGPU_EINVAL;
+  *out = 0;
+  rgpu_comm* cm = new (std::nothrow) rgpu_comm();
+  if (!cm) return RGPU_ENOMEM;
+  *out = cm;   // returned on failure too, for rgpu_comm_last_error
+  cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1;
+  if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
+  if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
+  if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");
+  if (cm->p.slab_rank != rank || cm->p.slab_count != nranks) return fail(cm, RGPU_EINVAL, "comm_create: the context was created for another slab_rank / slab_count");
+  (void)rgpu_stream_handle(ctx);   // makes the context's device current (every rgpu entry point does)
+  if (rgpu_transport::create(&cm->tc, rank, nranks, id)) return fail(cm, RGPU_EHIP, "transport: " + (cm->tc ? cm->tc->err : std::string("allocation")));
+  build_ops(cm, 0);
+  build_ops(cm, 1);
+  return RGPU_OK;
+}
+
+void rgpu_comm_destroy(rgpu_comm* cm) {
+  if (!cm) return;
+  if (cm->tc) rgpu_transport::destroy(cm->tc);
+  delete cm;
+}
+
+const char* rgpu_comm_last_error(rgpu_comm* cm) { return cm ? cm->err.c_str() : "null communicator"; }
+const char* rgpu_comm_transport_name(void) { return RG_TRANSPORT_NAME; }
+int rgpu_comm_set_device(int device) { rgpu_transport::set_device(device); return RGPU_OK; }
+
+#define RG_CHECK_CM(cm) do { if (!(cm) || !(cm)->tc) return RGPU_EINVAL; } while (0)
+
+int rgpu_comm_exchange_z_start(rgpu_comm* cm, int parity) { RG_CHECK_CM(cm); return exchange_start(cm, parity); }
+int rgpu_comm_exchange_z_wait(rgpu_comm* cm) { RG_CHECK_CM(cm); return exchange_wait(cm); }
+int rgpu_comm_make_all_boundaries(rgpu_comm* cm, int parity, double totalTime, double dt) { RG_CHECK_CM(cm); return make_all_boundaries(cm, parity & 1, totalTime, dt); }
+int rgpu_comm_compute_dt(rgpu_comm* cm, int useU, double* dt) { RG_CHECK_CM(cm); if (!dt) return RGPU_EINVAL; return compute_dt(cm, useU & 1, dt); }
+int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalTime) { RG_CHECK_CM(cm); return godunov_unsplit(cm, nStep, dt, totalTime); }
+int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = overlap != 0; return RGPU_OK; }
+
+int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt) {
+  RG_CHECK_CM(cm);
+  if (!nStep || !t || !dt) return fail(cm, RGPU_EINVAL, "one_step_integration: null pointer");
+  double d = 0.0;
+  if (int rc = compute_dt(cm, *nStep % 2, &d)) return rc;
+  *dt = d;
+  if (int rc = godunov_unsplit(cm, *nStep, d, *t)) return rc;
+  *nStep += 1;
+  *t += d;
+  return RGPU_OK;
+}
+
+// euler_hip --slabs: the time loop of start() (MHDRunGodunov.cpp:3801-4070) over the slabs, outputs left to the single-GPU
+// front end (each rank keeps its slab on its device)
+int rgpuh_run_slabs(const char* ini_path, const char* overrides, int rank, int nranks, int device,
+                    const char id[RGPU_COMM_ID_BYTES], double* mcell_per_s, char* err, int err_len) {
+  rgpu_transport::set_device(device);
+  auto say = [&](const std::string& m, int code) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); return code; };
+  if (!ini_path || !id) return say("run_slabs: null argument", RGPU_EINVAL);
+  char e2[512] = {0};
+  std::string ov = overrides ? overrides : "";
+  char slab[64];
+  std::snprintf(slab, sizeof(slab), "%sslab.rank=%d;slab.count=%d", ov.empty() ? "" : ";", rank, nranks);
+  ov += slab;
+  rgpu_params p;
+  if (int rc = rgpuh_params_from_ini(ini_path, ov.c_str(), &p, e2, sizeof(e2))) return say(e2, rc);
+  int nStepmax = 0, nOutput = 0; double tEnd = 0;
+  if (int rc = rgpuh_run_settings(ini_path, ov.c_str(), &nStepmax, &tEnd, &nOutput, e2, sizeof(e2))) return say(e2, rc);
+  std::vector<double> hU(rgpu_state_elems(&p));
+  if (int rc = rgpuh_init_condition(ini_path, ov.c_str(), &p, hU.data(), e2, sizeof(e2))) return say(e2, rc);
+  rgpu_ctx* ctx = 0;
+  if (int rc = rgpu_create(&p, &ctx)) { const std::string m = ctx ? rgpu_last_error(ctx) : "allocation"; if (ctx) rgpu_destroy(ctx); return say("rgpu_create: " + m, rc); }
+  rgpu_comm* cm = 0;
+  int rc = rgpu_upload(ctx, hU.data(), 0);
+  std::vector<double>().swap(hU);
+  if (!rc && p.gravityEnabled == 2) {
+    std::vector<double> hG(3 * (rgpu_state_elems(&p) / p.nbVar));
+    if (rgpuh_init_gravity(ini_path, ov.c_str(), &p, hG.data(), e2, sizeof(e2)) == 1) rc = rgpu_set_gravity_field(ctx, hG.data());
+  }
+  if (!rc && p.randomForcingEnabled) {
+    std::vector<double> hF(3 * (rgpu_state_elems(&p) / p.nbVar));
+    if (rgpuh_init_forcing(ini_path, ov.c_str(), &p, hF.data(), e2, sizeof(e2)) == 1) rc = rgpu_set_forcing_field(ctx, hF.data());
+  }
+  if (rc) { const std::string m = rgpu_last_error(ctx); rgpu_destroy(ctx); return say("initial state: " + m, rc); }
+  rc = rgpu_comm_create(ctx, rank, nranks, id, &cm);
+  int nStep = 0;
+  double t = 0.0, dt = 0.0;
+  if (!rc) rc = rgpu_comm_make_all_boundaries(cm, 0, 0.0, 0.0);
+  // (h_U.copyTo(h_U2) of the reference is not needed: every step writes the whole output array)
+  if (!rc) rc = rgpu_transport::barrier(cm->tc, rgpu_stream_handle(ctx)) ? RGPU_EHIP : 0;
+  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  while (!rc && t < tEnd && nStep < nStepmax) {
+    rc = rgpu_comm_one_step_integration(cm, &nStep, &t, &dt);
+    if (!rc && rank == 0 && nOutput > 0 && (nStep % nOutput) == 0) std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, t, dt);
+  }
+  if (!rc) rc = rgpu_synchronize(ctx);
+  if (!rc) rc = rgpu_transport::barrier(cm->tc, rgpu_stream_handle(ctx)) ? RGPU_EHIP : 0;
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::string msg;
+  if (rc) msg = cm && !cm->err.empty() ? cm->err : rgpu_last_error(ctx);
+  if (mcell_per_s) *mcell_per_s = wall > 0 ? (double)nStep * p.nx * p.ny * p.nz_global / wall / 1e6 : 0.0;
+  if (cm) rgpu_comm_destroy(cm);
+  rgpu_destroy(ctx);
+  if (rc) return say("run_slabs: " + msg, rc);
+  return nStep;
+}
+
+}  // extern "C"

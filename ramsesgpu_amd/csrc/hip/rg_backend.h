@@ -213,6 +213,7 @@ inline int rg_copy_h2d(void* d, const void* h, size_t bytes, rg_stream_t s) { re
 inline int rg_copy_d2h(void* h, const void* d, size_t bytes, rg_stream_t s) { return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s) == hipSuccess ? 0 : -1; }
 inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t s) { return hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : -1; }
 inline rg_stream_t rg_stream_from_handle(void* h) { return (hipStream_t)h; }
+inline void* rg_stream_to_handle(rg_stream_t s) { return (void*)s; }
 inline int rg_stream_sync(rg_stream_t s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : -1; }
 inline const char* rg_last_error_string() { return hipGetErrorString(hipGetLastError()); }
 

@@ -1,0 +1,102 @@
+// rg_transport.h (HIP / gfx950) -- RCCL transport of the z-slab driver (csrc/comm/rgpu_comm.cpp).
+// One communicator per process; point-to-point halo traffic on a dedicated stream, ordered against the compute stream
+// with events; collectives on the compute stream itself.  On MI355X RCCL moves the planes over xGMI peer links.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+#define RG_TRANSPORT_NAME "rccl"
+
+namespace rgpu_transport {
+
+struct P2P { double* ptr; size_t count; int peer; int send; };
+
+struct Comm {
+  ncclComm_t comm;
+  hipStream_t halo;
+  hipEvent_t ev_ready, ev_done;
+  double* scratch;   // device scratch for host-value reductions
+  int rank, nranks;
+  std::string err;
+};
+
+inline int fail(Comm* c, const std::string& m) { if (c) c->err = m; return -1; }
+
+inline int unique_id(char* id128) {
+  static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId does not fit RGPU_COMM_ID_BYTES");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+  std::memset(id128, 0, 128);
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+inline int create(Comm** out, int rank, int nranks, const char* id128) {
+  Comm* c = new Comm();
+  c->comm = 0; c->halo = 0; c->ev_ready = 0; c->ev_done = 0; c->scratch = 0; c->rank = rank; c->nranks = nranks;
+  *out = c;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  const ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+  if (r != ncclSuccess) return fail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  // the exchange is short and on the critical path of the neighbours: highest priority
+  if (hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, hi) != hipSuccess) return fail(c, "halo stream");
+  if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) return fail(c, "events");
+  if (hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) return fail(c, "scratch");
+  return 0;
+}
+
+inline void destroy(Comm* c) {
+  if (!c) return;
+  if (c->scratch) (void)hipFree(c->scratch);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->halo) (void)hipStreamDestroy(c->halo);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  delete c;
+}
+
+// all ops as ONE group on the halo stream, behind what the compute stream holds now
+inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nops) {
+  hipStream_t cs = (hipStream_t)compute_stream;
+  if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
+  ncclResult_t r = ncclGroupStart();
+  for (int i = 0; i < nops && r == ncclSuccess; ++i)
+    r = ops[i].send ? ncclSend(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo)
+                    : ncclRecv(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo);
+  const ncclResult_t re = ncclGroupEnd();
+  if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+  if (hipEventRecord(c->ev_done, c->halo) != hipSuccess) return fail(c, "event record");
+  return 0;
+}
+inline int exchange_wait(Comm* c, void* compute_stream) {
+  return hipStreamWaitEvent((hipStream_t)compute_stream, c->ev_done, 0) == hipSuccess ? 0 : fail(c, "stream wait");
+}
+
+// in place on a device buffer, queued on `stream`
+inline int allreduce_max(Comm* c, double* d, int n, void* stream) {
+  const ncclResult_t r = ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclMax, c->comm, (hipStream_t)stream);
+  return r == ncclSuccess ? 0 : fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+}
+// host values (n <= 64): through the device scratch, synchronous
+inline int allreduce_sum_host(Comm* c, double* h, int n, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(c->scratch, h, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return fail(c, "H2D");
+  const ncclResult_t r = ncclAllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclSum, c->comm, s);
+  if (r != ncclSuccess) return fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  if (hipMemcpyAsync(h, c->scratch, n * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return fail(c, "D2H");
+  return 0;
+}
+inline void set_device(int d) { if (d >= 0) (void)hipSetDevice(d); }
+inline int barrier(Comm* c, void* stream) {
+  double z = 0.0;
+  return allreduce_sum_host(c, &z, 1, stream);
+}
+
+}  // namespace rgpu_transport

@@ -877,6 +877,9 @@ int rgpu_download(rgpu_ctx* c, double* hU, int parity) {
 }
 
 double* rgpu_device_state(rgpu_ctx* c, int parity) { return c ? c->U[parity & 1] : 0; }
+int rgpu_get_params(rgpu_ctx* c, rgpu_params* out) { if (!c || !out) return RGPU_EINVAL; *out = c->p; return RGPU_OK; }
+void* rgpu_stream_handle(rgpu_ctx* c) { return c ? rg_stream_to_handle(c->stream) : 0; }
+double* rgpu_inv_dt_device_slot(rgpu_ctx* c) { return c ? reinterpret_cast<double*>(c->d_red) : 0; }
 
 int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out) {
   RG_CHECK_CTX(c);

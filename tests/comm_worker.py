@@ -1,0 +1,116 @@
+"""Worker of tests/test_comm_driver.py: one rank of a z-slab run through the C++ driver (include/rgpu_comm.h).
+
+CPU (default): tests/_build/librgpu_comm_emu.so = csrc/comm/rgpu_comm.cpp compiled against the TEST-ONLY callback transport
+(tests/emu/rg_transport.h) and the emulation backend; the callbacks registered here move the ghost planes and reduce
+1/dt with torch.distributed / gloo.  The schedule, the op lists and the dt logic under test are the product's C++.
+COMM_DEVICE=cuda:N: the product libraries (HIP + RCCL); torch.distributed only carries the 128-byte unique id.
+Result == the single-domain oracle, bit for bit."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle_api import Oracle  # noqa: E402
+from ramsesgpu_amd import comm as rcomm  # noqa: E402
+from ramsesgpu_amd.solver import Library, interior  # noqa: E402
+
+
+class P2P(C.Structure):
+    _fields_ = [("ptr", C.POINTER(C.c_double)), ("count", C.c_size_t), ("peer", C.c_int), ("send", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(P2P), C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+def _exchange(ops, nops):
+    """all sends / receives of one exchange as one gloo batch; tags pair the n-th send to a peer with its n-th receive"""
+    try:
+        batch, nsend, nrecv = [], {}, {}
+        for i in range(nops):
+            o = ops[i]
+            t = torch.from_numpy(np.ctypeslib.as_array(o.ptr, shape=(o.count,)))
+            if o.send:
+                tag = nsend.get(o.peer, 0); nsend[o.peer] = tag + 1
+                batch.append(dist.P2POp(dist.isend, t, o.peer, tag=tag))
+            else:
+                tag = nrecv.get(o.peer, 0); nrecv[o.peer] = tag + 1
+                batch.append(dist.P2POp(dist.irecv, t, o.peer, tag=tag))
+        for w in dist.batch_isend_irecv(batch):
+            w.wait()
+        return 0
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("exchange callback: %r\n" % (e,))
+        return 1
+
+
+def _allreduce(data, n, op):
+    try:
+        t = torch.from_numpy(np.ctypeslib.as_array(data, shape=(n,)))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 0 else dist.ReduceOp.SUM)
+        return 0
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("allreduce callback: %r\n" % (e,))
+        return 1
+
+
+def main():
+    base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = os.environ.get("COMM_DEVICE", "cpu")
+    keep = []
+    if device == "cpu":
+        lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
+        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+        assert b"test" in CL.rgpu_comm_transport_name()
+    else:
+        from ramsesgpu_amd.solver import load_library
+        lib = load_library()
+        CL = rcomm.load_comm_library()
+        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
+        assert CL.rgpu_comm_transport_name() == b"rccl"
+    ids = [rcomm.unique_id(CL) if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ini = os.path.join(ROOT, "configs", base + ".ini")
+    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0")
+    run.init_simulation()
+    dts = [run.oneStepIntegration() for _ in range(nsteps)]
+    local = torch.from_numpy(np.ascontiguousarray(run.local_interior()))
+    parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, parts, dst=0)
+    ok = True
+    if rank == 0:
+        got = torch.cat(parts, dim=1).numpy()
+        oracle = Oracle(os.path.join(ROOT, "oracle", "liboracle.so"))
+        p = lib.params_from_ini(ini, ov)
+        U0 = lib.init_condition(ini, ov, p)
+        oracle.set_gravity_field(lib.init_gravity(ini, ov, p))
+        oracle.set_forcing_field(lib.init_forcing(ini, ov, p))
+        ref_full, dts_ref, _ = oracle.run(p, U0, nsteps)
+        ref = interior(ref_full, p)
+        nbad = int((got != ref).sum())
+        ok = nbad == 0 and np.array_equal(np.array(dts), dts_ref)
+        if p.randomForcingEnabled:   # global normalisation sum: round-off agreement (stated tolerance 1e-12), see slab_worker.py
+            rel = float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
+            ok = rel < 1e-12 and np.allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
+        with open(out, "w") as f:
+            f.write("OK\n" if ok else "MISMATCH %d doubles, dt equal=%s\n" % (nbad, np.array_equal(np.array(dts), dts_ref)))
+    dist.barrier()
+    run.close()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,7 @@ inline int rg_copy_h2d(void* d, const void* h, size_t bytes, rg_stream_t) { std:
 inline int rg_copy_d2h(void* h, const void* d, size_t bytes, rg_stream_t) { std::memcpy(h, d, bytes); return 0; }
 inline int rg_copy_d2d(void* d, const void* s_, size_t bytes, rg_stream_t) { std::memcpy(d, s_, bytes); return 0; }
 inline rg_stream_t rg_stream_from_handle(void*) { return 0; }
+inline void* rg_stream_to_handle(rg_stream_t) { return 0; }
 inline int rg_stream_sync(rg_stream_t) { return 0; }
 inline const char* rg_last_error_string() { return "emulation"; }
 inline int rg_stream_create(rg_stream_t* s, int = 0) { *s = 1; return 0; }

@@ -1,0 +1,128 @@
+"""The C++ z-slab driver (include/rgpu_comm.h, csrc/comm/rgpu_comm.cpp).
+
+not gpu:  librgpu_comm.so loads and exports every symbol the header declares; world sizes 1, 2, 3 on CPU through the driver's
+          real schedule with the TEST-ONLY callback transport (gloo underneath): == single-domain oracle, bit for bit.
+gpu:      nranks = 1 on the GPU box through the product libraries: the RCCL code path (ncclCommInitRank, grouped
+          ncclSend / ncclRecv to itself on the halo stream, event ordering, ncclAllReduce-free dt) with periodic z."""
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, ini
+from ramsesgpu_amd import comm as rcomm
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "rgpu_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgpuh?_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_comm_library_exports_every_declared_symbol(product_lib):
+    declared = header_functions()
+    assert declared and set(declared) == set(rcomm.DECLARED_SYMBOLS), (declared, rcomm.DECLARED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rcomm.comm_lib_path()], universal_newlines=True)
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    for sym in declared:
+        assert sym in exported, "%s is declared in include/rgpu_comm.h but not exported" % sym
+    CL = rcomm.load_comm_library()     # loads on a machine without GPUs too (no compute call is made)
+    assert CL.rgpu_comm_transport_name() == b"rccl"
+
+
+@pytest.fixture(scope="session")
+def comm_emu_lib(emu_lib):
+    """TEST-ONLY build of the driver against the callback transport and the emulation library"""
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    so = os.path.join(out_dir, "librgpu_comm_emu.so")
+    src = os.path.join(ROOT, "ramsesgpu_amd", "csrc", "comm", "rgpu_comm.cpp")
+    deps = [src, os.path.join(ROOT, "tests", "emu", "rg_transport.h"), os.path.join(ROOT, "include", "rgpu_comm.h"),
+            os.path.join(out_dir, "librgpu_emu.so")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "emu"), src,
+                               "-L", out_dir, "-lrgpu_emu", "-Wl,-rpath,$ORIGIN", "-o", so])
+    return so
+
+
+OPEN_BC = ";mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_ymin=1;mesh.boundary_ymax=2;mesh.boundary_zmin=2;mesh.boundary_zmax=1"
+# (ini, overrides, steps, world, overlap)
+CASES = [
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.02", 3, 1, 1),        # self ring: the rank is its own neighbour
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 3, 1, 1),
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12;hydro.riemannSolver=hllc", 3, 1, 1),  # no slab interface at all
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                      # plain MHD, periodic ring, no inner planes
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 4, 2, 1),                      # ... with inner planes
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 3, 2, 0),                      # serial schedule
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=20" + OPEN_BC, 4, 2, 1),            # open / reflecting faces: dt sees unfilled ghosts
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=20;MHD.omega0=0.02", 4, 2, 1),        # rotating + shearing box
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.02", 3, 2, 0),
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16", 4, 2, 1),                          # hydro, Dirichlet ends
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=27", 3, 3, 1),                         # three slabs, inner planes
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12", 3, 3, 1),                         # three slabs thinner than 2 gw
+    ("orszag-tang3d", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.nu=0.005;MHD.eta=0.01", 3, 3, 1),   # dissipative stage: second exchange
+    ("turbulence_hydro", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                   # random forcing: SUM all-reduce
+    ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 2, 1),
+]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=None, timeout=300):
+    out = str(tmp_path / "result.txt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "comm_worker.py"), base, ov, str(nsteps), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1", COMM_OVERLAP=str(overlap), **(env_extra or {}))
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert open(out).read().strip() == "OK", open(out).read()
+
+
+@pytest.mark.parametrize("base,ov,nsteps,world,overlap", CASES,
+                         ids=["%s-%d-x%d-%s" % (c[0], n, c[3], "overlap" if c[4] else "serial") for n, c in enumerate(CASES)])
+def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm_emu_lib, oracle, tmp_path):
+    run_worker(base, ov, nsteps, world, overlap, tmp_path)
+
+
+GPU_CASES = [
+    ("mhd_mri_3d", "mesh.nx=32;mesh.ny=48;mesh.nz=40", 4, 1),            # periodic z: grouped ncclSend / ncclRecv to itself
+    ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 1),
+    ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 0),         # serial schedule
+    ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=32;hydro.riemannSolver=hllc", 4, 1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ov,nsteps,overlap", GPU_CASES, ids=["%s-%s" % (c[0], "overlap" if c[3] else "serial") for c in GPU_CASES])
+def test_rccl_driver_single_rank_on_gpu(base, ov, nsteps, overlap, gpu_lib, oracle, tmp_path):
+    """the RCCL transport with nranks = 1 on the 1-GPU box (a ring of one): product libraries, no torch in the data path"""
+    run_worker(base, ov, nsteps, 1, overlap, tmp_path, env_extra={"COMM_DEVICE": "cuda:0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
+
+
+@pytest.mark.gpu
+def test_euler_hip_slabs_front_end_single_rank(gpu_lib, tmp_path):
+    """euler_hip --slabs 1: rendezvous file, rgpuh_run_slabs, RCCL self ring -- same step count and dt log as the single-GPU run"""
+    exe = os.path.join(ROOT, "ramsesgpu_amd", "euler_hip")
+    ov = "mesh.nx=16;mesh.ny=24;mesh.nz=16;run.nstepmax=6;run.noutput=1;output.outputVtk=no;output.outputHdf5=no"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    a = subprocess.run([exe, "--param", ini("mhd_mri_3d"), "--set", ov, "--slabs", "1", "--rendezvous", str(tmp_path / "rdv")],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    b = subprocess.run([exe, "--param", ini("mhd_mri_3d"), "--set", ov], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       universal_newlines=True, timeout=300)
+    assert a.returncode == 0, a.stdout[-2000:]
+    assert b.returncode == 0, b.stdout[-2000:]
+    dts = lambda txt: re.findall(r"step=\s*(\d+) t=\s*([0-9.eE+-]+) dt=\s*([0-9.eE+-]+)", txt)
+    da, db = dts(a.stdout), dts(b.stdout)
+    assert "steps 6" in a.stdout and da, a.stdout[-1000:]
+    # the slab front end prints after each step, the single-GPU one before: compare the (t, dt) pairs they share
+    assert set(x[1:] for x in da) & set(x[1:] for x in db), (da, db)
