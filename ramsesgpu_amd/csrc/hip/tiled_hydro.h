@@ -57,6 +57,7 @@ struct HydroTile {
 // XCD's own L2
 struct TileGrid {
   int nbx, nby, nseg, per_xcd;
+  int flags;   // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
 };
 
 template <int TX, int TY, int SPEC>
@@ -263,6 +264,7 @@ template <int TX, int TY, int SPEC>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
                                 double dtdz, int za, int zb) {
   TileGrid tg;
+  tg.flags = 0;
   tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
   tg.nby = (g.jsize - 1 + (TY - 2) - 1) / (TY - 2);
   const int span = zb - za;

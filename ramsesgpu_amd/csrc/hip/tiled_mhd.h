@@ -1,26 +1,27 @@
-// tiled_mhd.h (HIP / gfx950 only) -- trace + Riemann problems of the 3D MHD unsplit step as ONE cooperative,
-// LDS-tiled, z-marching kernel: the 38-double compact traced state T never reaches HBM.
+// tiled_mhd.h (HIP / gfx950 only) -- primitives, edge electric field, trace and Riemann problems of the 3D MHD unsplit
+// step as ONE cooperative, LDS-tiled, z-marching kernel: U -> F, emf.  Neither the primitive variables Q, nor the electric
+// field E, nor the 38-double compact traced state T ever reach HBM.
 //
-// Flat pipeline (kernels_mhd3d.h): K_mhd_trace3d writes T (304 B/cell), K_mhd_flux3d reads it back with its 2x2x2
-// neighbourhood -- half of the step's HBM traffic.  Here a 512-thread workgroup (8 waves, 2 per SIMD: the edge solvers
-// need ~250 VGPRs) owns a tile of OX x OY = 16 x 8 cells and marches along z:
-//
-//   trace(kk)    threads 0..152 (the tile + one low-side halo row / column: cell m needs T of m-1 in x, y, z) compute
-//                mhd_trace3d_at and put the 38 components into LDS buffer kk & 1            (2 x 46.5 KB of LDS)
-//   barrier
-//   Riemann(kk)  the six Riemann problems of a cell are dealt to FOUR threads: wave pair 0 solves the x-edge EMF
-//                (2D HLLD), pair 1 the y-edge EMF, pair 2 the z-edge EMF, pair 3 the three face fluxes (HLLD) -- each
-//                pair covers the 128 cells of the tile, all reading T(kk-1), T(kk) from LDS; F and emf go to HBM
-//                with nontemporal stores
-//   barrier      (buffer (kk-1) & 1 is overwritten by trace(kk+1))
-//
-// The task split is what lets one workgroup per CU (LDS-limited) keep all four SIMDs busy with two waves each: a
-// one-thread-per-cell kernel would run two waves per CU.  Costs per cell: EMF ~1200 VALU instructions each, the three
-// HLLD fluxes ~1050 together, trace ~914 (+20 % for the halo).
+// Flat pipeline (kernels_mhd3d.h): K_mhd_prim writes Q, K_mhd_elec writes E, K_mhd_trace3d writes T (304 B/cell),
+// K_mhd_flux3d reads T back with its 2x2x2 neighbourhood -- 120 of the step's 155 GB of HBM traffic at 512^3.  Here a
+// 512-thread workgroup (8 waves, 2 per SIMD: the edge solvers need ~250 VGPRs) owns a tile of 16 x 8 cells and marches
+// along z.  Wave roles (waves w and w + 4 share a SIMD):
+//   waves 0,1,2 and 4,5,6   Riemann problems of direction d = w & 3 for the cells [64 (w >> 2), +64) of the tile: edge
+//                           EMF along d (2D HLLD, ~1100 VALU instructions) + flux through the low d face (HLLD, ~470)
+//   waves 3 and 7           producers: primitives of plane kk+3 (from U, prefetched into registers), trace of plane kk+1
+// Iteration kk:
+//   Riemann waves  problems of plane kk from T(kk) in LDS and the states carried in registers from T(kk-1)
+//   producers      issue the loads of U(kk+3); trace(kk+1) -> the other T buffer; prim(kk+3); [pair rendezvous] store
+//                  Q / B (kk+3) into the LDS slot plane kk vacated; [pair rendezvous] edge electric field of plane kk+3
+//                  from Q / B (kk+2, kk+3) -> the slot E(kk+1) vacated.  Q, B, E are private to the producer pair, which
+//                  synchronises through an LDS counter
+//   barrier        ONE workgroup barrier per plane: T(kk+1) complete, T(kk) free
+// LDS: T 2 x 46.5 KB, Q / B 3 x 18.4 KB, E 2 x 5 KB = 158 KB (one workgroup per CU).
 // (Reference idiom: the shared-memory staging of trace_v4 / flux_update_hydro_v4, godunov_unsplit_mhd.cuh:3260, 4595.)
 //
-// Arithmetic: the same device functions as the flat kernels (mhd_trace3d_at, mhd_flux3d_at), instantiated with an LDS
-// accessor instead of the global-array one -- same expressions, same operand order, same bits.
+// Arithmetic: the same device functions as the flat kernels (mhd_prim, mhd_elec_comp, mhd_trace3d_at, face_state3d,
+// edge_state3d, edge_emf, mhd_face_flux), instantiated with LDS accessors instead of the global-array ones -- same
+// expressions, same operand order, same bits.
 #pragma once
 #include "tiled_hydro.h"
 
@@ -31,13 +32,13 @@ constexpr int MH_PX = MH_OX + 1, MH_PY = MH_OY + 1;
 constexpr int MH_CELLS = MH_PX * MH_PY;           // 153 traced cells per plane (tile + low-side halo)
 constexpr int MH_BUF = T_COUNT * MH_CELLS;        // doubles per plane buffer of T
 constexpr int MH_QX = MH_OX + 3, MH_QY = MH_OY + 3;
-constexpr int MH_QCELLS = MH_QX * MH_QY;          // 209 staged input cells per plane (traced cells +- 1)
-constexpr int MH_NQB = 11;                        // staged per cell: 8 primitives + 3 face-field components
+constexpr int MH_QCELLS = MH_QX * MH_QY;          // 209 input cells per plane (traced cells +- 1), origin (i0-2, j0-2)
+constexpr int MH_NQB = 11;                        // per input cell: 8 primitives + 3 face-field components
 constexpr int MH_QBSLOT = MH_NQB * MH_QCELLS;     // doubles per plane slot of Q / B
-constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E
-constexpr int MH_ITEMS = MH_QBSLOT + MH_ESLOT;    // doubles staged per plane
+constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E (same cell geometry as Q)
+constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
+constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
-constexpr int MH_NSTAGE = (MH_ITEMS + MH_THREADS - 1) / MH_THREADS;   // 6 loads per thread and plane
 
 struct TLdsRead {
   const double* base; unsigned skoff;   // skoff: from a cell of plane kk-1 to the same cell of plane kk (mod 2^32)
@@ -50,6 +51,13 @@ struct TLdsWrite {
 };
 struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B, planes kk, kk+1 of E
   const double* qb[3]; const double* eb[2];
+  const int* flag; int want;   // E of plane kk+1 is complete once *flag >= want (written by the Riemann waves)
+  RG_DEVFN void e_ready() const {
+    if (flag) {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
   RG_DEVFN double q(int v, int dz, unsigned m) const { return qb[dz + 1][v * MH_QCELLS + m]; }
   RG_DEVFN double bf(int comp, int dz, unsigned m) const { return qb[dz + 1][(8 + comp) * MH_QCELLS + m]; }
   RG_DEVFN double e(int comp, int dz, unsigned m) const { return eb[dz][comp * MH_QCELLS + m]; }
@@ -77,9 +85,13 @@ struct TLdsPlane {
 // left state of the z face) were built one iteration earlier from T(kk-1) -- except their one component that lives on
 // plane kk, which is filled in here -- and are carried in registers (c0, c1): T(kk-1) need not stay in LDS.
 // After solving, the states plane kk contributes to iteration kk+1 are built into c0, c1.
+// prio_drop: the wave entered with raised priority (s_setprio 1) and gives it up after the EMF, i.e. after ~70 % of its
+// work.  The two Riemann waves of a SIMD are arbitrated oldest-first: left alone the older one finishes at ~60 % of the
+// phase and the younger one runs the rest alone at single-wave issue efficiency; with the younger wave favoured for the
+// first 70 % of its work both finish together.
 template <int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
-                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve) {
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
   const size_t N = g.ncell;
   const unsigned sx = 1u, sj = (unsigned)MH_PX;
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
@@ -88,6 +100,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<XD>(g, L, R, xPos, fl);
@@ -101,6 +114,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<YD>(g, L, R, xPos, fl);
@@ -113,6 +127,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
       Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
       double fl[8];
@@ -123,25 +138,16 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
   }
 }
 
-// Wave roles (8 waves; waves w and w + 4 share a SIMD):
-//   waves 0,1,2 and 4,5,6   Riemann problems of direction d = w & 3 for the cells [64 * (w >> 2), +64) of the tile:
-//                           edge EMF along d (2D HLLD, ~1100 VALU instructions) + flux through the low d face (~470)
-//   wave 3                  trace of cells 0..63 of the (tile + halo) plane, then of cells 128..152
-//   wave 7                  trace of cells 64..127
-// so every SIMD carries ~3100 (Riemann) or ~2700 (trace) wave-instructions per plane, both of its waves busy.
-// Per iteration kk (ONE phase, then a short one):  all threads issue the loads of the inputs of plane kk+3;
-// trace waves: T(kk+1) -> buffer (kk+1) & 1 from the staged Q / B (kk .. kk+2), E (kk+1, kk+2);
-// Riemann waves: problems of plane kk from T(kk) (buffer kk & 1) and the carried states;  barrier;
-// the staged values go to the LDS slots plane kk (Q / B) and kk+1 (E) have just vacated;  barrier.
 template <int SPEC>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
-                                                               const double* __restrict__ Q, const double* __restrict__ E,
                                                                double* __restrict__ F, double* __restrict__ emf,
-                                                               double dtdx, double dtdy, double dtdz, int ra, int rb) {
+                                                               double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   spec_assume<SPEC>(g);
   __shared__ double LT[2 * MH_BUF];          // T of planes kk (read) and kk+1 (written)   (buffer = plane & 1)
   __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk .. kk+2                  (slot = plane % 3)
   __shared__ double LE[2 * MH_ESLOT];        // E of planes kk+1, kk+2                      (slot = plane & 1)
+  __shared__ int Lsync;                      // arrival counter of the producer pair
+  __shared__ int Lesync;                     // arrival counter of the Riemann waves: E planes completed x 6
 
   const int b = (int)blockIdx.x;
   const int lin = (b & 7) * tg.per_xcd + (b >> 3);
@@ -159,100 +165,183 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int t = (int)threadIdx.x;
   const size_t N = g.ncell;
   const unsigned sk = g.sk;
+  const int wave = t >> 6, lane = t & 63;
+  const bool producer = (wave & 3) == 3;
 
-  // staging role: item it = r * 512 + t is component it / 209 (0-7 Q, 8-10 face field, 11-13 E) of input cell it % 209
-  const double* sp[MH_NSTAGE];
+  // ---- producer role: primitives of two input cells per thread (cells pw and pw + 128 of the 19 x 11 input tile) ----
+  const int pw = (wave >> 2) * 64 + lane;
+  bool pok[2]; unsigned pidx2[2];
 #pragma unroll
-  for (int r = 0; r < MH_NSTAGE; ++r) {
-    const int it = r * MH_THREADS + t;
-    const int comp = it / MH_QCELLS, cell = it - comp * MH_QCELLS;
+  for (int r = 0; r < 2; ++r) {
+    const int cell = pw + 128 * r;
     const int qy = cell / MH_QX, qx = cell - qy * MH_QX;
-    const int si = i0 - 2 + qx, sj_ = j0 - 2 + qy;
-    const double* base = comp < 8 ? Q + (size_t)comp * N : comp < 11 ? U + (size_t)(IA + comp - 8) * N : E + (size_t)(comp - 11) * N;
-    sp[r] = (it < MH_ITEMS && si < g.isize && sj_ < g.jsize) ? base + (size_t)si + (size_t)sj_ * g.sj : nullptr;
+    const int pi = i0 - 2 + qx, pj = j0 - 2 + qy;
+    pok[r] = producer && cell < MH_QCELLS && pi < g.isize - 1 && pj < g.jsize - 1;   // range of mhd_prim_cell
+    pidx2[r] = pok[r] ? (unsigned)pi + (unsigned)pj * g.sj : 0u;
   }
-  double sv[MH_NSTAGE];
-  auto stage_load = [&](int k) {
+  // State a wave keeps from one iteration to the next, in ONE array because the register allocator cannot know that a
+  // wave is either a producer or a Riemann wave for its whole life: producers hold pu[2][11] = the loaded U (8), Ua(i+1),
+  // Ub(j+1), Uc(k+1) and then the primitives (8) + the cell's own face field (3) of their two input cells; Riemann waves
+  // hold the two carried states c0, c1 (8 doubles each) in the first 16 entries.
+  double keep[22];
 #pragma unroll
-    for (int r = 0; r < MH_NSTAGE; ++r) sv[r] = sp[r] ? sp[r][(size_t)k * sk] : 0.0;
+  for (int v = 0; v < 22; ++v) keep[v] = 0.0;
+  double (*pu)[11] = reinterpret_cast<double (*)[11]>(keep);
+  auto prim_load = [&](int k) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+        const double* u = U + pidx2[r] + (size_t)k * sk;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) pu[r][v] = u[(size_t)v * N];
+        pu[r][8] = u[(size_t)IA * N + 1];
+        pu[r][9] = u[(size_t)IB * N + g.sj];
+        pu[r][10] = u[(size_t)IC * N + sk];
+      }
   };
-  auto stage_store = [&](int k) {
-    double* qd = LQ + (k % 3) * MH_QBSLOT;
-    double* ed = LE + (k & 1) * MH_ESLOT;
+  auto prim_compute = [&]() {
 #pragma unroll
-    for (int r = 0; r < MH_NSTAGE; ++r) {
-      const int it = r * MH_THREADS + t;
-      if (it < MH_QBSLOT) qd[it] = sv[r];
-      else if (it < MH_ITEMS) ed[it - MH_QBSLOT] = sv[r];
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+        const Prim8 q = mhd_prim(g, pu[r], pu[r][8], pu[r][9], pu[r][10], dt);
+        const double fa = pu[r][IA], fb = pu[r][IB], fc = pu[r][IC];
+        pu[r][ID] = q.r; pu[r][IP] = q.p; pu[r][IU] = q.u; pu[r][IV] = q.v; pu[r][IW] = q.w; pu[r][IA] = q.a; pu[r][IB] = q.b; pu[r][IC] = q.c;
+        pu[r][8] = fa; pu[r][9] = fb; pu[r][10] = fc;
+      }
+  };
+  auto prim_store = [&](int k) {
+    double* qd = LQ + (k % 3) * MH_QBSLOT;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+#pragma unroll
+        for (int v = 0; v < MH_NQB; ++v) qd[v * MH_QCELLS + pw + 128 * r] = pu[r][v];
+      }
+  };
+
+  // ---- everybody: edge electric field of plane k from Q / B of planes k-1, k.  The trace of the 17 x 9 traced cells reads
+  // Ex at (c, c+y), Ey at (c, c+x), Ez at (c, c+x, c+y): 17 x 10 + 18 x 9 + 18 x 10 = 512 values -- one per thread. ----
+  // value e of the 512: computed by thread `first` + n * `stride`
+  auto elec_plane = [&](int k, int first, int stride) {
+    const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT}, {0, 0}, 0, 0};
+    double* ed = LE + (k & 1) * MH_ESLOT;
+    constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY;
+    static_assert(NEX + NEY + (MH_PX + 1) * (MH_PY + 1) == MH_THREADS, "512 edge values per plane");
+    for (int e = first; e < MH_THREADS; e += stride) {
+      int comp, ex, ey;
+      if (e < NEX) { comp = 0; ey = e / MH_PX; ex = e - ey * MH_PX; }
+      else if (e < NEX + NEY) { comp = 1; const int c = e - NEX; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+      else { comp = 2; const int c = e - NEX - NEY; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+      const int ei = i0 - 1 + ex, ej = j0 - 1 + ey;
+      if (ei < g.isize - 1 && ej < g.jsize - 1) {   // range of mhd_elec_cell (low bounds hold by construction)
+        const unsigned qm = (unsigned)((ey + 1) * MH_QX + ex + 1);
+        const double xPos = g.xMin + g.dx / 2 + (ei - gw) * g.dx;
+        double v;
+        if (comp == 0) v = mhd_elec_comp<0>(g, in, xPos, qm);
+        else if (comp == 1) v = mhd_elec_comp<1>(g, in, xPos, qm);
+        else v = mhd_elec_comp<2>(g, in, xPos, qm);
+        ed[comp * MH_QCELLS + qm] = v;
+      }
     }
   };
 
-  const int wave = t >> 6, lane = t & 63;
-  const bool tracer = (wave & 3) == 3;
+  // rendezvous of the TWO producer waves (the only readers and writers of Q / B / E) through an LDS counter: lets them
+  // recycle the Q / B and E slots inside the main phase, while the six Riemann waves keep solving -- the workgroup barrier
+  // is then needed once per plane only (for T).  LDS operations of a wave complete in order, so a wave that has seen the
+  // partner's increment also sees the stores the partner issued before it.
+  int npair = 0;
+  auto pair_sync = [&]() {
+    npair += 2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&Lsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&Lsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < npair) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
 
-  // trace role
-  auto trace_cell = [&](int k, int cell) {
+  // ---- producer role: trace ----
+  auto trace_cell = [&](int k, int cell, int e_want) {
     const int ty = cell / MH_PX, tx = cell - ty * MH_PX;
     const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
     if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
       const IJK c = {ti, tj, k};
       const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
       const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
-                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}};
+                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
       mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
     }
   };
 
-  // Riemann role
+  // ---- Riemann role ----
+  const int rthread = (wave - (wave >> 2)) * 64 + lane;   // 0..383 over the six Riemann waves (wave 3 skipped)
+  const bool prio_mode = (tg.flags & 1) == 0;             // RGPU_SWEEP_FLAGS=1 switches the priority scheme off
   const int dir = wave & 3;
   const int cl = (wave >> 2) * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
-  const bool fl_ok = !tracer && ci <= g.isize - gw && cj <= g.jsize - gw;
+  const bool fl_ok = !producer && ci <= g.isize - gw && cj <= g.jsize - gw;
   const unsigned cidx2 = fl_ok ? (unsigned)ci + (unsigned)cj * g.sj : 0u;
   const unsigned cm = (unsigned)((oy + 1) * MH_PX + ox + 1);
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
-  Prim8 c0, c1;
-  c0.r = c0.p = 1.0; c0.u = c0.v = c0.w = c0.a = c0.b = c0.c = 0.0;
-  c1 = c0;
 
 #ifdef RG_SWEEP_PROF
   long long acc[4] = {0, 0, 0, 0};
 #endif
-  // prologue: inputs of planes sa-2, sa-1, sa (trace(sa-1) reads them)
-  stage_load(sa - 2); stage_store(sa - 2);
-  stage_load(sa - 1); stage_store(sa - 1);
-  __syncthreads();   // E of plane sa-2 and of plane sa share a slot
-  stage_load(sa); stage_store(sa);
+  // prologue: primitives of planes sa-2, sa-1, sa; electric field of plane sa-1
+  if (t == 0) { Lsync = 0; Lesync = 0; }
+  for (int k = sa - 2; k <= sa; ++k) {
+    prim_load(k);
+    prim_compute();
+    prim_store(k);
+    __syncthreads();
+    if (k == sa - 1) elec_plane(k, t, MH_THREADS);
+  }
   __syncthreads();
-  // iteration kk: trace(kk+1) next to the Riemann problems of plane kk.  kk = sa-2 only traces plane sa-1, kk = sa-1 traces
-  // plane sa and builds the carried states from T(sa-1); the last iteration kk = sb-1 has nothing left to trace.
+  // iteration kk.  Riemann waves: electric field of plane kk+2 (from Q / B of planes kk+1, kk+2, complete since the last
+  // barrier) into the slot E(kk) vacated, announce it, then the Riemann problems of plane kk.  Producers: loads of U(kk+3),
+  // trace(kk+1) (waits for that announcement just before it reads E), prim(kk+3) -> the slot Q / B (kk) vacated.
+  // kk = sa-2 only traces plane sa-1, kk = sa-1 traces plane sa and builds the carried states from T(sa-1); the last
+  // planes have nothing left to produce.
+  int nit = 0;
   for (int kk = sa - 2; kk < sb; ++kk) {
     RG_PROF_T(tA);
+    ++nit;
     const bool more = kk + 3 <= sb;
-    if (more) stage_load(kk + 3);
-    if (tracer) {
-      if (kk + 1 < sb) {
-        if (wave == 3) { trace_cell(kk + 1, lane); trace_cell(kk + 1, 128 + lane); }
-        else trace_cell(kk + 1, 64 + lane);
+    const bool tracing = kk + 1 < sb;
+    if (producer) {
+      if (more) prim_load(kk + 3);
+      if (tracing) {
+        if (wave == 3) { trace_cell(kk + 1, lane, 6 * nit); trace_cell(kk + 1, 128 + lane, 6 * nit); }
+        else trace_cell(kk + 1, 64 + lane, 6 * nit);
       }
-    } else if (fl_ok && kk >= sa - 1) {
-      const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
-      const unsigned idx = cidx2 + (unsigned)kk * sk;
-      const bool solve = kk >= sa;
-      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
-      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
-      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve);
+      if (more) {
+        prim_compute();
+        pair_sync();                     // both producers are done reading Q / B (kk)
+        prim_store(kk + 3);              // -> the Q / B slot of plane kk
+      }
+    } else {
+      if (tracing) elec_plane(kk + 2, rthread, 384);   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (fl_ok && kk >= sa - 1) {
+        const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
+        const unsigned idx = cidx2 + (unsigned)kk * sk;
+        const bool solve = kk >= sa;
+        const bool raise = prio_mode && solve && wave >= 4;
+        if (raise) __builtin_amdgcn_s_setprio(1);
+        Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
+        Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
+        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+        keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
+        keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
+      }
     }
     RG_PROF_T(tB);
-    __syncthreads();
-    RG_PROF_T(tC);
-    if (more) stage_store(kk + 3);   // Q / B slot of plane kk and E slot of plane kk+1: dead since trace(kk+1)
-    RG_PROF_T(tD);
-    __syncthreads();
+    __syncthreads();   // T(kk+1) and Q / B (kk+3) complete, T(kk) free
 #ifdef RG_SWEEP_PROF
     const long long tE = (long long)__builtin_readcyclecounter();
-    acc[0] += tB - tA; acc[1] += tC - tB; acc[2] += tD - tC; acc[3] += tE - tD;
+    acc[0] += tB - tA; acc[1] += tE - tB;
 #endif
   }
 #ifdef RG_SWEEP_PROF
@@ -262,9 +351,11 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 }
 
 template <int SPEC>
-inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, const double* Q, const double* E, double* F,
-                              double* emf, double dtdx, double dtdy, double dtdz, int ra, int rb) {
+inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   TileGrid tg;
+  static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
+  tg.flags = flags_env;
   tg.nbx = (g.isize - 2 * g.gw + 1 + MH_OX - 1) / MH_OX;   // cells gw .. isize-gw
   tg.nby = (g.jsize - 2 * g.gw + 1 + MH_OY - 1) / MH_OY;
   const int span = rb - ra;
@@ -272,10 +363,10 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   int nseg;
   if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
   else {
-    // one workgroup per CU is resident; a segment costs two extra iterations (pipeline fill).  Segments of ~64 planes
-    // measured best at 512^3 (35.1 ms against 36.2 for one 513-plane march and 35.6 for 32-plane segments): enough
+    // one workgroup per CU is resident; a segment costs two extra iterations (pipeline fill).  Segments of ~128 planes
+    // measured best at 512^3 (35.5 ms against 35.8 for 64-plane segments): enough
     // workgroups to even out the last round over the 256 CUs.  Small boxes: at least ~8 rounds, segments >= 8 planes.
-    nseg = (span + 63) / 64;
+    nseg = (span + 127) / 128;
     const int want = (2048 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
     if (nseg < want) nseg = want;
     if (nseg > span / 8) nseg = span / 8;
@@ -285,8 +376,8 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   tg.nseg = nseg;
   const int total = tg.nbx * tg.nby * tg.nseg;
   tg.per_xcd = (total + 7) / 8;
-  hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, Q, E, F, emf,
-                     dtdx, dtdy, dtdz, ra, rb);
+  hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
+                     dt, dtdx, dtdy, dtdz, ra, rb);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -301,16 +392,17 @@ extern "C" inline void rgpu_prof_read_impl(unsigned long long* out, int reset) {
 inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && g.mhd; }
 
 // spec: 0 = generic, 1 = isothermal rotating box (MRI), 2 = adiabatic inertial box (the driver's pick_spec)
-// Solves the Riemann problems of planes [ra, rb) (already clipped to [gw, ksize-gw]) from U, Q, E.
-// Returns 0 = done, 1 = not applicable (caller runs trace + Riemann as flat kernels), < 0 = launch error.
+// Solves the Riemann problems of planes [ra, rb) (already clipped to [gw, ksize-gw]) from U alone (primitives, electric
+// field and traced state are produced on the way).  Returns 0 = done, 1 = not applicable (the caller runs prim, elec,
+// trace and Riemann as flat kernels), < 0 = launch error.
 template <int SPEC_MRI, int SPEC_PLAIN>
-inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, const double* Q, const double* E, double* F,
-                       double* emf, double dtdx, double dtdy, double dtdz, int ra, int rb) {
+inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
+                       double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, Q, E, F, emf, dtdx, dtdy, dtdz, ra, rb);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, Q, E, F, emf, dtdx, dtdy, dtdz, ra, rb);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, Q, E, F, emf, dtdx, dtdy, dtdz, ra, rb);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb);
 }
 
 }  // namespace rgpu_tiled

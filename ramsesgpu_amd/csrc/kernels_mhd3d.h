@@ -61,6 +61,7 @@ struct TraceInGlobal {
   RG_DEVFN double bf(int comp, int dz, unsigned m) const { return U[(size_t)(IA + comp) * N + (m + (unsigned)(dz * (int)sk_))]; }
   RG_DEVFN double e(int comp, int dz, unsigned m) const { return E[(size_t)comp * N + (m + (unsigned)(dz * (int)sk_))]; }
   RG_DEVFN unsigned sj() const { return sj_; }
+  RG_DEVFN void e_ready() const {}   // called once before the first e(): the tiled kernel waits for its E producers here
 };
 struct TGlobalWrite {   // bound to one cell
   double* t; size_t N;
@@ -89,38 +90,52 @@ RG_DEVFN void mhd_prim_cell(const DevParams& g, const double* __restrict__ U, do
 // ------------------------------------------------------------------------------------------------------------
 // edge-centred electric field, defined at the low corner edges of cell (i,j,k)
 // ------------------------------------------------------------------------------------------------------------
+// One component (0 = Ex, 1 = Ey, 2 = Ez) of the electric field at the low corner edges of cell m, from the primitives /
+// face field around it (accessor interface of the trace inputs; planes dz = -1, 0).  xPos = cell-centre x of cell m.
+template <int COMP, class TIN>
+RG_DEVFN double mhd_elec_comp(const DevParams& g, const TIN& in, double xPos, unsigned m) {
+  const unsigned sj = in.sj();
+  double u, v, w, A, B, C, e;
+  if (COMP == 0) {   // Ex : average over the 4 cells around the x-edge (j-1..j, k-1..k)
+    v = 0.25 * (in.q(IV, -1, m - sj) + in.q(IV, 0, m - sj) + in.q(IV, -1, m) + in.q(IV, 0, m));
+    w = 0.25 * (in.q(IW, -1, m - sj) + in.q(IW, 0, m - sj) + in.q(IW, -1, m) + in.q(IW, 0, m));
+    B = 0.5 * (in.bf(1, -1, m) + in.bf(1, 0, m));
+    C = 0.5 * (in.bf(2, 0, m - sj) + in.bf(2, 0, m));
+    e = v * C - w * B;
+    if (g.rot) { const double shear = -1.5 * g.Omega0 * xPos; e += shear * C; }
+    return e;
+  }
+  if (COMP == 1) {   // Ey
+    u = 0.25 * (in.q(IU, -1, m - 1) + in.q(IU, 0, m - 1) + in.q(IU, -1, m) + in.q(IU, 0, m));
+    w = 0.25 * (in.q(IW, -1, m - 1) + in.q(IW, 0, m - 1) + in.q(IW, -1, m) + in.q(IW, 0, m));
+    A = 0.5 * (in.bf(0, -1, m) + in.bf(0, 0, m));
+    C = 0.5 * (in.bf(2, 0, m - 1) + in.bf(2, 0, m));
+    return w * A - u * C;
+  }
+  // Ez
+  u = 0.25 * (in.q(IU, 0, m - 1 - sj) + in.q(IU, 0, m - 1) + in.q(IU, 0, m - sj) + in.q(IU, 0, m));
+  v = 0.25 * (in.q(IV, 0, m - 1 - sj) + in.q(IV, 0, m - 1) + in.q(IV, 0, m - sj) + in.q(IV, 0, m));
+  A = 0.5 * (in.bf(0, 0, m - sj) + in.bf(0, 0, m));
+  B = 0.5 * (in.bf(1, 0, m - 1) + in.bf(1, 0, m));
+  e = u * B - v * A;
+  if (g.rot) { const double shear = -1.5 * g.Omega0 * (xPos - g.dx / 2); e -= shear * A; }
+  return e;
+}
+
+RG_DEVFN bool elec_in_range(const DevParams& g, const IJK c) {
+  return !(c.i < 1 || c.i >= g.isize - 1 || c.j < 1 || c.j >= g.jsize - 1 || c.k < 1 || c.k >= g.ksize - 1);
+}
+
 RG_DEVFN void mhd_elec_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Q,
                             double* __restrict__ E, unsigned idx) {
   const IJK c = unflatten(g, idx);
-  if (c.i < 1 || c.i >= g.isize - 1 || c.j < 1 || c.j >= g.jsize - 1 || c.k < 1 || c.k >= g.ksize - 1) return;
+  if (!elec_in_range(g, c)) return;
   const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
-  const double* Qu = Q + IU * N; const double* Qv = Q + IV * N; const double* Qw = Q + IW * N;
-  const double* Ua = U + IA * N; const double* Ub = U + IB * N; const double* Uc = U + IC * N;
   const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
-  double u, v, w, A, B, C, e;
-  // Ex : average over the 4 cells around the x-edge (j-1..j, k-1..k)
-  v = 0.25 * (Qv[idx - sj - sk] + Qv[idx - sj] + Qv[idx - sk] + Qv[idx]);
-  w = 0.25 * (Qw[idx - sj - sk] + Qw[idx - sj] + Qw[idx - sk] + Qw[idx]);
-  B = 0.5 * (Ub[idx - sk] + Ub[idx]);
-  C = 0.5 * (Uc[idx - sj] + Uc[idx]);
-  e = v * C - w * B;
-  if (g.rot) { const double shear = -1.5 * g.Omega0 * xPos; e += shear * C; }
-  E[idx] = e;
-  // Ey
-  u = 0.25 * (Qu[idx - 1 - sk] + Qu[idx - 1] + Qu[idx - sk] + Qu[idx]);
-  w = 0.25 * (Qw[idx - 1 - sk] + Qw[idx - 1] + Qw[idx - sk] + Qw[idx]);
-  A = 0.5 * (Ua[idx - sk] + Ua[idx]);
-  C = 0.5 * (Uc[idx - 1] + Uc[idx]);
-  E[idx + N] = w * A - u * C;
-  // Ez
-  u = 0.25 * (Qu[idx - 1 - sj] + Qu[idx - 1] + Qu[idx - sj] + Qu[idx]);
-  v = 0.25 * (Qv[idx - 1 - sj] + Qv[idx - 1] + Qv[idx - sj] + Qv[idx]);
-  A = 0.5 * (Ua[idx - sj] + Ua[idx]);
-  B = 0.5 * (Ub[idx - 1] + Ub[idx]);
-  e = u * B - v * A;
-  if (g.rot) { const double shear = -1.5 * g.Omega0 * (xPos - g.dx / 2); e -= shear * A; }
-  E[idx + 2 * N] = e;
+  const TraceInGlobal in = {U, Q, 0, N, g.sj, g.sk};
+  E[idx] = mhd_elec_comp<0>(g, in, xPos, idx);
+  E[idx + N] = mhd_elec_comp<1>(g, in, xPos, idx);
+  E[idx + 2 * N] = mhd_elec_comp<2>(g, in, xPos, idx);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -242,6 +257,7 @@ RG_DEVFN void mhd_trace3d_at(const DevParams& g, const TIN& in, const TW& tw, do
       dz_[v] = tvd_slope(st, in.q(v, -1, m), q[v], in.q(v, +1, m));
     }
   }
+  in.e_ready();
   const double E9[9] = {in.e(0, 0, m), in.e(0, +1, m), in.e(0, 0, m + sj), in.e(1, 0, m), in.e(1, +1, m), in.e(1, 0, m + 1),
                         in.e(2, 0, m), in.e(2, 0, m + sj), in.e(2, 0, m + 1)};
   mhd_trace3d_finish(g, in, tw, c, m, q, dx_, dy_, dz_, E9, dtdx, dtdy, dtdz);

@@ -538,7 +538,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // LDS-tiled fused trace + Riemann sweep over the Riemann planes r (hip/tiled_mhd.h); 1 = not covered
   auto sweep_planes = [&](rg_stream_t s, PlaneRange r) -> int {
     const int lo = r.lo < g.gw ? g.gw : r.lo, hi = r.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r.hi;
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, Q, E, c->F, c->emf, dtdx, dtdy, dtdz, lo, hi);
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
@@ -571,8 +571,10 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   const bool serial = c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks);
   if (serial) {
     rg_stream_t s = c->stream;
-    { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
-    { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+    if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)
+      { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
+      { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+    }
     if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
@@ -591,9 +593,9 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   for (int ci = 0; ci <= C; ++ci) {
     if (ci < C) {
       const int kb = (ci + 1 == C) ? b : a + (int)(((long long)span * (ci + 1)) / C);
-      if (prim_planes(sm, clip(d_prim, kb + 2, ks))) return -1;
+      if (!use_sweep && prim_planes(sm, clip(d_prim, kb + 2, ks))) return -1;
       d_prim = kb + 2;
-      if (elec_planes(sm, clip(d_elec, kb + 2, ks))) return -1;
+      if (!use_sweep && elec_planes(sm, clip(d_elec, kb + 2, ks))) return -1;
       d_elec = kb + 2;
       if (!use_sweep && trace_planes(sm, clip(d_trace, kb + 1, ks))) return -1;
       d_trace = kb + 1;
