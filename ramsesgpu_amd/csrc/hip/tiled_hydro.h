@@ -60,8 +60,8 @@ struct TileGrid {
   int flags;   // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
 };
 
-template <int TX, int TY, int SPEC>
-__global__ void __launch_bounds__(TX * TY) hydro3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ Uin,
+template <int TX, int TY, int SPEC, int MINW = 1>
+__global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ Uin,
                                                               double* __restrict__ Uout, double dtdx, double dtdy,
                                                               double dtdz, int za, int zb) {
   spec_assume<SPEC>(g);
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(TX * TY) hydro3d_sweep_kernel(DevParams g, Til
   (void)tr2d; (void)fl2d;
 }
 
-template <int TX, int TY, int SPEC>
+template <int TX, int TY, int SPEC, int MINW = 1>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
                                 double dtdz, int za, int zb) {
   TileGrid tg;
@@ -281,16 +281,19 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   tg.nseg = nseg;
   const int total = tg.nbx * tg.nby * tg.nseg;
   tg.per_xcd = (total + 7) / 8;
-  hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
+  hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC, MINW>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
                      dtdx, dtdy, dtdz, za, zb);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// configurations the fused sweep covers (uniform or per-cell gravity excluded by the driver: it knows the run's setting)
+inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && !g.mhd && g.nvar == 5 && !g.dirwise_update; }
 
 // Complete the update of planes [a,b) of a 3D hydro step.  Returns 0 = done, 1 = not applicable (the caller runs the
 // flat kernels), < 0 = launch error.
 inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
                          double dtdz, int a, int b) {
-  if (!tiled_enabled() || !g.three_d || g.mhd || g.nvar != 5 || g.grav_on != 0 || g.dirwise_update) return 1;
+  if (!hydro3d_sweep_covers(g) || g.grav_on != 0) return 1;
   const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
   // ghost planes inside [a,b): plain copy, like the flat update kernel
   const K_copy_cells kc = {in, out, g.ncell, 5};
@@ -300,8 +303,26 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
     if (rgpu::rg_launch_range<256>(s, (unsigned)lo * g.sk, (unsigned)(b - lo) * g.sk, kc)) return -1;
   }
   if (zb <= za) return 0;
-  constexpr int TX = 32, TY = 8;
+  // thread tile: 16 x 16 measured best at 256^3 (sweep 1.18 ms; 32 x 8: 1.24, 32 x 16: 1.19-1.26, 64 x 8: 1.43, 64 x 4: 1.75;
+  // a 168-VGPR build for three workgroups per CU: 1.46) -- the squarest tile recomputes the least halo (196 of 256 threads
+  // update a cell)
+  constexpr int TX = 16, TY = 16;
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
+#ifdef RG_HYDRO_TILE_EXPERIMENT   // experiment builds only: other thread-tile shapes for the HLLC / slope-1 kernel
+  {
+    static const char* tile = std::getenv("RGPU_HYDRO_TILE");
+    const int SP = SPEC_HYDRO_HLLC | SPEC_SLOPE1 | SPEC_NO_GRAVITY;
+    if (tile && spec_matches(SP, g)) {
+      const std::string ts = tile;
+      if (ts == "32x16") return launch_hydro3d_sweep<32, 16, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "64x8") return launch_hydro3d_sweep<64, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "64x4") return launch_hydro3d_sweep<64, 4, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "32x8") return launch_hydro3d_sweep<32, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "32x8w3") return launch_hydro3d_sweep<32, 8, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "64x4w3") return launch_hydro3d_sweep<64, 4, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+    }
+  }
+#endif
   if (!no_spec) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
 #define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb)

@@ -147,6 +147,7 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
 
 // number of scratch doubles per cell for each array of the active solver family
 struct ScratchPlan { int q, e, t, f, emf; };
+void fill_dev_params(const rgpu_params& p, DevParams* g);
 ScratchPlan plan_for(const rgpu_params& p) {
   const bool three_d = p.nz_global != 1;
   ScratchPlan s;
@@ -158,6 +159,14 @@ ScratchPlan plan_for(const rgpu_params& p) {
   } else {
     s.q = 8; s.e = 3; s.t = T_COUNT; s.f = F_COUNT; s.emf = 3;
   }
+  // The LDS-tiled sweeps keep primitives, electric field and traced state on chip: when the backend covers the run's
+  // configuration those arrays are never touched and are not allocated (518^3 MHD: 38 instead of 92 GB of device memory).
+  // F stays (hydro: scratch of the viscous fluxes and of the history sums); T keeps three components when the resistive
+  // stage borrows it for its emf.
+  DevParams g;
+  fill_dev_params(p, &g);
+  if (three_d && !p.mhdEnabled && rgpu_tiled::hydro3d_sweep_covers(g) && p.gravityEnabled == 0) { s.q = 0; s.t = 0; }
+  if (three_d && p.mhdEnabled && rgpu_tiled::mhd3d_sweep_covers(g) && p.gravityEnabled != 2) { s.q = 0; s.e = 0; s.t = (p.eta > 0) ? 3 : 0; }
   return s;
 }
 

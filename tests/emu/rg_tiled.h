@@ -5,6 +5,7 @@
 namespace rgpu_tiled {
 inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int) { return 1; }
 inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
+inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const double*, double*, double*,
                        double, double, double, double, int, int) { return 1; }
