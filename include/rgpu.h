@@ -242,6 +242,13 @@ int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out);
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
 
+/* Self-test of the device arithmetic the parity contract rests on: for n operand pairs computes on the device
+ *   quot[i]  = rg_div(num[i], rg_recip(den[i]))   the shared-reciprocal division of csrc/hip/rg_backend.h
+ *   quot2[i] = num[i] / den[i]                    the compiler's IEEE division
+ *   root[i]  = rg_sqrt(num[i]),  root2[i] = sqrt(num[i])
+ * (host arrays).  Inside the documented operand range all four equal the correctly rounded results bit for bit. */
+int rgpu_selftest_arith(int n, const double* num, const double* den, double* quot, double* quot2, double* root, double* root2);
+
 /* name of the device backend the library was built for ("hip-gfx950") */
 const char* rgpu_backend_name(void);
 

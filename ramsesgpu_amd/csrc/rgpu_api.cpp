@@ -797,6 +797,16 @@ int step_forcing(rgpu_ctx* c, int nStep, double dt) {
 
 // every entry point makes the context's device current: a multi-GPU process (or a thread whose current device differs)
 // would otherwise launch on the wrong device
+struct K_selftest_arith {
+  const double* num; const double* den; double* quot; double* quot2; double* root; double* root2;
+  RG_DEVFN void operator()(unsigned i) const {
+    quot[i] = rg_div(num[i], rg_recip(den[i]));
+    quot2[i] = num[i] / den[i];
+    root[i] = rg_sqrt(num[i]);
+    root2[i] = sqrt(num[i]);
+  }
+};
+
 #define RG_CHECK_CTX(c) do { if (!(c)) return RGPU_EINVAL; if ((c)->device >= 0) rg_set_device((c)->device); } while (0)
 #define RG_HIPFAIL(c, what) fail((c), RGPU_EHIP, std::string(what) + ": " + rg_last_error_string())
 
@@ -1121,6 +1131,22 @@ int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, 
 }
 
 const char* rgpu_backend_name(void) { return RG_BACKEND_NAME; }
+
+int rgpu_selftest_arith(int n, const double* num, const double* den, double* quot, double* quot2, double* root, double* root2) {
+  if (n <= 0 || !num || !den || !quot || !quot2 || !root || !root2) return RGPU_EINVAL;
+  if (rg_device_count() < 1) return RGPU_ENODEVICE;
+  double* d = 0;
+  const size_t N = (size_t)n;
+  if (rg_malloc((void**)&d, 6 * N * sizeof(double))) return RGPU_ENOMEM;
+  const rg_stream_t s = (rg_stream_t)0;
+  int rc = rg_copy_h2d(d, num, N * sizeof(double), s) || rg_copy_h2d(d + N, den, N * sizeof(double), s);
+  K_selftest_arith k = {d, d + N, d + 2 * N, d + 3 * N, d + 4 * N, d + 5 * N};
+  rc = rc || rg_launch<kBlock>(s, (unsigned)n, k);
+  rc = rc || rg_copy_d2h(quot, d + 2 * N, N * sizeof(double), s) || rg_copy_d2h(quot2, d + 3 * N, N * sizeof(double), s) ||
+       rg_copy_d2h(root, d + 4 * N, N * sizeof(double), s) || rg_copy_d2h(root2, d + 5 * N, N * sizeof(double), s) || rg_stream_sync(s);
+  rg_free(d);
+  return rc ? RGPU_EHIP : RGPU_OK;
+}
 
 #ifdef RG_SWEEP_PROF
 void rgpu_prof_read(unsigned long long* out, int reset) { rgpu_tiled::rgpu_prof_read_impl(out, reset); }

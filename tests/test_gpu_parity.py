@@ -290,3 +290,30 @@ def test_launch_specialised_kernels_equal_generic_ones(base, ov, tmp_path):
         assert res.returncode == 0, res.stderr[-2000:]
         digests.append(res.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1]
+
+
+def test_shared_reciprocal_division_and_sqrt_are_ieee(gpu_lib):
+    """rg_recip / rg_div / rg_sqrt (csrc/hip/rg_backend.h) are hand-rolled forms of the compiler's fp64 division and sqrt
+    without v_div_scale / v_div_fixup.  The parity contract needs them correctly rounded for every value a simulation
+    state can take: checked here against numpy's IEEE results on random operands over 2^+-400 and on edge operands
+    (exact quotients, powers of two, near-ties, tiny / huge but in range); the compiler's own '/' and sqrt as well."""
+    import ctypes as C
+    rng = np.random.RandomState(7)
+    n = 1 << 20
+    num = (rng.rand(n) + 0.5) * np.exp2(rng.randint(-400, 400, n)) * np.where(rng.rand(n) < 0.5, -1.0, 1.0)
+    den = (rng.rand(n) + 0.5) * np.exp2(rng.randint(-400, 400, n)) * np.where(rng.rand(n) < 0.5, -1.0, 1.0)
+    edge_n = np.array([1.0, 3.0, 1.0, 2.0, 10.0, 1e-300, 1e300, 7.0, 0.1, 5e-324 * 2 ** 60, 1.0 + 2 ** -52, 9.0, 1e200, 1e-200])
+    edge_d = np.array([3.0, 1.0, 7.0, 2.0 ** 300, 0.1, 1e-10, 1e10, 7.0, 0.3, 3.0, 1.0 - 2 ** -53, 3.0, 1e-90, 1e95])
+    num[:edge_n.size], den[:edge_d.size] = edge_n, edge_d
+    quot, quot2, root, root2 = (np.empty(n) for _ in range(4))
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    gpu_lib.lib.rgpu_selftest_arith.restype = C.c_int
+    gpu_lib.lib.rgpu_selftest_arith.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
+    assert gpu_lib.lib.rgpu_selftest_arith(n, P(num), P(den), P(quot), P(quot2), P(root), P(root2)) == 0
+    want_q = num / den
+    assert np.array_equal(quot2, want_q), "compiler division differs from IEEE"
+    assert np.array_equal(quot, want_q), "rg_div differs from IEEE on %d operands" % int((quot != want_q).sum())
+    pos = np.abs(num)
+    quot, quot2, root, root2 = (np.empty(n) for _ in range(4))
+    assert gpu_lib.lib.rgpu_selftest_arith(n, P(pos), P(den), P(quot), P(quot2), P(root), P(root2)) == 0
+    assert np.array_equal(root2, np.sqrt(pos)) and np.array_equal(root, np.sqrt(pos))
