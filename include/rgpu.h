@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RGPU_ABI_VERSION 4   /* layout of rgpu_params; new entry points do not change it */
+#define RGPU_ABI_VERSION 5   /* layout of rgpu_params; new entry points do not change it */
 
 /* component indexes -- constants.h:59-71 */
 enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA = 5, RGPU_IB = 6, RGPU_IC = 7 };
@@ -101,6 +101,13 @@ typedef struct rgpu_params {
                                  * rgpu_set_forcing_field is added to the momenta at the end of every step, scaled so that
                                  * the kinetic energy input rate is randomForcingEdot (3D, no rotating frame) */
   double  randomForcingEdot;    /* [turbulence] edot, or the Mac Low (1999) estimate when negative (HydroRunBase.cpp:7175-7194) */
+  /* problem "turbulence-Ornstein-Uhlenbeck" (HydroRunBase.cpp:230-247): 31 Fourier modes of a forcing field driven by an
+   * Ornstein-Uhlenbeck process (ForcingOrnsteinUhlenbeck, Forcing_OrnsteinUhlenbeck.cpp) are advanced on the host every
+   * step and their real-space sum accelerates the gas at the end of the step (3D, no rotating frame).  The context owns
+   * the process (mode signs, projection tensor, the four-digit base-4096 seed of RandomGen); every z-slab runs the same one. */
+  int32_t ouForcingEnabled;
+  int32_t ouInitRandom;         /* [turbulence-Ornstein-Uhlenbeck] init_random (seed of the Gaussian generator) */
+  double  ouTimeScaleTurb, ouAmplitudeTurb, ouKsi;   /* timeScaleTurb, amplitudeTurb, ksi (1 solenoidal .. 0 compressive) */
 } rgpu_params;
 
 typedef struct rgpu_ctx rgpu_ctx;
@@ -147,6 +154,15 @@ int rgpu_set_gravity_field(rgpu_ctx* c, const double* hG);
  * (add_random_forcing, HydroRunBase.cpp:1397-1428).  The sums are accumulated in a fixed order that is not the
  * reference's loop order: results agree with the reference to round-off, not bit for bit. */
 int rgpu_set_forcing_field(rgpu_ctx* c, const double* hF);
+/* ForcingOrnsteinUhlenbeck::add_forcing_field (Forcing_OrnsteinUhlenbeck.cpp:498-549, 597-686) on U[parity]: one
+ * Ornstein-Uhlenbeck update of the 31 modes with time step dt (host; RandomGen::gaussDev), then momenta and total energy
+ * of every interior cell get the real-space sum of the modes.  rgpu_godunov_unsplit calls it itself after the dissipative
+ * stage like the reference (HydroRunGodunov.cpp:2940-2945, mhd_godunov_unsplit_cpu_v3.cpp:706-710); a z-slab driver calls
+ * it on every slab (same process on every rank, no communication).  The device evaluates cos() with its own libm: states
+ * agree with the reference to round-off (relative L2 ~1e-16 per step), not bit for bit.
+ * rgpu_ou_forcing_state copies out mode[3][31], forcingField[3][31] (what output_forcing writes, :392-444). */
+int rgpu_step_ou_forcing(rgpu_ctx* c, int parity, double dt);
+int rgpu_ou_forcing_state(rgpu_ctx* c, double* mode93, double* forcingField93);
 int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out);
 int rgpu_add_forcing(rgpu_ctx* c, int parity, double norm);
 /* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */
@@ -234,6 +250,12 @@ int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt);
 int rgpu_history_columns(rgpu_ctx* c, int parity, double* cols);
 int rgpu_history_reynolds(rgpu_ctx* c, int parity, const double* mean_vx, const double* mean_vy, double dTau, double* cols);
 int rgpu_history_mri(rgpu_ctx* c, int parity, double* out);
+/* MHDRunBase::history_turbulence (MHDRunBase.cpp:3626-3810; problems "turbulence" and "turbulence-Ornstein-Uhlenbeck", 3D),
+ * reduced on the device: out[18] = the columns of the reference's history file after totalTime and dt --
+ * mass divB eKin eMag helicity mean_rho mean_B mean_Bx mean_By mean_Bz mean_rhovx mean_rhovy mean_rhovz Ma_s Ma_alfven
+ * coef_x coef_y coef_z (the three high-k DFT amplitudes of Bx it monitors).  Single-domain contexts; fixed summation order,
+ * device cos / sin: agreement with the reference to round-off. */
+int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out);
 /* One cell of the state, out[nbVar] = U(i,j,k,:) with ghost-inclusive local indices: what history_inertial_wave
  * (MHDRunBase.cpp:3414-3469) probes -- U(ghostWidth + nx/2, ghostWidth) in 2D, U(ghostWidth + nx/2, 1, ghostWidth) in 3D --
  * without copying the whole array back (the reference calls copyGpuToCpu first). */

@@ -41,6 +41,12 @@ struct RgpuBinding : public HydroRunBase {
     p.nu = r._gParams.nu; p.eta = r._gParams.eta;  // dissipative stage inside rgpu_godunov_unsplit
     p.zStratifiedFloor = r.configMap.getBool("MRI", "floor", false) ? 1 : 0;   // BC_Z_STRATIFIED (HydroRunBase.cpp:2206)
     p.randomForcingEnabled = r.randomForcingEnabled ? 1 : 0; p.randomForcingEdot = r.randomForcingEdot;
+    // problem "turbulence-Ornstein-Uhlenbeck": the library owns the process (same parameters as ForcingOrnsteinUhlenbeck reads)
+    p.ouForcingEnabled = r.randomForcingOrnsteinUhlenbeckEnabled ? 1 : 0;
+    p.ouInitRandom = r.configMap.getInteger("turbulence-Ornstein-Uhlenbeck", "init_random", 600);
+    p.ouTimeScaleTurb = r.configMap.getFloat("turbulence-Ornstein-Uhlenbeck", "timeScaleTurb", 0.1);
+    p.ouAmplitudeTurb = r.configMap.getFloat("turbulence-Ornstein-Uhlenbeck", "amplitudeTurb", 0.0001);
+    p.ouKsi = r.configMap.getFloat("turbulence-Ornstein-Uhlenbeck", "ksi", 0.0);
     *out = p;
   }
   static void check(rgpu_ctx* ctx, int rc) {

@@ -86,6 +86,11 @@ CASES = {
     # --- driven turbulence: static driving field + normalisation sums (sequential in the reference: the device agrees to round-off) ---
     "turb_hydro_16": ("turbulence_hydro", "mesh.nx=16;mesh.ny=16;mesh.nz=16;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=10;run.noutput=1000", [0, 10]),
     "turb_hydro_12x12x18_hllc": ("turbulence_hydro", "mesh.nx=12;mesh.ny=12;mesh.nz=18;hydro.riemannSolver=hllc;hydro.unsplitVersion=2;turbulence.edot=-1.0;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [6]),
+    # --- Ornstein-Uhlenbeck forcing: the host process is reproduced exactly; the device evaluates cos() itself (round-off agreement) ---
+    "turb_ou_hydro_16": ("turbulence_hydro_ou", "mesh.nx=16;mesh.ny=16;mesh.nz=16;turbulence-Ornstein-Uhlenbeck.initialDensityPerturbationAmplitude=0.1;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=10;run.noutput=1000", [0, 10]),
+    "turb_ou_hydro_12x16x20_hllc_ksi": ("turbulence_hydro_ou", "mesh.nx=12;mesh.ny=16;mesh.nz=20;hydro.riemannSolver=hllc;hydro.cIso=0;turbulence-Ornstein-Uhlenbeck.ksi=0.3;turbulence-Ornstein-Uhlenbeck.init_random=77;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [6]),
+    "turb_ou_mhd_12": ("turbulence_mhd_ou", "mesh.nx=12;mesh.ny=12;mesh.nz=12;history.enabled=no;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [0, 6]),
+    "turb_ou_mhd_12_history": ("turbulence_mhd_ou", "mesh.nx=12;mesh.ny=12;mesh.nz=12;history.dtHist=0.02;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=8;run.noutput=1000", [8]),
     "turb_mhd_12": ("turbulence_mhd", "mesh.nx=12;mesh.ny=12;mesh.nz=12;output.outputVtk=yes;output.outputHdf5=no;output.ghostIncluded=no;run.nstepmax=6;run.noutput=1000", [0, 6]),
     "rotor_32_ic": ("mhd_rotor", "mesh.nx=32;mesh.ny=32;run.nstepmax=0;run.noutput=100", [0]),   # IC only: with implementationVersion=1 the reference itself turns this problem into NaN within a few steps
     "fieldloop2d_32x20": ("mhd_fieldloop2d", "mesh.nx=32;mesh.ny=20;run.nstepmax=10;run.noutput=100", [0, 10]),

@@ -92,12 +92,93 @@ void orc_history_mri(const rgpu_params* p, const double* U, double* out) {
   out[0] = mass; out[1] = maxwell; out[2] = reynolds; out[3] = magp; out[4] = mean_Bx; out[5] = mean_By; out[6] = mean_Bz; out[7] = divB;
 }
 
+// history_turbulence (MHDRunBase.cpp:3626-3810), 3D: the reference's two loops in its order.  out[18] = the columns after
+// totalTime and dt: mass divB eKin eMag helicity mean_rho mean_B mean_Bx mean_By mean_Bz mean_rhovx mean_rhovy mean_rhovz
+// Ma_s Ma_alfven coef_x coef_y coef_z
+void orc_history_turbulence(const rgpu_params* p, const double* U, double* out) {
+  Ctx c(*p);
+  const int ghostWidth = c.gw, isize = c.isize, jsize = c.jsize, ksize = c.ksize;
+  const int nx = p->nx, ny = p->ny, nz = p->nz;
+  const size_t N = c.ncell;
+  const double dx = p->dx, dy = p->dy, dz = p->dz;
+  const double pi = 2 * asin(1.0);
+  double mass = 0.0, eKin = 0.0, eMag = 0.0;
+  double helicity = 0.0;
+  double mean_Bx = 0.0, mean_By = 0.0, mean_Bz = 0.0;
+  double mean_rhovx = 0.0, mean_rhovy = 0.0, mean_rhovz = 0.0;
+  double mean_v2 = 0.0, mean_rho = 0.0;
+  int kfft = nx - 3;
+  double coef_x_re = 0.0, coef_x_im = 0.0, coef_y_re = 0.0, coef_y_im = 0.0, coef_z_re = 0.0, coef_z_im = 0.0;
+#define SQR(x) ((x) * (x))
+  for (int k = ghostWidth; k < ksize - ghostWidth; k++)
+    for (int j = ghostWidth; j < jsize - ghostWidth; j++)
+      for (int i = ghostWidth; i < isize - ghostWidth; i++) {
+        const size_t o = c.idx(i, j, k);
+        double rho = U[o + ID * N];
+        double bx = U[o + IA * N];
+        mass += rho;
+        eKin += SQR(U[o + IU * N]) / rho;
+        eKin += SQR(U[o + IV * N]) / rho;
+        eKin += SQR(U[o + IW * N]) / rho;
+        mean_v2 += SQR(U[o + IU * N] / rho);
+        mean_v2 += SQR(U[o + IV * N] / rho);
+        mean_v2 += SQR(U[o + IW * N] / rho);
+        eMag += SQR(U[o + IA * N]);
+        eMag += SQR(U[o + IB * N]);
+        eMag += SQR(U[o + IC * N]);
+        helicity += U[o + IU * N] * U[o + IA * N] / sqrt(rho);
+        helicity += U[o + IV * N] * U[o + IB * N] / sqrt(rho);
+        helicity += U[o + IW * N] * U[o + IC * N] / sqrt(rho);
+        mean_Bx += U[o + IA * N];
+        mean_By += U[o + IB * N];
+        mean_Bz += U[o + IC * N];
+        mean_rhovx += U[o + IU * N];
+        mean_rhovy += U[o + IV * N];
+        mean_rhovz += U[o + IW * N];
+        mean_rho += rho;
+        coef_x_re += bx * cos(2 * pi * kfft * i / nx);
+        coef_x_im += bx * sin(2 * pi * kfft * i / nx);
+        coef_y_re += bx * cos(2 * pi * kfft * j / ny);
+        coef_y_im += bx * sin(2 * pi * kfft * j / ny);
+        coef_z_re += bx * cos(2 * pi * kfft * k / nz);
+        coef_z_im += bx * sin(2 * pi * kfft * k / nz);
+      }
+  double dTau = dx * dy * dz / (p->xMax - p->xMin) / (p->yMax - p->yMin) / (p->zMax - p->zMin);
+  mass = mass * dTau;
+  eKin = eKin * dTau;
+  eMag = eMag * dTau;
+  helicity *= dTau;
+  mean_Bx = mean_Bx * dTau; mean_By = mean_By * dTau; mean_Bz = mean_Bz * dTau;
+  double mean_B = sqrt(SQR(mean_Bx) + SQR(mean_By) + SQR(mean_Bz));
+  mean_rhovx = mean_rhovx * dTau; mean_rhovy = mean_rhovy * dTau; mean_rhovz = mean_rhovz * dTau;
+  mean_v2 = mean_v2 * dTau;
+  mean_rho = mean_rho * dTau;
+  double coef_x = sqrt(SQR(coef_x_re) + SQR(coef_x_im)); coef_x *= dTau;
+  double coef_y = sqrt(SQR(coef_y_re) + SQR(coef_y_im)); coef_y *= dTau;
+  double coef_z = sqrt(SQR(coef_z_re) + SQR(coef_z_im)); coef_z *= dTau;
+  double divB = 0.0;
+  for (int k = ghostWidth; k < ksize - ghostWidth; k++)
+    for (int j = ghostWidth; j < jsize - ghostWidth; j++)
+      for (int i = ghostWidth; i < isize - ghostWidth; i++) {
+        const size_t o = c.idx(i, j, k);
+        divB += (U[c.idx(i + 1, j, k) + IA * N] - U[o + IA * N]) / dx + (U[c.idx(i, j + 1, k) + IB * N] - U[o + IB * N]) / dy +
+                (U[c.idx(i, j, k + 1) + IC * N] - U[o + IC * N]) / dz;
+      }
+#undef SQR
+  double Ma_alfven = sqrt(mean_v2) / (mean_B / sqrt(4 * pi * mean_rho));
+  double Ma_s = sqrt(mean_v2) / p->cIso;
+  const double v[18] = {mass, divB, eKin, eMag, helicity, mean_rho, mean_B, mean_Bx, mean_By, mean_Bz, mean_rhovx, mean_rhovy, mean_rhovz,
+                        Ma_s, Ma_alfven, coef_x, coef_y, coef_z};
+  for (int q = 0; q < 18; q++) out[q] = v[q];
+}
+
 static int check_scope(const rgpu_params* p) {
   if (p->slope_type != 0 && p->slope_type != 1 && p->slope_type != 2 && p->slope_type != 3) return RGPU_EUNSUPPORTED;
   // slope_type 3 (positivity preserving) exists in the 2D MHD and the plain 3D MHD steps only; the hydro steps and
   // the rotating 3D step call slope routines that leave dq unset for it (slope.h:97-147,324-427; slope_mhd.h:436-502)
   if (p->slope_type == 3 && (!p->mhdEnabled || (p->Omega0 > 0 && p->nz_global != 1))) return RGPU_EUNSUPPORTED;
   if (p->randomForcingEnabled && (p->nz_global == 1 || (p->mhdEnabled && p->Omega0 > 0))) return RGPU_EUNSUPPORTED;
+  if (p->ouForcingEnabled && (p->nz_global == 1 || (p->mhdEnabled && p->Omega0 > 0))) return RGPU_EUNSUPPORTED;
   if (p->mhdEnabled) {
     const bool three_d = p->nz_global != 1;
     if (p->magRiemannSolver != RGPU_MAG_HLLD && p->magRiemannSolver != RGPU_MAG_HLLA && p->magRiemannSolver != RGPU_MAG_HLLF &&
@@ -122,6 +203,7 @@ int orc_godunov_unsplit(const rgpu_params* p, double* Uold, double* Unew, double
   const int rc = check_scope(p);
   if (rc) return rc;
   Ctx c(*p);
+  ou_forget();   // a single step carries no forcing process (orc_run owns one)
   if (!p->mhdEnabled) hydro_step(c, Uold, Unew, dt);
   else if (!c.three_d) mhd_step_2d(c, Uold, Unew, dt);
   else mhd_step_3d(c, Uold, Unew, dt, totalTime);
@@ -139,6 +221,7 @@ int orc_run(const rgpu_params* p, double* U, int nStepmax, double tEnd, int* nst
   std::vector<double> U2(n);
   make_all_boundaries(c, U, 0.0, 0.0);
   std::memcpy(U2.data(), U, sizeof(double) * n);
+  ou_init(*p);   // init_forcing() of the initial condition (HydroRunBase.cpp:6990)
   double t = 0.0;
   int nStep = 0;
   while (t < tEnd && nStep < nStepmax) {
@@ -152,6 +235,7 @@ int orc_run(const rgpu_params* p, double* U, int nStepmax, double tEnd, int* nst
     nStep++;
     t += dt;
   }
+  ou_forget();
   if (nStep % 2 == 1) std::memcpy(U, U2.data(), sizeof(double) * n);
   if (nsteps_done) *nsteps_done = nStep;
   if (t_final) *t_final = t;

@@ -54,6 +54,11 @@ struct Ctx {
 
 // random forcing at the end of a 3D step (HydroRunBase.cpp:1201-1312, 1397-1428)
 void random_forcing(const Ctx& c, double* U, double dt);
+// Ornstein-Uhlenbeck forcing (Forcing_OrnsteinUhlenbeck.cpp): ou_init at the start of a run (init_forcing), ou_forcing at
+// the end of every 3D step (add_forcing_field); the process is a run-long state like the reference's pForcingOrnsteinUhlenbeck
+void ou_init(const rgpu_params& p);
+void ou_forget();
+void ou_forcing(const Ctx& c, double* U, double dt);
 
 // A component-major field with the reference's HostArray index map (Arrays.h:95-98).
 struct Field {

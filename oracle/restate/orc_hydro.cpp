@@ -132,6 +132,7 @@ void hydro_step_t(const Ctx& c, double* Uold_d, double* Unew_d, double dt) {
   }
   dissipative_stage(c, Unew_d, dt, 0.0);   // [hydro] nu > 0 (HydroRunGodunov.cpp:2620-2640, 2908-2925)
   random_forcing(c, Unew_d, dt);           // problem "turbulence" (HydroRunGodunov.cpp:2930-2938, 3830-3838)
+  ou_forcing(c, Unew_d, dt);               // problem "turbulence-Ornstein-Uhlenbeck" (:2940-2945)
 }
 
 }  // namespace

@@ -438,6 +438,7 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
 
   dissipative_stage(c, Unew_d, dt, totalTime);   // nu / eta > 0 (..._cpu_v3.cpp:662-694, MHDRunGodunov.cpp:3379-3420)
   if (!rot) random_forcing(c, Unew_d, dt);       // problem "turbulence" (..._cpu_v3.cpp:696-704); the rotating step has none
+  if (!rot) ou_forcing(c, Unew_d, dt);           // problem "turbulence-Ornstein-Uhlenbeck" (..._cpu_v3.cpp:706-710)
   if (rot) make_all_boundaries(c, Unew_d, totalTime, dt);  // rotating path: ghosts of the OUTPUT at step end
 }
 

@@ -1,7 +1,7 @@
 """ctypes view of include/rgpu.h (the C ABI) -- plain structs and prototypes, no compute here."""
 import ctypes as C
 
-RGPU_ABI_VERSION = 4
+RGPU_ABI_VERSION = 5
 
 ID, IP, IU, IV, IW, IA, IB, IC = range(8)
 BC_UNDEFINED, BC_DIRICHLET, BC_NEUMANN, BC_PERIODIC, BC_SHEARINGBOX, BC_COPY, BC_Z_STRATIFIED = range(7)
@@ -41,6 +41,8 @@ class RgpuParams(C.Structure):
         ("gravity_x", C.c_double), ("gravity_y", C.c_double), ("gravity_z", C.c_double),
         ("nu", C.c_double), ("eta", C.c_double),
         ("zStratifiedFloor", C.c_int32), ("randomForcingEnabled", C.c_int32), ("randomForcingEdot", C.c_double),
+        ("ouForcingEnabled", C.c_int32), ("ouInitRandom", C.c_int32),
+        ("ouTimeScaleTurb", C.c_double), ("ouAmplitudeTurb", C.c_double), ("ouKsi", C.c_double),
     ]
 
     @property
@@ -101,6 +103,12 @@ def declare_device_api(lib):
     lib.rgpu_download.argtypes = [ctx, C.c_void_p, C.c_int]
     lib.rgpu_device_state.restype = C.c_void_p
     lib.rgpu_device_state.argtypes = [ctx, C.c_int]
+    lib.rgpu_history_turbulence.restype = C.c_int
+    lib.rgpu_history_turbulence.argtypes = [ctx, C.c_int, c_double_p]
+    lib.rgpu_step_ou_forcing.restype = C.c_int
+    lib.rgpu_step_ou_forcing.argtypes = [ctx, C.c_int, C.c_double]
+    lib.rgpu_ou_forcing_state.restype = C.c_int
+    lib.rgpu_ou_forcing_state.argtypes = [ctx, c_double_p, c_double_p]
     lib.rgpu_get_params.restype = C.c_int
     lib.rgpu_get_params.argtypes = [ctx, P]
     lib.rgpu_stream_handle.restype = C.c_void_p
@@ -168,9 +176,9 @@ def declare_device_api(lib):
 DECLARED_SYMBOLS = [
     "rgpu_create", "rgpu_create_external", "rgpu_destroy", "rgpu_state_elems", "rgpu_device_bytes", "rgpu_last_error",
     "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_get_params", "rgpu_stream_handle", "rgpu_inv_dt_device_slot", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
-    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
+    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_history_turbulence", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
-    "rgpu_backend_name", "rgpu_selftest_arith", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
+    "rgpu_backend_name", "rgpu_selftest_arith", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
 ]

@@ -143,6 +143,7 @@ int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
     RG_TRY(rgpu_step_dissipative(c, nStep, dt, t), "step_dissipative");
   }
   if (cm->p.randomForcingEnabled) { if (int rc = random_forcing(cm, nStep, dt)) return rc; }
+  if (cm->p.ouForcingEnabled) RG_TRY(rgpu_step_ou_forcing(c, (nStep + 1) % 2, dt), "step_ou_forcing");   // same process on every rank
   RG_TRY(rgpu_step_post_a(c, nStep, dt, t), "step_post_a");
   if (rot) { if (int rc = exchange(cm, (nStep + 1) % 2)) return rc; }     // rotating path: ghosts of the OUTPUT
   RG_TRY(rgpu_step_post_b(c, nStep, dt, t), "step_post_b");
@@ -154,7 +155,7 @@ int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
 int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
   // the dissipative stage needs a second exchange inside the step, the random forcing a global sum and a change of the
   // whole updated state: both use the serial schedule
-  if (!cm->overlap || dissipative(cm) || cm->p.randomForcingEnabled) return godunov_unsplit_serial(cm, nStep, dt, t);
+  if (!cm->overlap || dissipative(cm) || cm->p.randomForcingEnabled || cm->p.ouForcingEnabled) return godunov_unsplit_serial(cm, nStep, dt, t);
   rgpu_ctx* c = cm->ctx;
   const int pin = nStep % 2, pout = (nStep + 1) % 2;
   const bool rot = rotating(cm);

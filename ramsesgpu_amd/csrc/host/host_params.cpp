@@ -107,6 +107,16 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
     }
     p->randomForcingEdot = eDot;
   }
+  // problem "turbulence-Ornstein-Uhlenbeck" (HydroRunBase.cpp:230-247; parameters read by the ForcingOrnsteinUhlenbeck
+  // constructor, Forcing_OrnsteinUhlenbeck.cpp:57-60)
+  p->ouForcingEnabled = 0; p->ouInitRandom = 600; p->ouTimeScaleTurb = 0.1; p->ouAmplitudeTurb = 0.0001; p->ouKsi = 0.0;
+  if (cfg.get_string("hydro", "problem", "unknown") == "turbulence-Ornstein-Uhlenbeck") {
+    p->ouForcingEnabled = 1;
+    p->ouTimeScaleTurb = cfg.get_float("turbulence-Ornstein-Uhlenbeck", "timeScaleTurb", 0.1f);
+    p->ouAmplitudeTurb = cfg.get_float("turbulence-Ornstein-Uhlenbeck", "amplitudeTurb", 0.0001f);
+    p->ouKsi = cfg.get_float("turbulence-Ornstein-Uhlenbeck", "ksi", 0.0f);
+    p->ouInitRandom = static_cast<int>(cfg.get_integer("turbulence-Ornstein-Uhlenbeck", "init_random", 600));
+  }
   p->zStratifiedFloor = cfg.get_bool("MRI", "floor", false) ? 1 : 0;   // read by the z-stratified ghost fill (HydroRunBase.cpp:2206)
   p->nu = cfg.get_float("hydro", "nu", 0.0f);     // HydroParameters.h:327-328
   p->eta = cfg.get_float("MHD", "eta", 0.0f);

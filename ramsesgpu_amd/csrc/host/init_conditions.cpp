@@ -764,6 +764,43 @@ void init_turbulence(const IniConfig& cfg, const rgpu_params& p, const Grid& g) 
       }
 }
 
+// problem "turbulence-Ornstein-Uhlenbeck" (HydroRunBase.cpp:6973-7019, MHDRunBase.cpp:3107-3159): gas at rest, density
+// perturbed with libc rand() (double arithmetic here, unlike "turbulence"), uniform pressure; MHD adds a uniform field.
+// The forcing process itself lives in the context (rgpu_params::ouForcingEnabled).
+void init_turbulence_ou(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
+  const char* S = "turbulence-Ornstein-Uhlenbeck";
+  if (!g.three_d) throw std::runtime_error("the turbulence-Ornstein-Uhlenbeck problem is not available in 2D");
+  const double d0 = cfg.get_float(S, "density", 1.0f);
+  const double ampl = cfg.get_float(S, "initialDensityPerturbationAmplitude", 0.0f);
+  const double P0 = cfg.get_float(S, "pressure", 1.0f);
+  GlibcRand rng(static_cast<unsigned>(cfg.get_integer(S, "random_seed", 33)));
+  for (long n = 0; n < (long)g.k_shift * g.ny * g.nx; ++n) rng.next();   // interior cells of the slabs below
+  double Bx0 = 0, By0 = 0, Bz0 = 0;
+  if (p.mhdEnabled) {
+    Bx0 = cfg.get_float(S, "bx", 1e-8f);
+    By0 = cfg.get_float(S, "by", 1e-8f);
+    Bz0 = cfg.get_float(S, "bz", 1e-8f);
+    const double beta = cfg.get_float(S, "beta", 0.0f);
+    if (beta > 0) {
+      const double cIso2 = p.cIso * p.cIso;
+      Bx0 = std::sqrt(2 * cIso2 * d0 / beta);
+      By0 = 0.0; Bz0 = 0.0;
+      if (cIso2 <= 0.0) Bx0 = cfg.get_float(S, "Bx0", static_cast<float>(2.0 * d0 / beta));
+    }
+  }
+  for (int k = g.gw; k < g.ksize - g.gw; ++k)
+    for (int j = g.gw; j < g.jsize - g.gw; ++j)
+      for (int i = g.gw; i < g.isize - g.gw; ++i) {
+        g.at(i, j, k, RGPU_ID) = d0 * (1.0 + ampl * ((1.0 * rng.next()) / GlibcRand::kRandMax - 0.5));
+        g.at(i, j, k, RGPU_IU) = 0.0; g.at(i, j, k, RGPU_IV) = 0.0; g.at(i, j, k, RGPU_IW) = 0.0;
+        g.at(i, j, k, RGPU_IP) = P0 / (p.gamma0 - 1.0);
+        if (p.mhdEnabled) {
+          g.at(i, j, k, RGPU_IA) = Bx0; g.at(i, j, k, RGPU_IB) = By0; g.at(i, j, k, RGPU_IC) = Bz0;
+          g.at(i, j, k, RGPU_IP) += 0.5 * (Bx0 * Bx0 + By0 * By0 + Bz0 * Bz0);
+        }
+      }
+}
+
 // ---- MHD: compressive shear wave in the shearing box (MHDRunBase.cpp:2574-2658), every cell, ghosts included --------
 void init_mhd_shear_wave(const IniConfig& cfg, const rgpu_params& p, const Grid& g) {
   if (!(p.bc[0] == RGPU_BC_SHEARINGBOX && p.bc[1] == RGPU_BC_SHEARINGBOX))
@@ -1067,6 +1104,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "CurrentSheet" || problem == "currentsheet" || problem == "Currentsheet" || problem == "current-sheet" || problem == "Current-Sheet") init_mhd_current_sheet(cfg, p, g);
     else if (problem == "ShearWave" || problem == "shearwave" || problem == "Shear-Wave" || problem == "shear-wave" || problem == "Shearwave") init_mhd_shear_wave(cfg, p, g);
     else if (problem == "turbulence") init_turbulence(cfg, p, g);
+    else if (problem == "turbulence-Ornstein-Uhlenbeck") init_turbulence_ou(cfg, p, g);
     else if (problem == "InertialWave" || problem == "inertialwave" || problem == "Inertial-Wave" || problem == "inertial-wave" || problem == "Inertialwave") init_mhd_inertial_wave(cfg, p, g);
     else throw std::runtime_error("MHD problem '" + problem + "' is outside the implemented scope");
   } else {
@@ -1081,6 +1119,7 @@ void init_condition(const IniConfig& cfg, const rgpu_params& p, double* hU) {
     else if (problem == "falling-bubble") init_hydro_falling_bubble(cfg, p, g);
     else if (problem == "Keplerian-disk") init_hydro_keplerian_disk(cfg, p, g);
     else if (problem == "turbulence") init_turbulence(cfg, p, g);
+    else if (problem == "turbulence-Ornstein-Uhlenbeck") init_turbulence_ou(cfg, p, g);
     else throw std::runtime_error("hydro problem '" + problem + "' is outside the implemented scope");
   }
 }

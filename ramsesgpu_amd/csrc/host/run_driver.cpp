@@ -106,7 +106,7 @@ void GodunovRun::outputVtk(int nStep) {
 // MHDRunGodunov.cpp:3801-4070 / HydroRunGodunov.cpp:3857-4080 (no restart, no history, VTI outputs only)
 // history(nStep, dt): the history file of the MHD runs (MHDRunBase.cpp:3285-3619), one row per call, same columns and
 // ostream formatting: MRI problems get history_mri's eleven columns, Orszag-Tang history_default's four, every other
-// problem none (history_empty; the turbulence variant is outside the implemented scope).  The sums come from the device
+// problem none (history_empty); the turbulence problems get history_turbulence's twenty columns.  The sums come from the device
 // (rgpu_history_mri) instead of a copy of the state to the host.  The inertial-wave problem gets history_inertial_wave's
 // probe row (:3414-3469): the velocity of one cell in units of cIso, read with rgpu_read_cell.
 void GodunovRun::history(int nStep, double dt) {
@@ -134,6 +134,22 @@ void GodunovRun::history(int nStep, double dt) {
     histo << " ";
     histo << " " << std::setw(12) << std::setprecision(8) << std::fixed << dvy / p_.cIso;
     histo.flags(flags);
+    histo << "\n";
+    return;
+  }
+  if (problem == "turbulence" || problem == "turbulence-Ornstein-Uhlenbeck") {   // history_turbulence (MHDRunBase.cpp:3626-3810)
+    if (p_.nz_global == 1) return;
+    double h[18];
+    check(rgpu_history_turbulence(ctx_, nStep % 2, h), "history");
+    const std::string fileName = cfg_.get_string("output", "outputDir", "./") + "/" + cfg_.get_string("output", "outputPrefix", "output") +
+                                 "_" + cfg_.get_string("history", "filename", "history.txt");
+    std::ofstream histo(fileName.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+    if (totalTime_ <= 0) {
+      histo << "# history" << std::endl;
+      histo << "# totalTime dt mass divB eKin eMag helicity mean_rho mean_B mean_Bx mean_By mean_Bz mean_rhovx mean_rhovy mean_rhovz Ma_s Ma_alfven coef_x coef_y coef_z\n";
+    }
+    histo << totalTime_ << "\t" << dt;
+    for (int q = 0; q < 18; ++q) histo << "\t" << h[q];
     histo << "\n";
     return;
   }

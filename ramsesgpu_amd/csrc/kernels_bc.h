@@ -4,6 +4,7 @@
 //   shear_ghost_cell    make_boundaries_shear            MHDRunGodunov.cpp:3539-3759
 //   hydro/mhd_invdt     compute_dt / compute_dt_mhd      HydroRunBase.cpp:372-426 / MHDRunBase.cpp:140-250
 #pragma once
+#include "ou_forcing.h"
 #include "kernels_mhd3d.h"
 
 namespace rgpu_dev {
@@ -282,6 +283,46 @@ RG_DEVFN void hist_row_cell(const DevParams& g, const double* __restrict__ U, do
   for (int q = 0; q < HIST_NQ; ++q) rows[(size_t)q * R + idx] = acc[q];
 }
 
+// history_turbulence (MHDRunBase.cpp:3626-3810): row sums over the interior y of the 19 quantities of its two loops, interior
+// i only.  q = 0 mass, 1 eKin, 2 mean_v2, 3 eMag, 4 helicity, 5-7 mean_B, 8-10 mean_rhov, 11-16 the high-k DFT coefficients of
+// Bx (x re/im, y re/im, z re/im; phases from the ghost-inclusive integer indices like the reference), 17 divB, 18 unused
+enum { HIST_TURB_NQ = 18 };
+RG_DEVFN void hist_turb_row_cell(const DevParams& g, const double* __restrict__ U, double* __restrict__ rows, unsigned idx) {
+  const int nk = g.nz;
+  const int i = (int)(idx % (unsigned)g.isize), kk = (int)(idx / (unsigned)g.isize);
+  if (kk >= nk) return;
+  const int k = kk + g.gw;
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  double acc[HIST_TURB_NQ];
+#pragma unroll
+  for (int q = 0; q < HIST_TURB_NQ; ++q) acc[q] = 0.0;
+  if (i >= g.gw && i < g.isize - g.gw) {
+    const double pi = 2 * asin(1.0);
+    const int kfft = g.nx - 3;
+    for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+      const unsigned o = (unsigned)i + sj * (unsigned)j + sk * (unsigned)k;
+      const double rho = U[o + ID * N];
+      const double mu = U[o + IU * N], mv = U[o + IV * N], mw = U[o + IW * N];
+      const double bx = U[o + IA * N], by = U[o + IB * N], bz = U[o + IC * N];
+      acc[0] += rho;
+      acc[1] += (mu * mu) / rho; acc[1] += (mv * mv) / rho; acc[1] += (mw * mw) / rho;
+      acc[2] += (mu / rho) * (mu / rho); acc[2] += (mv / rho) * (mv / rho); acc[2] += (mw / rho) * (mw / rho);
+      acc[3] += bx * bx; acc[3] += by * by; acc[3] += bz * bz;
+      acc[4] += mu * bx / sqrt(rho); acc[4] += mv * by / sqrt(rho); acc[4] += mw * bz / sqrt(rho);
+      acc[5] += bx; acc[6] += by; acc[7] += bz;
+      acc[8] += mu; acc[9] += mv; acc[10] += mw;
+      acc[11] += bx * cos(2 * pi * kfft * i / g.nx); acc[12] += bx * sin(2 * pi * kfft * i / g.nx);
+      acc[13] += bx * cos(2 * pi * kfft * j / g.ny); acc[14] += bx * sin(2 * pi * kfft * j / g.ny);
+      acc[15] += bx * cos(2 * pi * kfft * k / g.nz); acc[16] += bx * sin(2 * pi * kfft * k / g.nz);
+      acc[17] += (U[o + 1 + IA * N] - bx) / g.dx + (U[o + sj + IB * N] - by) / g.dy + (U[o + sk + IC * N] - bz) / g.dz;
+    }
+  }
+  const size_t R = (size_t)g.isize * nk;
+#pragma unroll
+  for (int q = 0; q < HIST_TURB_NQ; ++q) rows[(size_t)q * R + idx] = acc[q];
+}
+
 // random forcing (problem "turbulence"): row sums over the interior y of  rho v.f  and  rho f.f  (the two sums the
 // normalisation needs, HydroRunBase.cpp:1229-1243), same rows / columns layout as the history sums, interior i only
 RG_DEVFN void forcing_row_cell(const DevParams& g, const double* __restrict__ U, const double* __restrict__ Frc,
@@ -324,6 +365,36 @@ RG_DEVFN void add_forcing_cell(const DevParams& g, double* __restrict__ U, const
   U[idx + IU * N] += rho * fx * norm;
   U[idx + IV * N] += rho * fy * norm;
   U[idx + IW * N] += rho * fz * norm;
+}
+
+// ForcingOrnsteinUhlenbeck::add_forcing_field, steps 2 and 3 (Forcing_OrnsteinUhlenbeck.cpp:621-683): the real-space sum of
+// the 31 modes at the cell centre accelerates the gas; the internal energy is kept.  kz0 = first global plane of this slab.
+RG_DEVFN void ou_forcing_cell(const DevParams& g, double* __restrict__ U, const rgpu_ou::OuModes& M, double dt, double yMin,
+                              double zMin, int kz0, unsigned idx) {
+  const IJK c = unflatten(g, idx);
+  if (c.i < g.gw || c.i >= g.isize - g.gw || c.j < g.gw || c.j >= g.jsize - g.gw || c.k < g.gw || c.k >= g.ksize - g.gw) return;
+  const size_t N = g.ncell;
+  const double twoPi = 2 * 3.14159265358979323846;
+  const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
+  const double yPos = yMin + g.dy / 2 + (c.j - g.gw) * g.dy;
+  const double zPos = zMin + g.dz / 2 + (c.k - g.gw + kz0) * g.dz;
+  double A[3] = {0.0, 0.0, 0.0};
+  for (int im = 0; im < rgpu_ou::NMODE; ++im) {
+    const double phase = xPos * M.mode[im] + yPos * M.mode[rgpu_ou::NMODE + im] + zPos * M.mode[2 * rgpu_ou::NMODE + im];
+    const double cs = cos(twoPi * phase);
+    A[0] += M.force[im] * cs;
+    A[1] += M.force[rgpu_ou::NMODE + im] * cs;
+    A[2] += M.force[2 * rgpu_ou::NMODE + im] * cs;
+  }
+  const double rho = U[idx + ID * N];
+  double mu = U[idx + IU * N], mv = U[idx + IV * N], mw = U[idx + IW * N];
+  double eInt = 0.5 * (mu * mu + mv * mv + mw * mw) / rho;
+  eInt = U[idx + IP * N] - eInt;
+  mu += A[0] * dt * rho;
+  mv += A[1] * dt * rho;
+  mw += A[2] * dt * rho;
+  U[idx + IU * N] = mu; U[idx + IV * N] = mv; U[idx + IW * N] = mw;
+  U[idx + IP * N] = eInt + 0.5 * (mu * mu + mv * mv + mw * mw) / rho;
 }
 
 // column sums: thread (i,q) adds rows[q][k][i] over k

@@ -123,6 +123,10 @@ struct K_hist_rows {
   DevParams g; const double* U; double* rows;
   RG_DEVFN void operator()(unsigned idx) const { hist_row_cell(g, U, rows, idx); }
 };
+struct K_hist_turb_rows {
+  DevParams g; const double* U; double* rows;
+  RG_DEVFN void operator()(unsigned idx) const { hist_turb_row_cell(g, U, rows, idx); }
+};
 struct K_hist_cols {
   DevParams g; const double* rows; double* cols; int nq;
   RG_DEVFN void operator()(unsigned idx) const { hist_col_cell(g, rows, cols, nq, idx); }
@@ -170,6 +174,10 @@ struct K_forcing_rows {
 struct K_add_forcing {
   DevParams g; double* U; const double* Frc; double norm;
   RG_DEVFN void operator()(unsigned idx) const { add_forcing_cell(g, U, Frc, norm, idx); }
+};
+struct K_ou_forcing {
+  DevParams g; double* U; rgpu_ou::OuModes M; double dt, yMin, zMin; int kz0;
+  RG_DEVFN void operator()(unsigned idx) const { ou_forcing_cell(g, U, M, dt, yMin, zMin, kz0, idx); }
 };
 struct K_bc_zstrat {
   DevParams g; ZStrat zs; double* U; int side;

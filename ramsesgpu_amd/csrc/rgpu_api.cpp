@@ -34,6 +34,7 @@ struct rgpu_ctx {
   double *Q, *E, *T, *F, *emf, *shear_save, *shear_remap;
   double* G;   // per-cell static gravity field (gravityEnabled == 2), 3 components
   double* Frc; // static driving field of the "turbulence" problem (randomForcingEnabled), 3 components
+  rgpu_ou::OuProcess* ou;   // Ornstein-Uhlenbeck forcing process (ouForcingEnabled)
   unsigned long long* d_red;
   unsigned long long* h_red;
   size_t ncell, scratch_bytes;
@@ -104,6 +105,8 @@ int validate(const rgpu_params* p, std::string* why) {
   if (p->nu < 0 || p->eta < 0) { *why = "nu and eta must be >= 0"; return RGPU_EINVAL; }
   if (p->gravityEnabled < 0 || p->gravityEnabled > 2) { *why = "gravityEnabled must be 0, 1 (uniform vector) or 2 (per-cell field)"; return RGPU_EINVAL; }
   if (p->randomForcingEnabled && (!three_d || (p->mhdEnabled && p->Omega0 > 0))) { *why = "random forcing exists in the 3D non-rotating steps only (as in the reference)"; return RGPU_EUNSUPPORTED; }
+  if (p->ouForcingEnabled && (!three_d || (p->mhdEnabled && p->Omega0 > 0))) { *why = "Ornstein-Uhlenbeck forcing exists in the 3D non-rotating steps only (as in the reference)"; return RGPU_EUNSUPPORTED; }
+  if (p->ouForcingEnabled && !(p->ouTimeScaleTurb > 0)) { *why = "ouTimeScaleTurb must be > 0"; return RGPU_EINVAL; }
   for (int f = 0; f < 6; ++f) {
     const int b = p->bc[f];
     const bool ok = b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY ||
@@ -194,6 +197,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->Q = c->E = c->T = c->F = c->emf = c->shear_save = c->shear_remap = 0;
   c->G = 0;
   c->Frc = 0;
+  c->ou = 0;
   c->d_red = 0; c->h_red = 0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
@@ -228,6 +232,11 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   }
   const ScratchPlan sp = plan_for(*p);
   if (p->randomForcingEnabled && alloc_zero(c, &c->Frc, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the forcing field failed");
+  if (p->ouForcingEnabled) {   // == init_forcing() of the reference's init_hydro_turbulence_Ornstein_Uhlenbeck (HydroRunBase.cpp:6990)
+    c->ou = new (std::nothrow) rgpu_ou::OuProcess();
+    if (!c->ou) return fail(c, RGPU_ENOMEM, "allocation of the forcing process failed");
+    c->ou->init(p->ouInitRandom, p->ouTimeScaleTurb, p->ouAmplitudeTurb, p->ouKsi);
+  }
   if (p->gravityEnabled == 2 && alloc_zero(c, &c->G, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the gravity field failed");
   if (alloc_zero(c, &c->Q, c->ncell * sp.q) || alloc_zero(c, &c->E, c->ncell * sp.e) || alloc_zero(c, &c->T, c->ncell * sp.t) ||
       alloc_zero(c, &c->F, c->ncell * sp.f) || alloc_zero(c, &c->emf, c->ncell * sp.emf))
@@ -787,6 +796,15 @@ int add_forcing(rgpu_ctx* c, int parity, double norm) {
   return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
 }
 
+// Ornstein-Uhlenbeck forcing on U[parity]: advance the modes on the host, then one kernel over the interior planes
+int step_ou_forcing(rgpu_ctx* c, int parity, double dt) {
+  if (!c->ou) return 0;
+  Phase ph(c, RGPU_T_UPDATE);
+  c->ou->update(dt, c->p.cIso);
+  K_ou_forcing k = {c->g, c->U[parity & 1], c->ou->m, dt, c->p.yMin, c->p.zMin, c->p.slab_rank * c->p.nz};
+  return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
+}
+
 int step_forcing(rgpu_ctx* c, int nStep, double dt) {
   if (!c->p.randomForcingEnabled) return 0;
   Phase ph(c, RGPU_T_UPDATE);
@@ -826,6 +844,7 @@ void rgpu_destroy(rgpu_ctx* c) {
   if (c->device >= 0) rg_set_device(c->device);
   if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
   rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G); rg_free(c->Frc);
+  delete c->ou;
   rg_free(c->d_red); rg_host_free(c->h_red);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
   if (c->fork_ok) rg_event_destroy(c->ev_fork);
@@ -872,6 +891,21 @@ int rgpu_set_forcing_field(rgpu_ctx* c, const double* hF) {
   if (!hF) return fail(c, RGPU_EINVAL, "set_forcing_field: null pointer");
   if (!c->p.randomForcingEnabled || !c->Frc) return fail(c, RGPU_EINVAL, "set_forcing_field: the context was not created with randomForcingEnabled");
   if (rg_copy_h2d(c->Frc, hF, c->ncell * 3 * sizeof(double), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "set_forcing_field");
+  return RGPU_OK;
+}
+
+int rgpu_step_ou_forcing(rgpu_ctx* c, int parity, double dt) {
+  RG_CHECK_CTX(c);
+  if (!c->ou) return fail(c, RGPU_EINVAL, "step_ou_forcing: the context was not created with ouForcingEnabled");
+  if (step_ou_forcing(c, parity, dt)) return RG_HIPFAIL(c, "step_ou_forcing");
+  return RGPU_OK;
+}
+
+int rgpu_ou_forcing_state(rgpu_ctx* c, double* mode93, double* forcingField93) {
+  RG_CHECK_CTX(c);
+  if (!c->ou || !mode93 || !forcingField93) return fail(c, RGPU_EINVAL, "ou_forcing_state: no forcing process / null pointer");
+  std::memcpy(mode93, c->ou->m.mode, sizeof(c->ou->m.mode));
+  std::memcpy(forcingField93, c->ou->m.force, sizeof(c->ou->m.force));
   return RGPU_OK;
 }
 
@@ -1017,6 +1051,40 @@ int rgpu_history_mri(rgpu_ctx* c, int parity, double* out) {
   return RGPU_OK;
 }
 
+int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out) {
+  RG_CHECK_CTX(c);
+  if (!out || !c->U[0]) return fail(c, RGPU_EINVAL, "history_turbulence: null pointer / context without state");
+  if (!c->p.mhdEnabled || !c->g.three_d) return fail(c, RGPU_EUNSUPPORTED, "history_turbulence is defined for 3D MHD runs (it does nothing in 2D)");
+  if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "history_turbulence: single-domain contexts only");
+  const rgpu_params& p = c->p;
+  const int is = c->g.isize, gw = c->g.gw;
+  // rows [NQ][nz][isize] and columns [NQ][isize] in the flux array, dead between steps (F has 15 components per cell)
+  const size_t R = (size_t)is * c->g.nz;
+  double* rows = c->F;
+  double* cols = c->F + (size_t)HIST_TURB_NQ * R;
+  K_hist_turb_rows kr = {c->g, c->U[parity & 1], rows};
+  K_hist_cols kc = {c->g, rows, cols, HIST_TURB_NQ};
+  std::vector<double> h((size_t)HIST_TURB_NQ * is);
+  if (rg_launch<kBlock>(c->stream, (unsigned)R, kr) || rg_launch<kBlock>(c->stream, (unsigned)(HIST_TURB_NQ * is), kc) ||
+      rg_copy_d2h(h.data(), cols, sizeof(double) * h.size(), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "history_turbulence");
+  double s[HIST_TURB_NQ];
+  for (int q = 0; q < HIST_TURB_NQ; ++q) { s[q] = 0.0; for (int i = gw; i < is - gw; ++i) s[q] += h[(size_t)q * is + i]; }
+  const double dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin);
+  const double pi = 2 * std::asin(1.0);
+  const double mass = s[0] * dTau, eKin = s[1] * dTau, mean_v2 = s[2] * dTau, eMag = s[3] * dTau, helicity = s[4] * dTau;
+  const double mBx = s[5] * dTau, mBy = s[6] * dTau, mBz = s[7] * dTau;
+  const double mean_B = std::sqrt(mBx * mBx + mBy * mBy + mBz * mBz);
+  const double mean_rho = s[0] * dTau;
+  out[0] = mass; out[1] = s[17]; out[2] = eKin; out[3] = eMag; out[4] = helicity; out[5] = mean_rho; out[6] = mean_B;
+  out[7] = mBx; out[8] = mBy; out[9] = mBz; out[10] = s[8] * dTau; out[11] = s[9] * dTau; out[12] = s[10] * dTau;
+  out[13] = std::sqrt(mean_v2) / p.cIso;                                        // Ma_s
+  out[14] = std::sqrt(mean_v2) / (mean_B / std::sqrt(4 * pi * mean_rho));       // Ma_alfven
+  out[15] = std::sqrt(s[11] * s[11] + s[12] * s[12]) * dTau;
+  out[16] = std::sqrt(s[13] * s[13] + s[14] * s[14]) * dTau;
+  out[17] = std::sqrt(s[15] * s[15] + s[16] * s[16]) * dTau;
+  return RGPU_OK;
+}
+
 double rgpu_compute_dt(rgpu_ctx* c, int useU) {
   double v = 0;
   if (!c || rgpu_compute_inv_dt(c, useU, &v) != RGPU_OK) return std::numeric_limits<double>::quiet_NaN();
@@ -1077,7 +1145,7 @@ int rgpu_godunov_unsplit(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "slab contexts must use rgpu_step_pre/core/post_a/post_b around the halo exchange");
   if (step_pre(c, nStep) || step_core(c, nStep, dt, totalTime) || step_dissipative(c, nStep, dt, totalTime) ||
-      step_forcing(c, nStep, dt) || step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
+      step_forcing(c, nStep, dt) || step_ou_forcing(c, (nStep + 1) % 2, dt) || step_post_a(c, nStep, dt, totalTime) || step_post_b(c, nStep))
     return RG_HIPFAIL(c, "godunov_unsplit");
   return RGPU_OK;
 }

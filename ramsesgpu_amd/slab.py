@@ -176,6 +176,8 @@ class SlabRun:
             s.step_dissipative(nStep, dt, t)
         if self.p.randomForcingEnabled:
             self._random_forcing(nStep, dt)
+        if self.p.ouForcingEnabled:      # Ornstein-Uhlenbeck forcing: the same process on every rank, no communication
+            s._chk(s.lib.rgpu_step_ou_forcing(s.ctx, (nStep + 1) % 2, dt), "step_ou_forcing")
         s.step_post_a(nStep, dt, t)
         if self._rotating:
             self.exchange_z((nStep + 1) % 2)    # rotating path: ghosts of the OUTPUT
@@ -217,7 +219,7 @@ class SlabRun:
     def godunov_unsplit(self, nStep, dt):
         # the dissipative stage needs a second exchange inside the step; the random forcing changes the whole updated
         # state after it (and needs a global sum first): both use the serial schedule
-        if not self.overlap or self._dissipative or self.p.randomForcingEnabled:
+        if not self.overlap or self._dissipative or self.p.randomForcingEnabled or self.p.ouForcingEnabled:
             return self.godunov_unsplit_serial(nStep, dt)
         s, t = self.solver, self.totalTime
         pin, pout = nStep % 2, (nStep + 1) % 2

@@ -223,6 +223,13 @@ class Solver:
         self._chk(self.lib.rgpu_history_mri(self.ctx, parity, out), "history_mri")
         return dict(zip(self.HISTORY_NAMES, [float(v) for v in out]))
 
+    def history_turbulence(self, nStep=None):
+        """history_turbulence (MHDRunBase.cpp:3626-3810) reduced on the device: the 18 columns after totalTime and dt"""
+        parity = (self.nStep if nStep is None else nStep) % 2
+        out = (C.c_double * 18)()
+        self._chk(self.lib.rgpu_history_turbulence(self.ctx, parity, out), "history_turbulence")
+        return [float(v) for v in out]
+
     def history_columns(self, parity):
         isz = self.p.nx + 2 * self.p.ghostWidth
         cols = np.zeros((9, isz), dtype=np.float64)

@@ -101,7 +101,7 @@ def main():
         ref = interior(ref_full, p)
         nbad = int((got != ref).sum())
         ok = nbad == 0 and np.array_equal(np.array(dts), dts_ref)
-        if p.randomForcingEnabled:   # global normalisation sum: round-off agreement (stated tolerance 1e-12), see slab_worker.py
+        if p.randomForcingEnabled or (p.ouForcingEnabled and device != "cpu"):   # (OU on a GPU: the device's cos())   # global normalisation sum: round-off agreement (stated tolerance 1e-12), see slab_worker.py
             rel = float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
             ok = rel < 1e-12 and np.allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
         with open(out, "w") as f:

@@ -18,6 +18,8 @@ class Oracle:
         self.lib.orc_compute_inv_dt.argtypes = [P, C.c_void_p]
         self.lib.orc_compute_dt.restype = C.c_double
         self.lib.orc_compute_dt.argtypes = [P, C.c_void_p]
+        self.lib.orc_history_turbulence.restype = None
+        self.lib.orc_history_turbulence.argtypes = [P, C.c_void_p, c_double_p]
         self.lib.orc_history_mri.restype = None
         self.lib.orc_history_mri.argtypes = [P, C.c_void_p, c_double_p]
         self.lib.orc_godunov_unsplit.argtypes = [P, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
@@ -55,6 +57,12 @@ class Oracle:
 
     def compute_dt(self, p, U):
         return self.lib.orc_compute_dt(C.byref(p), self._arr(U))
+
+    def history_turbulence(self, p, U):
+        """the 18 columns of MHDRunBase::history_turbulence after totalTime and dt, in its loop order"""
+        out = (C.c_double * 18)()
+        self.lib.orc_history_turbulence(C.byref(p), self._arr(U), out)
+        return [out[i] for i in range(18)]
 
     def history_mri(self, p, U):
         """mass, maxwell, reynolds, magp, mean_Bx, mean_By, mean_Bz, divB (MHDRunBase::history_mri, in its loop order)"""

@@ -21,9 +21,10 @@ def rel_l2(a, b):
 
 
 def assert_same(got, ref, what, exact=True):
-    """bit-identical, except (exact=False) for runs with the random forcing of the "turbulence" problem: its
+    """bit-identical, except (exact=False) for runs with (a) the random forcing of the "turbulence" problem: its
     normalisation is a sum over the whole domain that the reference accumulates sequentially and the device in a
-    fixed parallel order, so those agree to round-off -- well inside the stated L2 tolerance -- not bit for bit"""
+    fixed parallel order; (b) the Ornstein-Uhlenbeck forcing: 31 cos() per cell from the device's libm instead of
+    glibc's.  Those agree to round-off -- well inside the stated L2 tolerance -- not bit for bit"""
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert np.isfinite(got).all(), "%s: non-finite values" % what
     err = rel_l2(got, ref)
@@ -61,7 +62,7 @@ def check_golden_case(lib, name):
             attach_gravity(lib, case["base"], case["overrides"], p, sv=sv)
             sv.start(U0, s)
             assert_same(interior(sv.getDataHost(), p), g["step_%d" % s], "%s step %d vs reference" % (name, s),
-                        exact=not p.randomForcingEnabled)
+                        exact=not (p.randomForcingEnabled or p.ouForcingEnabled))
             if s == max(case["steps"]) and np.isfinite(g["total_time"]):
                 assert abs(sv.totalTime - float(g["total_time"])) <= 1e-11 * max(1.0, abs(sv.totalTime))
         finally:
@@ -158,7 +159,7 @@ def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
     try:
         attach_gravity(lib, base, ov, p, sv=sv)
         dts = sv.start(U0, nsteps)
-        if p.randomForcingEnabled:   # round-off level agreement only (see assert_same)
+        if p.randomForcingEnabled or p.ouForcingEnabled:   # round-off level agreement only (see assert_same)
             np.testing.assert_allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
             assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps), exact=False)
             return
@@ -296,3 +297,35 @@ def check_history(lib, oracle, base, ov, nsteps):
              "divB": np.abs(I[5:8]).sum() * 6.0 / min(p.dx, p.dy) + 1e-300}
     for k in Solver.HISTORY_NAMES:
         assert abs(got[k] - ref[k]) <= 1e-12 * scale[k], (k, got[k], ref[k], scale[k])
+
+
+TURB_HISTORY_CASES = [
+    ("turbulence_mhd_ou", "mesh.nx=12;mesh.ny=10;mesh.nz=8;turbulence-Ornstein-Uhlenbeck.bx=0.01;turbulence-Ornstein-Uhlenbeck.by=0.02", 5),
+    ("turbulence_mhd", "mesh.nx=12;mesh.ny=12;mesh.nz=12", 4),
+]
+
+
+def check_history_turbulence(lib, oracle, base, ov, nsteps):
+    """device-reduced history_turbulence (rgpu_history_turbulence) == the oracle's sequential restatement of
+    MHDRunBase::history_turbulence to round-off (fixed parallel summation order, device cos / sin): every column is compared
+    with a tolerance of 1e-11 x the magnitude of the terms of its sum"""
+    p = lib.params_from_ini(ini(base), ov)
+    sv = Solver(p, lib)
+    try:
+        attach_gravity(lib, base, ov, p, sv=sv)
+        sv.start(lib.init_condition(ini(base), ov, p), nsteps)
+        U = sv.getDataHost()
+        got = sv.history_turbulence()
+    finally:
+        sv.close()
+    ref = oracle.history_turbulence(p, U)
+    gw = p.ghostWidth
+    I = U[:, gw:-gw, gw:-gw, gw:-gw]
+    dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin)
+    bmax, mmax = np.abs(U[5:8]).max(), np.abs(I[2:5]).max()
+    n = I[0].size
+    mag = {1: bmax / min(p.dx, p.dy, p.dz) * n, 4: mmax * bmax * n * dTau, 10: mmax * n * dTau, 11: mmax * n * dTau, 12: mmax * n * dTau,
+           15: bmax * n * dTau, 16: bmax * n * dTau, 17: bmax * n * dTau, 7: bmax * n * dTau, 8: bmax * n * dTau, 9: bmax * n * dTau}
+    for q, (a, b) in enumerate(zip(got, ref)):
+        tol = 1e-11 * max(abs(b), mag.get(q, 0.0))
+        assert abs(a - b) <= tol, "history_turbulence column %d: device %r oracle %r tol %g" % (q, a, b, tol)

@@ -317,3 +317,32 @@ def test_shared_reciprocal_division_and_sqrt_are_ieee(gpu_lib):
     quot, quot2, root, root2 = (np.empty(n) for _ in range(4))
     assert gpu_lib.lib.rgpu_selftest_arith(n, P(pos), P(den), P(quot), P(quot2), P(root), P(root2)) == 0
     assert np.array_equal(root2, np.sqrt(pos)) and np.array_equal(root, np.sqrt(pos))
+
+
+@pytest.mark.parametrize("base,ov,nsteps", pc.TURB_HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.TURB_HISTORY_CASES])
+def test_turbulence_history(base, ov, nsteps, gpu_lib, oracle):
+    pc.check_history_turbulence(gpu_lib, oracle, base, ov, nsteps)
+
+
+def test_run_driver_writes_turbulence_history_file(gpu_lib, tmp_path):
+    """rgpuh_run on the Ornstein-Uhlenbeck MHD run with [history] enabled=yes writes <prefix>_history.txt like
+    MHDRunGodunov::start + history_turbulence: same rows (same crossing times), same 20 columns; the physically meaningful
+    ones equal the reference's file (tests/golden/turb_ou_mhd_12_history.npz) to the printed digits, the cancellation-noise
+    ones (divB, the DFT amplitude along x) stay noise sized"""
+    import ctypes as C
+    from conftest import golden_cases, load_golden
+    case = golden_cases()["turb_ou_mhd_12_history"]
+    H = load_golden("turb_ou_mhd_12_history")["history"]
+    ov = case["overrides"] + ";output.outputVtk=no;output.outputHdf5=no;output.outputDir=%s" % tmp_path
+    err = C.create_string_buffer(512)
+    mc = C.c_double(0)
+    n = gpu_lib.lib.rgpuh_run(ini(case["base"]).encode(), ov.encode(), C.byref(mc), err, 512)
+    assert n == 8, err.value
+    rows = np.array([[float(x) for x in ln.split()] for ln in open(tmp_path / "turbulence_mhd_ou_history.txt") if not ln.startswith("#")])
+    assert rows.shape == H.shape
+    for col in (0, 1, 2, 4, 5, 7, 8, 11, 12, 13, 14, 15, 16):   # totalTime dt mass eKin eMag mean_rho mean_B mean_Bz mean_rhov(3) Ma_s Ma_alfven
+        assert np.allclose(rows[:, col], H[:, col], rtol=2e-5, atol=1e-12), (col, rows[:, col], H[:, col])
+    assert np.allclose(rows[:, 6], H[:, 6], rtol=1e-3, atol=1e-12)                # helicity: small but physical
+    assert np.allclose(rows[:, [18, 19]], H[:, [18, 19]], rtol=1e-3, atol=1e-15)  # coef_y, coef_z: Bx picks up structure along y, z
+    assert np.abs(rows[:, 3]).max() <= 1e-12                                       # divB: round-off
+    assert np.abs(rows[:, 17]).max() <= 1e-18                                      # coef_x: Bx stays uniform along x to round-off

@@ -58,3 +58,8 @@ def test_run_driver_inertial_wave_history_file(emu_lib, tmp_path):
     assert n == 8, err.value
     got = [ln.rstrip("\n") for ln in open(tmp_path / "mhd_inertialWave_2d_history.txt") if ln.strip() and not ln.startswith("#")]
     assert got == want
+
+
+@pytest.mark.parametrize("base,ov,nsteps", pc.TURB_HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.TURB_HISTORY_CASES])
+def test_turbulence_history(base, ov, nsteps, emu_lib, oracle):
+    pc.check_history_turbulence(emu_lib, oracle, base, ov, nsteps)

@@ -54,3 +54,31 @@ def test_oracle_history_matches_reference_history_file(name, oracle, product_lib
             mine = [h[0], h[7]]
         for a, b in zip(mine, H[n, 2:]):
             assert float("%.5e" % a) == float("%.5e" % b) or abs(a - b) <= 2e-6 * abs(b), (n, a, b)
+
+
+def test_oracle_turbulence_history_matches_reference_history_file(oracle, product_lib):
+    """history_turbulence (MHDRunBase.cpp:3626-3810) of the Ornstein-Uhlenbeck MHD run: the reference prints a row whenever
+    the time crosses the next multiple of dtHist (MHDRunGodunov.cpp:3975-3984); the oracle's restatement on its own
+    (bit-identical) states prints the same 6 significant digits.  Columns that are pure cancellation noise (divB, the
+    momenta means, the DFT amplitudes of an almost uniform field) are compared against the scale of their terms."""
+    from conftest import golden_cases
+    name = "turb_ou_mhd_12_history"
+    case = golden_cases()[name]
+    L = product_lib
+    p = L.params_from_ini(ini(case["base"]), case["overrides"])
+    H = load_golden(name)["history"]
+    assert H.shape[1] == 20 and H.shape[0] >= 4
+    U0 = L.init_condition(ini(case["base"]), case["overrides"], p)
+    _, dts, _ = oracle.run(p, U0.copy(), 8)
+    times = np.concatenate([[0.0], np.cumsum(dts)])
+    for row in H:
+        n = int(np.argmin(np.abs(times - row[0])))
+        assert abs(times[n] - row[0]) <= 1e-5 * max(1.0, row[0])
+        U, _, _ = oracle.run(p, L.init_condition(ini(case["base"]), case["overrides"], p), n)
+        h = oracle.history_turbulence(p, U)
+        scale = {1: 1e-4 / p.dx, 10: 1.0, 11: 1.0, 12: 1.0, 15: 1e-8, 16: 1e-8, 17: 1e-8, 4: 1e-4}   # magnitudes of the terms of the cancelling sums
+        for q, (a, b) in enumerate(zip(h, row[2:])):
+            if q in scale:
+                assert abs(a - b) <= 1e-12 * scale[q] * p.nx * p.ny * p.nz + 6e-6 * abs(b), (n, q, a, b)   # 6 printed digits
+            else:
+                assert float("%.5e" % a) == float("%.5e" % b) or abs(a - b) <= 2e-6 * abs(b), (n, q, a, b)

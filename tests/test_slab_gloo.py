@@ -41,6 +41,8 @@ CASES = [
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 3, 0),       # ... three slabs, serial schedule
     ("turbulence_hydro", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                                              # random forcing: all-reduced normalisation sums (round-off agreement)
     ("turbulence_mhd", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.slope_type=2.0", 3, 3, 1),
+    ("turbulence_hydro_ou", "mesh.nx=8;mesh.ny=8;mesh.nz=12;turbulence-Ornstein-Uhlenbeck.initialDensityPerturbationAmplitude=0.1", 3, 2, 1),   # Ornstein-Uhlenbeck forcing: same process on every rank
+    ("turbulence_mhd_ou", "mesh.nx=6;mesh.ny=6;mesh.nz=18", 3, 3, 1),
 ]
 
 
