@@ -163,6 +163,12 @@ int rgpu_set_forcing_field(rgpu_ctx* c, const double* hF);
  * rgpu_ou_forcing_state copies out mode[3][31], forcingField[3][31] (what output_forcing writes, :392-444). */
 int rgpu_step_ou_forcing(rgpu_ctx* c, int parity, double dt);
 int rgpu_ou_forcing_state(rgpu_ctx* c, double* mode93, double* forcingField93);
+/* The whole process (modes, amplitudes, projection tensor, generator) as RGPU_OU_STATE_DOUBLES doubles, for restart files:
+ * get before writing one, set after rgpu_create when resuming (the reference keeps a *_forcing_NNNNNNN.npz for the same
+ * purpose, output_forcing / init_forcing(restart), Forcing_OrnsteinUhlenbeck.cpp:236-352, 392-444). */
+#define RGPU_OU_STATE_DOUBLES 471
+int rgpu_ou_forcing_get_state(rgpu_ctx* c, double* state);
+int rgpu_ou_forcing_set_state(rgpu_ctx* c, const double* state);
 int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out);
 int rgpu_add_forcing(rgpu_ctx* c, int parity, double norm);
 /* raw device pointers of U (parity 0) / U2 (parity 1), for zero-copy halo exchange */

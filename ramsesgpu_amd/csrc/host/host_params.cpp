@@ -190,6 +190,13 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   rs->outputDir = cfg.get_string("output", "outputDir", "./");
   rs->outputPrefix = cfg.get_string("output", "outputPrefix", "output");
   rs->outputVtk = cfg.get_bool("output", "outputVtk", true);
+  rs->outputRestart = cfg.get_bool("output", "outputHdf5", false);
+  rs->ghostIncluded = cfg.get_bool("output", "ghostIncluded", false);
+  rs->restartEnabled = cfg.get_bool("run", "restart", false);
+  rs->restartResetTotalTime = cfg.get_bool("run", "restart_reset_totaltime", false);
+  rs->restartFilename = cfg.get_string("run", "restart_filename", "");
+  if (rs->restartEnabled && cfg.get_bool("run", "restart_upscale", false))
+    throw std::runtime_error("restart_upscale (resuming from a run at half the resolution) is outside the implemented scope");
 }
 
 }  // namespace rgpu_host

@@ -19,6 +19,10 @@ struct RunSettings {
   std::string problem;
   std::string outputDir, outputPrefix;
   bool outputVtk;
+  // [run] restart / restart_filename / restart_reset_totaltime (HydroRunBase.cpp:7033-7066, MHDRunGodunov.cpp:3805, 3866-3880)
+  bool outputRestart, ghostIncluded;   // [output] outputHdf5 (served by the raw restart dump, no HDF5 library here), ghostIncluded
+  bool restartEnabled, restartResetTotalTime;
+  std::string restartFilename;
 };
 
 // Fills *p for slab `slab_rank` of `slab_count` (0,1 = whole domain).  Throws std::runtime_error on

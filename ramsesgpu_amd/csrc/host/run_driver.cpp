@@ -1,6 +1,10 @@
 #include "run_driver.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iterator>
 #include <cstdint>
 #include <cstdio>
 #include <fstream>
@@ -13,7 +17,7 @@
 
 namespace rgpu_host {
 
-GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0) {
+GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0), restart_has_ghosts_(false) {
   params_from_config(cfg_, 0, 1, &p_, &rs_);
   const int rc = rgpu_create(&p_, &ctx_);
   if (rc) {
@@ -34,7 +38,22 @@ void GodunovRun::check(int rc, const char* what) {
 }
 
 int GodunovRun::init_simulation() {
-  init_condition(cfg_, p_, h_U_.data());
+  int timeStep = 0;
+  if (rs_.restartEnabled) {
+    // restart run (HydroRunBase.cpp:7033-7066): the state comes from a file of an earlier run instead of the problem's
+    // initial condition; the static gravity / forcing fields below are rebuilt as in a fresh run.  The reference reads
+    // HDF5 (inputHdf5, :4818-5160); this image has no HDF5 library, so the file is the .vti this driver writes: interior
+    // cells, raw doubles -- a lossless copy of the state -- plus the step count and the time in its header.
+    std::fill(h_U_.begin(), h_U_.end(), 0.0);
+    const std::string path = rs_.outputDir + "/" + rs_.restartFilename;
+    restart_has_ghosts_ = false;
+    if (path.size() > 4 && path.substr(path.size() - 4) == ".rgr") timeStep = inputRestart(path, &restart_has_ghosts_);
+    else timeStep = inputVtk(path);
+    restore_forcing_process(timeStep);
+    std::cout << "### This is a restarted run ! Current time is " << totalTime_ << " (step " << timeStep << ") ###\n";
+  } else {
+    init_condition(cfg_, p_, h_U_.data());
+  }
   check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
   if (p_.gravityEnabled == 2) {   // h_gravity of the problem, copied to the device once (d_gravity.copyFromHost)
     std::vector<double> hG(3 * (h_U_.size() / p_.nbVar));
@@ -44,7 +63,7 @@ int GodunovRun::init_simulation() {
     std::vector<double> hF(3 * (h_U_.size() / p_.nbVar));
     if (init_forcing_field(cfg_, p_, hF.data())) check(rgpu_set_forcing_field(ctx_, hF.data()), "set_forcing_field");
   }
-  return 0;
+  return timeStep;
 }
 
 void GodunovRun::make_all_boundaries(int parity) { check(rgpu_make_all_boundaries(ctx_, parity, totalTime_, 0.0), "make_all_boundaries"); }
@@ -81,7 +100,13 @@ void GodunovRun::outputVtk(int nStep) {
   std::ofstream out(fn.str().c_str(), std::ios::binary);
   if (!out) throw std::runtime_error("cannot write " + fn.str());
   const uint32_t nbytes = static_cast<uint32_t>(sizeof(double) * nx * ny * nz);
-  out << "<?xml version=\"1.0\"?>\n<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
+  out << "<?xml version=\"1.0\"?>\n";
+  {   // what a restart needs besides the fields (the reference keeps them as HDF5 attributes "time step" / "total time")
+    char line[160];
+    std::snprintf(line, sizeof(line), "<!-- rgpu restart: nStep=%d totalTime=%a (%.17g) -->\n", nStep, totalTime_, totalTime_);
+    out << line;
+  }
+  out << "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
   out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
   out << "  <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\">\n    <PointData>\n";
   for (int v = 0; v < p_.nbVar; ++v) {
@@ -101,6 +126,154 @@ void GodunovRun::outputVtk(int nStep) {
       }
   }
   out << "  </AppendedData>\n</VTKFile>\n";
+}
+
+// Raw restart dump: one text line "RGPU-RESTART 1 nx ny nz ghostWidth nbVar ghostIncluded nStep totalTime(hex float)",
+// then nbVar arrays of little-endian doubles, x fastest -- the whole ghost-inclusive arrays when ghostIncluded (what a
+// shearing-box run needs: the field on the first high x face is evolved by the CT update and not rebuilt by the ghost
+// fill), the interior otherwise.  Stands in for outputHdf5 / inputHdf5 (HydroRunBase.cpp:3308-3640, 4818-5160).
+void GodunovRun::outputRestart(int nStep) {
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
+  const bool three_d = p_.nz_global != 1;
+  const int nz = three_d ? p_.nz : 1;
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1;
+  const size_t ncell = isize * jsize * ksize;
+  std::ostringstream fn;
+  fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".rgr";
+  std::ofstream out(fn.str().c_str(), std::ios::binary);
+  if (!out) throw std::runtime_error("cannot write " + fn.str());
+  char line[256];
+  std::snprintf(line, sizeof(line), "RGPU-RESTART 1 %d %d %d %d %d %d %d %a\n", nx, ny, nz, gw, p_.nbVar, rs_.ghostIncluded ? 1 : 0, nStep, totalTime_);
+  out << line;
+  if (rs_.ghostIncluded) {
+    out.write(reinterpret_cast<const char*>(h_U_.data()), sizeof(double) * ncell * p_.nbVar);
+  } else {
+    for (int v = 0; v < p_.nbVar; ++v)
+      for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j) {
+          const size_t kk = three_d ? k + gw : 0;
+          out.write(reinterpret_cast<const char*>(&h_U_[gw + isize * ((j + gw) + jsize * kk) + ncell * v]), sizeof(double) * nx);
+        }
+  }
+}
+
+int GodunovRun::inputRestart(const std::string& path, bool* ghosts_read) {
+  std::ifstream in(path.c_str(), std::ios::binary);
+  if (!in) throw std::runtime_error("restart: cannot read " + path);
+  std::string line;
+  std::getline(in, line);
+  int ver = 0, nx = 0, ny = 0, nz = 0, gw = 0, nv = 0, gi = 0, nStep = 0;
+  char hex[64] = {0};
+  if (std::sscanf(line.c_str(), "RGPU-RESTART %d %d %d %d %d %d %d %d %63s", &ver, &nx, &ny, &nz, &gw, &nv, &gi, &nStep, hex) != 9 || ver != 1)
+    throw std::runtime_error("restart: " + path + " is not a restart dump of this code");
+  const bool three_d = p_.nz_global != 1;
+  if (nx != p_.nx || ny != p_.ny || nz != (three_d ? p_.nz : 1) || gw != p_.ghostWidth || nv != p_.nbVar)
+    throw std::runtime_error("restart: " + path + " holds another box than [mesh] nx, ny, nz / other variables");
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1;
+  const size_t ncell = isize * jsize * ksize;
+  if (gi) {
+    in.read(reinterpret_cast<char*>(h_U_.data()), sizeof(double) * ncell * nv);
+  } else {
+    for (int v = 0; v < nv; ++v)
+      for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j) {
+          const size_t kk = three_d ? k + gw : 0;
+          in.read(reinterpret_cast<char*>(&h_U_[gw + isize * ((j + gw) + jsize * kk) + ncell * v]), sizeof(double) * nx);
+        }
+  }
+  if (!in) throw std::runtime_error("restart: " + path + " is truncated");
+  if (ghosts_read) *ghosts_read = gi != 0;
+  totalTime_ = rs_.restartResetTotalTime ? 0.0 : std::strtod(hex, 0);
+  return nStep;
+}
+
+// Reads a .vti written by outputVtk (same box, same variables) into the interior of h_U_; returns the step count of the
+// file and sets totalTime_ (0 / 0 for files without the restart comment).  Ghost cells stay zero: start() fills them.
+int GodunovRun::inputVtk(const std::string& path) {
+  std::ifstream in(path.c_str(), std::ios::binary);
+  if (!in) throw std::runtime_error("restart: cannot read " + path);
+  std::string blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  const size_t mark = blob.find("<AppendedData encoding=\"raw\">");
+  if (mark == std::string::npos) throw std::runtime_error("restart: " + path + " is not an appended-raw .vti");
+  const std::string head = blob.substr(0, mark);
+  int nStep = 0;
+  double t = 0.0;
+  {
+    const size_t c = head.find("rgpu restart: nStep=");
+    if (c != std::string::npos) {
+      char hex[64] = {0};
+      if (std::sscanf(head.c_str() + c, "rgpu restart: nStep=%d totalTime=%63s", &nStep, hex) == 2) t = std::strtod(hex, 0);
+    }
+  }
+  int e[6] = {0, 0, 0, 0, 0, 0};
+  {
+    const size_t w = head.find("WholeExtent=\"");
+    if (w == std::string::npos || std::sscanf(head.c_str() + w, "WholeExtent=\"%d %d %d %d %d %d\"", &e[0], &e[1], &e[2], &e[3], &e[4], &e[5]) != 6)
+      throw std::runtime_error("restart: no WholeExtent in " + path);
+  }
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
+  const bool three_d = p_.nz_global != 1;
+  const int nz = three_d ? p_.nz : 1;
+  if (e[1] - e[0] + 1 != nx || e[3] - e[2] + 1 != ny || e[5] - e[4] + 1 != nz)
+    throw std::runtime_error("restart: " + path + " holds another box than [mesh] nx, ny, nz");
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1;
+  const size_t ncell = isize * jsize * ksize;
+  const size_t start = blob.find('_', mark) + 1;
+  const size_t nbytes = sizeof(double) * nx * ny * nz;
+  size_t pos = 0;
+  int nvar = 0;
+  while ((pos = head.find("format=\"appended\" offset=\"", pos)) != std::string::npos) {
+    pos += std::strlen("format=\"appended\" offset=\"");
+    const size_t off = std::strtoull(head.c_str() + pos, 0, 10);
+    if (nvar >= p_.nbVar) throw std::runtime_error("restart: " + path + " holds more variables than this run");
+    uint32_t count = 0;
+    if (start + off + sizeof(count) + nbytes > blob.size()) throw std::runtime_error("restart: " + path + " is truncated");
+    std::memcpy(&count, blob.data() + start + off, sizeof(count));
+    if (count != nbytes) throw std::runtime_error("restart: unexpected array size in " + path);
+    const char* src = blob.data() + start + off + sizeof(count);
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const size_t kk = three_d ? k + gw : 0;
+        std::memcpy(&h_U_[gw + isize * ((j + gw) + jsize * kk) + ncell * nvar], src + sizeof(double) * nx * (j + (size_t)ny * k), sizeof(double) * nx);
+      }
+    ++nvar;
+  }
+  if (nvar != p_.nbVar) throw std::runtime_error("restart: " + path + " holds fewer variables than this run");
+  totalTime_ = rs_.restartResetTotalTime ? 0.0 : t;
+  return nStep;
+}
+
+// the forcing process of a step, next to the fields (the reference: <prefix>_forcing_NNNNNNN.npz, output_forcing)
+void GodunovRun::save_forcing_process(int nStep) {
+  if (p_.ouForcingEnabled) {
+    double st[RGPU_OU_STATE_DOUBLES];
+    check(rgpu_ou_forcing_get_state(ctx_, st), "ou_forcing_get_state");
+    std::ostringstream fo;
+    fo << rs_.outputDir << "/" << rs_.outputPrefix << "_forcing_" << std::setw(7) << std::setfill('0') << nStep << ".txt";
+    std::ofstream f(fo.str().c_str());
+    if (!f) throw std::runtime_error("cannot write " + fo.str());
+    char buf[64];
+    for (int i = 0; i < RGPU_OU_STATE_DOUBLES; ++i) { std::snprintf(buf, sizeof(buf), "%a\n", st[i]); f << buf; }
+  }
+}
+
+// the Ornstein-Uhlenbeck process of step nStep, if the earlier run wrote it (outputVtk / outputRestart do)
+void GodunovRun::restore_forcing_process(int nStep) {
+  if (p_.ouForcingEnabled) {   // the forcing process of that step, if the earlier run wrote it
+    std::ostringstream fo;
+    fo << rs_.outputDir << "/" << rs_.outputPrefix << "_forcing_" << std::setw(7) << std::setfill('0') << nStep << ".txt";
+    std::ifstream f(fo.str().c_str());
+    if (f) {
+      double st[RGPU_OU_STATE_DOUBLES];
+      std::string tok;
+      int n = 0;
+      while (n < RGPU_OU_STATE_DOUBLES && (f >> tok)) st[n++] = std::strtod(tok.c_str(), 0);
+      if (n != RGPU_OU_STATE_DOUBLES) throw std::runtime_error("restart: " + fo.str() + " is incomplete");
+      check(rgpu_ou_forcing_set_state(ctx_, st), "ou_forcing_set_state");
+    } else {
+      std::cerr << "restart: no " << fo.str() << ", the forcing process starts afresh\n";
+    }
+  }
 }
 
 // MHDRunGodunov.cpp:3801-4070 / HydroRunGodunov.cpp:3857-4080 (no restart, no history, VTI outputs only)
@@ -174,25 +347,30 @@ void GodunovRun::history(int nStep, double dt) {
 
 int GodunovRun::start(double* mcell_per_s) {
   int nStep = init_simulation();
-  make_all_boundaries(0);
-  // h_U.copyTo(h_U2): refresh both device arrays from the ghost-filled one
-  copyGpuToCpu(0);
-  check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
-  totalTime_ = 0.0;
+  if (!(rs_.restartEnabled && restart_has_ghosts_)) {   // a restart file with ghosts needs no fill (MHDRunGodunov.cpp:3818-3824)
+    make_all_boundaries(0);
+    // h_U.copyTo(h_U2): refresh both device arrays from the ghost-filled one
+    copyGpuToCpu(0);
+    check(rgpu_upload(ctx_, h_U_.data(), 1), "upload");
+  }
+  if (!rs_.restartEnabled) totalTime_ = 0.0;   // a restarted run keeps the time of its file (MHDRunGodunov.cpp:3866-3880)
   double dt = compute_dt(0);
   std::cout << "Initial dt : " << std::setprecision(8) << dt << std::endl;
   double io_seconds = 0.0;
   // history cadence of MHDRunGodunov::start (MHDRunGodunov.cpp:3913-3916, 3975-3984)
   const bool historyEnabled = p_.mhdEnabled && cfg_.get_bool("history", "enabled", false);
   const double dtHist = cfg_.get_float("history", "dtHist", static_cast<float>(10 * dt));
-  double tHist = 0.0;
+  double tHist = totalTime_;   // MHDRunGodunov.cpp:3916
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
     if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0)
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     if (rs_.nOutput > 0 && (nStep % rs_.nOutput) == 0) {   // noutput <= 0: no output (the reference divides by zero here)
       const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
-      if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
+      if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
+      if (rs_.outputVtk) outputVtk(nStep);
+      if (rs_.outputRestart) outputRestart(nStep);
+      if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     }
@@ -205,7 +383,10 @@ int GodunovRun::start(double* mcell_per_s) {
   check(rgpu_synchronize(ctx_), "synchronize");
   {
     const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
-    if (rs_.outputVtk) { copyGpuToCpu(nStep); outputVtk(nStep); }
+    if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
+    if (rs_.outputVtk) outputVtk(nStep);
+    if (rs_.outputRestart) outputRestart(nStep);
+    if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
     io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
   const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

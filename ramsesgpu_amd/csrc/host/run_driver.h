@@ -30,6 +30,14 @@ class GodunovRun {
   // time loop of start(); returns the number of steps; *mcell = "cell updates per second" / 1e6
   int start(double* mcell_per_s);
   void outputVtk(int nStep);
+  // restart=yes: read the interior fields, the step count and the time back from a .vti this driver wrote
+  int inputVtk(const std::string& path);
+  // [output] outputHdf5=yes is served by a raw dump <prefix>_NNNNNNN.rgr (this image has no HDF5 library): the role of the
+  // reference's HDF5 files -- lossless state, optionally with the ghost cells ([output] ghostIncluded), step count and time
+  void outputRestart(int nStep);
+  int inputRestart(const std::string& path, bool* ghosts_read);
+  void save_forcing_process(int nStep);
+  void restore_forcing_process(int nStep);
   void history(int nStep, double dt);                     // [history] enabled=yes: <outputDir>/<outputPrefix>_history.txt
 
   const rgpu_params& params() const { return p_; }
@@ -42,6 +50,7 @@ class GodunovRun {
   rgpu_ctx* ctx_;
   std::vector<double> h_U_;
   double totalTime_;
+  bool restart_has_ghosts_;
   void check(int rc, const char* what);
 };
 

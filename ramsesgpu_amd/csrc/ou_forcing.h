@@ -77,6 +77,29 @@ class OuProcess {
     }
   }
 
+  // whole state of the process as doubles (restart files; what output_forcing / init_forcing(restart) exchange through
+  // an .npz in the reference, Forcing_OrnsteinUhlenbeck.cpp:392-444, 236-352 -- plus the Box-Muller spare, which the
+  // reference loses across a restart): mode, force, proj, the four seed digits, the spare flag and value
+  enum { STATE_DOUBLES = 2 * NDIM * NMODE + NDIM * NDIM * NMODE + 6 };
+  void get_state(double* out) const {
+    int n = 0;
+    for (int i = 0; i < NDIM * NMODE; ++i) out[n++] = m.mode[i];
+    for (int i = 0; i < NDIM * NMODE; ++i) out[n++] = m.force[i];
+    for (int i = 0; i < NDIM * NDIM * NMODE; ++i) out[n++] = proj[i];
+    for (int i = 0; i < 4; ++i) out[n++] = seed_[i];
+    out[n++] = igauss_;
+    out[n++] = spare_;
+  }
+  void set_state(const double* in) {
+    int n = 0;
+    for (int i = 0; i < NDIM * NMODE; ++i) m.mode[i] = in[n++];
+    for (int i = 0; i < NDIM * NMODE; ++i) m.force[i] = in[n++];
+    for (int i = 0; i < NDIM * NDIM * NMODE; ++i) proj[i] = in[n++];
+    for (int i = 0; i < 4; ++i) seed_[i] = (int)in[n++];
+    igauss_ = (int)in[n++];
+    spare_ = in[n++];
+  }
+
  private:
   int seed_[4];
   int igauss_;

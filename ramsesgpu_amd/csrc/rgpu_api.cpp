@@ -909,6 +909,20 @@ int rgpu_ou_forcing_state(rgpu_ctx* c, double* mode93, double* forcingField93) {
   return RGPU_OK;
 }
 
+static_assert(RGPU_OU_STATE_DOUBLES == rgpu_ou::OuProcess::STATE_DOUBLES, "rgpu.h out of sync with ou_forcing.h");
+int rgpu_ou_forcing_get_state(rgpu_ctx* c, double* state) {
+  RG_CHECK_CTX(c);
+  if (!c->ou || !state) return fail(c, RGPU_EINVAL, "ou_forcing_get_state: no forcing process / null pointer");
+  c->ou->get_state(state);
+  return RGPU_OK;
+}
+int rgpu_ou_forcing_set_state(rgpu_ctx* c, const double* state) {
+  RG_CHECK_CTX(c);
+  if (!c->ou || !state) return fail(c, RGPU_EINVAL, "ou_forcing_set_state: no forcing process / null pointer");
+  c->ou->set_state(state);
+  return RGPU_OK;
+}
+
 int rgpu_forcing_sums(rgpu_ctx* c, int parity, double* out) {
   RG_CHECK_CTX(c);
   if (!out || !c->Frc) return fail(c, RGPU_EINVAL, "forcing_sums: null pointer / context without forcing field");
