@@ -60,10 +60,13 @@ struct TileGrid {
   int flags;   // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
 };
 
+// dslot != 0: the CFL scan of the NEW state rides along -- every updated cell contributes sum_d (c + |v_d|) / delta_d
+// (hydro_invdt_cell) to a 64-bit atomicMax on *dslot, so that the next compute_dt needs no pass over U (all values are
+// >= 0: the bit pattern orders like an unsigned integer; max is order independent, hence the same double as the scan)
 template <int TX, int TY, int SPEC, int MINW = 1>
 __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ Uin,
                                                               double* __restrict__ Uout, double dtdx, double dtdy,
-                                                              double dtdz, int za, int zb) {
+                                                              double dtdz, int za, int zb, unsigned long long* dslot) {
   spec_assume<SPEC>(g);
   constexpr int NV = 5;
   constexpr int NT = TX * TY;
@@ -116,6 +119,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
   double up[NV];                     // cell (i,j,kk-1) with every flux but the one through its high z face applied
 #pragma unroll
   for (int v = 0; v < NV; ++v) { qA[v] = 1.0; qB[v] = 1.0; qC[v] = 1.0; uB[v] = 1.0; uC[v] = 1.0; uN[v] = 1.0; qmz[v] = 1.0; up[v] = 0.0; }
+  double inv_dt = 0.0;
 
   // prologue: planes sa-2, sa-1, sa
   {
@@ -227,6 +231,11 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     if (own && kk - 1 >= sa) {
       if (inner2d) {
         up[ID] -= fz[ID] * dtdz; up[IP] -= fz[IP] * dtdz; up[IU] -= fz[IW] * dtdz; up[IV] -= fz[IV] * dtdz; up[IW] -= fz[IU] * dtdz;
+        if (dslot) {
+          double qn[NV];
+          const double cs = hydro_prim<NV>(g, up, qn);
+          inv_dt = fmax(inv_dt, (cs + fabs(qn[IU])) / g.dx + (cs + fabs(qn[IV])) / g.dy + (cs + fabs(qn[IW])) / g.dz);
+        }
       }
       double* o = Uout + idx2 + (size_t)(kk - 1) * sk;
 #pragma unroll
@@ -258,11 +267,23 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     if (more) hydro_prim<NV>(g, uN, qC);
   }
   (void)tr2d; (void)fl2d;
+  if (dslot) {   // workgroup maximum: wave64 butterfly, one LDS slot per wave (the flux buffer is free now), one atomic
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) inv_dt = fmax(inv_dt, __shfl_down(inv_dt, off, 64));
+    double* wmax = &L.f[0][0][0][0];
+    if ((t & 63) == 0) wmax[t >> 6] = inv_dt;
+    __syncthreads();
+    if (t == 0) {
+      double m = 0.0;
+      for (int w = 0; w < NT / 64; ++w) m = fmax(m, wmax[w]);
+      atomicMax(dslot, (unsigned long long)__double_as_longlong(m));
+    }
+  }
 }
 
 template <int TX, int TY, int SPEC, int MINW = 1>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                                double dtdz, int za, int zb) {
+                                double dtdz, int za, int zb, unsigned long long* dslot = 0) {
   TileGrid tg;
   tg.flags = 0;
   tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
@@ -282,7 +303,7 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   const int total = tg.nbx * tg.nby * tg.nseg;
   tg.per_xcd = (total + 7) / 8;
   hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC, MINW>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
-                     dtdx, dtdy, dtdz, za, zb);
+                     dtdx, dtdy, dtdz, za, zb, dslot);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -291,8 +312,9 @@ inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() &&
 
 // Complete the update of planes [a,b) of a 3D hydro step.  Returns 0 = done, 1 = not applicable (the caller runs the
 // flat kernels), < 0 = launch error.
+// dslot: device slot for the CFL maximum of the new state (reset by the caller), or 0
 inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                         double dtdz, int a, int b) {
+                         double dtdz, int a, int b, unsigned long long* dslot = 0) {
   if (!hydro3d_sweep_covers(g) || g.grav_on != 0) return 1;
   const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
   // ghost planes inside [a,b): plain copy, like the flat update kernel
@@ -325,13 +347,13 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
 #endif
   if (!no_spec) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
-#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb)
+#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot)
     RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
     RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
     RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
 #undef RG_TRY
   }
-  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
 }
 
 }  // namespace rgpu_tiled

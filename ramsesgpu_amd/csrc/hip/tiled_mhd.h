@@ -40,11 +40,6 @@ constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
 constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
 
-struct TLdsRead {
-  const double* base; unsigned skoff;   // skoff: from a cell of plane kk-1 to the same cell of plane kk (mod 2^32)
-  RG_DEVFN double get(int slot, unsigned m) const { return base[slot * MH_CELLS + m]; }
-  RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)MH_PX : skoff; }
-};
 struct TLdsWrite {
   double* cell;
   RG_DEVFN void put(int slot, double v) const { cell[slot * MH_CELLS] = v; }

@@ -54,6 +54,7 @@ struct rgpu_ctx {
   bool fork_ok;
   int device;           // HIP device the context was created on; every entry point makes it current
   unsigned xcd_sub;     // sub-band size (cells) of the XCD-aware workgroup order of THIS context, 0 = linear
+  int fused_dt_parity;  // parity of the state whose CFL maximum the last sweep left in d_red (-1: none)
   std::string err;
 };
 
@@ -208,6 +209,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->n_order_events = 0; c->fork_ok = false;
   c->device = -1;
   c->xcd_sub = 4096;
+  c->fused_dt_parity = -1;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
   c->device = rg_current_device();
@@ -430,7 +432,12 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   const int ks = g.ksize;
   if (ND == 3) {   // LDS-tiled z-marching sweep: the whole step in one kernel (hip/tiled_hydro.h)
     Phase ph(c, RGPU_T_SWEEP);
-    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b);
+    // whole-domain steps whose output nothing modifies afterwards carry the CFL scan of the new state along
+    const bool scan = a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
+                      rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on == 0;
+    if (scan && rg_memset_async(c->d_red, 0, sizeof(unsigned long long), c->stream)) return -1;
+    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, scan ? c->d_red : 0);
+    if (rc == 0 && scan) c->fused_dt_parity = (out == c->U[0]) ? 0 : 1;
     if (rc <= 0) return rc;
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
@@ -635,6 +642,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 }
 
 int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
+  c->fused_dt_parity = -1;   // the output array is about to change (a whole-domain hydro sweep sets it again)
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
   c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && (c->p.implementationVersion != 0 || c->g.rot))) ? 1 : 0;
@@ -685,6 +693,7 @@ int dissipative_nd(rgpu_ctx* c, double* U, double dt, double nu, double eta) {
 int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime, bool fill_ghosts = true) {
   const double nu = c->p.nu, eta = c->p.mhdEnabled ? c->p.eta : 0.0;
   if (!(nu > 0 || eta > 0)) return 0;
+  c->fused_dt_parity = -1;
   Phase ph(c, RGPU_T_DISSIPATIVE);
   double* U = c->U[(nStep + 1) % 2];
   int rc = 0;
@@ -706,6 +715,7 @@ int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
 
 // max of the per-cell 1/dt over the flat index range [idx0, idx0+n) into the device slot (reset or accumulate)
 int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) {
+  c->fused_dt_parity = -1;   // the slot is rewritten
   Phase ph(c, RGPU_T_DT);
   const double* U = c->U[parity & 1];
   if (c->p.mhdEnabled) {
@@ -733,6 +743,7 @@ int inv_dt_fetch(rgpu_ctx* c, double* invDt) {
 }
 
 int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
+  if (c->fused_dt_parity == (parity & 1)) return inv_dt_fetch(c, invDt);   // the sweep that wrote this state scanned it
   return inv_dt_scan(c, parity, 0, c->n32, true) || inv_dt_fetch(c, invDt);
 }
 
@@ -792,6 +803,7 @@ double forcing_norm(const rgpu_params& p, const double* s, double dt) {   // Hyd
 }
 
 int add_forcing(rgpu_ctx* c, int parity, double norm) {
+  c->fused_dt_parity = -1;
   K_add_forcing k = {c->g, c->U[parity & 1], c->Frc, norm};
   return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
 }
@@ -799,6 +811,7 @@ int add_forcing(rgpu_ctx* c, int parity, double norm) {
 // Ornstein-Uhlenbeck forcing on U[parity]: advance the modes on the host, then one kernel over the interior planes
 int step_ou_forcing(rgpu_ctx* c, int parity, double dt) {
   if (!c->ou) return 0;
+  c->fused_dt_parity = -1;
   Phase ph(c, RGPU_T_UPDATE);
   c->ou->update(dt, c->p.cIso);
   K_ou_forcing k = {c->g, c->U[parity & 1], c->ou->m, dt, c->p.yMin, c->p.zMin, c->p.slab_rank * c->p.nz};
@@ -870,6 +883,7 @@ const char* rgpu_last_error(rgpu_ctx* c) { return c ? c->err.c_str() : "null con
 
 int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
   RG_CHECK_CTX(c);
+  c->fused_dt_parity = -1;
   if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "upload: null pointer / context without state");
   const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
   if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");

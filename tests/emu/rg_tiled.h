@@ -3,7 +3,7 @@
 // covered", so the step driver runs the flat per-cell kernels, which the CPU tests check as a second implementation.
 #pragma once
 namespace rgpu_tiled {
-inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int) { return 1; }
+inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int, unsigned long long* = 0) { return 1; }
 inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 template <int SPEC_MRI, int SPEC_PLAIN>
