@@ -83,6 +83,14 @@ RG_DEVFN double rg_sqrt_pos(double x) {
   return __builtin_fma(e, h, g);
 }
 
+// max of non-negative doubles into one of several device slots (the CFL scan that rides in the MHD update kernel): the
+// plain read filters out almost every call once a slot holds a large value (a stale read can only cause a redundant atomic,
+// never a missed one: stale values are <= the current one)
+RG_DEVFN void rg_slot_max(unsigned long long* slot, double v) {
+  if (v > __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long*>(slot))) atomicMax(slot, (unsigned long long)__double_as_longlong(v));
+}
+enum { RG_DT_SLOTS = 1024 };
+
 // ---- flat per-cell kernels ---------------------------------------------------------------------------------
 // One thread per array element, x fastest: every SoA component load / store of a wave is one contiguous
 // 512-byte segment.  BLOCK is a multiple of the 64-lane wavefront.

@@ -538,11 +538,15 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
 // ------------------------------------------------------------------------------------------------------------
 struct RotCoef { double lambda, ratio, alpha1, alpha2; };  // MHDRunGodunov.cpp:2039-2053
 
+// dt_slots != 0: the CFL scan of the NEW state rides along (compute_dt_mhd of the next step, MHDRunBase.cpp:140-250): an
+// interior cell needs the new field on its three high faces, which belong to its +1 neighbours -- their CT update is
+// repeated here from the same emf values (same expressions as below, hence the same bits) -- then the value of
+// mhd_invdt_cell goes to one of RG_DT_SLOTS maxima.
 template <bool ROT, bool GF>
 RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
                                 double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
                                 const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
-                                unsigned idx) {
+                                unsigned idx, unsigned long long* dt_slots = 0) {
   const IJK c = unflatten(g, idx);
   const size_t N = g.ncell;
   const unsigned sj = g.sj, sk = g.sk;
@@ -633,6 +637,26 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
   }
 #pragma unroll
   for (int v = 0; v < 8; ++v) RG_STREAM_STORE(&Unew[idx + v * N], u[v]);
+  if (dt_slots && in_i && in_j && in_k) {
+    const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
+    unsigned m = idx + 1;    // low x face of cell i+1
+    double bnx = Uold[m + IA * N];
+    bnx += (eZ[m + sj] - eZ[m]) * dtdy;          // (k < ksize - gw holds for an interior cell)
+    bnx -= (eY[m + sk] - eY[m]) * dtdz;
+    m = idx + sj;            // low y face of cell j+1
+    double bny = Uold[m + IB * N];
+    bny -= (eZ[m + 1] - eZ[m]) * dtdx;
+    bny += (eX[m + sk] - eX[m]) * dtdz;
+    m = idx + sk;            // low z face of cell k+1
+    double bnz = Uold[m + IC * N];
+    bnz += (eY[m + 1] - eY[m]) * dtdx;
+    bnz -= (eX[m + sj] - eX[m]) * dtdy;
+    const Prim8 q = mhd_prim(g, u, bnx, bny, bnz, 0.0);
+    double sx, sy, sz;
+    info_speeds(g, q, sx, sy, sz);
+    if (g.Omega0 > 0) sy += 1.5 * g.Omega0 * g.deltaX / 2;  // shear velocity at the box edge (MHDRunBase.cpp:223-225)
+    rgpu::rg_slot_max(dt_slots + ((idx >> 6) & (rgpu::RG_DT_SLOTS - 1)), sx / g.dx + sy / g.dy + sz / g.dz);
+  }
 }
 
 }  // namespace rgpu_dev

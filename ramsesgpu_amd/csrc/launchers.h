@@ -194,8 +194,8 @@ struct K_shear_remap {
 template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_update3d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
-  double dt, dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx); }
+  double dt, dtdx, dtdy, dtdz; unsigned long long* dt_slots;
+  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx, dt_slots); }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------

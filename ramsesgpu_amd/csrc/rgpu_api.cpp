@@ -55,6 +55,7 @@ struct rgpu_ctx {
   int device;           // HIP device the context was created on; every entry point makes it current
   unsigned xcd_sub;     // sub-band size (cells) of the XCD-aware workgroup order of THIS context, 0 = linear
   int fused_dt_parity;  // parity of the state whose CFL maximum the last sweep left in d_red (-1: none)
+  int fused_dt_slots;   // how many slots of d_red hold it (1: hydro sweep; RG_DT_SLOTS: MHD update kernel)
   std::string err;
 };
 
@@ -210,6 +211,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->device = -1;
   c->xcd_sub = 4096;
   c->fused_dt_parity = -1;
+  c->fused_dt_slots = 1;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
   c->device = rg_current_device();
@@ -248,7 +250,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (alloc_zero(c, &c->shear_save, 2 * P) || alloc_zero(c, &c->shear_remap, 2 * P))
       return fail(c, RGPU_ENOMEM, "device allocation of the shear buffers failed");
   }
-  if (rg_malloc((void**)&c->d_red, sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, sizeof(unsigned long long)))
+  if (rg_malloc((void**)&c->d_red, RG_DT_SLOTS * sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, RG_DT_SLOTS * sizeof(unsigned long long)))
     return fail(c, RGPU_ENOMEM, "allocation of the reduction slot failed");
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
@@ -437,7 +439,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
                       rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on == 0;
     if (scan && rg_memset_async(c->d_red, 0, sizeof(unsigned long long), c->stream)) return -1;
     const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, scan ? c->d_red : 0);
-    if (rc == 0 && scan) c->fused_dt_parity = (out == c->U[0]) ? 0 : 1;
+    if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }
     if (rc <= 0) return rc;
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
@@ -580,14 +582,28 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
     return rg_launch_range<kBlock>(s, j0, jn, k_ssave) || rg_launch_range<kBlock>(s, j0, jn, k_sremap);
   };
+  // The CFL scan of the new state rides in the update kernel when the whole domain is updated in one call and the
+  // next compute_dt will see exactly this state: nothing modifies it afterwards (no dissipative stage / forcing), and the
+  // field on the three high boundary faces keeps its CT value -- always true on the plain path (the reference scans
+  // before the ghosts are refilled), on the rotating path when y, z are periodic (the refilled faces are bit-identical
+  // copies) and x is periodic or the shearing box (its ghost fill skips the first outer Bx face).
+  bool scan = a <= 0 && b >= ks && !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
+  if (scan && g.rot) {
+    const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
+    scan = xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && p.bc[4] == RGPU_BC_PERIODIC && p.bc[5] == RGPU_BC_PERIODIC;
+  }
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  if (no_fused_dt) scan = false;
+  unsigned long long* slots = scan ? c->d_red : 0;
+  if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
     if (gf) {
-      K_mhd_update3d<true, true> kr = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz};
-      K_mhd_update3d<false, true> kp = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz};
+      K_mhd_update3d<true, true> kr = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots};
+      K_mhd_update3d<false, true> kp = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots};
       return g.rot ? launch_planes<kBlock, 1>(s, g, r, kr) : launch_planes<kBlock, 1>(s, g, r, kp);
     }
-    return g.rot ? launch_spec<K_upd_rot_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz)
-                 : launch_spec<K_upd_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz);
+    return g.rot ? launch_spec<K_upd_rot_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots)
+                 : launch_spec<K_upd_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots);
   };
 
   // the fused sweep marches along z inside one launch: cutting the range into chunks only adds prologues (measured 60.4
@@ -603,6 +619,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
     { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
+    if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     return 0;
   }
 
@@ -638,6 +655,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       d_upd = kb_prev;
     }
   }
+  if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
   return 0;
 }
 
@@ -730,10 +748,14 @@ int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) 
   return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset);
 }
 
-int inv_dt_fetch(rgpu_ctx* c, double* invDt) {
-  if (rg_copy_d2h(c->h_red, c->d_red, sizeof(unsigned long long), c->stream) || rg_stream_sync(c->stream)) return -1;
-  double v;
-  std::memcpy(&v, c->h_red, sizeof(double));
+int inv_dt_fetch(rgpu_ctx* c, double* invDt, int nslots = 1) {
+  if (rg_copy_d2h(c->h_red, c->d_red, (size_t)nslots * sizeof(unsigned long long), c->stream) || rg_stream_sync(c->stream)) return -1;
+  double v = 0.0;
+  for (int s = 0; s < nslots; ++s) {
+    double x;
+    std::memcpy(&x, c->h_red + s, sizeof(double));
+    v = std::fmax(v, x);
+  }
   // seeds and jet term of the CPU paths (HydroRunBase.cpp:382,420-422 ; MHDRunBase.cpp:144,184-186,228-231)
   const rgpu_params& p = c->p;
   if (p.mhdEnabled) v = std::fmax(v, p.smallc / std::fmin(p.dx, p.dy));
@@ -743,7 +765,7 @@ int inv_dt_fetch(rgpu_ctx* c, double* invDt) {
 }
 
 int inv_dt(rgpu_ctx* c, int parity, double* invDt) {
-  if (c->fused_dt_parity == (parity & 1)) return inv_dt_fetch(c, invDt);   // the sweep that wrote this state scanned it
+  if (c->fused_dt_parity == (parity & 1)) return inv_dt_fetch(c, invDt, c->fused_dt_slots);   // the kernel that wrote this state scanned it
   return inv_dt_scan(c, parity, 0, c->n32, true) || inv_dt_fetch(c, invDt);
 }
 

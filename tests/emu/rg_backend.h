@@ -33,6 +33,13 @@ inline double rg_div(double n, const rg_recip_t& R) { return n / R.d; }
 inline double rg_sqrt(double x) { return std::sqrt(x); }
 inline double rg_sqrt_pos(double x) { return std::sqrt(x); }
 
+inline void rg_slot_max(unsigned long long* slot, double v) {
+  double cur;
+  std::memcpy(&cur, slot, sizeof(double));
+  if (v > cur) std::memcpy(slot, &v, sizeof(double));
+}
+enum { RG_DT_SLOTS = 1024 };
+
 template <int BLOCK, int MINW = 1, class K>
 inline int rg_launch(rg_stream_t, unsigned n, const K& k) {
   for (unsigned idx = 0; idx < n; ++idx) k(idx);
