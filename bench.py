@@ -240,6 +240,7 @@ def main():
     ov = overrides_for(w, nx, ny, nz)
     replicas = two_d and world > 1      # 2D boxes do not shard: independent replicas
 
+    driver = ""
     if world == 1 or replicas:
         p = L.params_from_ini(ini, ov)
         U0 = L.init_condition(ini, ov, p)
@@ -250,22 +251,40 @@ def main():
         # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
         step = run.oneStepIntegration
         timers_src = run
-    elif os.environ.get("RGPU_BENCH_DRIVER", "cpp") == "python" or os.environ.get("RGPU_BENCH_BACKEND", "nccl") != "nccl":
-        # legacy harness: the same schedule in Python over torch.distributed (the only way to put two ranks on ONE GPU,
-        # which RCCL refuses: the RGPU_BENCH_ONE_DEVICE / RGPU_BENCH_BACKEND=gloo test hook)
-        srun = SlabRun(ini, ov, library=L, device="cuda:%d" % local_rank)
-        srun.init_simulation()
-        step = srun.oneStepIntegration
-        timers_src = srun.solver
-        p = srun.p
     else:
-        # the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the device;
-        # torch.distributed only carries the 128-byte unique id and the barriers of the timing contract
-        from ramsesgpu_amd import comm as rcomm
-        CL = rcomm.load_comm_library()
-        ids = [rcomm.unique_id(CL) if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        srun = rcomm.CommRun(ini, ov, rank, world, ids[0], library=L, comm_library=CL)
+        # default: the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the
+        # device; torch.distributed only carries the 128-byte unique id and the barriers of the timing contract.
+        # RGPU_BENCH_DRIVER=python (or a non-nccl backend: the RGPU_BENCH_ONE_DEVICE / RGPU_BENCH_BACKEND=gloo test hook, the
+        # only way to put two ranks on ONE GPU, which RCCL refuses) selects the same schedule in Python over torch.distributed.
+        use_cpp = os.environ.get("RGPU_BENCH_DRIVER", "cpp") != "python" and os.environ.get("RGPU_BENCH_BACKEND", "nccl") == "nccl"
+        srun, driver = None, "python harness over torch.distributed (ramsesgpu_amd/slab.py)"
+        if use_cpp:
+            CL, cid = None, None
+            try:
+                from ramsesgpu_amd import comm as rcomm
+                CL = rcomm.load_comm_library()
+                cid = rcomm.unique_id(CL) if rank == 0 else None
+            except Exception as e:  # noqa: BLE001 -- keep the scaling run alive; the line says which driver ran
+                sys.stderr.write("bench.py: C++ slab driver unavailable on rank %d (%r)\n" % (rank, e))
+                CL = None
+            ids = [cid]
+            dist.broadcast_object_list(ids, src=0)       # every rank takes part, whatever happened above
+            if CL is not None and ids[0] is not None:
+                try:
+                    srun = rcomm.CommRun(ini, ov, rank, world, ids[0], library=L, comm_library=CL)
+                    driver = "C++ RCCL driver, include/rgpu_comm.h"
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("bench.py: rgpu_comm_create failed on rank %d (%r); falling back to the Python harness\n" % (rank, e))
+                    srun = None
+            ok = torch.tensor([1 if srun is not None else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # all ranks must agree on the driver
+            if int(ok.item()) == 0:
+                if srun is not None:
+                    srun.close()
+                srun = None
+        if srun is None:
+            driver = "python harness over torch.distributed (ramsesgpu_amd/slab.py)"
+            srun = SlabRun(ini, ov, library=L, device="cuda:%d" % local_rank)
         srun.init_simulation()
         step = srun.oneStepIntegration
         timers_src = srun.solver
@@ -326,7 +345,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["desc"] % dims,
                        "nx": nx, "ny": ny, "nz": nz,
-                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d%s" % (world, " (C++ RCCL driver, include/rgpu_comm.h)" if world > 1 else ""),
+                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d%s" % (world, " (%s)" % driver if world > 1 and not replicas else ""),
                        "path": w["path"],
                        "parity": "bit-identical to euler_cpu on all golden fixtures (tests/)"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
