@@ -51,8 +51,12 @@ RG_DEVFN rg_recip_t rg_recip(double d) {
 }
 RG_DEVFN double rg_div(double n, const rg_recip_t& R) {
   const double q0 = n * R.r;
+#ifdef RG_ARITH_FAST
+  return q0;
+#else
   const double rem = __builtin_fma(-R.d, q0, n);
   return __builtin_fma(rem, R.r, q0);
+#endif
 }
 // the compiler's sqrt minus its rescaling of arguments below 2^-767 (v_cmp, v_cndmask x2, v_ldexp x2)
 RG_DEVFN double rg_sqrt(double x) {
@@ -64,8 +68,10 @@ RG_DEVFN double rg_sqrt(double x) {
   h = __builtin_fma(h, r, h);
   double e = __builtin_fma(-g, g, x);
   g = __builtin_fma(e, h, g);
+#ifndef RG_ARITH_FAST
   e = __builtin_fma(-g, g, x);
   g = __builtin_fma(e, h, g);
+#endif
   return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0 and +inf map to themselves
 }
 
@@ -79,8 +85,12 @@ RG_DEVFN double rg_sqrt_pos(double x) {
   h = __builtin_fma(h, r, h);
   double e = __builtin_fma(-g, g, x);
   g = __builtin_fma(e, h, g);
+#ifdef RG_ARITH_FAST
+  return g;
+#else
   e = __builtin_fma(-g, g, x);
   return __builtin_fma(e, h, g);
+#endif
 }
 
 // max of non-negative doubles into one of several device slots (the CFL scan that rides in the MHD update kernel): the

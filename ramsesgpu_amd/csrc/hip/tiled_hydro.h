@@ -10,9 +10,9 @@
 //   * the x / y neighbourhood goes through LDS: the primitives of plane kk (tile + a one-cell ring without corners,
 //     the ring recomputed from U by the first 2(TX+TY) threads), the x / y face states qm (the left states of the
 //     neighbours' low faces) and the x / y fluxes (the high-face fluxes of the neighbours);
-//   * per plane: prim(kk+2) | barrier | slopes + trace(kk) | barrier | 3 Riemann problems at the low faces of
-//     (i,j,kk) | finish cell (i,j,kk-1) with the z flux just computed and store it | barrier | gather the x / y
-//     fluxes into cell (i,j,kk).
+//   * per plane, two barriers: slopes + trace(kk) | barrier | 3 Riemann problems at the low faces of (i,j,kk) | finish
+//     cell (i,j,kk-1) with the z flux just computed and store it | publish the x / y fluxes and the primitives of plane
+//     kk+1 | barrier | gather the x / y fluxes into cell (i,j,kk) | prim(kk+2).
 //
 // Thread tiles overlap by one cell on each side (the outermost threads only supply face states), so a TX x TY
 // workgroup updates (TX-2) x (TY-2) columns.  HBM traffic per cell update: 40 B read (+ the tile overlap, served by L2
@@ -31,6 +31,13 @@ namespace rgpu_tiled {
 
 using namespace rgpu_dev;
 using rgpu::rg_stream_t;
+
+#ifdef RG_SWEEP_PROF   // experiment builds only (scripts/probe_sweep.py --prof): per-wave cycle accounting of the phases
+__device__ unsigned long long rg_prof[8 * 4];
+#define RG_PROF_T(x) const long long x = (long long)__builtin_readcyclecounter()
+#else
+#define RG_PROF_T(x)
+#endif
 
 inline bool tiled_enabled() {
   static const bool on = !(std::getenv("RGPU_TILED") && std::atoi(std::getenv("RGPU_TILED")) == 0);
@@ -120,10 +127,20 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #pragma unroll
   for (int v = 0; v < NV; ++v) { qA[v] = 1.0; qB[v] = 1.0; qC[v] = 1.0; uB[v] = 1.0; uC[v] = 1.0; uN[v] = 1.0; qmz[v] = 1.0; up[v] = 0.0; }
   double inv_dt = 0.0;
+  // ring threads: U of the ring cell one plane AHEAD.  Loaded and converted in the same iteration, the conversion would
+  // wait for the load (and, the memory counter being in-order, for the prefetch of plane kk+2 issued before it) with the
+  // whole workgroup queued behind it at the barrier: one exposed memory latency per plane.
+  double urn[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) urn[v] = 1.0;
 
   // prologue: planes sa-2, sa-1, sa
   {
     const int k0 = sa - 1;
+    if (ring) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) urn[v] = Uin[ridx2 + (size_t)k0 * sk + v * N];
+    }
     if (ina) {
       double ua[NV];
 #pragma unroll
@@ -136,28 +153,37 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
       hydro_prim<NV>(g, uB, qB);
       hydro_prim<NV>(g, uC, qC);
     }
-  }
-
-  for (int kk = sa - 1; kk <= sb; ++kk) {
-    // ---- A: issue the loads of plane kk+2 (consumed at the bottom of the iteration) and of the ring of plane kk ----
-    const bool more = (kk + 2 <= sb + 1) && ina;
-    if (more) {
-#pragma unroll
-      for (int v = 0; v < NV; ++v) uN[v] = Uin[idx2 + (size_t)(kk + 2) * sk + v * N];
-    }
+    // primitives of plane sa-1 into LDS (every later plane is put there by the iteration before it)
     if (ring) {
-      double ur[NV], rq[NV];
-#pragma unroll
-      for (int v = 0; v < NV; ++v) ur[v] = Uin[ridx2 + (size_t)kk * sk + v * N];
-      hydro_prim<NV>(g, ur, rq);
+      double rq[NV];
+      hydro_prim<NV>(g, urn, rq);
 #pragma unroll
       for (int v = 0; v < NV; ++v) L.q[v][rtj + 1][rti + 1] = rq[v];
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) L.q[v][tj + 1][ti + 1] = qB[v];
     __syncthreads();
+  }
+
+#ifdef RG_SWEEP_PROF
+  long long pacc[4] = {0, 0, 0, 0};
+  const long long tStart = (long long)__builtin_readcyclecounter();
+#endif
+  for (int kk = sa - 1; kk <= sb; ++kk) {
+    // ---- A: issue the loads of plane kk+2 (consumed at the bottom of the iteration) and of the ring of plane kk+1
+    // (consumed in E).  The primitives of plane kk are in LDS since the last barrier. ----
+    const bool more = (kk + 2 <= sb + 1) && ina;
+    if (more) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) uN[v] = Uin[idx2 + (size_t)(kk + 2) * sk + v * N];
+    }
+    if (ring && kk < sb) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) urn[v] = Uin[ridx2 + (size_t)(kk + 1) * sk + v * N];
+    }
 
     // ---- B: slopes and trace of cell (i,j,kk)  (hydro_trace_cell) ----
+    RG_PROF_T(tA);
     double q[NV], h[3][NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -200,7 +226,9 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #pragma unroll
       for (int n = 0; n < NV; ++n) { L.qm[0][n][tj][ti] = qmx[n]; L.qm[1][n][tj][ti] = qmy[n]; }
     }
+    RG_PROF_T(tB);
     __syncthreads();
+    RG_PROF_T(tC);
 
     // ---- C: Riemann problems at the three low faces of cell (i,j,kk)  (hydro_flux_cell) ----
     double fx[NV], fy[NV], fz[NV];
@@ -245,7 +273,24 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     // ---- E: gather the x / y fluxes of plane kk  (hydro_update_cell, unsplitVersion 1 order) ----
 #pragma unroll
     for (int n = 0; n < NV; ++n) { L.f[0][n][tj][ti] = fx[n]; L.f[1][n][tj][ti] = fy[n]; }
+    if (kk < sb) {   // the same barrier publishes the primitives of plane kk+1 (L.q was last read before the barrier above)
+      if (ring) {
+        double rq[NV];
+        hydro_prim<NV>(g, urn, rq);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) L.q[v][rtj + 1][rti + 1] = rq[v];
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) L.q[v][tj + 1][ti + 1] = qC[v];
+    }
+    RG_PROF_T(tD);
     __syncthreads();
+#ifdef RG_SWEEP_PROF
+    {
+      const long long tE = (long long)__builtin_readcyclecounter();
+      pacc[0] += tB - tA; pacc[1] += tC - tB; pacc[2] += tD - tC; pacc[3] += tE - tD;
+    }
+#endif
     if (kk < sb) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) up[v] = uB[v];
@@ -267,6 +312,12 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     if (more) hydro_prim<NV>(g, uN, qC);
   }
   (void)tr2d; (void)fl2d;
+#ifdef RG_SWEEP_PROF
+  if ((t & 63) == 0) {
+    for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)pacc[q]);
+    atomicAdd(&rg_prof[(4 + (t >> 6)) * 4], (unsigned long long)((long long)__builtin_readcyclecounter() - tStart));
+  }
+#endif
   if (dslot) {   // workgroup maximum: wave64 butterfly, one LDS slot per wave (the flux buffer is free now), one atomic
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) inv_dt = fmax(inv_dt, __shfl_down(inv_dt, off, 64));
@@ -293,9 +344,19 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   int nseg;
   if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
   else {
-    // enough workgroups for >= two rounds over 256 CUs x 3 resident workgroups, segments of >= 16 planes
-    nseg = (1536 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
-    if (nseg > span / 16) nseg = span / 16;
+    // Two workgroups are resident per CU (190 VGPRs), all of them take the same time: the launch proceeds in rounds of
+    // 512 workgroups and the last round should be full.  A segment costs two extra iterations (pipeline fill).  Pick the
+    // segment count with the best (occupancy of the last round) x (useful iterations): at 256^3 (19 x 19 tiles) that is
+    // 7 segments of ~37 planes, 4.94 rounds (measured: 1.075 ms per sweep against 1.125 with 5 segments, 3.5 rounds).
+    const int tiles = tg.nbx * tg.nby, slots = 512;
+    double best = -1.0;
+    nseg = 1;
+    for (int n = 1; n <= span / 12 && n <= 64; ++n) {
+      const int total = tiles * n, rounds = (total + slots - 1) / slots;
+      const double len = (double)span / n;
+      const double eff = (double)total / ((double)rounds * slots) * (len / (len + 2.0));
+      if (eff > best * 1.005) { best = eff; nseg = n; }   // ties: the fewer, longer segments
+    }
   }
   if (nseg < 1) nseg = 1;
   if (nseg > span) nseg = span;

@@ -59,13 +59,6 @@ struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q 
   RG_DEVFN unsigned sj() const { return (unsigned)MH_QX; }
 };
 
-#ifdef RG_SWEEP_PROF   // experiment builds only (scripts/probe_sweep.py --prof): per-wave cycle accounting of the phases
-__device__ unsigned long long rg_prof[8 * 4];
-#define RG_PROF_T(x) const long long x = (long long)__builtin_readcyclecounter()
-#else
-#define RG_PROF_T(x)
-#endif
-
 // T accessor of ONE plane buffer: the +z neighbour of a cell is not in it.  stride(ZD) = 0 makes the one component of a
 // state that reads the plane above (the face field on the + side) read this plane instead; the caller replaces that
 // component when the plane above has been traced (see "carried states" below).
@@ -304,7 +297,11 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const bool tracing = kk + 1 < sb;
     if (producer) {
       if (more) prim_load(kk + 3);
+#ifdef RG_SWEEP_PROF
+      if (tracing && !(tg.flags & 4)) {   // experiment: RGPU_SWEEP_FLAGS=4 times the kernel without the trace
+#else
       if (tracing) {
+#endif
         if (wave == 3) { trace_cell(kk + 1, lane, 6 * nit); trace_cell(kk + 1, 128 + lane, 6 * nit); }
         else trace_cell(kk + 1, 64 + lane, 6 * nit);
       }
@@ -317,7 +314,11 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       if (tracing) elec_plane(kk + 2, rthread, 384);   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef RG_SWEEP_PROF
+      if (fl_ok && kk >= sa - 1 && !(tg.flags & 2)) {   // experiment: RGPU_SWEEP_FLAGS=2 times the kernel without the Riemann problems
+#else
       if (fl_ok && kk >= sa - 1) {
+#endif
         const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;

@@ -195,8 +195,7 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   rs->restartEnabled = cfg.get_bool("run", "restart", false);
   rs->restartResetTotalTime = cfg.get_bool("run", "restart_reset_totaltime", false);
   rs->restartFilename = cfg.get_string("run", "restart_filename", "");
-  if (rs->restartEnabled && cfg.get_bool("run", "restart_upscale", false))
-    throw std::runtime_error("restart_upscale (resuming from a run at half the resolution) is outside the implemented scope");
+  rs->restartUpscale = cfg.get_bool("run", "restart_upscale", false);
 }
 
 }  // namespace rgpu_host

@@ -47,9 +47,15 @@ int GodunovRun::init_simulation() {
     std::fill(h_U_.begin(), h_U_.end(), 0.0);
     const std::string path = rs_.outputDir + "/" + rs_.restartFilename;
     restart_has_ghosts_ = false;
-    if (path.size() > 4 && path.substr(path.size() - 4) == ".rgr") timeStep = inputRestart(path, &restart_has_ghosts_);
-    else timeStep = inputVtk(path);
-    restore_forcing_process(timeStep);
+    const bool dump = path.size() > 4 && path.substr(path.size() - 4) == ".rgr";
+    if (rs_.restartUpscale) {
+      if (!dump) throw std::runtime_error("restart_upscale reads a .rgr restart dump ([output] outputHdf5=yes in the coarse run)");
+      if (p_.nx % 2 || p_.ny % 2 || (p_.nz_global != 1 && p_.nz % 2)) throw std::runtime_error("restart_upscale: nx, ny, nz must be even");
+      inputRestartUpscaled(path, &restart_has_ghosts_);   // timeStep stays 0; the forcing process starts afresh (:7084-7088)
+    } else {
+      timeStep = dump ? inputRestart(path, &restart_has_ghosts_) : inputVtk(path);
+      restore_forcing_process(timeStep);
+    }
     std::cout << "### This is a restarted run ! Current time is " << totalTime_ << " (step " << timeStep << ") ###\n";
   } else {
     init_condition(cfg_, p_, h_U_.data());
@@ -157,7 +163,9 @@ void GodunovRun::outputRestart(int nStep) {
   }
 }
 
-int GodunovRun::inputRestart(const std::string& path, bool* ghosts_read) {
+// Reads a dump of an nx x ny x nz box (ghost width and variables of this run) into dst, a ghost-inclusive array of that
+// box; without ghosts in the file the ghost cells of dst are left as they are.
+int GodunovRun::read_restart(const std::string& path, int nx_want, int ny_want, int nz_want, double* dst, bool* ghosts_read) {
   std::ifstream in(path.c_str(), std::ios::binary);
   if (!in) throw std::runtime_error("restart: cannot read " + path);
   std::string line;
@@ -167,24 +175,65 @@ int GodunovRun::inputRestart(const std::string& path, bool* ghosts_read) {
   if (std::sscanf(line.c_str(), "RGPU-RESTART %d %d %d %d %d %d %d %d %63s", &ver, &nx, &ny, &nz, &gw, &nv, &gi, &nStep, hex) != 9 || ver != 1)
     throw std::runtime_error("restart: " + path + " is not a restart dump of this code");
   const bool three_d = p_.nz_global != 1;
-  if (nx != p_.nx || ny != p_.ny || nz != (three_d ? p_.nz : 1) || gw != p_.ghostWidth || nv != p_.nbVar)
-    throw std::runtime_error("restart: " + path + " holds another box than [mesh] nx, ny, nz / other variables");
+  if (nx != nx_want || ny != ny_want || nz != nz_want || gw != p_.ghostWidth || nv != p_.nbVar)
+    throw std::runtime_error("restart: " + path + " holds another box than expected from [mesh] nx, ny, nz / other variables");
   const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1;
   const size_t ncell = isize * jsize * ksize;
   if (gi) {
-    in.read(reinterpret_cast<char*>(h_U_.data()), sizeof(double) * ncell * nv);
+    in.read(reinterpret_cast<char*>(dst), sizeof(double) * ncell * nv);
   } else {
     for (int v = 0; v < nv; ++v)
       for (int k = 0; k < nz; ++k)
         for (int j = 0; j < ny; ++j) {
           const size_t kk = three_d ? k + gw : 0;
-          in.read(reinterpret_cast<char*>(&h_U_[gw + isize * ((j + gw) + jsize * kk) + ncell * v]), sizeof(double) * nx);
+          in.read(reinterpret_cast<char*>(&dst[gw + isize * ((j + gw) + jsize * kk) + ncell * v]), sizeof(double) * nx);
         }
   }
   if (!in) throw std::runtime_error("restart: " + path + " is truncated");
   if (ghosts_read) *ghosts_read = gi != 0;
   totalTime_ = rs_.restartResetTotalTime ? 0.0 : std::strtod(hex, 0);
   return nStep;
+}
+
+int GodunovRun::inputRestart(const std::string& path, bool* ghosts_read) {
+  const bool three_d = p_.nz_global != 1;
+  return read_restart(path, p_.nx, p_.ny, three_d ? p_.nz : 1, h_U_.data(), ghosts_read);
+}
+
+// [run] restart_upscale: the dump holds the same problem on nx/2 x ny/2 (x nz/2) cells; every cell of this run's arrays,
+// ghosts included, takes the value of the coarse cell under it -- (index + ghostWidth) / 2 per direction -- except the
+// face-centred field: a fine face lying on a coarse face takes that face's value, one in the middle of a coarse cell the
+// mean of the two coarse faces around it along the component's own direction, which keeps div B = 0
+// (HydroRunBase::upscale, HydroRunBase.cpp:5170-5278; call site :7047-7062).  In 2D Bz is cell-like.  The step count of
+// the coarse run is not taken over (the reference drops inputHdf5's return value there), its time is.
+void GodunovRun::inputRestartUpscaled(const std::string& path, bool* ghosts_read) {
+  const bool three_d = p_.nz_global != 1;
+  const int gw = p_.ghostWidth, nv = p_.nbVar;
+  const int lnx = p_.nx / 2, lny = p_.ny / 2, lnz = three_d ? p_.nz / 2 : 1;
+  const size_t li = lnx + 2 * gw, lj = lny + 2 * gw, lk = three_d ? lnz + 2 * gw : 1, lcell = li * lj * lk;
+  std::vector<double> low(lcell * nv, 0.0);
+  read_restart(path, lnx, lny, lnz, low.data(), ghosts_read);
+  const size_t isize = p_.nx + 2 * gw, jsize = p_.ny + 2 * gw, ksize = three_d ? p_.nz + 2 * gw : 1, ncell = isize * jsize * ksize;
+  const bool mhd = nv == 8;
+  const int ncopy = mhd ? 5 : nv;   // cell-centred variables (2D MHD: density, energy and the three momenta)
+  for (size_t k = 0; k < ksize; ++k) {
+    const size_t kl = three_d ? (k + gw) / 2 : 0;
+    for (size_t j = 0; j < jsize; ++j) {
+      const size_t jl = (j + gw) / 2;
+      for (size_t i = 0; i < isize; ++i) {
+        const size_t il = (i + gw) / 2;
+        const size_t hi = i + isize * (j + jsize * k), lo = il + li * (jl + lj * kl);
+        for (int v = 0; v < ncopy; ++v) h_U_[hi + ncell * v] = low[lo + lcell * v];
+        if (mhd) {
+          const double* bx = &low[lcell * 5]; const double* by = &low[lcell * 6]; const double* bz = &low[lcell * 7];
+          h_U_[hi + ncell * 5] = (i + gw == 2 * il) ? bx[lo] : (bx[lo] + bx[lo + 1]) / 2;
+          h_U_[hi + ncell * 6] = (j + gw == 2 * jl) ? by[lo] : (by[lo] + by[lo + li]) / 2;
+          if (!three_d) h_U_[hi + ncell * 7] = bz[lo];
+          else h_U_[hi + ncell * 7] = (k + gw == 2 * kl) ? bz[lo] : (bz[lo] + bz[lo + li * lj]) / 2;
+        }
+      }
+    }
+  }
 }
 
 // Reads a .vti written by outputVtk (same box, same variables) into the interior of h_U_; returns the step count of the

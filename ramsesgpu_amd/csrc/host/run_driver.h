@@ -36,6 +36,8 @@ class GodunovRun {
   // reference's HDF5 files -- lossless state, optionally with the ghost cells ([output] ghostIncluded), step count and time
   void outputRestart(int nStep);
   int inputRestart(const std::string& path, bool* ghosts_read);
+  int read_restart(const std::string& path, int nx, int ny, int nz, double* dst, bool* ghosts_read);
+  void inputRestartUpscaled(const std::string& path, bool* ghosts_read);
   void save_forcing_process(int nStep);
   void restore_forcing_process(int nStep);
   void history(int nStep, double dt);                     // [history] enabled=yes: <outputDir>/<outputPrefix>_history.txt

@@ -17,7 +17,7 @@ if prof:   # experiment build with per-wave phase cycle counters (RG_SWEEP_PROF)
     from ramsesgpu_amd import build as rb
     L = Library(rb.build(verbose=False, extra_flags=["-DRG_SWEEP_PROF"], out_name="librgpu_prof.so"))
 else:
-    L = Library(lib_path())
+    L = Library(os.environ.get('RGPU_LIB') or lib_path())   # RGPU_LIB: an experiment build of the library
 ini = os.path.join(ROOT, "configs", base + ".ini")
 p = L.params_from_ini(ini, ov)
 U0 = L.init_condition(ini, ov, p)

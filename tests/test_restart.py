@@ -87,3 +87,104 @@ def test_restart_rejects_a_file_of_another_box(emu_lib, tmp_path):
     ov = "run.restart=yes;run.restart_upscale=yes;run.restart_filename=x.vti"
     n = emu_lib.lib.rgpuh_run(ini("orszag-tang").encode(), ov.encode(), C.byref(mc), err, 512)
     assert n < 0 and b"restart_upscale" in err.value
+
+
+# ---- [run] restart_upscale: resume on a mesh twice as fine (HydroRunBase::upscale, HydroRunBase.cpp:5170-5278) ----
+def read_dump(path):
+    """the raw restart dump of the run driver -> (header dict, array [nbVar, ksize, jsize, isize] incl. ghosts; zeros where
+    the file holds the interior only)"""
+    with open(path, "rb") as f:
+        w = f.readline().split()
+        assert w[0] == b"RGPU-RESTART" and w[1] == b"1"
+        nx, ny, nz, gw, nv, gi, nstep = (int(x) for x in w[2:9])
+        t = float.fromhex(w[9].decode())
+        three_d = nz != 1
+        shape = (nv, nz + 2 * gw if three_d else 1, ny + 2 * gw, nx + 2 * gw)
+        if gi:
+            a = np.frombuffer(f.read(), dtype="<f8").reshape(shape).copy()
+        else:
+            a = np.zeros(shape)
+            inner = np.frombuffer(f.read(), dtype="<f8").reshape(nv, nz, ny, nx)
+            ks = slice(gw, gw + nz) if three_d else slice(0, 1)
+            a[:, ks, gw:gw + ny, gw:gw + nx] = inner
+    return dict(nx=nx, ny=ny, nz=nz, gw=gw, nv=nv, ghosts=bool(gi), nstep=nstep, t=t), a
+
+
+def upscale_expected(low, gw, three_d, mhd):
+    """numpy statement of the rule: every fine cell (ghosts included) takes coarse cell (index + gw) // 2; the face field on
+    a fine face in the middle of a coarse cell is the mean of the two coarse faces along its own direction"""
+    nv, lk, lj, li = low.shape
+    isz, jsz = 2 * (li - 2 * gw) + 2 * gw, 2 * (lj - 2 * gw) + 2 * gw
+    ksz = 2 * (lk - 2 * gw) + 2 * gw if three_d else 1
+    I = (np.arange(isz) + gw) // 2; J = (np.arange(jsz) + gw) // 2
+    K = (np.arange(ksz) + gw) // 2 if three_d else np.zeros(1, dtype=int)
+    out = low[:, K][:, :, J][:, :, :, I].copy()
+    if mhd:
+        oi = (np.arange(isz) + gw) % 2 == 1
+        out[5][:, :, oi] = (low[5][K][:, J][:, :, I[oi]] + low[5][K][:, J][:, :, I[oi] + 1]) / 2
+        oj = (np.arange(jsz) + gw) % 2 == 1
+        out[6][:, oj, :] = (low[6][K][:, J[oj]][:, :, I] + low[6][K][:, J[oj] + 1][:, :, I]) / 2
+        if three_d:
+            ok = (np.arange(ksz) + gw) % 2 == 1
+            out[7][ok] = (low[7][K[ok]][:, J][:, :, I] + low[7][K[ok] + 1][:, J][:, :, I]) / 2
+    return out
+
+
+UPSCALE_CASES = [
+    ("orszag-tang", "mesh.nx=%d;mesh.ny=%d", (12, 8, 1), "yes"),
+    ("orszag-tang", "mesh.nx=%d;mesh.ny=%d", (12, 8, 1), "no"),
+    ("orszag-tang3d", "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d", (6, 8, 6), "yes"),
+    ("implode3d", "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d;hydro.riemannSolver=hllc", (6, 6, 8), "yes"),
+    ("jet2d_cpu", "mesh.nx=%d;mesh.ny=%d;jet.ijet=2;jet.offsetJet=1", (8, 20, 1), "no"),
+]
+
+
+def check_upscale(lib, base, ovf, dims, ghosts, tmp_path):
+    a, b = tmp_path / "coarse", tmp_path / "fine"
+    a.mkdir(); b.mkdir()
+    d = dims[:2] if dims[2] == 1 else dims
+    common = ";run.noutput=1;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=%s" % ghosts
+    err = C.create_string_buffer(512); mc = C.c_double(0)
+    ov = (ovf % d) + common + ";run.nstepmax=4;output.outputDir=%s" % a
+    assert lib.lib.rgpuh_run(ini(base).encode(), ov.encode(), C.byref(mc), err, 512) == 4, err.value
+    src = sorted(f for f in os.listdir(a) if f.endswith("0000004.rgr"))[0]
+    (b / src).write_bytes((a / src).read_bytes())
+    hl, low = read_dump(str(a / src))
+    assert hl["nstep"] == 4 and hl["ghosts"] == (ghosts == "yes")
+    fine = tuple(2 * x for x in d)
+    ov = (ovf % fine) + common + ";run.nstepmax=3;run.restart=yes;run.restart_upscale=yes;run.restart_filename=%s;output.outputDir=%s" % (src, b)
+    assert lib.lib.rgpuh_run(ini(base).encode(), ov.encode(), C.byref(mc), err, 512) == 3, err.value
+    h0, u0 = read_dump(str(b / [f for f in os.listdir(b) if f.endswith("0000000.rgr")][0]))
+    assert h0["nstep"] == 0 and h0["t"] == hl["t"]          # the time of the coarse run, a fresh step count
+    gw, three_d, mhd = hl["gw"], dims[2] != 1, hl["nv"] == 8
+    want = upscale_expected(low, gw, three_d, mhd)
+    assert want.shape == u0.shape
+    if ghosts == "yes":      # every cell comes from the file: no boundary fill at the start (MHDRunGodunov.cpp:3818-3824)
+        assert np.array_equal(u0, want)
+    else:
+        ks = slice(gw, -gw) if three_d else slice(0, 1)
+        assert np.array_equal(u0[:, ks, gw:-gw, gw:-gw], want[:, ks, gw:-gw, gw:-gw])
+    if mhd and ghosts == "yes":   # the interpolation keeps the discrete divergence of the face field at round-off (the high
+                                  # faces of the last cells are ghost-side values: in the file only with ghostIncluded)
+        bx, by, bz = u0[5], u0[6], u0[7]
+        ks = slice(gw, -gw) if three_d else slice(0, 1)
+        div = (bx[ks, gw:-gw, gw + 1:-gw + 1] - bx[ks, gw:-gw, gw:-gw]) * fine[0] + (by[ks, gw + 1:-gw + 1, gw:-gw] - by[ks, gw:-gw, gw:-gw]) * fine[1]
+        if three_d:
+            div = div + (bz[gw + 1:-gw + 1, gw:-gw, gw:-gw] - bz[gw:-gw, gw:-gw, gw:-gw]) * fine[2]
+        assert np.abs(div).max() < 1e-10 * max(1.0, np.abs(bx).max() * max(fine))
+    h3, u3 = read_dump(str(b / [f for f in os.listdir(b) if f.endswith("0000003.rgr")][0]))
+    assert h3["nstep"] == 3 and h3["t"] > hl["t"] and np.isfinite(u3).all()
+
+
+UIDS = ["%s-ghosts_%s" % (c[0], c[3]) for c in UPSCALE_CASES]
+
+
+@pytest.mark.parametrize("base,ovf,dims,ghosts", UPSCALE_CASES, ids=UIDS)
+def test_restart_upscale_emu(base, ovf, dims, ghosts, emu_lib, tmp_path):
+    check_upscale(emu_lib, base, ovf, dims, ghosts, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ovf,dims,ghosts", UPSCALE_CASES[:3], ids=UIDS[:3])
+def test_restart_upscale_gpu(base, ovf, dims, ghosts, gpu_lib, tmp_path):
+    check_upscale(gpu_lib, base, ovf, dims, ghosts, tmp_path)
