@@ -184,6 +184,28 @@ def pmc_traffic(workload, kernel_phase):
         return None
 
 
+PARITY = {"exact": "bit-identical to euler_cpu on all golden fixtures (tests/)",
+          "contracted": "librgpu_fast.so (FMA contraction, ~1-ulp division / sqrt): relative L2 < 1e-12 to euler_cpu on all golden fixtures "
+                        "(worst measured 2e-14, tests/test_contracted.py); not bit-identical"}
+
+
+def valu_ceiling(workload, kernel_phase, launch_ms):
+    """The second ceiling of SURVEY.md 8(d): share of the fp64 vector-issue capacity the dominant kernel uses.  Wave-level
+    VALU instruction counts per launch come from the committed rocprofv3 --pmc summary (SQ_INSTS_VALU,
+    SQ_INSTS_VALU_TRANS_F64); an fp64 instruction occupies a SIMD for 4 cycles (16 lanes per cycle), rcp / rsq / sqrt for 16;
+    1024 SIMDs at the 2.4 GHz peak clock.  None without the summary."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload][kernel_phase]
+        insts, trans = d["valu_wave_insts"], d.get("valu_trans_f64_wave_insts", 0.0)
+    except Exception:
+        return None
+    cycles = 4.0 * insts + 12.0 * trans
+    cap = 1024 * 2.4e9 * launch_ms * 1e-3
+    return {"valu_wave_insts_per_launch": insts, "trans_f64_wave_insts_per_launch": trans, "issue_cycles": cycles,
+            "capacity_cycles": cap, "frac": cycles / cap, "clock_ghz": 2.4, "simds": 1024,
+            "note": "fraction of the fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq) the kernel fills at its measured duration"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +217,9 @@ def main():
     ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--nz", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arith", choices=["exact", "contracted"], default=os.environ.get("RGPU_ARITH", "exact"),
+                    help="exact: librgpu.so, bit-identical to the reference (default, the headline); contracted: librgpu_fast.so")
+    ap.add_argument("--no-contracted", action="store_true", help="skip the second measurement with librgpu_fast.so (N=1, --arith exact)")
     ap.add_argument("--timeline-only", action="store_true", help="stop after the timed region (for rocprofv3 --kernel-trace concurrency analysis)")
     args = ap.parse_args()
 
@@ -210,7 +235,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ramsesgpu_amd.slab import SlabRun
-    from ramsesgpu_amd.solver import Solver, load_library
+    from ramsesgpu_amd.solver import Library, Solver, lib_path
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,7 +260,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    L = load_library()
+    L = Library(lib_path(args.arith))
+    assert L.arithmetic == args.arith
     ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
     ov = overrides_for(w, nx, ny, nz)
     replicas = two_d and world > 1      # 2D boxes do not shard: independent replicas
@@ -262,7 +288,7 @@ def main():
             CL, cid = None, None
             try:
                 from ramsesgpu_amd import comm as rcomm
-                CL = rcomm.load_comm_library()
+                CL = rcomm.load_comm_library(rcomm.comm_lib_path(args.arith))
                 cid = rcomm.unique_id(CL) if rank == 0 else None
             except Exception as e:  # noqa: BLE001 -- keep the scaling run alive; the line says which driver ran
                 sys.stderr.write("bench.py: C++ slab driver unavailable on rank %d (%r)\n" % (rank, e))
@@ -347,16 +373,42 @@ def main():
                        "nx": nx, "ny": ny, "nz": nz,
                        "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d%s" % (world, " (%s)" % driver if world > 1 and not replicas else ""),
                        "path": w["path"],
-                       "parity": "bit-identical to euler_cpu on all golden fixtures (tests/)"},
+                       "arithmetic": L.arithmetic,
+                       "parity": PARITY[L.arithmetic]},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(args.workload, dom_name),
                          "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
                          "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
-                                  "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md")},
+                                  "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
+                         "valu_ceiling": valu_ceiling(args.workload, dom_name, dom_ms / max(dom_launches / nprof, 1.0)) if L.arithmetic == "exact" else None},
             "roofline_step": {"bound": "hbm", "achieved": step_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": step_bytes / (elapsed / args.steps) / HBM_PEAK,
                               "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": step_ms_events},
         }
+        if world == 1 and args.arith == "exact" and not args.no_contracted:
+            # the same workload through the opt-in contracted-arithmetic variant (never the headline value)
+            try:
+                run.close()
+                L2 = Library(lib_path("contracted"))
+                p2 = L2.params_from_ini(ini, ov)
+                U0 = L2.init_condition(ini, ov, p2)
+                run2 = Solver(p2, L2)
+                run2.upload(U0, both=False)
+                del U0
+                run2.make_all_boundaries(0, 0.0, 0.0)
+                for _ in range(args.warmup):
+                    run2.oneStepIntegration()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    run2.oneStepIntegration()
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t1
+                run2.close()
+                out["contracted_arithmetic"] = {"value": args.steps * cells_global / e2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": e2 / args.steps * 1e3,
+                                                "library": "ramsesgpu_amd/librgpu_fast.so", "parity": PARITY["contracted"]}
+            except Exception as e:  # noqa: BLE001 -- a secondary number: report why it is missing
+                out["contracted_arithmetic"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, (nx, ny, nz))
             allc = cpu_baseline_all_cores(w)

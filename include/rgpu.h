@@ -280,6 +280,14 @@ int rgpu_selftest_arith(int n, const double* num, const double* den, double* quo
 /* name of the device backend the library was built for ("hip-gfx950") */
 const char* rgpu_backend_name(void);
 
+/* floating-point arithmetic of the kernels in this library:
+ *   "exact"       librgpu.so       no FMA contraction, correctly rounded division / square root, the reference's operand
+ *                                  order: results bit-identical to the reference's CPU path
+ *   "contracted"  librgpu_fast.so  the same sources with FMA contraction and ~1-ulp division / square root: results agree
+ *                                  with the reference to round-off (relative L2 < 1e-12 on every golden fixture), ~15 %
+ *                                  faster on the 3D MHD step.  Same ABI: link one or the other. */
+const char* rgpu_arithmetic(void);
+
 /* block until all queued work of this context is complete */
 int rgpu_synchronize(rgpu_ctx* c);
 

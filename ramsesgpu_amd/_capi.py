@@ -173,6 +173,8 @@ def declare_device_api(lib):
     lib.rgpu_dominant_kernel.argtypes = [ctx, C.c_char_p, C.c_int, c_double_p, C.POINTER(C.c_long)]
     lib.rgpu_backend_name.restype = C.c_char_p
     lib.rgpu_backend_name.argtypes = []
+    lib.rgpu_arithmetic.restype = C.c_char_p
+    lib.rgpu_arithmetic.argtypes = []
     return lib
 
 
@@ -184,5 +186,5 @@ DECLARED_SYMBOLS = [
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
-    "rgpu_backend_name", "rgpu_selftest_arith", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpu_ou_forcing_get_state", "rgpu_ou_forcing_set_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
+    "rgpu_backend_name", "rgpu_arithmetic", "rgpu_selftest_arith", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpu_ou_forcing_get_state", "rgpu_ou_forcing_set_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
 ]

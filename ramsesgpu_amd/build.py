@@ -5,6 +5,12 @@
 -ffp-contract=off is part of the parity contract: the reference CPU path is built without FMA contraction and the
 kernels reproduce its operand order, so results are bit-identical ("Exactness").
 hipcc cross-compiles without a GPU, so this also runs in the build container.
+
+Second, opt-in variant of the same sources: librgpu_fast.so (+ librgpu_comm_fast.so), "contracted" arithmetic --
+-ffp-contract=fast -DRG_ARITH_FAST=2: mul+add pairs fuse into FMAs, the shared-reciprocal division and the square root
+drop their last correction step (results within ~1 ulp instead of correctly rounded).  Same operand order, same
+algorithms; results agree with the reference to round-off (worst relative L2 over all golden fixtures 2e-14, stated
+tolerance 1e-12), not bit for bit.  Same C ABI, same symbol names: a host program links -lrgpu OR -lrgpu_fast.
 """
 import os
 import subprocess
@@ -26,8 +32,16 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+FAST_FLAGS = ["-DRG_ARITH_FAST=2", "-ffp-contract=fast"]
+
+
 def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
+    """out_name "librgpu.so": the product (+ librgpu_comm.so, euler_hip); "librgpu_fast.so": the contracted-arithmetic
+    variant (FAST_FLAGS are added, + librgpu_comm_fast.so); any other name: an experiment build of the library alone"""
     out = os.path.join(HERE, out_name)
+    fast = out_name == "librgpu_fast.so"
+    if fast:
+        extra_flags = list(extra_flags) + FAST_FLAGS
     exe = os.path.join(HERE, "euler_hip")
     srcs = [os.path.join(CSRC, "rgpu_api.cpp")] + [os.path.join(CSRC, "host", s) for s in HOST_SRC]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
@@ -55,11 +69,11 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         subprocess.check_call(cmd)
     # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code only
     comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
-    comm_out = os.path.join(HERE, "librgpu_comm.so")
+    comm_out = os.path.join(HERE, "librgpu_comm_fast.so" if fast else "librgpu_comm.so")
     comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
-    if out_name == "librgpu.so" and (force or _newer(comm_out, comm_deps)):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu",
+    if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
                "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", comm_out]
         if verbose:
             print(" ".join(cmd))
@@ -73,5 +87,12 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     return out
 
 
+def build_all(verbose=True, force=False):
+    """the product library and its contracted-arithmetic variant"""
+    out = build(verbose=verbose, force=force)
+    build(verbose=verbose, force=force, out_name="librgpu_fast.so")
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build_all(force="--force" in sys.argv)

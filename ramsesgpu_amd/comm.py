@@ -14,8 +14,10 @@ from .solver import RgpuError, Solver, load_library
 ID_BYTES = 128
 
 
-def comm_lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgpu_comm.so")
+def comm_lib_path(arithmetic="exact"):
+    """librgpu_comm.so drives librgpu.so, librgpu_comm_fast.so the contracted-arithmetic librgpu_fast.so (one variant per
+    process: both export the same symbols)"""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgpu_comm.so" if arithmetic == "exact" else "librgpu_comm_fast.so")
 
 
 def load_comm_library(path=None):

@@ -1249,6 +1249,11 @@ int rgpu_dominant_kernel(rgpu_ctx* c, char* name, int name_len, double* avg_ms, 
 }
 
 const char* rgpu_backend_name(void) { return RG_BACKEND_NAME; }
+#ifdef RG_ARITH_FAST
+const char* rgpu_arithmetic(void) { return "contracted"; }
+#else
+const char* rgpu_arithmetic(void) { return "exact"; }
+#endif
 
 int rgpu_selftest_arith(int n, const double* num, const double* den, double* quot, double* quot2, double* root, double* root2) {
   if (n <= 0 || !num || !den || !quot || !quot2 || !root || !root2) return RGPU_EINVAL;

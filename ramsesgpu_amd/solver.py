@@ -16,11 +16,16 @@ from ._capi import RgpuParams
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def lib_path():
-    if os.environ.get("RGPU_LIB"):
+def lib_path(arithmetic=None):
+    """in-tree location of the product library (built by __graft_entry__.build / ramsesgpu_amd/build.py).
+    arithmetic: "exact" (librgpu.so: bit-identical to the reference) or "contracted" (librgpu_fast.so: FMA contraction,
+    ~1-ulp division / square root; agrees with the reference to round-off); default from $RGPU_ARITH, else exact."""
+    if os.environ.get("RGPU_LIB"):   # an experiment build (scripts/)
         return os.environ["RGPU_LIB"]
-    """in-tree location of the product library (built by __graft_entry__.build / ramsesgpu_amd/build.py)"""
-    return os.path.join(_HERE, "librgpu.so")
+    arithmetic = arithmetic or os.environ.get("RGPU_ARITH", "exact")
+    if arithmetic not in ("exact", "contracted"):
+        raise ValueError("arithmetic must be 'exact' or 'contracted', not %r" % (arithmetic,))
+    return os.path.join(_HERE, "librgpu.so" if arithmetic == "exact" else "librgpu_fast.so")
 
 
 class RgpuError(RuntimeError):
@@ -57,6 +62,11 @@ class Library:
     @property
     def backend(self):
         return self.lib.rgpu_backend_name().decode()
+
+    @property
+    def arithmetic(self):
+        """"exact" or "contracted" (see lib_path)"""
+        return self.lib.rgpu_arithmetic().decode()
 
     # ---- host side: parameter file and initial condition ------------------------------------------------------
     def params_from_ini(self, ini_path, overrides="", slab=None):

@@ -68,8 +68,15 @@ for w in ("mri", "implode3d"):
             out.write("%s,%d,%s,%.1f,%.1f\n" % (ph, n, ",".join("%.6g" % v for v in vals), valu, hbm))
             if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
                 traffic[w][ph] = {"hbm_bytes_per_launch": (m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
-                                  "fetch_bytes": m["FETCH_SIZE"] * 1024.0, "write_bytes": m["WRITE_SIZE"] * 1024.0}
-    traffic[w]["_step_total_bytes"] = sum(v["hbm_bytes_per_launch"] for k, v in traffic[w].items() if not k.startswith("_"))
+                                  "fetch_bytes": m["FETCH_SIZE"] * 1024.0, "write_bytes": m["WRITE_SIZE"] * 1024.0,
+                                  "launches_sampled": n}
+                if "SQ_INSTS_VALU" in m:   # wave-level instruction counts of one launch (for the fp64-VALU ceiling in bench.py)
+                    traffic[w][ph]["valu_wave_insts"] = m["SQ_INSTS_VALU"]
+                    traffic[w][ph]["valu_trans_f64_wave_insts"] = m.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    # kernels launched every step (a phase sampled far less often -- the one CFL scan of the initial state -- is not one)
+    nmax = max([v["launches_sampled"] for k, v in traffic[w].items() if not k.startswith("_")] or [0])
+    traffic[w]["_step_total_bytes"] = sum(v["hbm_bytes_per_launch"] for k, v in traffic[w].items()
+                                          if not k.startswith("_") and 2 * v["launches_sampled"] >= nmax)
 traffic["_note"] = ("rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE), one whole-domain launch per kernel and step; KiB x 1024. "
                     "WRITE_SIZE matches the byte count of the stores; FETCH_SIZE is a LOWER bound on gfx950 (128-B requests tallied as "
                     "64 B, MI355X_MICROARCH.md HBM section): 0.62-0.78x of the known unique bytes on the pure streaming kernels. "

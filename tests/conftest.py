@@ -58,10 +58,20 @@ def oracle():
 def product_lib():
     """the shipped library (HIP backend).  Built in-tree by __graft_entry__.build()."""
     from ramsesgpu_amd.solver import Library, lib_path
-    if not os.path.exists(lib_path()):
+    if not os.path.exists(lib_path("exact")):
         import __graft_entry__
         __graft_entry__.build()
-    return Library(lib_path())
+    return Library(lib_path("exact"))
+
+
+@pytest.fixture(scope="session")
+def contracted_lib():
+    """the opt-in variant of the product with contracted arithmetic (librgpu_fast.so, see rgpu_arithmetic() in rgpu.h)"""
+    from ramsesgpu_amd.solver import Library, lib_path
+    if not os.path.exists(lib_path("contracted")):
+        import __graft_entry__
+        __graft_entry__.build()
+    return Library(lib_path("contracted"))
 
 
 @pytest.fixture(scope="session")
@@ -92,3 +102,11 @@ def gpu_lib(product_lib):
     p = product_lib.params_from_ini(ini("orszag-tang"), "mesh.nx=8;mesh.ny=8")
     Solver(p, product_lib).close()  # raises RgpuError(RGPU_ENODEVICE) without a GPU: no silent fallback
     return product_lib
+
+
+@pytest.fixture(scope="session")
+def gpu_contracted_lib(contracted_lib):
+    from ramsesgpu_amd.solver import Solver
+    p = contracted_lib.params_from_ini(ini("orszag-tang"), "mesh.nx=8;mesh.ny=8")
+    Solver(p, contracted_lib).close()
+    return contracted_lib

@@ -32,6 +32,19 @@ def test_library_exports_every_declared_symbol(product_lib):
         assert sym in exported, "%s is declared in include/rgpu.h but not exported by %s" % (sym, product_lib.path)
 
 
+def test_contracted_variant_exports_the_same_abi(product_lib, contracted_lib):
+    """librgpu_fast.so: same entry points, another arithmetic (rgpu_arithmetic() tells which library a process holds)"""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", contracted_lib.path], universal_newlines=True)
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    for sym in header_functions():
+        assert sym in exported, "%s is declared in include/rgpu.h but not exported by %s" % (sym, contracted_lib.path)
+    assert product_lib.arithmetic == "exact" and contracted_lib.arithmetic == "contracted"
+    assert contracted_lib.backend == "hip-gfx950"
+    comm = os.path.join(os.path.dirname(contracted_lib.path), "librgpu_comm_fast.so")
+    needed = subprocess.check_output(["readelf", "-d", comm], universal_newlines=True)
+    assert "librgpu_fast.so" in needed and "[librgpu.so]" not in needed      # the slab driver of the variant drives the variant
+
+
 def test_params_struct_layout_matches_c(tmp_path):
     """sizeof / offsets of rgpu_params as seen by a C compiler == the ctypes mirror"""
     src = tmp_path / "layout.c"
@@ -47,7 +60,7 @@ def test_params_struct_layout_matches_c(tmp_path):
 
 def test_product_is_the_hip_backend(product_lib):
     assert product_lib.backend == "hip-gfx950"
-    assert os.path.samefile(product_lib.path, lib_path())
+    assert os.path.samefile(product_lib.path, lib_path("exact"))
 
 
 def test_no_cpu_fallback_without_gpu(product_lib):

@@ -34,6 +34,19 @@ def test_bench_line_single_gpu(args, gpu_lib):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the headline is the exact library; the contracted-arithmetic variant is reported beside it, never instead of it
+    assert d["config"]["arithmetic"] == "exact" and "bit-identical" in d["config"]["parity"]
+    c = d["contracted_arithmetic"]
+    assert c["value"] > 0 and "librgpu_fast.so" in c["library"] and "not bit-identical" in c["parity"]
+
+
+def test_bench_line_contracted_on_request(gpu_lib):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--arith", "contracted",
+                          "--workload", "mri", "--nx", "32", "--ny", "48", "--nz", "32"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = last_json(res.stdout)
+    assert d["config"]["arithmetic"] == "contracted" and "not bit-identical" in d["config"]["parity"] and "contracted_arithmetic" not in d
 
 
 def test_bench_two_ranks_through_the_launch_line(gpu_lib):
