@@ -229,6 +229,13 @@ int rgpu_step_post_b(rgpu_ctx* c, int nStep, double dt, double totalTime);
  * X,Y faces (HydroRunBase.cpp:2333-2342) or, shearing box, Y + shear remap + Y (MHDRunGodunov.cpp:3779-3793 with
  * the z copy commuted out: all three act within one z plane). */
 int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
+/* The same piece in two halves, for solvers whose update is a kernel of its own (3D MHD): RGPU_CORE_FLUXES computes the
+ * face fluxes and edge EMFs the update of planes [k_lo,k_hi) needs (one z-marching launch -- over the whole slab it costs one
+ * pipeline fill instead of one per plane range), RGPU_CORE_UPDATE then completes planes [k_lo,k_hi) -- any sub-ranges of a
+ * FLUXES range, in any order.  For every other solver FLUXES does nothing and UPDATE is rgpu_step_core_planes, so the
+ * schedule  FLUXES [0,ksize) ; UPDATE boundary ranges ; exchange || UPDATE inner range  is valid for all of them. */
+enum { RGPU_CORE_FLUXES = 1, RGPU_CORE_UPDATE = 2 };
+int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int what);
 /* The dissipative stage of the step ([hydro] nu / [MHD] eta > 0; no-op otherwise) on U[(nStep+1)%2], WITHOUT the ghost
  * fill that precedes it in rgpu_godunov_unsplit: a slab driver calls it between rgpu_step_core and rgpu_step_post_a after
  * it has filled the ghosts of the output itself (rgpu_make_boundaries / _shear + its z exchange), as the reference's MPI

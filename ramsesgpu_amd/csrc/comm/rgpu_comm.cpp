@@ -173,12 +173,15 @@ int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
     snd[0][0] = gw; snd[0][1] = 2 * gw; snd[1][0] = nz; snd[1][1] = nz + gw; has_inner = true;
   }
   const bool scan = !rot;   // rotating path: the reference's compute_dt sees the refilled ghosts -> full scan next step
-  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes(c, nStep, dt, t, bnd[n][0], bnd[n][1]), "step_core_planes");
+  // fluxes / EMFs of the whole slab in one z-marching launch (3D MHD; a no-op for the solvers whose sweep is the whole step),
+  // then the update range by range: the boundary-planes-first order costs no extra pipeline fill of the sweep
+  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES), "step_core_planes(fluxes)");
+  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE), "step_core_planes(update)");
   if (scan) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
   for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
   if (int rc = exchange_start(cm, pout)) return rc;
   if (has_inner) {
-    RG_TRY(rgpu_step_core_planes(c, nStep, dt, t, 2 * gw, nz), "step_core_planes");
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE), "step_core_planes(update)");
     if (scan) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
     RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, 2 * gw, nz), "step_fill_planes");
   }

@@ -544,7 +544,9 @@ template <int S> using K_upd_t = K_mhd_update3d<false, false, S>;
 // (prim, elec, trace, update) go to the context stream, the fp64-VALU-bound Riemann stages (flux, emf) to a second
 // stream, ordering-only events in between, so that trace of chunk c+1 runs next to flux/emf of chunk c.  With the
 // phase timers on (or RGPU_CHUNKS=1) everything is issued on the context stream in one chunk.
-int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b) {
+// what: 0 = the whole update of planes [a,b); RGPU_CORE_FLUXES = only F, emf (+ the shear remap buffers) that update needs;
+// RGPU_CORE_UPDATE = only the update, from F, emf computed by an earlier RGPU_CORE_FLUXES call covering [a,b)
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what = 0) {
   const DevParams& g = c->g;
   const rgpu_params& p = c->p;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
@@ -600,7 +602,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // field on the three high boundary faces keeps its CT value -- always true on the plain path (the reference scans
   // before the ghosts are refilled), on the rotating path when y, z are periodic (the refilled faces are bit-identical
   // copies) and x is periodic or the shearing box (its ghost fill skips the first outer Bx face).
-  bool scan = a <= 0 && b >= ks && !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
+  bool scan = what == 0 && a <= 0 && b >= ks && !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
   if (scan && g.rot) {
     const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
     scan = xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && p.bc[4] == RGPU_BC_PERIODIC && p.bc[5] == RGPU_BC_PERIODIC;
@@ -631,17 +633,21 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // the fused sweep marches along z inside one launch: cutting the range into chunks only adds prologues (measured 60.4
   // against 55.3 ms/step at 512^3), so the two-stream chunk schedule is kept for the flat kernels only (RGPU_CHUNKS forces it)
   static const bool force_chunks = std::getenv("RGPU_CHUNKS") != 0;
-  const bool serial = c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks);
+  const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks);
   if (serial) {
     rg_stream_t s = c->stream;
-    if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)
-      { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
-      { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+    if (what != RGPU_CORE_UPDATE) {
+      if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)
+        { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
+        { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+      }
+      if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
+      { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     }
-    if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
-    { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
-    { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
-    if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
+    if (what != RGPU_CORE_FLUXES) {
+      { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
+      if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
+    }
     return 0;
   }
 
@@ -681,7 +687,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   return 0;
 }
 
-int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
+// what != 0 (RGPU_CORE_FLUXES / RGPU_CORE_UPDATE) splits the 3D MHD step, the only one whose update is a kernel of its own;
+// for every other solver FLUXES is a no-op and UPDATE the whole piece, so a driver may use the split schedule blindly
+int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int what = 0) {
+  const bool splittable = c->g.three_d && c->p.mhdEnabled;
+  if (what != 0 && !splittable) { if (what == RGPU_CORE_FLUXES) return 0; what = 0; }
   c->fused_dt_parity = -1;   // the output array is about to change (a whole-domain hydro sweep sets it again)
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
@@ -702,7 +712,7 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   if (b > c->g.ksize) b = c->g.ksize;
   if (b <= a) return 0;
   if (!c->p.mhdEnabled) return hydro_core<3, 5>(c, in, out, dt, a, b);
-  return mhd3d_core(c, in, out, dt, totalTime, a, b);
+  return mhd3d_core(c, in, out, dt, totalTime, a, b, what);
 }
 
 // Dissipative stage ([hydro] nu, [MHD] eta) on the state the step has just written: refill its ghosts (plain or
@@ -1180,6 +1190,13 @@ int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi)) return RG_HIPFAIL(c, "step_core_planes");
+  return RGPU_OK;
+}
+int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int what) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (what != RGPU_CORE_FLUXES && what != RGPU_CORE_UPDATE) return fail(c, RGPU_EINVAL, "step_core_planes_split: what must be RGPU_CORE_FLUXES or RGPU_CORE_UPDATE");
+  if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi, what)) return RG_HIPFAIL(c, "step_core_planes_split");
   return RGPU_OK;
 }
 int rgpu_step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime) {

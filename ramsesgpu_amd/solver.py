@@ -287,6 +287,10 @@ class Solver:
     def step_core_planes(self, nStep, dt, t, k_lo, k_hi):
         self._chk(self.lib.rgpu_step_core_planes(self.ctx, nStep, dt, t, k_lo, k_hi), "step_core_planes")
 
+    def step_core_planes_split(self, nStep, dt, t, k_lo, k_hi, what):
+        """what: 1 = RGPU_CORE_FLUXES, 2 = RGPU_CORE_UPDATE (include/rgpu.h)"""
+        self._chk(self.lib.rgpu_step_core_planes_split(self.ctx, nStep, dt, t, k_lo, k_hi, what), "step_core_planes_split")
+
     def step_fill_planes(self, nStep, dt, t, k_lo, k_hi):
         self._chk(self.lib.rgpu_step_fill_planes(self.ctx, nStep, dt, t, k_lo, k_hi), "step_fill_planes")
 

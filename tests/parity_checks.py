@@ -246,27 +246,35 @@ BOUNDARY_CASES = [
 
 
 def check_core_plane_pieces(lib, base, ov):
-    """rgpu_step_core_planes over a partition of [0,ksize) (odd cuts, out of order) == rgpu_step_core"""
+    """rgpu_step_core_planes over a partition of [0,ksize) (odd cuts, out of order) == rgpu_step_core; so is the split form
+    (rgpu_step_core_planes_split: the fluxes of the whole box once, then the update piece by piece -- the slab driver's order)"""
     p = lib.params_from_ini(ini(base), ov)
     U0 = lib.init_condition(ini(base), ov, p)
     ks = p.nz + 2 * p.ghostWidth
+    cuts = [0, 1, 7, 8, ks - 15, ks]
+    pieces = list(reversed(list(zip(cuts[:-1], cuts[1:]))))
     outs = []
-    for cuts in (None, [0, 1, 7, 8, ks - 15, ks]):
+    for mode in ("whole", "pieces", "split"):
         sv = Solver(p, lib)
         sv.upload(U0)
         sv.make_all_boundaries(0, 0.0, 0.0)
         dt = sv.compute_dt(0)
         sv.step_pre(0, dt, 0.0)
-        if cuts is None:
+        if mode == "whole":
             sv.step_core(0, dt, 0.0)
-        else:
-            for a, b in reversed(list(zip(cuts[:-1], cuts[1:]))):
+        elif mode == "pieces":
+            for a, b in pieces:
                 sv.step_core_planes(0, dt, 0.0, a, b)
+        else:
+            sv.step_core_planes_split(0, dt, 0.0, 0, ks, 1)
+            for a, b in pieces:
+                sv.step_core_planes_split(0, dt, 0.0, a, b, 2)
         sv.step_post_a(0, dt, 0.0)
         sv.step_post_b(0, dt, 0.0)
         outs.append(sv.getDataHost(1))
         sv.close()
     assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[2])
 
 
 HISTORY_CASES = [
