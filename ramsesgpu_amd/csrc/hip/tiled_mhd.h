@@ -359,13 +359,19 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   int nseg;
   if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
   else {
-    // one workgroup per CU is resident; a segment costs two extra iterations (pipeline fill).  Segments of ~128 planes
-    // measured best at 512^3 (35.5 ms against 35.8 for 64-plane segments): enough
-    // workgroups to even out the last round over the 256 CUs.  Small boxes: at least ~8 rounds, segments >= 8 planes.
-    nseg = (span + 127) / 128;
-    const int want = (2048 + tg.nbx * tg.nby - 1) / (tg.nbx * tg.nby);
-    if (nseg < want) nseg = want;
-    if (nseg > span / 8) nseg = span / 8;
+    // One workgroup per CU is resident and all take the same time: the launch proceeds in rounds of 256 workgroups.  A
+    // segment costs two extra iterations (pipeline fill).  Pick the segment count with the best (occupancy of the last
+    // round) x (useful iterations), segments of >= 8 planes: 5 segments at 512^3 (2145 tiles, 41.9 rounds), 2 for a
+    // 64-plane slab (16.8 rounds instead of 8.4).
+    const int tiles = tg.nbx * tg.nby, slots = 256;
+    double best = -1.0;
+    nseg = 1;
+    for (int n = 1; n <= span / 8 && n <= 64; ++n) {
+      const int total = tiles * n, rounds = (total + slots - 1) / slots;
+      const double len = (double)span / n;
+      const double eff = (double)total / ((double)rounds * slots) * (len / (len + 2.0));
+      if (eff > best * 1.005) { best = eff; nseg = n; }   // ties: the fewer, longer segments
+    }
   }
   if (nseg < 1) nseg = 1;
   if (nseg > span) nseg = span;
