@@ -127,6 +127,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #pragma unroll
   for (int v = 0; v < NV; ++v) { qA[v] = 1.0; qB[v] = 1.0; qC[v] = 1.0; uB[v] = 1.0; uC[v] = 1.0; uN[v] = 1.0; qmz[v] = 1.0; up[v] = 0.0; }
   double inv_dt = 0.0;
+  double rho_old = 1.0;             // old density of cell (i,j,kk-1): the gravity source needs it when the cell is finished
   // ring threads: U of the ring cell one plane AHEAD.  Loaded and converted in the same iteration, the conversion would
   // wait for the load (and, the memory counter being in-order, for the prefetch of plane kk+2 issued before it) with the
   // whole workgroup queued behind it at the barrier: one exposed memory latency per plane.
@@ -223,6 +224,11 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #define RG_FLOOR(a) a[ID] = fmax(g.smallr, a[ID]); a[IP] = fmax(g.smallp * a[ID], a[IP])
       RG_FLOOR(qmx); RG_FLOOR(qpx); RG_FLOOR(qmy); RG_FLOOR(qpy); RG_FLOOR(qmz_new); RG_FLOOR(qpz);
 #undef RG_FLOOR
+      if (g.grav_on) {   // uniform static gravity: predictor on the traced states, after the floors (hydro_face_state)
+#define RG_GRAV(a) a[IU] += g.hgx; a[IV] += g.hgy; a[IW] += g.hgz
+        RG_GRAV(qmx); RG_GRAV(qpx); RG_GRAV(qmy); RG_GRAV(qpy); RG_GRAV(qmz_new); RG_GRAV(qpz);
+#undef RG_GRAV
+      }
 #pragma unroll
       for (int n = 0; n < NV; ++n) { L.qm[0][n][tj][ti] = qmx[n]; L.qm[1][n][tj][ti] = qmy[n]; }
     }
@@ -259,6 +265,10 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     if (own && kk - 1 >= sa) {
       if (inner2d) {
         up[ID] -= fz[ID] * dtdz; up[IP] -= fz[IP] * dtdz; up[IU] -= fz[IW] * dtdz; up[IV] -= fz[IV] * dtdz; up[IW] -= fz[IU] * dtdz;
+        if (g.grav_on) {   // momentum source with the mean of the old and new density (hydro_update_cell); energy untouched
+          const double rho_sum = rho_old + up[ID];
+          up[IU] += g.hgx * rho_sum; up[IV] += g.hgy * rho_sum; up[IW] += g.hgz * rho_sum;
+        }
         if (dslot) {
           double qn[NV];
           const double cs = hydro_prim<NV>(g, up, qn);
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     if (kk < sb) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) up[v] = uB[v];
+      rho_old = uB[ID];
       if (own && inner2d) {
         const int tip = ti + 1 < TX ? ti + 1 : ti, tjp = tj + 1 < TY ? tj + 1 : tj;
         up[ID] += fx[ID] * dtdx; up[IP] += fx[IP] * dtdx; up[IU] += fx[IU] * dtdx; up[IV] += fx[IV] * dtdx; up[IW] += fx[IW] * dtdx;
@@ -368,7 +379,7 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// configurations the fused sweep covers (uniform or per-cell gravity excluded by the driver: it knows the run's setting)
+// configurations the fused sweep covers (the per-cell gravity field is excluded by the caller: it knows the step's setting)
 inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && !g.mhd && g.nvar == 5 && !g.dirwise_update; }
 
 // Complete the update of planes [a,b) of a 3D hydro step.  Returns 0 = done, 1 = not applicable (the caller runs the
@@ -376,7 +387,7 @@ inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() &&
 // dslot: device slot for the CFL maximum of the new state (reset by the caller), or 0
 inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
                          double dtdz, int a, int b, unsigned long long* dslot = 0) {
-  if (!hydro3d_sweep_covers(g) || g.grav_on != 0) return 1;
+  if (!hydro3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
   // ghost planes inside [a,b): plain copy, like the flat update kernel
   const K_copy_cells kc = {in, out, g.ncell, 5};
@@ -412,6 +423,9 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
     RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
     RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
     RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
+    // with uniform gravity (g.grav_on == 1)
+    RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE1);
+    RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE1);
 #undef RG_TRY
   }
   return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);

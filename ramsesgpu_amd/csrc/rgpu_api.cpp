@@ -170,7 +170,7 @@ ScratchPlan plan_for(const rgpu_params& p) {
   // stage borrows it for its emf.
   DevParams g;
   fill_dev_params(p, &g);
-  if (three_d && !p.mhdEnabled && rgpu_tiled::hydro3d_sweep_covers(g) && p.gravityEnabled == 0) { s.q = 0; s.t = 0; }
+  if (three_d && !p.mhdEnabled && rgpu_tiled::hydro3d_sweep_covers(g) && p.gravityEnabled != 2) { s.q = 0; s.t = 0; }
   if (three_d && p.mhdEnabled && rgpu_tiled::mhd3d_sweep_covers(g) && p.gravityEnabled != 2) { s.q = 0; s.e = 0; s.t = (p.eta > 0) ? 3 : 0; }
   return s;
 }
@@ -436,7 +436,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     Phase ph(c, RGPU_T_SWEEP);
     // whole-domain steps whose output nothing modifies afterwards carry the CFL scan of the new state along
     const bool scan = a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
-                      rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on == 0;
+                      rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on != 2;
     if (scan && rg_memset_async(c->d_red, 0, sizeof(unsigned long long), c->stream)) return -1;
     const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, scan ? c->d_red : 0);
     if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }

@@ -44,6 +44,10 @@ MEDIUM = [
     ("implode3d", "mesh.nx=48;mesh.ny=48;mesh.nz=48;hydro.riemannSolver=hllc", 10),
     ("implode3d", "mesh.nx=128;mesh.ny=128;mesh.nz=128;hydro.riemannSolver=hllc", 2),
     ("jet2d_cpu", "mesh.nx=100;mesh.ny=400", 30),
+    # uniform static gravity inside the LDS-tiled hydro sweep (several tiles and z segments), both specialised solvers + generic
+    ("rayleigh_taylor_gpu_3d", "mesh.nx=40;mesh.ny=36;mesh.nz=48", 6),
+    ("rayleigh_taylor_gpu_3d", "mesh.nx=40;mesh.ny=36;mesh.nz=48;hydro.riemannSolver=hllc;hydro.slope_type=1", 6),
+    ("rayleigh_taylor_gpu_3d", "mesh.nx=24;mesh.ny=40;mesh.nz=32;hydro.riemannSolver=hll", 6),
 ]
 
 
