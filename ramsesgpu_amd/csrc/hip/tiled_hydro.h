@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
       for (int v = 0; v < NV; ++v) RG_STREAM_STORE(&o[v * N], up[v]);
     }
 
-    // ---- E: gather the x / y fluxes of plane kk  (hydro_update_cell, unsplitVersion 1 order) ----
+    // ---- E: gather the x / y fluxes of plane kk  (hydro_update_cell; the high z flux follows in D of the next iteration) ----
 #pragma unroll
     for (int n = 0; n < NV; ++n) { L.f[0][n][tj][ti] = fx[n]; L.f[1][n][tj][ti] = fy[n]; }
     if (kk < sb) {   // the same barrier publishes the primitives of plane kk+1 (L.q was last read before the barrier above)
@@ -307,13 +307,20 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
       rho_old = uB[ID];
       if (own && inner2d) {
         const int tip = ti + 1 < TX ? ti + 1 : ti, tjp = tj + 1 < TY ? tj + 1 : tj;
-        up[ID] += fx[ID] * dtdx; up[IP] += fx[IP] * dtdx; up[IU] += fx[IU] * dtdx; up[IV] += fx[IV] * dtdx; up[IW] += fx[IW] * dtdx;
-        up[ID] += fy[ID] * dtdy; up[IP] += fy[IP] * dtdy; up[IU] += fy[IV] * dtdy; up[IV] += fy[IU] * dtdy; up[IW] += fy[IW] * dtdy;
-        up[ID] += fz[ID] * dtdz; up[IP] += fz[IP] * dtdz; up[IU] += fz[IW] * dtdz; up[IV] += fz[IV] * dtdz; up[IW] += fz[IU] * dtdz;
-        up[ID] -= L.f[0][ID][tj][tip] * dtdx; up[IP] -= L.f[0][IP][tj][tip] * dtdx; up[IU] -= L.f[0][IU][tj][tip] * dtdx;
-        up[IV] -= L.f[0][IV][tj][tip] * dtdx; up[IW] -= L.f[0][IW][tj][tip] * dtdx;
-        up[ID] -= L.f[1][ID][tjp][ti] * dtdy; up[IP] -= L.f[1][IP][tjp][ti] * dtdy; up[IU] -= L.f[1][IV][tjp][ti] * dtdy;
-        up[IV] -= L.f[1][IU][tjp][ti] * dtdy; up[IW] -= L.f[1][IW][tjp][ti] * dtdy;
+#define RG_LOW_X up[ID] += fx[ID] * dtdx; up[IP] += fx[IP] * dtdx; up[IU] += fx[IU] * dtdx; up[IV] += fx[IV] * dtdx; up[IW] += fx[IW] * dtdx
+#define RG_LOW_Y up[ID] += fy[ID] * dtdy; up[IP] += fy[IP] * dtdy; up[IU] += fy[IV] * dtdy; up[IV] += fy[IU] * dtdy; up[IW] += fy[IW] * dtdy
+#define RG_LOW_Z up[ID] += fz[ID] * dtdz; up[IP] += fz[IP] * dtdz; up[IU] += fz[IW] * dtdz; up[IV] += fz[IV] * dtdz; up[IW] += fz[IU] * dtdz
+#define RG_HIGH_X up[ID] -= L.f[0][ID][tj][tip] * dtdx; up[IP] -= L.f[0][IP][tj][tip] * dtdx; up[IU] -= L.f[0][IU][tj][tip] * dtdx; \
+                  up[IV] -= L.f[0][IV][tj][tip] * dtdx; up[IW] -= L.f[0][IW][tj][tip] * dtdx
+#define RG_HIGH_Y up[ID] -= L.f[1][ID][tjp][ti] * dtdy; up[IP] -= L.f[1][IP][tjp][ti] * dtdy; up[IU] -= L.f[1][IV][tjp][ti] * dtdy; \
+                  up[IV] -= L.f[1][IU][tjp][ti] * dtdy; up[IW] -= L.f[1][IW][tjp][ti] * dtdy
+        if (!g.dirwise_update) { RG_LOW_X; RG_LOW_Y; RG_LOW_Z; RG_HIGH_X; RG_HIGH_Y; }   // unsplitVersion 1: low faces, then high faces
+        else { RG_LOW_X; RG_HIGH_X; RG_LOW_Y; RG_HIGH_Y; RG_LOW_Z; }                     // unsplitVersion 2: direction by direction
+#undef RG_LOW_X
+#undef RG_LOW_Y
+#undef RG_LOW_Z
+#undef RG_HIGH_X
+#undef RG_HIGH_Y
       }
     }
 
@@ -380,7 +387,7 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
 }
 
 // configurations the fused sweep covers (the per-cell gravity field is excluded by the caller: it knows the step's setting)
-inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && !g.mhd && g.nvar == 5 && !g.dirwise_update; }
+inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && !g.mhd && g.nvar == 5; }
 
 // Complete the update of planes [a,b) of a 3D hydro step.  Returns 0 = done, 1 = not applicable (the caller runs the
 // flat kernels), < 0 = launch error.

@@ -48,6 +48,7 @@ MEDIUM = [
     ("rayleigh_taylor_gpu_3d", "mesh.nx=40;mesh.ny=36;mesh.nz=48", 6),
     ("rayleigh_taylor_gpu_3d", "mesh.nx=40;mesh.ny=36;mesh.nz=48;hydro.riemannSolver=hllc;hydro.slope_type=1", 6),
     ("rayleigh_taylor_gpu_3d", "mesh.nx=24;mesh.ny=40;mesh.nz=32;hydro.riemannSolver=hll", 6),
+    ("implode3d", "mesh.nx=48;mesh.ny=40;mesh.nz=36;hydro.riemannSolver=hllc;hydro.unsplitVersion=2", 8),   # direction-wise update order
 ]
 
 
