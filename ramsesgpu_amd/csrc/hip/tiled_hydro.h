@@ -104,8 +104,6 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
   // cells this thread writes: the inner threads of the tile, plus array row / column 0 (never inside an inner range)
   const bool own = ina && ((ti >= 1 && ti < TX - 1) || i == 0) && ((tj >= 1 && tj < TY - 1) || j == 0);
   const bool inner2d = i >= gw && i < g.isize - gw && j >= gw && j < g.jsize - gw;
-  const bool tr2d = i >= 1 && i < g.isize - 1 && j >= 1 && j < g.jsize - 1 && ina;
-  const bool fl2d = i >= gw && i <= g.isize - gw && j >= gw && j <= g.jsize - gw && ina;
 
   // ring cell of this thread (threads 0 .. RING-1): the one-cell frame around the tile, corners excluded
   int rti, rtj;
@@ -329,7 +327,6 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     for (int v = 0; v < NV; ++v) { qA[v] = qB[v]; qB[v] = qC[v]; uB[v] = uC[v]; uC[v] = uN[v]; }
     if (more) hydro_prim<NV>(g, uN, qC);
   }
-  (void)tr2d; (void)fl2d;
 #ifdef RG_SWEEP_PROF
   if ((t & 63) == 0) {
     for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)pacc[q]);

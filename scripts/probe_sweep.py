@@ -9,7 +9,7 @@ from ramsesgpu_amd.solver import Library, Solver, lib_path
 
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 base = args[0]; n = int(args[1]); nst = int(args[2]) if len(args) > 2 else 10
-ov = "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (n, n, n)
+ov = "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (n, n, int(os.environ.get("PROBE_NZ", n)))
 if base == "implode3d":
     ov += ";hydro.riemannSolver=hllc"
 prof = "--prof" in sys.argv
