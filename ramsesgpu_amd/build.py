@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-HOST_SRC = ["ini_config.cpp", "host_params.cpp", "init_conditions.cpp", "host_capi.cpp", "run_driver.cpp"]
+HOST_SRC = ["ini_config.cpp", "host_params.cpp", "init_conditions.cpp", "host_capi.cpp", "run_driver.cpp", "hdf5_io.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I", os.path.join(CSRC, "hip"), "-I", CSRC]
 
 
@@ -63,7 +63,7 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             objs.append(obj)
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out]
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,4 +1,5 @@
 #include "run_driver.h"
+#include "hdf5_io.h"
 
 #include <algorithm>
 #include <chrono>
@@ -17,7 +18,7 @@
 
 namespace rgpu_host {
 
-GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0), restart_has_ghosts_(false) {
+GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0), restart_has_ghosts_(false), warned_no_hdf5_(false), wrote_hdf5_(false) {
   params_from_config(cfg_, 0, 1, &p_, &rs_);
   const int rc = rgpu_create(&p_, &ctx_);
   if (rc) {
@@ -47,9 +48,10 @@ int GodunovRun::init_simulation() {
     std::fill(h_U_.begin(), h_U_.end(), 0.0);
     const std::string path = rs_.outputDir + "/" + rs_.restartFilename;
     restart_has_ghosts_ = false;
-    const bool dump = path.size() > 4 && path.substr(path.size() - 4) == ".rgr";
+    const bool h5 = path.size() > 3 && path.substr(path.size() - 3) == ".h5";
+    const bool dump = h5 || (path.size() > 4 && path.substr(path.size() - 4) == ".rgr");
     if (rs_.restartUpscale) {
-      if (!dump) throw std::runtime_error("restart_upscale reads a .rgr restart dump ([output] outputHdf5=yes in the coarse run)");
+      if (!dump) throw std::runtime_error("restart_upscale reads an .h5 file or a .rgr dump ([output] outputHdf5=yes in the coarse run)");
       if (p_.nx % 2 || p_.ny % 2 || (p_.nz_global != 1 && p_.nz % 2)) throw std::runtime_error("restart_upscale: nx, ny, nz must be even");
       inputRestartUpscaled(path, &restart_has_ghosts_);   // timeStep stays 0; the forcing process starts afresh (:7084-7088)
     } else {
@@ -138,6 +140,31 @@ void GodunovRun::outputVtk(int nStep) {
 // then nbVar arrays of little-endian doubles, x fastest -- the whole ghost-inclusive arrays when ghostIncluded (what a
 // shearing-box run needs: the field on the first high x face is evolved by the CT update and not rebuilt by the ghost
 // fill), the interior otherwise.  Stands in for outputHdf5 / inputHdf5 (HydroRunBase.cpp:3308-3640, 4818-5160).
+H5Box GodunovRun::h5_box(int nx, int ny, int nz) const {
+  H5Box b;
+  b.nx = nx; b.ny = ny; b.nz = nz;
+  b.ghostWidth = p_.ghostWidth; b.nbVar = p_.nbVar;
+  b.three_d = p_.nz_global != 1; b.mhd = p_.mhdEnabled != 0;
+  return b;
+}
+
+// [output] outputHdf5=yes: the reference's HDF5 file (hdf5_io.h) when libhdf5 can be loaded, the raw dump below otherwise
+void GodunovRun::outputHdf5(int nStep) {
+  const char* fmt = std::getenv("RGPU_RESTART_FORMAT");   // "rgr": the raw dump even when HDF5 is there
+  if (fmt && std::string(fmt) == "rgr") { outputRestart(nStep); return; }
+  std::string why;
+  if (!hdf5_available(&why)) {
+    if (!warned_no_hdf5_) { std::cerr << "outputHdf5: " << why << " -- writing raw .rgr dumps instead\n"; warned_no_hdf5_ = true; }
+    outputRestart(nStep);
+    return;
+  }
+  std::ostringstream fn;
+  fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".h5";
+  const bool three_d = p_.nz_global != 1;
+  hdf5_write_state(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, three_d ? p_.nz : 1), rs_.ghostIncluded, nStep, totalTime_, rs_.hdf5CompressionLevel);
+  wrote_hdf5_ = true;
+}
+
 void GodunovRun::outputRestart(int nStep) {
   const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
   const bool three_d = p_.nz_global != 1;
@@ -166,6 +193,12 @@ void GodunovRun::outputRestart(int nStep) {
 // Reads a dump of an nx x ny x nz box (ghost width and variables of this run) into dst, a ghost-inclusive array of that
 // box; without ghosts in the file the ghost cells of dst are left as they are.
 int GodunovRun::read_restart(const std::string& path, int nx_want, int ny_want, int nz_want, double* dst, bool* ghosts_read) {
+  if (path.size() > 3 && path.substr(path.size() - 3) == ".h5") {   // inputHdf5 (HydroRunBase.cpp:4818-5155)
+    double t = 0.0;
+    const int step = hdf5_read_state(path, dst, h5_box(nx_want, ny_want, nz_want), &t, ghosts_read);
+    totalTime_ = rs_.restartResetTotalTime ? 0.0 : t;
+    return step;
+  }
   std::ifstream in(path.c_str(), std::ios::binary);
   if (!in) throw std::runtime_error("restart: cannot read " + path);
   std::string line;
@@ -418,7 +451,7 @@ int GodunovRun::start(double* mcell_per_s) {
       const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
       if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
       if (rs_.outputVtk) outputVtk(nStep);
-      if (rs_.outputRestart) outputRestart(nStep);
+      if (rs_.outputRestart) outputHdf5(nStep);
       if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
@@ -434,8 +467,10 @@ int GodunovRun::start(double* mcell_per_s) {
     const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
     if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
     if (rs_.outputVtk) outputVtk(nStep);
-    if (rs_.outputRestart) outputRestart(nStep);
+    if (rs_.outputRestart) outputHdf5(nStep);
     if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
+    // the XDMF index of the .h5 files of this run, in the current directory (MHDRunGodunov.cpp:4004)
+    if (wrote_hdf5_) xdmf_write_wrapper(rs_.outputPrefix, h5_box(p_.nx, p_.ny, (p_.nz_global != 1) ? p_.nz : 1), rs_.ghostIncluded, nStep, rs_.nOutput);
     io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
   const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

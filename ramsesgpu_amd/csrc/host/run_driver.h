@@ -14,6 +14,7 @@
 #include "ini_config.h"
 
 namespace rgpu_host {
+struct H5Box;
 
 class GodunovRun {
  public:
@@ -35,6 +36,9 @@ class GodunovRun {
   // [output] outputHdf5=yes is served by a raw dump <prefix>_NNNNNNN.rgr (this image has no HDF5 library): the role of the
   // reference's HDF5 files -- lossless state, optionally with the ghost cells ([output] ghostIncluded), step count and time
   void outputRestart(int nStep);
+  // [output] outputHdf5=yes with a loadable libhdf5: the reference's file format (hdf5_io.h), interchangeable with its files
+  void outputHdf5(int nStep);
+  struct H5Box h5_box(int nx, int ny, int nz) const;
   int inputRestart(const std::string& path, bool* ghosts_read);
   int read_restart(const std::string& path, int nx, int ny, int nz, double* dst, bool* ghosts_read);
   void inputRestartUpscaled(const std::string& path, bool* ghosts_read);
@@ -53,6 +57,7 @@ class GodunovRun {
   std::vector<double> h_U_;
   double totalTime_;
   bool restart_has_ghosts_;
+  bool warned_no_hdf5_, wrote_hdf5_;
   void check(int rc, const char* what);
 };
 

@@ -28,6 +28,7 @@ CASES = [
 
 
 def run(lib, base, ov, outdir, dump="no"):
+    os.environ["RGPU_RESTART_FORMAT"] = "rgr"   # these tests cover the raw dump (the fallback without libhdf5); .h5: test_hdf5_io.py
     err = C.create_string_buffer(512)
     mc = C.c_double(0)
     full = ov + ";output.outputVtk=yes;output.outputHdf5=%s;output.ghostIncluded=yes;output.outputDir=%s" % (dump, outdir)
@@ -110,6 +111,28 @@ def read_dump(path):
     return dict(nx=nx, ny=ny, nz=nz, gw=gw, nv=nv, ghosts=bool(gi), nstep=nstep, t=t), a
 
 
+def read_state(path, three_d):
+    """read_dump for both formats"""
+    if path.endswith(".rgr"):
+        return read_dump(path)
+    import h5util
+    d, at = h5util.read(path)
+    names = [n for n in h5util.NAMES if n in d]
+    gw = 3 if len(names) == 8 else 2
+    gi = bool(at["ghost zone included"])
+    nx, ny, nz = at["nx"], at["ny"], at["nz"]
+    shape = (len(names), nz + 2 * gw if three_d else 1, ny + 2 * gw, nx + 2 * gw)
+    a = np.zeros(shape)
+    for v, n in enumerate(names):
+        x = d[n] if three_d else d[n][None]
+        if gi:
+            a[v] = x
+        else:
+            ks = slice(gw, gw + nz) if three_d else slice(0, 1)
+            a[v][ks, gw:gw + ny, gw:gw + nx] = x
+    return dict(nx=nx, ny=ny, nz=nz, gw=gw, nv=len(names), ghosts=gi, nstep=at["time step"], t=at["total time"]), a
+
+
 def upscale_expected(low, gw, three_d, mhd):
     """numpy statement of the rule: every fine cell (ghosts included) takes coarse cell (index + gw) // 2; the face field on
     a fine face in the middle of a coarse cell is the mean of the two coarse faces along its own direction"""
@@ -139,22 +162,25 @@ UPSCALE_CASES = [
 ]
 
 
-def check_upscale(lib, base, ovf, dims, ghosts, tmp_path):
+def check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt="rgr"):
+    """fmt: "rgr" = the raw dump, "h5" = the reference's HDF5 format (needs libhdf5)"""
     a, b = tmp_path / "coarse", tmp_path / "fine"
     a.mkdir(); b.mkdir()
     d = dims[:2] if dims[2] == 1 else dims
     common = ";run.noutput=1;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=%s" % ghosts
     err = C.create_string_buffer(512); mc = C.c_double(0)
+    os.environ["RGPU_RESTART_FORMAT"] = fmt
+    ext = ".h5" if fmt == "h5" else ".rgr"
     ov = (ovf % d) + common + ";run.nstepmax=4;output.outputDir=%s" % a
     assert lib.lib.rgpuh_run(ini(base).encode(), ov.encode(), C.byref(mc), err, 512) == 4, err.value
-    src = sorted(f for f in os.listdir(a) if f.endswith("0000004.rgr"))[0]
+    src = sorted(f for f in os.listdir(a) if f.endswith("0000004" + ext))[0]
     (b / src).write_bytes((a / src).read_bytes())
-    hl, low = read_dump(str(a / src))
+    hl, low = read_state(str(a / src), dims[2] != 1)
     assert hl["nstep"] == 4 and hl["ghosts"] == (ghosts == "yes")
     fine = tuple(2 * x for x in d)
     ov = (ovf % fine) + common + ";run.nstepmax=3;run.restart=yes;run.restart_upscale=yes;run.restart_filename=%s;output.outputDir=%s" % (src, b)
     assert lib.lib.rgpuh_run(ini(base).encode(), ov.encode(), C.byref(mc), err, 512) == 3, err.value
-    h0, u0 = read_dump(str(b / [f for f in os.listdir(b) if f.endswith("0000000.rgr")][0]))
+    h0, u0 = read_state(str(b / [f for f in os.listdir(b) if f.endswith("0000000" + ext)][0]), dims[2] != 1)
     assert h0["nstep"] == 0 and h0["t"] == hl["t"]          # the time of the coarse run, a fresh step count
     gw, three_d, mhd = hl["gw"], dims[2] != 1, hl["nv"] == 8
     want = upscale_expected(low, gw, three_d, mhd)
@@ -172,7 +198,7 @@ def check_upscale(lib, base, ovf, dims, ghosts, tmp_path):
         if three_d:
             div = div + (bz[gw + 1:-gw + 1, gw:-gw, gw:-gw] - bz[gw:-gw, gw:-gw, gw:-gw]) * fine[2]
         assert np.abs(div).max() < 1e-10 * max(1.0, np.abs(bx).max() * max(fine))
-    h3, u3 = read_dump(str(b / [f for f in os.listdir(b) if f.endswith("0000003.rgr")][0]))
+    h3, u3 = read_state(str(b / [f for f in os.listdir(b) if f.endswith("0000003" + ext)][0]), dims[2] != 1)
     assert h3["nstep"] == 3 and h3["t"] > hl["t"] and np.isfinite(u3).all()
 
 
@@ -188,3 +214,11 @@ def test_restart_upscale_emu(base, ovf, dims, ghosts, emu_lib, tmp_path):
 @pytest.mark.parametrize("base,ovf,dims,ghosts", UPSCALE_CASES[:3], ids=UIDS[:3])
 def test_restart_upscale_gpu(base, ovf, dims, ghosts, gpu_lib, tmp_path):
     check_upscale(gpu_lib, base, ovf, dims, ghosts, tmp_path)
+
+
+@pytest.mark.parametrize("base,ovf,dims,ghosts", UPSCALE_CASES[:4], ids=UIDS[:4])
+def test_restart_upscale_from_hdf5_emu(base, ovf, dims, ghosts, emu_lib, tmp_path):
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    check_upscale(emu_lib, base, ovf, dims, ghosts, tmp_path, fmt="h5")
