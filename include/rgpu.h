@@ -350,6 +350,25 @@ int rgpuh_init_forcing(const char* ini_path, const char* overrides, const rgpu_p
  * MHDRunGodunov.cpp:4064-4068. */
 int rgpuh_run(const char* ini_path, const char* overrides, double* mcell_per_s, char* err, int err_len);
 
+/* The run loop of rgpuh_run with the stepping delegated -- the seam of the z-slab front end (include/rgpu_comm.h fills the
+ * hooks with the slab driver; euler_hip --slabs N).  The run builds the context of slab `slab_rank` of `slab_count` and its
+ * initial state (initial condition, or [run] restart from the .h5 of the whole box), calls attach(user, ctx, &hooks), then
+ * runs the reference's time loop through the hooks: ghost fill, dt, one step; outputs go to ONE HDF5 file per output step for
+ * the whole box (the ranks take turns, hooks.barrier between them) and are identical to the single-domain files; detach(user)
+ * at the end.  Returns the number of steps or a negative error code (message in err). */
+typedef struct rgpuh_step_hooks {
+  void* self;
+  int (*make_all_boundaries)(void* self, int parity, double totalTime, double dt);
+  int (*compute_dt)(void* self, int useU, double* dt);
+  int (*one_step_integration)(void* self, int* nStep, double* totalTime, double* dt);
+  int (*barrier)(void* self);
+  const char* (*last_error)(void* self);
+} rgpuh_step_hooks;
+typedef int (*rgpuh_attach_fn)(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* hooks);
+typedef void (*rgpuh_detach_fn)(void* user);
+int rgpuh_run_hooked(const char* ini_path, const char* overrides, int slab_rank, int slab_count, rgpuh_attach_fn attach,
+                     rgpuh_detach_fn detach, void* user, double* mcell_per_s, char* err, int err_len);
+
 #ifdef __cplusplus
 }
 #endif

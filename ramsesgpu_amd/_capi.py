@@ -188,5 +188,5 @@ DECLARED_SYMBOLS = [
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_core_planes_split", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
-    "rgpu_backend_name", "rgpu_arithmetic", "rgpu_selftest_arith", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpu_ou_forcing_get_state", "rgpu_ou_forcing_set_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run",
+    "rgpu_backend_name", "rgpu_arithmetic", "rgpu_selftest_arith", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpu_ou_forcing_get_state", "rgpu_ou_forcing_set_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run", "rgpuh_run_hooked",
 ]

@@ -247,59 +247,52 @@ int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double*
   return RGPU_OK;
 }
 
-// euler_hip --slabs: the time loop of start() (MHDRunGodunov.cpp:3801-4070) over the slabs, outputs left to the single-GPU
-// front end (each rank keeps its slab on its device)
+// euler_hip --slabs: the run loop of the single-GPU front end (rgpuh_run_hooked in librgpu: initial condition or restart of this
+// slab, the reference's time loop, HDF5 outputs of the whole box written slab after slab) stepping through this driver
+namespace {
+struct SlabAttach {
+  int rank, nranks;
+  const char* id;
+  rgpu_comm* cm;
+  std::string err;
+};
+int hook_make_all_boundaries(void* self, int parity, double t, double dt) { return rgpu_comm_make_all_boundaries(static_cast<SlabAttach*>(self)->cm, parity, t, dt); }
+int hook_compute_dt(void* self, int useU, double* dt) { return rgpu_comm_compute_dt(static_cast<SlabAttach*>(self)->cm, useU, dt); }
+int hook_one_step(void* self, int* nStep, double* t, double* dt) { return rgpu_comm_one_step_integration(static_cast<SlabAttach*>(self)->cm, nStep, t, dt); }
+int hook_barrier(void* self) {
+  rgpu_comm* cm = static_cast<SlabAttach*>(self)->cm;
+  if (rgpu_synchronize(cm->ctx)) return RGPU_EHIP;
+  return rgpu_transport::barrier(cm->tc, rgpu_stream_handle(cm->ctx)) ? RGPU_EHIP : 0;
+}
+const char* hook_last_error(void* self) {
+  SlabAttach* a = static_cast<SlabAttach*>(self);
+  if (!a->cm) return a->err.c_str();
+  return !a->cm->err.empty() ? a->cm->err.c_str() : rgpu_last_error(a->cm->ctx);
+}
+int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
+  SlabAttach* a = static_cast<SlabAttach*>(user);
+  h->self = a;
+  h->last_error = hook_last_error;
+  const int rc = rgpu_comm_create(ctx, a->rank, a->nranks, a->id, &a->cm);
+  if (rc) { a->err = a->cm ? a->cm->err : "rgpu_comm_create failed"; if (a->cm) { rgpu_comm_destroy(a->cm); a->cm = 0; } return rc; }
+  h->make_all_boundaries = hook_make_all_boundaries;
+  h->compute_dt = hook_compute_dt;
+  h->one_step_integration = hook_one_step;
+  h->barrier = hook_barrier;
+  return 0;
+}
+void slab_detach(void* user) {
+  SlabAttach* a = static_cast<SlabAttach*>(user);
+  if (a->cm) { rgpu_comm_destroy(a->cm); a->cm = 0; }
+}
+}  // namespace
+
 int rgpuh_run_slabs(const char* ini_path, const char* overrides, int rank, int nranks, int device,
                     const char id[RGPU_COMM_ID_BYTES], double* mcell_per_s, char* err, int err_len) {
+  if (!ini_path || !id) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "run_slabs: null argument"); return RGPU_EINVAL; }
   rgpu_transport::set_device(device);
-  auto say = [&](const std::string& m, int code) { if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", m.c_str()); return code; };
-  if (!ini_path || !id) return say("run_slabs: null argument", RGPU_EINVAL);
-  char e2[512] = {0};
-  std::string ov = overrides ? overrides : "";
-  char slab[64];
-  std::snprintf(slab, sizeof(slab), "%sslab.rank=%d;slab.count=%d", ov.empty() ? "" : ";", rank, nranks);
-  ov += slab;
-  rgpu_params p;
-  if (int rc = rgpuh_params_from_ini(ini_path, ov.c_str(), &p, e2, sizeof(e2))) return say(e2, rc);
-  int nStepmax = 0, nOutput = 0; double tEnd = 0;
-  if (int rc = rgpuh_run_settings(ini_path, ov.c_str(), &nStepmax, &tEnd, &nOutput, e2, sizeof(e2))) return say(e2, rc);
-  std::vector<double> hU(rgpu_state_elems(&p));
-  if (int rc = rgpuh_init_condition(ini_path, ov.c_str(), &p, hU.data(), e2, sizeof(e2))) return say(e2, rc);
-  rgpu_ctx* ctx = 0;
-  if (int rc = rgpu_create(&p, &ctx)) { const std::string m = ctx ? rgpu_last_error(ctx) : "allocation"; if (ctx) rgpu_destroy(ctx); return say("rgpu_create: " + m, rc); }
-  rgpu_comm* cm = 0;
-  int rc = rgpu_upload(ctx, hU.data(), 0);
-  std::vector<double>().swap(hU);
-  if (!rc && p.gravityEnabled == 2) {
-    std::vector<double> hG(3 * (rgpu_state_elems(&p) / p.nbVar));
-    if (rgpuh_init_gravity(ini_path, ov.c_str(), &p, hG.data(), e2, sizeof(e2)) == 1) rc = rgpu_set_gravity_field(ctx, hG.data());
-  }
-  if (!rc && p.randomForcingEnabled) {
-    std::vector<double> hF(3 * (rgpu_state_elems(&p) / p.nbVar));
-    if (rgpuh_init_forcing(ini_path, ov.c_str(), &p, hF.data(), e2, sizeof(e2)) == 1) rc = rgpu_set_forcing_field(ctx, hF.data());
-  }
-  if (rc) { const std::string m = rgpu_last_error(ctx); rgpu_destroy(ctx); return say("initial state: " + m, rc); }
-  rc = rgpu_comm_create(ctx, rank, nranks, id, &cm);
-  int nStep = 0;
-  double t = 0.0, dt = 0.0;
-  if (!rc) rc = rgpu_comm_make_all_boundaries(cm, 0, 0.0, 0.0);
-  // (h_U.copyTo(h_U2) of the reference is not needed: every step writes the whole output array)
-  if (!rc) rc = rgpu_transport::barrier(cm->tc, rgpu_stream_handle(ctx)) ? RGPU_EHIP : 0;
-  const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  while (!rc && t < tEnd && nStep < nStepmax) {
-    rc = rgpu_comm_one_step_integration(cm, &nStep, &t, &dt);
-    if (!rc && rank == 0 && nOutput > 0 && (nStep % nOutput) == 0) std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, t, dt);
-  }
-  if (!rc) rc = rgpu_synchronize(ctx);
-  if (!rc) rc = rgpu_transport::barrier(cm->tc, rgpu_stream_handle(ctx)) ? RGPU_EHIP : 0;
-  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::string msg;
-  if (rc) msg = cm && !cm->err.empty() ? cm->err : rgpu_last_error(ctx);
-  if (mcell_per_s) *mcell_per_s = wall > 0 ? (double)nStep * p.nx * p.ny * p.nz_global / wall / 1e6 : 0.0;
-  if (cm) rgpu_comm_destroy(cm);
-  rgpu_destroy(ctx);
-  if (rc) return say("run_slabs: " + msg, rc);
-  return nStep;
+  SlabAttach a = {rank, nranks, id, 0, std::string()};
+  return rgpuh_run_hooked(ini_path, overrides, rank, nranks, slab_attach, slab_detach, &a, mcell_per_s, err, err_len);
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ namespace {
 typedef int64_t hid_t;
 typedef int herr_t;
 typedef unsigned long long hsize_t;
-const unsigned kAccRdonly = 0x0000u, kAccTrunc = 0x0002u;   // H5F_ACC_RDONLY, H5F_ACC_TRUNC
+const unsigned kAccRdonly = 0x0000u, kAccRdwr = 0x0001u, kAccTrunc = 0x0002u;   // H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC
 const hid_t kDefault = 0;                                   // H5P_DEFAULT
 const int kScalar = 0, kSelectSet = 0, kScopeLocal = 0;     // H5S_SCALAR, H5S_SELECT_SET, H5F_SCOPE_LOCAL
 const size_t kVariable = (size_t)-1;                        // H5T_VARIABLE
@@ -138,21 +138,43 @@ std::vector<Field> fields_of(const H5Box& b) {
   return f;
 }
 
-// memory space = the ghosted array, with the whole of it or its interior selected; file space = what is on disk
+// memory space = the ghosted LOCAL array with planes [kmem0, kmem1) selected (all of x, y with ghosts, their interior
+// without); file space = the whole box on disk (nz_file planes of the same x-y extent) with the same number of planes
+// selected from plane kfile0 on.  2D: one "plane".
 struct Spaces { hid_t mem, file; int rank; };
-Spaces make_spaces(Api& a, const H5Box& b, bool ghosts) {
+Spaces make_spaces(Api& a, const H5Box& b, bool ghosts, hsize_t nz_file, hsize_t kmem0, hsize_t kmem1, hsize_t kfile0) {
   const hsize_t gw = (hsize_t)b.ghostWidth;
   const hsize_t full[3] = {(hsize_t)b.nz + 2 * gw, (hsize_t)b.ny + 2 * gw, (hsize_t)b.nx + 2 * gw};
   const hsize_t inner[3] = {(hsize_t)b.nz, (hsize_t)b.ny, (hsize_t)b.nx};
+  const hsize_t* xy = ghosts ? full : inner;
   const int rank = b.three_d ? 3 : 2, o = b.three_d ? 0 : 1;   // 2D: (ny, nx)
+  const hsize_t fdims[3] = {nz_file, xy[1], xy[2]};
+  const hsize_t count[3] = {kmem1 - kmem0, xy[1], xy[2]};
+  const hsize_t mstart[3] = {kmem0, ghosts ? 0 : gw, ghosts ? 0 : gw}, fstart[3] = {kfile0, 0, 0}, one[3] = {1, 1, 1};
   Spaces s;
   s.rank = rank;
   s.mem = a.Screate_simple(rank, full + o, 0);
-  s.file = a.Screate_simple(rank, (ghosts ? full : inner) + o, 0);
+  s.file = a.Screate_simple(rank, fdims + o, 0);
   chk(s.mem, "H5Screate_simple"); chk(s.file, "H5Screate_simple");
-  const hsize_t start_g[3] = {0, 0, 0}, start_i[3] = {gw, gw, gw}, one[3] = {1, 1, 1};
-  chk(a.Sselect_hyperslab(s.mem, kSelectSet, ghosts ? start_g : start_i, one, (ghosts ? full : inner) + o, one), "H5Sselect_hyperslab");
+  chk(a.Sselect_hyperslab(s.mem, kSelectSet, mstart + o, one, count + o, one), "H5Sselect_hyperslab");
+  chk(a.Sselect_hyperslab(s.file, kSelectSet, fstart + o, one, count + o, one), "H5Sselect_hyperslab");
   return s;
+}
+// the planes slab `r` of `n` contributes to / takes from a file of the whole box (see hdf5_io.h)
+struct ZRange { hsize_t nz_file, kmem0, kmem1, kfile0; };
+ZRange slab_range(const H5Box& b, int nz_global, int r, int n, bool ghosts, bool reading) {
+  const hsize_t gw = (hsize_t)b.ghostWidth, nzl = (hsize_t)b.nz;
+  ZRange z;
+  if (!b.three_d) { z.nz_file = 1; z.kmem0 = 0; z.kmem1 = 1; z.kfile0 = 0; return z; }
+  z.nz_file = (hsize_t)nz_global + (ghosts ? 2 * gw : 0);
+  if (!ghosts) { z.kmem0 = gw; z.kmem1 = gw + nzl; z.kfile0 = (hsize_t)r * nzl; }
+  else if (reading) { z.kmem0 = 0; z.kmem1 = nzl + 2 * gw; z.kfile0 = (hsize_t)r * nzl; }   // file plane = r * nzl + local plane
+  else {
+    z.kmem0 = (r == 0) ? 0 : gw;
+    z.kmem1 = (r == n - 1) ? nzl + 2 * gw : nzl + gw;
+    z.kfile0 = (hsize_t)r * nzl + z.kmem0;
+  }
+  return z;
 }
 
 template <class T>
@@ -182,33 +204,45 @@ bool hdf5_available(std::string* why) {
 
 void hdf5_write_state(const std::string& path, const double* U, const H5Box& b, bool ghostIncluded, int nStep, double totalTime,
                       int compressionLevel) {
+  hdf5_write_slab(path, U, b, b.nz, 0, 1, true, ghostIncluded, nStep, totalTime, compressionLevel);
+}
+
+void hdf5_write_slab(const std::string& path, const double* U, const H5Box& b, int nz_global, int slab_rank, int slab_count, bool create,
+                     bool ghostIncluded, int nStep, double totalTime, int compressionLevel) {
   Api& a = api();
   if (compressionLevel < 0 || compressionLevel > 9) compressionLevel = 0;   // the reference warns and falls back to 0
   const size_t gw = (size_t)b.ghostWidth;
   const size_t ncell = (b.nx + 2 * gw) * (b.ny + 2 * gw) * (b.three_d ? b.nz + 2 * gw : 1);
-  const hid_t file = a.Fcreate(path.c_str(), kAccTrunc, kDefault, kDefault);
-  chk(file, "H5Fcreate " + path);
-  const Spaces sp = make_spaces(a, b, ghostIncluded);
-  const hid_t dcpl = a.Pcreate(a.cls_dataset_create);
-  chk(dcpl, "H5Pcreate");
-  const hsize_t chunk[3] = {(hsize_t)b.nz, (hsize_t)b.ny, (hsize_t)b.nx};
-  chk(a.Pset_chunk(dcpl, sp.rank, chunk + (b.three_d ? 0 : 1)), "H5Pset_chunk");
-  chk(a.Pset_shuffle(dcpl), "H5Pset_shuffle");
-  chk(a.Pset_deflate(dcpl, (unsigned)compressionLevel), "H5Pset_deflate");
+  const hid_t file = create ? a.Fcreate(path.c_str(), kAccTrunc, kDefault, kDefault) : a.Fopen(path.c_str(), kAccRdwr, kDefault);
+  chk(file, (create ? "H5Fcreate " : "H5Fopen (read-write) ") + path);
+  const ZRange z = slab_range(b, nz_global, slab_rank, slab_count, ghostIncluded, false);
+  const Spaces sp = make_spaces(a, b, ghostIncluded, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
+  hid_t dcpl = -1;
+  if (create) {
+    dcpl = a.Pcreate(a.cls_dataset_create);
+    chk(dcpl, "H5Pcreate");
+    const hsize_t chunk[3] = {(hsize_t)(b.three_d ? nz_global : 1), (hsize_t)b.ny, (hsize_t)b.nx};
+    chk(a.Pset_chunk(dcpl, sp.rank, chunk + (b.three_d ? 0 : 1)), "H5Pset_chunk");
+    chk(a.Pset_shuffle(dcpl), "H5Pset_shuffle");
+    chk(a.Pset_deflate(dcpl, (unsigned)compressionLevel), "H5Pset_deflate");
+  }
+  // the extent of a dataset is that of the file space (the selection only says which part is written now)
   for (const Field& f : fields_of(b)) {
-    const hid_t ds = a.Dcreate2(file, f.name, a.native_double, sp.file, kDefault, dcpl, kDefault);
-    chk(ds, std::string("H5Dcreate2 ") + f.name);
+    const hid_t ds = create ? a.Dcreate2(file, f.name, a.native_double, sp.file, kDefault, dcpl, kDefault) : a.Dopen2(file, f.name, kDefault);
+    chk(ds, std::string(create ? "H5Dcreate2 " : "H5Dopen2 ") + f.name);
     chk(a.Dwrite(ds, a.native_double, sp.mem, sp.file, kDefault, U + (size_t)f.var * ncell), std::string("H5Dwrite ") + f.name);
     a.Dclose(ds);
   }
-  write_scalar_attr(a, file, "time step", a.native_int, nStep);
-  write_scalar_attr(a, file, "total time", a.native_double, totalTime);
-  write_scalar_attr(a, file, "nx", a.native_int, b.nx);
-  write_scalar_attr(a, file, "ny", a.native_int, b.ny);
-  write_scalar_attr(a, file, "nz", a.native_int, b.nz);
-  const int gi = ghostIncluded ? 1 : 0;
-  write_scalar_attr(a, file, "ghost zone included", a.native_int, gi);
-  {   // "creation date": one variable-length string
+  if (create) {
+    write_scalar_attr(a, file, "time step", a.native_int, nStep);
+    write_scalar_attr(a, file, "total time", a.native_double, totalTime);
+    write_scalar_attr(a, file, "nx", a.native_int, b.nx);
+    write_scalar_attr(a, file, "ny", a.native_int, b.ny);
+    const int nzg = b.three_d ? nz_global : b.nz;
+    write_scalar_attr(a, file, "nz", a.native_int, nzg);
+    const int gi = ghostIncluded ? 1 : 0;
+    write_scalar_attr(a, file, "ghost zone included", a.native_int, gi);
+    // "creation date": one variable-length string
     const std::string date = current_date_utc();
     const char* ptr = date.c_str();
     const hid_t st = a.Tcopy(a.c_s1);
@@ -220,8 +254,8 @@ void hdf5_write_state(const std::string& path, const double* U, const H5Box& b, 
     chk(at, "H5Acreate2 creation date");
     chk(a.Awrite(at, st, &ptr), "H5Awrite creation date");
     a.Aclose(at); a.Sclose(dsp); a.Tclose(st);
+    a.Pclose(dcpl);
   }
-  a.Pclose(dcpl);
   a.Sclose(sp.mem);
   a.Sclose(sp.file);
   a.Fflush(file, kScopeLocal);
@@ -229,6 +263,11 @@ void hdf5_write_state(const std::string& path, const double* U, const H5Box& b, 
 }
 
 int hdf5_read_state(const std::string& path, double* U, const H5Box& b, double* totalTime, bool* ghostsInFile) {
+  return hdf5_read_slab(path, U, b, b.nz, 0, 1, totalTime, ghostsInFile);
+}
+
+int hdf5_read_slab(const std::string& path, double* U, const H5Box& b, int nz_global, int slab_rank, int slab_count, double* totalTime,
+                   bool* ghostsInFile) {
   Api& a = api();
   const size_t gw = (size_t)b.ghostWidth;
   const size_t ncell = (b.nx + 2 * gw) * (b.ny + 2 * gw) * (b.three_d ? b.nz + 2 * gw : 1);
@@ -245,7 +284,7 @@ int hdf5_read_state(const std::string& path, double* U, const H5Box& b, double* 
     if (rank == (b.three_d ? 3 : 2)) a.Sget_simple_extent_dims(fs, dims, 0);
     a.Sclose(fs);
     a.Dclose(ds);
-    const hsize_t inner[3] = {(hsize_t)b.nz, (hsize_t)b.ny, (hsize_t)b.nx};
+    const hsize_t inner[3] = {(hsize_t)(b.three_d ? nz_global : 1), (hsize_t)b.ny, (hsize_t)b.nx};
     const int o = b.three_d ? 0 : 1, n = b.three_d ? 3 : 2;
     bool is_inner = rank == n, is_full = rank == n;
     for (int d = 0; d < n; ++d) {
@@ -262,7 +301,8 @@ int hdf5_read_state(const std::string& path, double* U, const H5Box& b, double* 
     }
     ghosts = is_full;
   }
-  const Spaces sp = make_spaces(a, b, ghosts);
+  const ZRange z = slab_range(b, nz_global, slab_rank, slab_count, ghosts, true);
+  const Spaces sp = make_spaces(a, b, ghosts, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
   for (const Field& f : fields_of(b)) {
     const hid_t ds = a.Dopen2(file, f.name, kDefault);
     if (ds < 0) { a.Fclose(file); throw std::runtime_error("restart: " + path + " has no dataset " + f.name); }

@@ -34,6 +34,17 @@ void hdf5_write_state(const std::string& path, const double* U, const H5Box& b, 
 // interior otherwise (ghost cells of U untouched).  Returns the "time step" attribute; *totalTime, *ghostsInFile set.
 int hdf5_read_state(const std::string& path, double* U, const H5Box& b, double* totalTime, bool* ghostsInFile);
 
+// z-slab runs (one process per slab, 3D): ONE file for the whole box, identical to the single-domain file.  b describes the
+// LOCAL slab (b.nz = its planes); the file holds nz_global planes.  Serial HDF5: the ranks take turns -- rank 0 first, with
+// create = true (creates the file, the datasets at the extents of the whole box, the attributes), then every other rank opens
+// it read-write and adds the planes it owns (its interior planes; with ghostIncluded the first / last rank also write the low /
+// high z ghost planes).  The caller provides the turn taking (a barrier between ranks).
+void hdf5_write_slab(const std::string& path, const double* U, const H5Box& b, int nz_global, int slab_rank, int slab_count, bool create,
+                     bool ghostIncluded, int nStep, double totalTime, int compressionLevel);
+// every rank reads its planes (with its z ghost planes when the file holds ghosts) from the file of the whole box
+int hdf5_read_slab(const std::string& path, double* U, const H5Box& b, int nz_global, int slab_rank, int slab_count, double* totalTime,
+                   bool* ghostsInFile);
+
 // <prefix>.xmf in the CURRENT directory (as the reference does), entries for steps 0, nOutput, ... <= totalNumberOfSteps
 void xdmf_write_wrapper(const std::string& outputPrefix, const H5Box& b, bool ghostIncluded, int totalNumberOfSteps, int nOutput);
 

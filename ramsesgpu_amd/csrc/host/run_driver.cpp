@@ -18,8 +18,11 @@
 
 namespace rgpu_host {
 
-GodunovRun::GodunovRun(const IniConfig& cfg) : cfg_(cfg), ctx_(0), totalTime_(0.0), restart_has_ghosts_(false), warned_no_hdf5_(false), wrote_hdf5_(false) {
-  params_from_config(cfg_, 0, 1, &p_, &rs_);
+GodunovRun::GodunovRun(const IniConfig& cfg, int slab_rank, int slab_count)
+    : cfg_(cfg), ctx_(0), totalTime_(0.0), restart_has_ghosts_(false), warned_no_hdf5_(false), wrote_hdf5_(false), hooked_(false),
+      noted_vtk_(false), noted_hist_(false) {
+  std::memset(&hooks_, 0, sizeof(hooks_));
+  params_from_config(cfg_, slab_rank, slab_count, &p_, &rs_);
   const int rc = rgpu_create(&p_, &ctx_);
   if (rc) {
     const std::string msg = ctx_ ? rgpu_last_error(ctx_) : "allocation failure";
@@ -50,6 +53,7 @@ int GodunovRun::init_simulation() {
     restart_has_ghosts_ = false;
     const bool h5 = path.size() > 3 && path.substr(path.size() - 3) == ".h5";
     const bool dump = h5 || (path.size() > 4 && path.substr(path.size() - 4) == ".rgr");
+    if (rs_.restartUpscale && slab()) throw std::runtime_error("restart_upscale is single-domain only");
     if (rs_.restartUpscale) {
       if (!dump) throw std::runtime_error("restart_upscale reads an .h5 file or a .rgr dump ([output] outputHdf5=yes in the coarse run)");
       if (p_.nx % 2 || p_.ny % 2 || (p_.nz_global != 1 && p_.nz % 2)) throw std::runtime_error("restart_upscale: nx, ny, nz must be even");
@@ -74,9 +78,21 @@ int GodunovRun::init_simulation() {
   return timeStep;
 }
 
-void GodunovRun::make_all_boundaries(int parity) { check(rgpu_make_all_boundaries(ctx_, parity, totalTime_, 0.0), "make_all_boundaries"); }
+void GodunovRun::hook_check(int rc, const char* what) {
+  if (rc) throw std::runtime_error(std::string(what) + ": " + (hooks_.last_error ? hooks_.last_error(hooks_.self) : "slab driver error"));
+}
+void GodunovRun::note_once(bool* flag, const char* msg) {
+  if (!*flag && p_.slab_rank == 0) std::cerr << msg << "\n";
+  *flag = true;
+}
+
+void GodunovRun::make_all_boundaries(int parity) {
+  if (hooked_) { hook_check(hooks_.make_all_boundaries(hooks_.self, parity, totalTime_, 0.0), "make_all_boundaries"); return; }
+  check(rgpu_make_all_boundaries(ctx_, parity, totalTime_, 0.0), "make_all_boundaries");
+}
 
 double GodunovRun::compute_dt(int useU) {
+  if (hooked_) { double d = 0.0; hook_check(hooks_.compute_dt(hooks_.self, useU, &d), "compute_dt"); return d; }
   const double dt = rgpu_compute_dt(ctx_, useU);
   if (!(dt == dt)) throw std::runtime_error(std::string("compute_dt: ") + rgpu_last_error(ctx_));
   return dt;
@@ -86,6 +102,7 @@ void GodunovRun::godunov_unsplit(int nStep, double dt) { check(rgpu_godunov_unsp
 
 // MHDRunGodunov.cpp:4077-4089 / HydroRunGodunov.cpp:4082-4126 (unsplit branch)
 void GodunovRun::oneStepIntegration(int& nStep, double& t, double& dt) {
+  if (hooked_) { hook_check(hooks_.one_step_integration(hooks_.self, &nStep, &t, &dt), "oneStepIntegration"); return; }
   dt = compute_dt(nStep % 2);
   godunov_unsplit(nStep, dt);
   nStep++;
@@ -151,8 +168,10 @@ H5Box GodunovRun::h5_box(int nx, int ny, int nz) const {
 // [output] outputHdf5=yes: the reference's HDF5 file (hdf5_io.h) when libhdf5 can be loaded, the raw dump below otherwise
 void GodunovRun::outputHdf5(int nStep) {
   const char* fmt = std::getenv("RGPU_RESTART_FORMAT");   // "rgr": the raw dump even when HDF5 is there
-  if (fmt && std::string(fmt) == "rgr") { outputRestart(nStep); return; }
   std::string why;
+  if (slab() && ((fmt && std::string(fmt) == "rgr") || !hdf5_available(&why)))
+    throw std::runtime_error("outputs of a z-slab run go to one HDF5 file for the whole box: " + (why.empty() ? std::string("RGPU_RESTART_FORMAT=rgr is single-domain only") : why));
+  if (fmt && std::string(fmt) == "rgr") { outputRestart(nStep); return; }
   if (!hdf5_available(&why)) {
     if (!warned_no_hdf5_) { std::cerr << "outputHdf5: " << why << " -- writing raw .rgr dumps instead\n"; warned_no_hdf5_ = true; }
     outputRestart(nStep);
@@ -161,7 +180,16 @@ void GodunovRun::outputHdf5(int nStep) {
   std::ostringstream fn;
   fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".h5";
   const bool three_d = p_.nz_global != 1;
-  hdf5_write_state(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, three_d ? p_.nz : 1), rs_.ghostIncluded, nStep, totalTime_, rs_.hdf5CompressionLevel);
+  if (slab()) {   // one file for the whole box: the slabs take turns, rank 0 creates it (hdf5_io.h)
+    for (int r = 0; r < p_.slab_count; ++r) {
+      if (r == p_.slab_rank)
+        hdf5_write_slab(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, p_.nz), p_.nz_global, p_.slab_rank, p_.slab_count, r == 0, rs_.ghostIncluded, nStep,
+                        totalTime_, rs_.hdf5CompressionLevel);
+      hook_check(hooks_.barrier(hooks_.self), "barrier");
+    }
+  } else {
+    hdf5_write_state(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, three_d ? p_.nz : 1), rs_.ghostIncluded, nStep, totalTime_, rs_.hdf5CompressionLevel);
+  }
   wrote_hdf5_ = true;
 }
 
@@ -195,10 +223,12 @@ void GodunovRun::outputRestart(int nStep) {
 int GodunovRun::read_restart(const std::string& path, int nx_want, int ny_want, int nz_want, double* dst, bool* ghosts_read) {
   if (path.size() > 3 && path.substr(path.size() - 3) == ".h5") {   // inputHdf5 (HydroRunBase.cpp:4818-5155)
     double t = 0.0;
-    const int step = hdf5_read_state(path, dst, h5_box(nx_want, ny_want, nz_want), &t, ghosts_read);
+    const int step = slab() ? hdf5_read_slab(path, dst, h5_box(nx_want, ny_want, nz_want), p_.nz_global, p_.slab_rank, p_.slab_count, &t, ghosts_read)
+                            : hdf5_read_state(path, dst, h5_box(nx_want, ny_want, nz_want), &t, ghosts_read);
     totalTime_ = rs_.restartResetTotalTime ? 0.0 : t;
     return step;
   }
+  if (slab()) throw std::runtime_error("restart: a z-slab run resumes from the .h5 file of the whole box");
   std::ifstream in(path.c_str(), std::ios::binary);
   if (!in) throw std::runtime_error("restart: cannot read " + path);
   std::string line;
@@ -427,8 +457,16 @@ void GodunovRun::history(int nStep, double dt) {
     histo << totalTime_ << "\t" << dt << "\t" << h[0] << "\t" << h[7] << "\n";
 }
 
-int GodunovRun::start(double* mcell_per_s) {
+int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
   int nStep = init_simulation();
+  if (attach) {   // the slab driver takes over the stepping from here (rgpuh_run_hooked)
+    rgpuh_step_hooks h;
+    std::memset(&h, 0, sizeof(h));
+    if (attach(user, ctx_, &h) || !h.make_all_boundaries || !h.compute_dt || !h.one_step_integration || !h.barrier)
+      throw std::runtime_error(std::string("attaching the slab driver failed") + (h.last_error ? std::string(": ") + h.last_error(h.self) : std::string()));
+    set_hooks(h);
+  }
+  if (slab() && !hooked_) throw std::runtime_error("a z-slab context needs the slab driver (rgpuh_run_hooked / euler_hip --slabs)");
   if (!(rs_.restartEnabled && restart_has_ghosts_)) {   // a restart file with ghosts needs no fill (MHDRunGodunov.cpp:3818-3824)
     make_all_boundaries(0);
     // h_U.copyTo(h_U2): refresh both device arrays from the ghost-filled one
@@ -437,7 +475,7 @@ int GodunovRun::start(double* mcell_per_s) {
   }
   if (!rs_.restartEnabled) totalTime_ = 0.0;   // a restarted run keeps the time of its file (MHDRunGodunov.cpp:3866-3880)
   double dt = compute_dt(0);
-  std::cout << "Initial dt : " << std::setprecision(8) << dt << std::endl;
+  if (p_.slab_rank == 0) std::cout << "Initial dt : " << std::setprecision(8) << dt << std::endl;
   double io_seconds = 0.0;
   // history cadence of MHDRunGodunov::start (MHDRunGodunov.cpp:3913-3916, 3975-3984)
   const bool historyEnabled = p_.mhdEnabled && cfg_.get_bool("history", "enabled", false);
@@ -445,45 +483,75 @@ int GodunovRun::start(double* mcell_per_s) {
   double tHist = totalTime_;   // MHDRunGodunov.cpp:3916
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
-    if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0)
+    if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0 && p_.slab_rank == 0)
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     if (rs_.nOutput > 0 && (nStep % rs_.nOutput) == 0) {   // noutput <= 0: no output (the reference divides by zero here)
       const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
       if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
-      if (rs_.outputVtk) outputVtk(nStep);
+      if (rs_.outputVtk && !slab()) outputVtk(nStep);
+      if (rs_.outputVtk && slab()) note_once(&noted_vtk_, "z-slab run: outputs go to HDF5 ([output] outputHdf5=yes), no .vti is written");
       if (rs_.outputRestart) outputHdf5(nStep);
-      if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
+      if ((rs_.outputVtk || rs_.outputRestart) && p_.slab_rank == 0) save_forcing_process(nStep);
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-      std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
+      if (p_.slab_rank == 0) std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     }
-    if (historyEnabled && (tHist == 0 || ((totalTime_ - dt <= tHist + dtHist) && (totalTime_ > tHist + dtHist)))) {
+    if (historyEnabled && slab()) note_once(&noted_hist_, "z-slab run: the history file is not written");
+    if (historyEnabled && !slab() && (tHist == 0 || ((totalTime_ - dt <= tHist + dtHist) && (totalTime_ > tHist + dtHist)))) {
       history(nStep, dt);
       tHist += dtHist;
     }
     oneStepIntegration(nStep, totalTime_, dt);
   }
   check(rgpu_synchronize(ctx_), "synchronize");
+  if (hooked_) hook_check(hooks_.barrier(hooks_.self), "barrier");
   {
     const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
     if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
-    if (rs_.outputVtk) outputVtk(nStep);
+    if (rs_.outputVtk && !slab()) outputVtk(nStep);
     if (rs_.outputRestart) outputHdf5(nStep);
-    if (rs_.outputVtk || rs_.outputRestart) save_forcing_process(nStep);
+    if ((rs_.outputVtk || rs_.outputRestart) && p_.slab_rank == 0) save_forcing_process(nStep);
     // the XDMF index of the .h5 files of this run, in the current directory (MHDRunGodunov.cpp:4004)
-    if (wrote_hdf5_) xdmf_write_wrapper(rs_.outputPrefix, h5_box(p_.nx, p_.ny, (p_.nz_global != 1) ? p_.nz : 1), rs_.ghostIncluded, nStep, rs_.nOutput);
+    if (wrote_hdf5_ && p_.slab_rank == 0)
+      xdmf_write_wrapper(rs_.outputPrefix, h5_box(p_.nx, p_.ny, (p_.nz_global != 1) ? p_.nz_global : 1), rs_.ghostIncluded, nStep, rs_.nOutput);
     io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
   }
   const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  const double nz = (p_.nz_global != 1) ? p_.nz : 1;
+  const double nz = (p_.nz_global != 1) ? p_.nz_global : 1;   // a slab reports the rate of the whole box
   const double rate = 1.0 * nStep * p_.nx * p_.ny * nz / (total - io_seconds);
-  std::cout << "DEBUG : totalTime " << std::setprecision(12) << totalTime_ << std::endl;
-  std::cout << "####################################\nGlobal performance                  \n"
-            << rate << " cell updates per seconds (based on wall time)\n####################################\n";
+  if (p_.slab_rank == 0) {
+    std::cout << "DEBUG : totalTime " << std::setprecision(12) << totalTime_ << std::endl;
+    std::cout << "####################################\nGlobal performance                  \n"
+              << rate << " cell updates per seconds (based on wall time)\n####################################\n";
+  }
   if (mcell_per_s) *mcell_per_s = rate / 1e6;
   return nStep;
 }
 
 }  // namespace rgpu_host
+
+extern "C" int rgpuh_run_hooked(const char* ini_path, const char* overrides, int slab_rank, int slab_count, rgpuh_attach_fn attach,
+                                rgpuh_detach_fn detach, void* user, double* mcell_per_s, char* err, int err_len) {
+  int n = RGPU_EINVAL;
+  try {
+    if (!attach) throw std::runtime_error("run_hooked: no attach function");
+    rgpu_host::IniConfig cfg;
+    const int rc = cfg.load_file(ini_path ? ini_path : "");
+    if (rc != 0) throw std::runtime_error(std::string("cannot read parameter file ") + (ini_path ? ini_path : "(null)"));
+    if (overrides) cfg.apply_overrides(overrides);
+    rgpu_host::GodunovRun run(cfg, slab_rank, slab_count);
+    try {
+      n = run.start(mcell_per_s, attach, user);
+    } catch (...) {
+      if (detach) detach(user);   // the slab driver refers to the context: release it before the run object goes
+      throw;
+    }
+    if (detach) detach(user);
+  } catch (const std::exception& e) {
+    if (err && err_len > 0) std::snprintf(err, static_cast<size_t>(err_len), "%s", e.what());
+    return RGPU_EINVAL;
+  }
+  return n;
+}
 
 extern "C" int rgpuh_run(const char* ini_path, const char* overrides, double* mcell_per_s, char* err, int err_len) {
   try {

@@ -18,7 +18,10 @@ struct H5Box;
 
 class GodunovRun {
  public:
-  explicit GodunovRun(const IniConfig& cfg);
+  // slab_count > 1: slab slab_rank of a z-slab run; the stepping then goes through hooks (set_hooks) of the slab driver
+  explicit GodunovRun(const IniConfig& cfg, int slab_rank = 0, int slab_count = 1);
+  void set_hooks(const rgpuh_step_hooks& h) { hooks_ = h; hooked_ = true; }
+  rgpu_ctx* ctx() { return ctx_; }
   ~GodunovRun();
 
   int init_simulation();                                   // initial condition -> h_U -> device U and U2
@@ -29,7 +32,8 @@ class GodunovRun {
   void copyGpuToCpu(int nStep);
   std::vector<double>& getDataHost() { return h_U_; }
   // time loop of start(); returns the number of steps; *mcell = "cell updates per second" / 1e6
-  int start(double* mcell_per_s);
+  // attach (may be 0): called once the context holds its initial state, before the first ghost fill (rgpuh_run_hooked)
+  int start(double* mcell_per_s, rgpuh_attach_fn attach = 0, void* user = 0);
   void outputVtk(int nStep);
   // restart=yes: read the interior fields, the step count and the time back from a .vti this driver wrote
   int inputVtk(const std::string& path);
@@ -58,6 +62,12 @@ class GodunovRun {
   double totalTime_;
   bool restart_has_ghosts_;
   bool warned_no_hdf5_, wrote_hdf5_;
+  bool hooked_;
+  rgpuh_step_hooks hooks_;
+  bool slab() const { return p_.slab_count > 1; }
+  void hook_check(int rc, const char* what);
+  void note_once(bool* flag, const char* msg);
+  bool noted_vtk_, noted_hist_;
   void check(int rc, const char* what);
 };
 

@@ -62,7 +62,56 @@ def _allreduce(data, n, op):
         return 1
 
 
+def frontend():
+    """--frontend base overrides outdir resultfile: the z-slab FRONT END (rgpuh_run_slabs: run loop, HDF5 outputs of the whole box
+    written slab after slab, restart) on the emulation libraries; rank 0 then runs the single-domain front end (rgpuh_run) with
+    the same settings and requires the .h5 files of both runs to hold the same datasets and attributes."""
+    import h5util
+    base, ov, outdir, out = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+    CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
+    keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+    CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+    ids = [rcomm.unique_id(CL) if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ini = os.path.join(ROOT, "configs", base + ".ini")
+    slabs, single = os.path.join(outdir, "slabs"), os.path.join(outdir, "single")
+    if rank == 0:
+        os.makedirs(slabs, exist_ok=True); os.makedirs(single, exist_ok=True)
+    dist.barrier()
+    os.chdir(slabs)
+    err = C.create_string_buffer(512); mc = C.c_double(0)
+    CL.rgpuh_run_slabs.restype = C.c_int
+    CL.rgpuh_run_slabs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    n = CL.rgpuh_run_slabs(ini.encode(), (ov + ";output.outputDir=%s" % slabs).encode(), rank, world, 0, ids[0], C.byref(mc), err, 512)
+    ok, msg = n >= 0, err.value.decode()
+    dist.barrier()
+    if rank == 0 and ok:
+        os.chdir(single)
+        m = lib.lib.rgpuh_run(ini.encode(), (ov.replace(slabs, single) + ";output.outputDir=%s" % single).encode(), C.byref(mc), err, 512)
+        ok, msg = m == n, "steps %d vs %d %s" % (n, m, err.value.decode())
+        files = sorted(f for f in os.listdir(single) if f.endswith(".h5"))
+        ok = ok and len(files) >= 2 and files == sorted(f for f in os.listdir(slabs) if f.endswith(".h5"))
+        for f in files if ok else []:
+            da, aa = h5util.read(os.path.join(slabs, f)); db, ab = h5util.read(os.path.join(single, f))
+            same = aa == ab and sorted(da) == sorted(db) and all(np.array_equal(da[k], db[k]) for k in db)
+            if not same:
+                ok, msg = False, "%s differs: attrs %s / %s, %s" % (f, aa, ab, {k: int((da[k] != db[k]).sum()) for k in db if da[k].shape == db[k].shape})
+        xa = [f for f in os.listdir(slabs) if f.endswith(".xmf")]
+        ok = ok and len(xa) == 1 and open(os.path.join(slabs, xa[0])).read() == open(os.path.join(single, xa[0])).read()
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("OK\n" if ok else "FAILED %s\n" % msg)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
 def main():
+    if sys.argv[1] == "--frontend":
+        return frontend()
     base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()

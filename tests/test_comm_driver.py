@@ -96,6 +96,58 @@ def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm
     run_worker(base, ov, nsteps, world, overlap, tmp_path)
 
 
+# ---- the z-slab FRONT END (euler_hip --slabs N = rgpuh_run_slabs): run loop, one HDF5 file of the whole box per output step
+# written slab after slab, restart of every slab from such a file -- against the single-domain front end ----
+FRONTEND_CASES = [
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12;MRI.amp=0.2;run.nstepmax=6;run.noutput=3;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=yes", 2),
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=18;MRI.amp=0.2;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=no", 3),
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12;hydro.riemannSolver=hllc;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=no", 2),
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.outputHdf5CompressionLevel=4", 2),
+]
+
+
+def run_frontend(base, ov, world, outdir, tmp_path, timeout=300):
+    out = str(tmp_path / "result.txt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "comm_worker.py"), "--frontend", base, ov, str(outdir), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("RGPU_RESTART_FORMAT", None)
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert open(out).read().strip() == "OK", open(out).read()
+
+
+@pytest.mark.parametrize("base,ov,world", FRONTEND_CASES, ids=["%s-x%d-%d" % (c[0], c[2], n) for n, c in enumerate(FRONTEND_CASES)])
+def test_slab_front_end_writes_the_single_domain_files(base, ov, world, comm_emu_lib, tmp_path):
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    run_frontend(base, ov, world, tmp_path / "run", tmp_path)
+
+
+def test_slab_front_end_restarts_from_the_file_of_the_whole_box(comm_emu_lib, tmp_path):
+    """3 slabs resume at step 3 from the ghost-inclusive .h5 a 2-slab run wrote and end in the files of the uninterrupted
+    single-domain run (the worker compares the restarted slabs with a restarted single-domain run; both are compared with the
+    uninterrupted one here)"""
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    base = "mhd_mri_3d"
+    ov = "mesh.nx=6;mesh.ny=8;mesh.nz=12;MRI.amp=0.2;run.nstepmax=6;run.noutput=3;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=yes"
+    run_frontend(base, ov, 2, tmp_path / "a", tmp_path)
+    first = tmp_path / "a" / "slabs"
+    f3 = [f for f in os.listdir(first) if f.endswith("0000003.h5")][0]
+    for sub in ("slabs", "single"):
+        os.makedirs(tmp_path / "b" / sub)
+        (tmp_path / "b" / sub / f3).write_bytes((first / f3).read_bytes())
+    run_frontend(base, ov + ";run.restart=yes;run.restart_filename=%s" % f3, 3, tmp_path / "b", tmp_path)
+    f6 = f3.replace("0000003", "0000006")
+    da, aa = h5util.read(str(first / f6))
+    db, ab = h5util.read(str(tmp_path / "b" / "slabs" / f6))
+    assert aa == ab and all(np.array_equal(da[k], db[k]) for k in da)
+
+
 GPU_CASES = [
     ("mhd_mri_3d", "mesh.nx=32;mesh.ny=48;mesh.nz=40", 4, 1),            # periodic z: grouped ncclSend / ncclRecv to itself
     ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 1),
