@@ -78,23 +78,11 @@ bool global_id(void* so, const char* name, hid_t* out) {
   return true;
 }
 
-bool load() {
-  if (g_state) return g_state > 0;
-  g_state = -1;
-  std::vector<std::string> names;
-  if (const char* e = std::getenv("RGPU_HDF5_LIB")) names.push_back(e);
-  const char* defaults[] = {"libhdf5.so", "libhdf5.so.103", "libhdf5_serial.so", "libhdf5_serial.so.103", "libhdf5.so.200", "libhdf5.so.310",
-                            "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so"};
-  for (const char* d : defaults) names.push_back(d);
-  void* so = 0;
-  std::string tried;
-  for (const std::string& n : names) {
-    so = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (so) break;
-    tried += (tried.empty() ? "" : ", ") + n;
-  }
-  if (!so) { g_why = "no HDF5 library could be loaded (tried " + tried + "; set RGPU_HDF5_LIB)"; return false; }
-  Api& a = g_api;
+// binds one candidate library; false (g_why set) if it cannot be loaded, lacks an entry point or is older than 1.10
+bool bind(const std::string& name) {
+  void* so = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!so) { g_why = name + " cannot be loaded"; return false; }
+  Api a;
   a.so = so;
   const bool ok =
       sym(so, "H5open", &a.open) && sym(so, "H5get_libversion", &a.get_libversion) && sym(so, "H5Eset_auto2", &a.Eset_auto2) &&
@@ -107,16 +95,37 @@ bool load() {
       sym(so, "H5Dwrite", &a.Dwrite) && sym(so, "H5Dread", &a.Dread) && sym(so, "H5Dclose", &a.Dclose) && sym(so, "H5Acreate2", &a.Acreate2) &&
       sym(so, "H5Aopen", &a.Aopen) && sym(so, "H5Awrite", &a.Awrite) && sym(so, "H5Aread", &a.Aread) && sym(so, "H5Aclose", &a.Aclose) &&
       sym(so, "H5Tcopy", &a.Tcopy) && sym(so, "H5Tset_size", &a.Tset_size) && sym(so, "H5Tclose", &a.Tclose);
-  if (!ok) return false;
   unsigned maj = 0, min = 0, rel = 0;
-  if (a.open() < 0 || a.get_libversion(&maj, &min, &rel) < 0) { g_why = "H5open failed"; return false; }
-  if (maj == 1 && min < 10) { g_why = "HDF5 older than 1.10 (32-bit handles)"; return false; }
-  if (!global_id(so, "H5T_NATIVE_DOUBLE_g", &a.native_double) || !global_id(so, "H5T_NATIVE_INT_g", &a.native_int) ||
-      !global_id(so, "H5T_C_S1_g", &a.c_s1) || !global_id(so, "H5P_CLS_DATASET_CREATE_ID_g", &a.cls_dataset_create))
+  if (ok && (a.open() < 0 || a.get_libversion(&maj, &min, &rel) < 0)) { g_why = name + ": H5open failed"; dlclose(so); return false; }
+  if (ok && maj == 1 && min < 10) { g_why = name + " is older than HDF5 1.10 (32-bit handles)"; dlclose(so); return false; }
+  if (!ok || !global_id(so, "H5T_NATIVE_DOUBLE_g", &a.native_double) || !global_id(so, "H5T_NATIVE_INT_g", &a.native_int) ||
+      !global_id(so, "H5T_C_S1_g", &a.c_s1) || !global_id(so, "H5P_CLS_DATASET_CREATE_ID_g", &a.cls_dataset_create)) {
+    g_why = name + ": " + g_why;
+    dlclose(so);
     return false;
+  }
   a.Eset_auto2(0, 0, 0);   // no error stack dumps on stderr: failures are reported through exceptions here
-  g_state = 1;
+  g_api = a;
   return true;
+}
+
+bool load() {
+  if (g_state) return g_state > 0;
+  g_state = -1;
+  std::vector<std::string> names;
+  if (const char* e = std::getenv("RGPU_HDF5_LIB")) names.push_back(e);   // "none": no HDF5 (the callers fall back to the raw dump)
+  else {
+    const char* defaults[] = {"libhdf5.so", "libhdf5.so.103", "libhdf5_serial.so", "libhdf5_serial.so.103", "libhdf5.so.200", "libhdf5.so.310",
+                              "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so"};
+    for (const char* d : defaults) names.push_back(d);
+  }
+  std::string reasons;
+  for (const std::string& n : names) {
+    if (bind(n)) { g_state = 1; return true; }
+    reasons += (reasons.empty() ? "" : "; ") + g_why;
+  }
+  g_why = "no usable HDF5 library (" + reasons + "; set RGPU_HDF5_LIB)";
+  return false;
 }
 
 Api& api() {
