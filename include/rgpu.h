@@ -291,7 +291,7 @@ const char* rgpu_backend_name(void);
  *   "exact"       librgpu.so       no FMA contraction, correctly rounded division / square root, the reference's operand
  *                                  order: results bit-identical to the reference's CPU path
  *   "contracted"  librgpu_fast.so  the same sources with FMA contraction and ~1-ulp division / square root: results agree
- *                                  with the reference to round-off (relative L2 < 1e-12 on every golden fixture), ~15 %
+ *                                  with the reference to round-off (relative L2 < 1e-12 on every golden fixture), ~20 %
  *                                  faster on the 3D MHD step.  Same ABI: link one or the other. */
 const char* rgpu_arithmetic(void);
 

@@ -16,6 +16,7 @@ using rgpu::rg_recip;
 using rgpu::rg_div;
 using rgpu::rg_sqrt;
 using rgpu::rg_sqrt_pos;
+using rgpu::rg_recip_sqrt_pos;
 
 enum { ID = 0, IP = 1, IU = 2, IV = 3, IW = 4, IA = 5, IB = 6, IC = 7 };
 enum { XD = 0, YD = 1, ZD = 2 };
@@ -552,16 +553,16 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rstarRR = rg_div(rstarRRx * (ST - RR.v), iST);
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
-  const rg_recip_t iqLL = rg_recip(rg_sqrt_pos(rstarLL)), iqLR = rg_recip(rg_sqrt_pos(rstarLR));
-  const rg_recip_t iqRL = rg_recip(rg_sqrt_pos(rstarRL)), iqRR = rg_recip(rg_sqrt_pos(rstarRR));
-  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip(rg_sqrt_pos(rstarLRx))), rg_div(fabs(AstarLR), iqLR)),
-                                                  rg_div(fabs(LL.a), rg_recip(rg_sqrt_pos(rstarLLx)))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
-  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip(rg_sqrt_pos(rstarRRx))), rg_div(fabs(AstarRR), iqRR)),
-                                                  rg_div(fabs(RL.a), rg_recip(rg_sqrt_pos(rstarRLx)))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
-  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip(rg_sqrt_pos(rstarLLy))), rg_div(fabs(BstarLL), iqLL)),
-                                                  rg_div(fabs(RL.b), rg_recip(rg_sqrt_pos(rstarRLy)))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
-  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip(rg_sqrt_pos(rstarLRy))), rg_div(fabs(BstarLR), iqLR)),
-                                                  rg_div(fabs(RR.b), rg_recip(rg_sqrt_pos(rstarRRy)))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
+  const rg_recip_t iqLL = rg_recip_sqrt_pos(rstarLL), iqLR = rg_recip_sqrt_pos(rstarLR);
+  const rg_recip_t iqRL = rg_recip_sqrt_pos(rstarRL), iqRR = rg_recip_sqrt_pos(rstarRR);
+  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip_sqrt_pos(rstarLRx)), rg_div(fabs(AstarLR), iqLR)),
+                                                  rg_div(fabs(LL.a), rg_recip_sqrt_pos(rstarLLx))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
+  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip_sqrt_pos(rstarRRx)), rg_div(fabs(AstarRR), iqRR)),
+                                                  rg_div(fabs(RL.a), rg_recip_sqrt_pos(rstarRLx))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
+  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip_sqrt_pos(rstarLLy)), rg_div(fabs(BstarLL), iqLL)),
+                                                  rg_div(fabs(RL.b), rg_recip_sqrt_pos(rstarRLy))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
+  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip_sqrt_pos(rstarLRy)), rg_div(fabs(BstarLR), iqLR)),
+                                                  rg_div(fabs(RR.b), rg_recip_sqrt_pos(rstarRRy))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
   const double SAL = fmin(ustar - calfvenL, 0.0);
   const double SAR = fmax(ustar + calfvenR, 0.0);
   const double SAB = fmin(vstar - calfvenB, 0.0);

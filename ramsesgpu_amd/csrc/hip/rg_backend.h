@@ -102,6 +102,23 @@ RG_DEVFN double rg_sqrt_pos(double x) {
 #endif
 }
 
+// reciprocal of sqrt(x), x positive and finite, for "n / sqrt(x)" (the Alfven speeds of the 2D HLLD solver divide by twelve
+// such roots per edge).  Exact arithmetic: the correctly rounded root, then its shared reciprocal -- the reference's two
+// operations.  Contracted arithmetic: one refined rsq.
+RG_DEVFN rg_recip_t rg_recip_sqrt_pos(double x) {
+#ifdef RG_ARITH_FAST
+  rg_recip_t R;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double t = x * y;                              // ~ sqrt(x)
+  const double e = __builtin_fma(-t, y, 1.0);          // 1 - x y^2
+  R.r = __builtin_fma(0.5 * y, e, y);
+  R.d = t;
+  return R;
+#else
+  return rg_recip(rg_sqrt_pos(x));
+#endif
+}
+
 // max of non-negative doubles into one of several device slots (the CFL scan that rides in the MHD update kernel): the
 // plain read filters out almost every call once a slot holds a large value (a stale read can only cause a redundant atomic,
 // never a missed one: stale values are <= the current one)
