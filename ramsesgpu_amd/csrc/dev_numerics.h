@@ -490,10 +490,18 @@ RG_DEVFN void mhd_riemann(const DevParams& g, Prim8& L, Prim8& R, double* flux) 
 // ---------------------------------------------------------------------------------------------------------
 // 2D magnetic Riemann problem at a cell edge (the EMF of constrained transport)
 // ---------------------------------------------------------------------------------------------------------
+// The reference's FMAX / FMIN chains are "a1 > ret ? a1 : ret" selections.  On operands without NaN they differ from the
+// IEEE maximum / minimum (v_max_f64 / v_min_f64: one instruction instead of a compare and two selects) only in the sign of a
+// zero result.  The max_of4 / min_of4 / pos_max chains below are therefore used where that sign cannot matter: all operands
+// non-negative magnitudes (speeds: square roots, |b| / sqrt(rho), smallc -- never -0), or a velocity extremum that is at once
+// added to / subtracted from a strictly positive fast speed.  sel_* keep the selection semantics for the rest.
 RG_DEVFN double sel_max(double a0, double a1) { return (a1 > a0) ? a1 : a0; }
 RG_DEVFN double sel_min(double a0, double a1) { return (a1 < a0) ? a1 : a0; }
-RG_DEVFN double max_of4(double a0, double a1, double a2, double a3) { return sel_max(sel_max(sel_max(a0, a1), a2), a3); }
-RG_DEVFN double min_of4(double a0, double a1, double a2, double a3) { return sel_min(sel_min(sel_min(a0, a1), a2), a3); }
+RG_DEVFN double sel_max_of4(double a0, double a1, double a2, double a3) { return sel_max(sel_max(sel_max(a0, a1), a2), a3); }
+RG_DEVFN double sel_min_of4(double a0, double a1, double a2, double a3) { return sel_min(sel_min(sel_min(a0, a1), a2), a3); }
+RG_DEVFN double pos_max(double a0, double a1) { return fmax(a0, a1); }
+RG_DEVFN double max_of4(double a0, double a1, double a2, double a3) { return fmax(fmax(fmax(a0, a1), a2), a3); }
+RG_DEVFN double min_of4(double a0, double a1, double a2, double a3) { return fmin(fmin(fmin(a0, a1), a2), a3); }
 
 // mag_riemann2d_hlld (riemann_mhd.h:616-821).  States are in the edge frame (u,v = the two in-plane
 // velocities, a,b = the two in-plane field components); E?? = u*b - v*a of each state.
@@ -555,13 +563,13 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
   const rg_recip_t iqLL = rg_recip_sqrt_pos(rstarLL), iqLR = rg_recip_sqrt_pos(rstarLR);
   const rg_recip_t iqRL = rg_recip_sqrt_pos(rstarRL), iqRR = rg_recip_sqrt_pos(rstarRR);
-  const double calfvenL = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.a), rg_recip_sqrt_pos(rstarLRx)), rg_div(fabs(AstarLR), iqLR)),
+  const double calfvenL = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.a), rg_recip_sqrt_pos(rstarLRx)), rg_div(fabs(AstarLR), iqLR)),
                                                   rg_div(fabs(LL.a), rg_recip_sqrt_pos(rstarLLx))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
-  const double calfvenR = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(RR.a), rg_recip_sqrt_pos(rstarRRx)), rg_div(fabs(AstarRR), iqRR)),
+  const double calfvenR = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(RR.a), rg_recip_sqrt_pos(rstarRRx)), rg_div(fabs(AstarRR), iqRR)),
                                                   rg_div(fabs(RL.a), rg_recip_sqrt_pos(rstarRLx))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
-  const double calfvenB = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LL.b), rg_recip_sqrt_pos(rstarLLy)), rg_div(fabs(BstarLL), iqLL)),
+  const double calfvenB = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LL.b), rg_recip_sqrt_pos(rstarLLy)), rg_div(fabs(BstarLL), iqLL)),
                                                   rg_div(fabs(RL.b), rg_recip_sqrt_pos(rstarRLy))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
-  const double calfvenT = sel_max(sel_max(sel_max(sel_max(rg_div(fabs(LR.b), rg_recip_sqrt_pos(rstarLRy)), rg_div(fabs(BstarLR), iqLR)),
+  const double calfvenT = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.b), rg_recip_sqrt_pos(rstarLRy)), rg_div(fabs(BstarLR), iqLR)),
                                                   rg_div(fabs(RR.b), rg_recip_sqrt_pos(rstarRRy))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
   const double SAL = fmin(ustar - calfvenL, 0.0);
   const double SAR = fmax(ustar + calfvenR, 0.0);
@@ -627,14 +635,14 @@ RG_DEVFN double mag_hll_average(const Prim8& LL, const Prim8& RR, double ELL, do
 RG_DEVFN double mag_hlla_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
                             double ELL, double ERL, double ELR, double ERR) {
   const rg_recip_t iLL = rg_recip(LL.r), iLR = rg_recip(LR.r), iRL = rg_recip(RL.r), iRR = rg_recip(RR.r);
-  const double cMaxx = sel_max(max_of4(rg_sqrt(rg_div(LL.a * LL.a, iLL)), rg_sqrt(rg_div(LR.a * LR.a, iLR)),
+  const double cMaxx = pos_max(max_of4(rg_sqrt(rg_div(LL.a * LL.a, iLL)), rg_sqrt(rg_div(LR.a * LR.a, iLR)),
                                        rg_sqrt(rg_div(RL.a * RL.a, iRL)), rg_sqrt(rg_div(RR.a * RR.a, iRR))), g.smallc);
-  const double cMaxy = sel_max(max_of4(rg_sqrt(rg_div(LL.b * LL.b, iLL)), rg_sqrt(rg_div(LR.b * LR.b, iLR)),
+  const double cMaxy = pos_max(max_of4(rg_sqrt(rg_div(LL.b * LL.b, iLL)), rg_sqrt(rg_div(LR.b * LR.b, iLR)),
                                        rg_sqrt(rg_div(RL.b * RL.b, iRL)), rg_sqrt(rg_div(RR.b * RR.b, iRR))), g.smallc);
-  const double SL = fmin(min_of4(LL.u, LR.u, RL.u, RR.u) - cMaxx, 0.0);
-  const double SR = fmax(max_of4(LL.u, LR.u, RL.u, RR.u) + cMaxx, 0.0);
-  const double SB = fmin(min_of4(LL.v, LR.v, RL.v, RR.v) - cMaxy, 0.0);
-  const double ST = fmax(max_of4(LL.v, LR.v, RL.v, RR.v) + cMaxy, 0.0);
+  const double SL = fmin(sel_min_of4(LL.u, LR.u, RL.u, RR.u) - cMaxx, 0.0);
+  const double SR = fmax(sel_max_of4(LL.u, LR.u, RL.u, RR.u) + cMaxx, 0.0);
+  const double SB = fmin(sel_min_of4(LL.v, LR.v, RL.v, RR.v) - cMaxy, 0.0);
+  const double ST = fmax(sel_max_of4(LL.v, LR.v, RL.v, RR.v) + cMaxy, 0.0);
   return mag_hll_average(LL, RR, ELL, ERL, ELR, ERR, SL, SR, SB, ST);
 }
 
