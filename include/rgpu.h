@@ -363,6 +363,7 @@ typedef struct rgpuh_step_hooks {
   int (*one_step_integration)(void* self, int* nStep, double* totalTime, double* dt);
   int (*barrier)(void* self);
   const char* (*last_error)(void* self);
+  int (*history_mri)(void* self, int parity, double* out8);   /* optional (may be 0): rgpu_history_mri over the whole box */
 } rgpuh_step_hooks;
 typedef int (*rgpuh_attach_fn)(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* hooks);
 typedef void (*rgpuh_detach_fn)(void* user);

@@ -67,6 +67,12 @@ int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalT
 /* == oneStepIntegration(nStep, t, dt) of the Mpi run classes */
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt);
 
+/* MHDRunBase::history_mri / history_default over the whole box (MHDRunBase.cpp:3476-3619; the MPI classes reduce on rank 0):
+ * out[8] as rgpu_history_mri -- mass, maxwell, reynolds, magnetic pressure, mean Bx, By, Bz, sum of divB.  Per-slab column
+ * sums on the device (rgpu_history_columns), SUM all-reduce of the isize-long columns (the y-z means need the global sums
+ * before the Reynolds stress can be formed, rgpu_history_reynolds), the same value on every rank. */
+int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out);
+
 /* 0: serial schedule (exchange between the step pieces), 1: overlapped (default) */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
 

@@ -247,6 +247,31 @@ int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double*
   return RGPU_OK;
 }
 
+int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out) {
+  RG_CHECK_CM(cm);
+  if (!out) return fail(cm, RGPU_EINVAL, "history_mri: null pointer");
+  const rgpu_params& p = cm->p;
+  if (!p.mhdEnabled) return fail(cm, RGPU_EUNSUPPORTED, "history diagnostics are defined for MHD runs");
+  const int gw = p.ghostWidth, is = p.nx + 2 * gw, NQ = 9;
+  std::vector<double> cols((size_t)NQ * is), rcol(is), mvx(is), mvy(is);
+  RG_TRY(rgpu_history_columns(cm->ctx, parity, cols.data()), "history_columns");
+  void* s = rgpu_stream_handle(cm->ctx);
+  if (cm->nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, cols.data(), NQ * is, s)) return tr_fail(cm, "allreduce(history columns)");
+  const bool three_d = p.nz_global != 1;
+  const double dTau = three_d ? p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin)
+                              : p.dx * p.dy / (p.xMax - p.xMin) / (p.yMax - p.yMin);
+  const double nyz = (double)p.ny * (three_d ? p.nz_global : 1);
+  for (int i = 0; i < is; ++i) { mvx[i] = cols[(size_t)1 * is + i] / nyz; mvy[i] = cols[(size_t)2 * is + i] / nyz; }
+  RG_TRY(rgpu_history_reynolds(cm->ctx, parity, mvx.data(), mvy.data(), dTau, rcol.data()), "history_reynolds");
+  if (cm->nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, rcol.data(), is, s)) return tr_fail(cm, "allreduce(history reynolds)");
+  double sum[9], reyn = 0.0;
+  for (int q = 0; q < NQ; ++q) { sum[q] = 0.0; for (int i = gw; i < is - gw; ++i) sum[q] += cols[(size_t)q * is + i]; }
+  for (int i = gw; i < is - gw; ++i) reyn += rcol[i];
+  out[0] = sum[0] * dTau; out[1] = sum[4] * dTau; out[2] = reyn; out[3] = sum[3] * dTau / 2.;
+  out[4] = sum[5] * dTau; out[5] = sum[6] * dTau; out[6] = sum[7] * dTau; out[7] = sum[8];
+  return RGPU_OK;
+}
+
 // euler_hip --slabs: the run loop of the single-GPU front end (rgpuh_run_hooked in librgpu: initial condition or restart of this
 // slab, the reference's time loop, HDF5 outputs of the whole box written slab after slab) stepping through this driver
 namespace {
@@ -259,6 +284,7 @@ struct SlabAttach {
 int hook_make_all_boundaries(void* self, int parity, double t, double dt) { return rgpu_comm_make_all_boundaries(static_cast<SlabAttach*>(self)->cm, parity, t, dt); }
 int hook_compute_dt(void* self, int useU, double* dt) { return rgpu_comm_compute_dt(static_cast<SlabAttach*>(self)->cm, useU, dt); }
 int hook_one_step(void* self, int* nStep, double* t, double* dt) { return rgpu_comm_one_step_integration(static_cast<SlabAttach*>(self)->cm, nStep, t, dt); }
+int hook_history_mri(void* self, int parity, double* out) { return rgpu_comm_history_mri(static_cast<SlabAttach*>(self)->cm, parity, out); }
 int hook_barrier(void* self) {
   rgpu_comm* cm = static_cast<SlabAttach*>(self)->cm;
   if (rgpu_synchronize(cm->ctx)) return RGPU_EHIP;
@@ -279,6 +305,7 @@ int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
   h->compute_dt = hook_compute_dt;
   h->one_step_integration = hook_one_step;
   h->barrier = hook_barrier;
+  h->history_mri = hook_history_mri;
   return 0;
 }
 void slab_detach(void* user) {

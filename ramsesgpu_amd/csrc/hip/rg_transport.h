@@ -84,9 +84,14 @@ inline int allreduce_max(Comm* c, double* d, int n, void* stream) {
   const ncclResult_t r = ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclMax, c->comm, (hipStream_t)stream);
   return r == ncclSuccess ? 0 : fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
 }
-// host values (n <= 64): through the device scratch, synchronous
+// host values: through the device scratch (64 doubles at a time), synchronous
 inline int allreduce_sum_host(Comm* c, double* h, int n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (n > 64) {
+    for (int o = 0; o < n; o += 64)
+      if (allreduce_sum_host(c, h + o, n - o < 64 ? n - o : 64, stream)) return -1;
+    return 0;
+  }
   if (hipMemcpyAsync(c->scratch, h, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return fail(c, "H2D");
   const ncclResult_t r = ncclAllReduce(c->scratch, c->scratch, (size_t)n, ncclDouble, ncclSum, c->comm, s);
   if (r != ncclSuccess) return fail(c, std::string("ncclAllReduce: ") + ncclGetErrorString(r));

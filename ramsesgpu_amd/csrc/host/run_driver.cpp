@@ -441,7 +441,9 @@ void GodunovRun::history(int nStep, double dt) {
   if (!mri && !dflt) return;
   if (mri && p_.nz_global == 1) return;   // history_mri does nothing in 2D
   double h[8];
-  check(rgpu_history_mri(ctx_, nStep % 2, h), "history");
+  if (slab()) hook_check(hooks_.history_mri(hooks_.self, nStep % 2, h), "history");   // the same sums on every rank; rank 0 writes
+  else check(rgpu_history_mri(ctx_, nStep % 2, h), "history");
+  if (p_.slab_rank != 0) return;
   const std::string fileName = cfg_.get_string("output", "outputDir", "./") + "/" + cfg_.get_string("output", "outputPrefix", "output") +
                                "_" + cfg_.get_string("history", "filename", "history.txt");
   std::ofstream histo(fileName.c_str(), std::ios::out | std::ios::app | std::ios::ate);
@@ -481,6 +483,12 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
   const bool historyEnabled = p_.mhdEnabled && cfg_.get_bool("history", "enabled", false);
   const double dtHist = cfg_.get_float("history", "dtHist", static_cast<float>(10 * dt));
   double tHist = totalTime_;   // MHDRunGodunov.cpp:3916
+  // z-slab runs: the MRI / Orszag-Tang history goes through the slab driver's global sums; the other problems' do not
+  bool slab_history_ok = false;
+  if (slab() && hooks_.history_mri) {
+    const std::string problem = cfg_.get_string("hydro", "problem", "unknown");
+    slab_history_ok = problem == "MRI" || problem == "Mri" || problem == "mri" || problem == "Orszag-Tang" || problem == "OrszagTang";
+  }
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
     if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0 && p_.slab_rank == 0)
@@ -495,8 +503,8 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
       if (p_.slab_rank == 0) std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     }
-    if (historyEnabled && slab()) note_once(&noted_hist_, "z-slab run: the history file is not written");
-    if (historyEnabled && !slab() && (tHist == 0 || ((totalTime_ - dt <= tHist + dtHist) && (totalTime_ > tHist + dtHist)))) {
+    if (historyEnabled && slab() && !slab_history_ok) note_once(&noted_hist_, "z-slab run: this problem's history file is not written");
+    if (historyEnabled && (!slab() || slab_history_ok) && (tHist == 0 || ((totalTime_ - dt <= tHist + dtHist) && (totalTime_ > tHist + dtHist)))) {
       history(nStep, dt);
       tHist += dtHist;
     }

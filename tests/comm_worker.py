@@ -99,6 +99,13 @@ def frontend():
             same = aa == ab and sorted(da) == sorted(db) and all(np.array_equal(da[k], db[k]) for k in db)
             if not same:
                 ok, msg = False, "%s differs: attrs %s / %s, %s" % (f, aa, ab, {k: int((da[k] != db[k]).sum()) for k in db if da[k].shape == db[k].shape})
+        for f in [f for f in os.listdir(single) if f.endswith("history.txt")] if ok else []:   # global sums: round-off agreement, 6 printed digits
+            ra = [l.split() for l in open(os.path.join(slabs, f)) if not l.startswith("#")]
+            rb = [l.split() for l in open(os.path.join(single, f)) if not l.startswith("#")]
+            same = len(ra) == len(rb) and len(rb) >= 2 and all(
+                len(x) == len(y) and all(abs(float(u) - float(v)) <= 5e-6 * max(abs(float(v)), 1e-300) + 1e-14 for u, v in zip(x, y)) for x, y in zip(ra, rb))
+            if not same:
+                ok, msg = False, "history differs: %r / %r" % (ra, rb)
         xa = [f for f in os.listdir(slabs) if f.endswith(".xmf")]
         ok = ok and len(xa) == 1 and open(os.path.join(slabs, xa[0])).read() == open(os.path.join(single, xa[0])).read()
     if rank == 0:

@@ -103,6 +103,8 @@ FRONTEND_CASES = [
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=18;MRI.amp=0.2;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=no", 3),
     ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=12;hydro.riemannSolver=hllc;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.ghostIncluded=no", 2),
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;output.outputHdf5CompressionLevel=4", 2),
+    # + the history file of the MRI run: global sums through the slab driver (rgpu_comm_history_mri), written by rank 0
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=12;MRI.amp=0.2;run.nstepmax=6;run.noutput=3;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;history.enabled=yes;history.dtHist=1e-9", 3),
 ]
 
 
