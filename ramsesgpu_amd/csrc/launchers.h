@@ -203,6 +203,22 @@ struct K_bc_face {
   DevParams g; double* U; int dir, side, bct;
   RG_DEVFN void operator()(unsigned idx) const { bc_face_cell(g, U, dir, side, bct, idx); }
 };
+// both faces of one direction in one launch (they read interior cells only, so they do not depend on each other): the first
+// n indices are the low face, the next n the high face
+struct K_bc_faces {
+  DevParams g; double* U; int dir, bct_lo, bct_hi; unsigned n;
+  RG_DEVFN void operator()(unsigned idx) const {
+    if (idx < n) bc_face_cell(g, U, dir, 0, bct_lo, idx);
+    else bc_face_cell(g, U, dir, 1, bct_hi, idx - n);
+  }
+};
+struct K_bc_faces_range {   // ... restricted to the face indices [first, first + n) of each face (a range of z planes)
+  K_bc_faces f; unsigned first;
+  RG_DEVFN void operator()(unsigned idx) const {
+    if (idx < f.n) bc_face_cell(f.g, f.U, f.dir, 0, f.bct_lo, first + idx);
+    else bc_face_cell(f.g, f.U, f.dir, 1, f.bct_hi, first + (idx - f.n));
+  }
+};
 struct K_jet {
   DevParams g; JetParams jp; double* U;
   RG_DEVFN void operator()(unsigned idx) const { jet_cell(g, jp, U, idx); }

@@ -328,7 +328,26 @@ int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi 
   if (dir < 0 || dir > 2) return -1;
   if (!c->g.three_d && dir == 2) return 0;
   if (k_hi < 0) k_hi = c->g.ksize;
-  if (launch_face(c, U, dir, 0, k_lo, k_hi) || launch_face(c, U, dir, 1, k_lo, k_hi)) return -1;
+  {
+    // two faces of the same plain kind (mirror / copy / periodic): one launch for both
+    const int b0 = c->p.bc[2 * dir], b1 = c->p.bc[2 * dir + 1];
+    auto plain = [](int b) { return b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC; };
+    if (plain(b0) && plain(b1)) {
+      const DevParams& g = c->g;
+      K_bc_faces k = {g, U, dir, b0, b1, 0u};
+      if (dir == 2) {
+        k.n = (unsigned)g.isize * g.jsize * g.gw;
+        if (rg_launch<kBlock>(c->stream, 2u * k.n, k)) return -1;
+      } else {
+        // x and y faces are indexed with k slowest: planes [k_lo,k_hi) of a face are one contiguous index range
+        const unsigned per_plane = (dir == 0) ? (unsigned)g.gw * g.jsize : (unsigned)g.isize * g.gw;
+        const unsigned first = per_plane * (unsigned)k_lo, cnt = per_plane * (unsigned)(k_hi - k_lo);
+        K_bc_faces kr = {g, U, dir, b0, b1, cnt};
+        K_bc_faces_range kk = {kr, first};
+        if (rg_launch<kBlock>(c->stream, 2u * cnt, kk)) return -1;
+      }
+    } else if (launch_face(c, U, dir, 0, k_lo, k_hi) || launch_face(c, U, dir, 1, k_lo, k_hi)) return -1;
+  }
   // the jet is re-imposed after the Y fill in 2D and after the Z fill in 3D (HydroRunBase.cpp:2286-2312)
   if (c->p.enableJet && ((!c->g.three_d && dir == 1) || (c->g.three_d && dir == 2 && c->p.bc[4] != RGPU_BC_COPY)))
     return launch_jet(c, U);
