@@ -67,6 +67,19 @@ BENCH_GEOMETRY = [
 ]
 
 
+LONG_RUNS = [
+    # hundreds of steps: the perturbation grows, limiter / solver branches diversify -- every double and every dt still equal
+    ("mhd_mri_3d", "mesh.nx=24;mesh.ny=48;mesh.nz=24;MRI.amp=0.1", 400),
+    ("implode3d", "mesh.nx=40;mesh.ny=40;mesh.nz=40;hydro.riemannSolver=hllc", 300),
+    ("orszag-tang", "mesh.nx=96;mesh.ny=96", 400),
+]
+
+
+@pytest.mark.parametrize("base,ov,nsteps", LONG_RUNS, ids=["%s-%d" % (b, n) for b, _, n in LONG_RUNS])
+def test_long_runs_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
+    pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, nsteps)
+
+
 @pytest.mark.parametrize("base,ov,nsteps", BENCH_GEOMETRY, ids=["%s[%s]" % (b, o) for b, o, _ in BENCH_GEOMETRY])
 def test_bench_launch_geometry_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
     pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, nsteps)
