@@ -157,6 +157,54 @@ void GodunovRun::outputVtk(int nStep) {
 // then nbVar arrays of little-endian doubles, x fastest -- the whole ghost-inclusive arrays when ghostIncluded (what a
 // shearing-box run needs: the field on the first high x face is evolved by the CT update and not rebuilt by the ghost
 // fill), the interior otherwise.  Stands in for outputHdf5 / inputHdf5 (HydroRunBase.cpp:3308-3640, 4818-5160).
+// Xsmurf: one ASCII header line + the interior of ONE variable (the density: the reference's default argument) as raw doubles,
+// written to the current directory (no outputDir in the name, HydroRunBase.cpp:2535)
+void GodunovRun::outputXsm(int nStep) {
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
+  const bool three_d = p_.nz_global != 1;
+  const int nz = three_d ? p_.nz : 1;
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw;
+  std::ostringstream fn;
+  fn << rs_.outputPrefix << "_d_" << std::setw(7) << std::setfill('0') << nStep << ".xsm";
+  std::ofstream out(fn.str().c_str(), std::ios::binary);
+  if (!out) throw std::runtime_error("cannot write " + fn.str());
+  if (three_d) out << "Binary 1 " << nx << "x" << ny << "x" << nz << " " << nx * ny * nz << "(" << sizeof(double) << " byte reals)\n";
+  else out << "Binary 1 " << nx << "x" << ny << " " << nx * ny << "(" << sizeof(double) << " byte reals)\n";
+  for (int k = 0; k < nz; ++k)
+    for (int j = 0; j < ny; ++j) {
+      const size_t kk = three_d ? k + gw : 0;
+      out.write(reinterpret_cast<const char*>(&h_U_[gw + isize * ((j + gw) + jsize * kk)]), sizeof(double) * nx);
+    }
+}
+
+// NRRD: a text header + the interior of each variable converted to 32-bit floats, one file per variable (d, p, u, v, w, a, b, c)
+void GodunovRun::outputNrrd(int nStep) {
+  static const char* prefix[8] = {"d", "p", "u", "v", "w", "a", "b", "c"};
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
+  const bool three_d = p_.nz_global != 1;
+  const int nz = three_d ? p_.nz : 1;
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = three_d ? nz + 2 * gw : 1, ncell = isize * jsize * ksize;
+  std::vector<float> row(nx);
+  for (int v = 0; v < p_.nbVar; ++v) {
+    const int pv = (p_.nbVar == 4 && v == 3) ? 3 : v;   // 2D hydro: d, p, u, v
+    std::ostringstream fn;
+    fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << prefix[pv] << "_" << std::setw(7) << std::setfill('0') << nStep << ".nrrd";
+    std::ofstream out(fn.str().c_str(), std::ios::binary);
+    if (!out) throw std::runtime_error("cannot write " + fn.str());
+    out << "NRRD0004\n# Complete NRRD file format specification at:\n# http://teem.sourceforge.net/nrrd/format.html\ntype: float\n";
+    if (three_d) out << "dimension: 3\nsizes: " << nx << " " << ny << " " << nz << "\nspace directions: (1,0,0) (0,1,0) (0,0,1)\n";
+    else out << "dimension: 2\nsizes: " << nx << " " << ny << "\nspace directions: (1,0) (0,1)\n";
+    out << "endian: little\nencoding: raw\n\n";
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j) {
+        const size_t kk = three_d ? k + gw : 0;
+        const double* src = &h_U_[gw + isize * ((j + gw) + jsize * kk) + ncell * v];
+        for (int i = 0; i < nx; ++i) row[i] = (float)src[i];
+        out.write(reinterpret_cast<const char*>(row.data()), sizeof(float) * nx);
+      }
+  }
+}
+
 H5Box GodunovRun::h5_box(int nx, int ny, int nz) const {
   H5Box b;
   b.nx = nx; b.ny = ny; b.nz = nz;
@@ -495,7 +543,10 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
       std::printf("  step=%9d t=%14.8f dt=%16.12f\n", nStep, totalTime_, dt);
     if (rs_.nOutput > 0 && (nStep % rs_.nOutput) == 0) {   // noutput <= 0: no output (the reference divides by zero here)
       const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
-      if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
+      const bool raw = (rs_.outputXsm || rs_.outputNrrd) && !slab();
+      if (rs_.outputVtk || rs_.outputRestart || raw) copyGpuToCpu(nStep);
+      if (raw && rs_.outputXsm) outputXsm(nStep);
+      if (raw && rs_.outputNrrd) outputNrrd(nStep);
       if (rs_.outputVtk && !slab()) outputVtk(nStep);
       if (rs_.outputVtk && slab()) note_once(&noted_vtk_, "z-slab run: outputs go to HDF5 ([output] outputHdf5=yes), no .vti is written");
       if (rs_.outputRestart) outputHdf5(nStep);
@@ -514,7 +565,10 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
   if (hooked_) hook_check(hooks_.barrier(hooks_.self), "barrier");
   {
     const std::chrono::steady_clock::time_point w0 = std::chrono::steady_clock::now();
-    if (rs_.outputVtk || rs_.outputRestart) copyGpuToCpu(nStep);
+    const bool raw = (rs_.outputXsm || rs_.outputNrrd) && !slab();
+    if (rs_.outputVtk || rs_.outputRestart || raw) copyGpuToCpu(nStep);
+    if (raw && rs_.outputXsm) outputXsm(nStep);
+    if (raw && rs_.outputNrrd) outputNrrd(nStep);
     if (rs_.outputVtk && !slab()) outputVtk(nStep);
     if (rs_.outputRestart) outputHdf5(nStep);
     if ((rs_.outputVtk || rs_.outputRestart) && p_.slab_rank == 0) save_forcing_process(nStep);

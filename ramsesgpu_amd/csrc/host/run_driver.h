@@ -35,6 +35,10 @@ class GodunovRun {
   // attach (may be 0): called once the context holds its initial state, before the first ghost fill (rgpuh_run_hooked)
   int start(double* mcell_per_s, rgpuh_attach_fn attach = 0, void* user = 0);
   void outputVtk(int nStep);
+  // the reference's two raw single-variable formats: Xsmurf (density, doubles, current directory; HydroRunBase.cpp:2520-2562)
+  // and NRRD (every variable as 32-bit floats, output directory; :4266-4335)
+  void outputXsm(int nStep);
+  void outputNrrd(int nStep);
   // restart=yes: read the interior fields, the step count and the time back from a .vti this driver wrote
   int inputVtk(const std::string& path);
   // [output] outputHdf5=yes is served by a raw dump <prefix>_NNNNNNN.rgr (this image has no HDF5 library): the role of the

@@ -1,0 +1,41 @@
+"""[output] outputXsm / outputNrrd of the run driver against the files the reference binary wrote (tests/golden/raw/,
+generator oracle/gen_golden_raw.py): same names, same bytes (Xsmurf: density as doubles behind a one-line header, in the
+current directory; NRRD: every variable as 32-bit floats behind a text header, in the output directory)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+from conftest import ROOT, ini
+
+RAW = os.path.join(ROOT, "tests", "golden", "raw")
+CASES = json.load(open(os.path.join(RAW, "cases.json")))
+
+
+def check(lib, name, tmp_path):
+    c = CASES[name]
+    ov = c["overrides"] + ";run.nstepmax=%d;run.noutput=%d;run.tend=1e9;output.outputVtk=no;output.outputHdf5=no;output.outputXsm=yes;output.outputNrrd=yes;output.outputDir=%s" % (
+        c["last_step"], c["last_step"], tmp_path)
+    err = C.create_string_buffer(512); mc = C.c_double(0)
+    old = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert lib.lib.rgpuh_run(ini(c["base"]).encode(), ov.encode(), C.byref(mc), err, 512) == c["last_step"], err.value
+    finally:
+        os.chdir(old)
+    ref = sorted(os.listdir(os.path.join(RAW, name)))
+    assert len(ref) >= 5
+    for f in ref:
+        assert open(tmp_path / f, "rb").read() == open(os.path.join(RAW, name, f), "rb").read(), f
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_xsm_and_nrrd_equal_the_reference_emu(name, emu_lib, tmp_path):
+    check(emu_lib, name, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_xsm_and_nrrd_equal_the_reference_gpu(name, gpu_lib, tmp_path):
+    check(gpu_lib, name, tmp_path)
