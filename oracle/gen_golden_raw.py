@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Xsmurf (.xsm) and NRRD (.nrrd) files written by the reference binary (oracle/_ref/euler_cpu; HydroRunBase.cpp:2520-2562,
+"""Xsmurf (.xsm), NRRD (.nrrd) and text-mode VTI (.vti, outputVtkAscii) files written by the reference binary (oracle/_ref/euler_cpu; HydroRunBase.cpp:2520-2562,
 4266-4335) for two tiny runs -> tests/golden/raw/<case>/: byte-for-byte fixtures of the run driver's two raw output formats.
 usage: python oracle/gen_golden_raw.py"""
 import json
@@ -24,7 +24,7 @@ CASES = {
 def main():
     listing = {}
     for name, (base, ov, last) in sorted(CASES.items()):
-        full = ov + ";run.nstepmax=%d;run.noutput=%d;run.tend=1e9;output.outputVtk=no;output.outputHdf5=no;output.outputXsm=yes;output.outputNrrd=yes;output.outputDir=./" % (last, last)
+        full = ov + ";run.nstepmax=%d;run.noutput=%d;run.tend=1e9;output.outputVtk=yes;output.outputVtkAscii=yes;output.outputHdf5=no;output.outputXsm=yes;output.outputNrrd=yes;output.outputDir=./" % (last, last)
         ini = apply_overrides(open(os.path.join(ROOT, "configs", base + ".ini")).read(), full)
         dst = os.path.join(OUT, name)
         shutil.rmtree(dst, ignore_errors=True)
@@ -33,7 +33,7 @@ def main():
             open(os.path.join(td, "case.ini"), "w").write(ini)
             subprocess.run([os.path.join(HERE, "_ref", "euler_cpu"), "--param", "case.ini"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
             for f in sorted(os.listdir(td)):
-                if f.endswith(("%07d.xsm" % last, "%07d.nrrd" % last)):
+                if f.endswith(("%07d.xsm" % last, "%07d.nrrd" % last, "%07d.vti" % last)):
                     shutil.copy(os.path.join(td, f), dst)
         listing[name] = {"base": base, "overrides": ov, "last_step": last}
         print(name, sorted(os.listdir(dst)))

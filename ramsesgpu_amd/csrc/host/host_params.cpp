@@ -196,6 +196,7 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
   rs->restartResetTotalTime = cfg.get_bool("run", "restart_reset_totaltime", false);
   rs->restartFilename = cfg.get_string("run", "restart_filename", "");
   rs->restartUpscale = cfg.get_bool("run", "restart_upscale", false);
+  rs->outputVtkAscii = cfg.get_bool("output", "outputVtkAscii", false);
   rs->outputXsm = cfg.get_bool("output", "outputXsm", false);
   rs->outputNrrd = cfg.get_bool("output", "outputNrrd", false);
   rs->hdf5CompressionLevel = static_cast<int>(cfg.get_integer("output", "outputHdf5CompressionLevel", 0));

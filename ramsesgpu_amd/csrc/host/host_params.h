@@ -22,6 +22,7 @@ struct RunSettings {
   // [run] restart / restart_filename / restart_reset_totaltime (HydroRunBase.cpp:7033-7066, MHDRunGodunov.cpp:3805, 3866-3880)
   bool outputRestart, ghostIncluded;   // [output] outputHdf5 (served by the raw restart dump, no HDF5 library here), ghostIncluded
   bool restartEnabled, restartResetTotalTime;
+  bool outputVtkAscii;          // [output] outputVtkAscii: the .vti as text (12 significant digits) instead of appended raw doubles
   bool outputXsm, outputNrrd;   // [output] outputXsm / outputNrrd (HydroParameters.h:478,485)
   int hdf5CompressionLevel;   // [output] outputHdf5CompressionLevel (0..9, HydroRunBase.cpp:3408-3414)
   bool restartUpscale;   // [run] restart_upscale: the restart file holds the box at half the resolution (HydroRunBase.cpp:7044-7062)

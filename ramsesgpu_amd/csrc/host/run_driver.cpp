@@ -124,6 +124,25 @@ void GodunovRun::outputVtk(int nStep) {
   fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".vti";
   std::ofstream out(fn.str().c_str(), std::ios::binary);
   if (!out) throw std::runtime_error("cannot write " + fn.str());
+  if (rs_.outputVtkAscii) {   // [output] outputVtkAscii=yes: the reference's text form, byte for byte (HydroRunBase.cpp:2919-2973)
+    out << "<?xml version=\"1.0\"?>\n<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
+    out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
+    out << "  <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\">\n    <PointData>\n";
+    for (int v = 0; v < p_.nbVar; ++v) {
+      const char* nm = (p_.nbVar == 4 && v == 3) ? "my" : names[v];
+      out << "      <DataArray type=\"Float64\" Name=\"" << nm << "\" format=\"ascii\" >\n";
+      for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j) {
+          const size_t kk = three_d ? k + gw : 0;
+          const double* src = &h_U_[(gw) + isize * ((j + gw) + jsize * kk) + ncell * v];
+          for (int i = 0; i < nx; ++i) out << std::setprecision(12) << src[i] << " ";
+          out << "\n";
+        }
+      out << "      </DataArray>\n";
+    }
+    out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n</VTKFile>\n";
+    return;
+  }
   const uint32_t nbytes = static_cast<uint32_t>(sizeof(double) * nx * ny * nz);
   out << "<?xml version=\"1.0\"?>\n";
   {   // what a restart needs besides the fields (the reference keeps them as HDF5 attributes "time step" / "total time")
@@ -153,10 +172,6 @@ void GodunovRun::outputVtk(int nStep) {
   out << "  </AppendedData>\n</VTKFile>\n";
 }
 
-// Raw restart dump: one text line "RGPU-RESTART 1 nx ny nz ghostWidth nbVar ghostIncluded nStep totalTime(hex float)",
-// then nbVar arrays of little-endian doubles, x fastest -- the whole ghost-inclusive arrays when ghostIncluded (what a
-// shearing-box run needs: the field on the first high x face is evolved by the CT update and not rebuilt by the ghost
-// fill), the interior otherwise.  Stands in for outputHdf5 / inputHdf5 (HydroRunBase.cpp:3308-3640, 4818-5160).
 // Xsmurf: one ASCII header line + the interior of ONE variable (the density: the reference's default argument) as raw doubles,
 // written to the current directory (no outputDir in the name, HydroRunBase.cpp:2535)
 void GodunovRun::outputXsm(int nStep) {
@@ -241,6 +256,10 @@ void GodunovRun::outputHdf5(int nStep) {
   wrote_hdf5_ = true;
 }
 
+// Raw restart dump: one text line "RGPU-RESTART 1 nx ny nz ghostWidth nbVar ghostIncluded nStep totalTime(hex float)",
+// then nbVar arrays of little-endian doubles, x fastest -- the whole ghost-inclusive arrays when ghostIncluded (what a
+// shearing-box run needs: the field on the first high x face is evolved by the CT update and not rebuilt by the ghost
+// fill), the interior otherwise.  Stands in for outputHdf5 / inputHdf5 (HydroRunBase.cpp:3308-3640, 4818-5160).
 void GodunovRun::outputRestart(int nStep) {
   const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
   const bool three_d = p_.nz_global != 1;

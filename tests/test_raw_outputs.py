@@ -1,6 +1,7 @@
-"""[output] outputXsm / outputNrrd of the run driver against the files the reference binary wrote (tests/golden/raw/,
+"""[output] outputXsm / outputNrrd / outputVtkAscii of the run driver against the files the reference binary wrote (tests/golden/raw/,
 generator oracle/gen_golden_raw.py): same names, same bytes (Xsmurf: density as doubles behind a one-line header, in the
-current directory; NRRD: every variable as 32-bit floats behind a text header, in the output directory)."""
+current directory; NRRD: every variable as 32-bit floats behind a text header, in the output directory; the .vti in text mode, 12 significant
+digits)."""
 import ctypes as C
 import json
 import os
@@ -15,7 +16,7 @@ CASES = json.load(open(os.path.join(RAW, "cases.json")))
 
 def check(lib, name, tmp_path):
     c = CASES[name]
-    ov = c["overrides"] + ";run.nstepmax=%d;run.noutput=%d;run.tend=1e9;output.outputVtk=no;output.outputHdf5=no;output.outputXsm=yes;output.outputNrrd=yes;output.outputDir=%s" % (
+    ov = c["overrides"] + ";run.nstepmax=%d;run.noutput=%d;run.tend=1e9;output.outputVtk=yes;output.outputVtkAscii=yes;output.outputHdf5=no;output.outputXsm=yes;output.outputNrrd=yes;output.outputDir=%s" % (
         c["last_step"], c["last_step"], tmp_path)
     err = C.create_string_buffer(512); mc = C.c_double(0)
     old = os.getcwd()
