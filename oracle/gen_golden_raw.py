@@ -35,6 +35,13 @@ def main():
             for f in sorted(os.listdir(td)):
                 if f.endswith(("%07d.xsm" % last, "%07d.nrrd" % last, "%07d.vti" % last)):
                     shutil.copy(os.path.join(td, f), dst)
+            # the default, appended-raw .vti of the same run
+            open(os.path.join(td, "bin.ini"), "w").write(apply_overrides(ini, "output.outputVtkAscii=no;output.outputXsm=no;output.outputNrrd=no"))
+            bd = os.path.join(td, "bin"); os.makedirs(bd)
+            subprocess.run([os.path.join(HERE, "_ref", "euler_cpu"), "--param", "../bin.ini"], cwd=bd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+            for f in sorted(os.listdir(bd)):
+                if f.endswith("%07d.vti" % last):
+                    shutil.copy(os.path.join(bd, f), os.path.join(dst, f.replace(".vti", ".binary.vti")))
         listing[name] = {"base": base, "overrides": ov, "last_step": last}
         print(name, sorted(os.listdir(dst)))
     json.dump(listing, open(os.path.join(OUT, "cases.json"), "w"), indent=1, sort_keys=True)

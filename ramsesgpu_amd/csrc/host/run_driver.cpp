@@ -112,7 +112,7 @@ void GodunovRun::oneStepIntegration(int& nStep, double& t, double& dt) {
 void GodunovRun::copyGpuToCpu(int nStep) { check(rgpu_download(ctx_, h_U_.data(), nStep % 2), "download"); }
 
 // Hand-written VTI writer of the reference (HydroRunBase.cpp:2681-2995): ImageData, PointData, appended raw
-// little-endian Float64, one uint32 byte count per array, INTERIOR cells only, names density..bz.
+// little-endian Float64, one uint32 byte count per array, INTERIOR cells only, names density..bz -- the reference's bytes.
 void GodunovRun::outputVtk(int nStep) {
   static const char* names[8] = {"density", "energy", "mx", "my", "mz", "bx", "by", "bz"};
   const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny;
@@ -143,13 +143,9 @@ void GodunovRun::outputVtk(int nStep) {
     out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n</VTKFile>\n";
     return;
   }
+  // appended raw doubles: the bytes of the reference's file (no XML declaration in this mode), followed by ONE comment line
+  // with what a restart needs besides the fields (the reference keeps them as HDF5 attributes "time step" / "total time")
   const uint32_t nbytes = static_cast<uint32_t>(sizeof(double) * nx * ny * nz);
-  out << "<?xml version=\"1.0\"?>\n";
-  {   // what a restart needs besides the fields (the reference keeps them as HDF5 attributes "time step" / "total time")
-    char line[160];
-    std::snprintf(line, sizeof(line), "<!-- rgpu restart: nStep=%d totalTime=%a (%.17g) -->\n", nStep, totalTime_, totalTime_);
-    out << line;
-  }
   out << "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
   out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
   out << "  <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\">\n    <PointData>\n";
@@ -170,6 +166,9 @@ void GodunovRun::outputVtk(int nStep) {
       }
   }
   out << "  </AppendedData>\n</VTKFile>\n";
+  char tail[160];
+  std::snprintf(tail, sizeof(tail), "<!-- rgpu restart: nStep=%d totalTime=%a (%.17g) -->\n", nStep, totalTime_, totalTime_);
+  out << tail;
 }
 
 // Xsmurf: one ASCII header line + the interior of ONE variable (the density: the reference's default argument) as raw doubles,
@@ -378,10 +377,13 @@ int GodunovRun::inputVtk(const std::string& path) {
   int nStep = 0;
   double t = 0.0;
   {
-    const size_t c = head.find("rgpu restart: nStep=");
-    if (c != std::string::npos) {
+    // the comment line after </VTKFile> (files of earlier versions carried it in the header)
+    const std::string tail = blob.substr(blob.size() > 256 ? blob.size() - 256 : 0);
+    const size_t ct = tail.find("rgpu restart: nStep="), ch = head.find("rgpu restart: nStep=");
+    const char* at = ct != std::string::npos ? tail.c_str() + ct : ch != std::string::npos ? head.c_str() + ch : 0;
+    if (at) {
       char hex[64] = {0};
-      if (std::sscanf(head.c_str() + c, "rgpu restart: nStep=%d totalTime=%63s", &nStep, hex) == 2) t = std::strtod(hex, 0);
+      if (std::sscanf(at, "rgpu restart: nStep=%d totalTime=%63s", &nStep, hex) == 2) t = std::strtod(hex, 0);
     }
   }
   int e[6] = {0, 0, 0, 0, 0, 0};

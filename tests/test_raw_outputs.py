@@ -25,10 +25,19 @@ def check(lib, name, tmp_path):
         assert lib.lib.rgpuh_run(ini(c["base"]).encode(), ov.encode(), C.byref(mc), err, 512) == c["last_step"], err.value
     finally:
         os.chdir(old)
-    ref = sorted(os.listdir(os.path.join(RAW, name)))
+    ref = sorted(f for f in os.listdir(os.path.join(RAW, name)) if not f.endswith(".binary.vti"))
     assert len(ref) >= 5
     for f in ref:
         assert open(tmp_path / f, "rb").read() == open(os.path.join(RAW, name, f), "rb").read(), f
+    # the default appended-raw .vti: the reference's bytes + one trailing comment line (step count and time for a restart)
+    b = tmp_path / "bin"
+    b.mkdir()
+    ov2 = ov.replace("output.outputVtkAscii=yes", "output.outputVtkAscii=no").replace(str(tmp_path), str(b)).replace("outputXsm=yes", "outputXsm=no").replace("outputNrrd=yes", "outputNrrd=no")
+    assert lib.lib.rgpuh_run(ini(c["base"]).encode(), ov2.encode(), C.byref(mc), err, 512) == c["last_step"], err.value
+    for f in [f for f in os.listdir(os.path.join(RAW, name)) if f.endswith(".binary.vti")]:
+        mine = open(b / f.replace(".binary.vti", ".vti"), "rb").read()
+        want = open(os.path.join(RAW, name, f), "rb").read()
+        assert mine[:len(want)] == want and mine[len(want):].startswith(b"<!-- rgpu restart: nStep=%d " % c["last_step"]) and mine.count(b"\n", len(want)) == 1
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
