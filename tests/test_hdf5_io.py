@@ -25,6 +25,7 @@ pytestmark = pytest.mark.skipif(not h5util.available(), reason="no loadable libh
 
 
 def run(lib, base, ov, outdir, cwd):
+    os.environ.pop("RGPU_RESTART_FORMAT", None)   # (tests/test_restart.py forces the raw dump through it)
     err = C.create_string_buffer(512)
     mc = C.c_double(0)
     old = os.getcwd()

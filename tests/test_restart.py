@@ -32,7 +32,10 @@ def run(lib, base, ov, outdir, dump="no"):
     err = C.create_string_buffer(512)
     mc = C.c_double(0)
     full = ov + ";output.outputVtk=yes;output.outputHdf5=%s;output.ghostIncluded=yes;output.outputDir=%s" % (dump, outdir)
-    n = lib.lib.rgpuh_run(ini(base).encode(), full.encode(), C.byref(mc), err, 512)
+    try:
+        n = lib.lib.rgpuh_run(ini(base).encode(), full.encode(), C.byref(mc), err, 512)
+    finally:
+        os.environ.pop("RGPU_RESTART_FORMAT", None)
     assert n >= 0, err.value
     return n
 
@@ -164,6 +167,13 @@ UPSCALE_CASES = [
 
 def check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt="rgr"):
     """fmt: "rgr" = the raw dump, "h5" = the reference's HDF5 format (needs libhdf5)"""
+    try:
+        _check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt)
+    finally:
+        os.environ.pop("RGPU_RESTART_FORMAT", None)
+
+
+def _check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt):
     a, b = tmp_path / "coarse", tmp_path / "fine"
     a.mkdir(); b.mkdir()
     d = dims[:2] if dims[2] == 1 else dims
