@@ -599,7 +599,15 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // LDS-tiled fused trace + Riemann sweep over the Riemann planes r (hip/tiled_mhd.h); 1 = not covered
   auto sweep_planes = [&](rg_stream_t s, PlaneRange r) -> int {
     const int lo = r.lo < g.gw ? g.gw : r.lo, hi = r.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r.hi;
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi);
+    // periodic faces whose fluxes / EMFs are bit-identical copies of the opposite layer (see K_copy_periodic_layer): y when both
+    // y faces are periodic; x when both x faces are periodic and the frame does not rotate (the rotating-frame terms carry xPos)
+    static const bool no_reuse = std::getenv("RGPU_NO_PERIODIC_REUSE") != 0;
+    int reuse = 0;
+    if (!no_reuse) {
+      if (p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC) reuse |= 2;
+      if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
+    }
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);

@@ -8,5 +8,5 @@ inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const double*, double*, double*,
-                       double, double, double, double, int, int) { return 1; }
+                       double, double, double, double, int, int, int = 0) { return 1; }
 }  // namespace rgpu_tiled
