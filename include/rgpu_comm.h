@@ -84,7 +84,10 @@ const char* rgpu_comm_transport_name(void);
 
 /* euler_hip --slabs: run [run] nstepmax / tend of an .ini on rank `rank` of `nranks`; this process drives HIP device
  * `device` (-1: the current one).  id as above.  Returns the steps done or a negative error; *mcell_per_s = whole-box
- * cell updates per second. */
+ * cell updates per second.  This is the single-GPU run loop (rgpuh_run_hooked, rgpu.h) stepping through this driver: each rank
+ * builds -- or, [run] restart, reads from the .h5 of the whole box -- its own slab; [output] outputHdf5 writes ONE file per
+ * output step for the whole box (the ranks take turns), identical to the single-domain file, plus the .xmf index; the MRI /
+ * Orszag-Tang history file is written by rank 0 from all-reduced sums.  (.vti, Xsmurf and NRRD outputs: single-domain runs.) */
 int rgpuh_run_slabs(const char* ini_path, const char* overrides, int rank, int nranks, int device,
                     const char id[RGPU_COMM_ID_BYTES], double* mcell_per_s, char* err, int err_len);
 
