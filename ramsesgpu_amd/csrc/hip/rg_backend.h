@@ -125,6 +125,15 @@ RG_DEVFN rg_recip_t rg_recip_sqrt_pos(double x) {
 RG_DEVFN void rg_slot_max(unsigned long long* slot, double v) {
   if (v > __longlong_as_double((long long)*reinterpret_cast<volatile unsigned long long*>(slot))) atomicMax(slot, (unsigned long long)__double_as_longlong(v));
 }
+// the same with the maximum of the wave formed first (ds_bpermute butterfly; a lane that has left the kernel reads as 0, the
+// neutral element here): one atomic per wave instead of up to 64 on one address.  Every lane still in the kernel must call it
+// (v = 0 for cells that do not take part).
+RG_DEVFN void rg_slot_max_wave(unsigned long long* slot, double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  const unsigned long long act = __ballot(1);   // after the xor butterfly every lane holds the maximum: the first active one stores it
+  if (__lane_id() == (unsigned)(__ffsll((long long)act) - 1)) rg_slot_max(slot, v);
+}
 enum { RG_DT_SLOTS = 1024 };
 
 // ---- flat per-cell kernels ---------------------------------------------------------------------------------

@@ -137,7 +137,8 @@ RG_DEVFN void hydro_flux_cell(const DevParams& g, const double* __restrict__ T, 
 
 template <int ND, int NV, bool GF>
 RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ Uold, double* __restrict__ Unew,
-                                const double* __restrict__ F, double dtdx, double dtdy, double dtdz, unsigned idx) {
+                                const double* __restrict__ F, double dtdx, double dtdy, double dtdz, unsigned idx,
+                                unsigned long long* dt_slots = 0) {
   const IJK c = unflatten(g, idx);
   const size_t N = g.ncell;
   const int gw = g.gw;
@@ -180,6 +181,16 @@ RG_DEVFN void hydro_update_cell(const DevParams& g, const double* __restrict__ U
       u[IV] += gy * rho_sum;
       if (NV == 5) u[NV - 1] += gz * rho_sum;
     }
+  }
+  if (dt_slots) {   // the CFL scan of the new state rides along (hydro_invdt_cell on the cell just updated); all lanes of the wave
+    double inv = 0.0;
+    if (inner) {
+      double q[NV];
+      const double cs = hydro_prim<NV>(g, u, q);
+      inv = (cs + fabs(q[IU])) / g.dx + (cs + fabs(q[IV])) / g.dy;
+      if (NV == 5) inv = (cs + fabs(q[IU])) / g.dx + (cs + fabs(q[IV])) / g.dy + (cs + fabs(q[IW])) / g.dz;
+    }
+    rgpu::rg_slot_max_wave(dt_slots + ((idx >> 6) & (rgpu::RG_DT_SLOTS - 1)), inv);
   }
 #pragma unroll
   for (int v = 0; v < NV; ++v) Unew[idx + v * N] = u[v];

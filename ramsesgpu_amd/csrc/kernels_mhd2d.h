@@ -226,7 +226,7 @@ RG_DEVFN void mhd_flux2d_cell(const DevParams& g, const double* __restrict__ T, 
 template <bool GF>
 RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
                                 double* __restrict__ Unew, const double* __restrict__ F, double dt, double dtdx, double dtdy,
-                                unsigned idx) {
+                                unsigned idx, unsigned long long* dt_slots = 0) {
   const IJK c = unflatten(g, idx);
   const size_t N = g.ncell;
   const unsigned sj = g.sj;
@@ -286,6 +286,23 @@ RG_DEVFN void mhd_update2d_cell(const DevParams& g, const RotCoef rc, const doub
     const double* e = F + (size_t)F2_EMF * N;
     u[IA] += (e[idx + sj] - e[idx]) * dtdy;
     u[IB] -= (e[idx + 1] - e[idx]) * dtdx;
+  }
+  // dt_slots != 0: the CFL scan of the NEW state rides along (as in mhd_update3d_cell): the new field on the two high faces
+  // belongs to the +1 neighbours, whose CT update is repeated here from the same emf values; 2D value of mhd_invdt_cell
+  if (dt_slots) {   // (all lanes of the wave: the maximum is formed wave-wide before it goes to a slot)
+    double inv = 0.0;
+    if (in_i && in_j) {
+      const double* e = F + (size_t)F2_EMF * N;
+      unsigned m = idx + 1;
+      const double bnx = Uold[m + IA * N] + (e[m + sj] - e[m]) * dtdy;
+      m = idx + sj;
+      const double bny = Uold[m + IB * N] - (e[m + 1] - e[m]) * dtdx;
+      const Prim8 q = mhd_prim(g, u, bnx, bny, 0.0, 0.0);
+      double sx, sy, sz;
+      info_speeds(g, q, sx, sy, sz);
+      inv = sx / g.dx + sy / g.dy;
+    }
+    rgpu::rg_slot_max_wave(dt_slots + ((idx >> 6) & (rgpu::RG_DT_SLOTS - 1)), inv);
   }
 #pragma unroll
   for (int v = 0; v < 8; ++v) Unew[idx + v * N] = u[v];

@@ -74,8 +74,8 @@ struct K_hydro_flux {
 };
 template <int ND, int NV, bool GF = false>
 struct K_hydro_update {
-  DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy, dtdz;
-  RG_DEVFN void operator()(unsigned idx) const { hydro_update_cell<ND, NV, GF>(g, Uold, Unew, F, dtdx, dtdy, dtdz, idx); }
+  DevParams g; const double* Uold; double* Unew; const double* F; double dtdx, dtdy, dtdz; unsigned long long* dt_slots;
+  RG_DEVFN void operator()(unsigned idx) const { hydro_update_cell<ND, NV, GF>(g, Uold, Unew, F, dtdx, dtdy, dtdz, idx, dt_slots); }
 };
 template <int NV>
 struct K_hydro_invdt {
@@ -146,8 +146,8 @@ struct K_mhd_flux2d {
 };
 template <bool GF = false>
 struct K_mhd_update2d {
-  DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; double dt, dtdx, dtdy;
-  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell<GF>(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx); }
+  DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; double dt, dtdx, dtdy; unsigned long long* dt_slots;
+  RG_DEVFN void operator()(unsigned idx) const { mhd_update2d_cell<GF>(g, rc, Uold, Unew, F, dt, dtdx, dtdy, idx, dt_slots); }
 };
 template <int SPEC = SPEC_NONE>
 struct K_mhd_elec {

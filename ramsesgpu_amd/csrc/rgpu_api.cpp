@@ -482,12 +482,19 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     K_hydro_flux<ND, NV, true> kg = {g, c->T, c->F};
     if (gf ? launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), kg) : launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1;
   }
+  // flat path (2D; 3D with a per-cell gravity field): the CFL scan of the new state rides in the update kernel when the
+  // whole domain is updated in this call and nothing modifies the state afterwards
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
+  unsigned long long* slots = scan2 ? c->d_red : 0;
+  if (scan2 && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   {
     Phase ph(c, RGPU_T_UPDATE);
-    K_hydro_update<ND, NV, false> k = {g, in, out, c->F, dtdx, dtdy, dtdz};
-    K_hydro_update<ND, NV, true> kg = {g, in, out, c->F, dtdx, dtdy, dtdz};
+    K_hydro_update<ND, NV, false> k = {g, in, out, c->F, dtdx, dtdy, dtdz, slots};
+    K_hydro_update<ND, NV, true> kg = {g, in, out, c->F, dtdx, dtdy, dtdz, slots};
     if (gf ? launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), kg) : launch_planes<kBlock, 1>(c->stream, g, clip(a, b, ks), k)) return -1;
   }
+  if (scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
   return 0;
 }
 
@@ -518,12 +525,23 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
     K_mhd_flux2d<true> kg = {g, c->T, c->F};
     if (gf ? rg_launch<kBlockHeavy>(c->stream, c->n32, kg) : rg_launch<kBlockHeavy>(c->stream, c->n32, k)) return -1;
   }
+  // the CFL scan of the new state rides in the update kernel under the conditions of the 3D step (mhd3d_core): nothing
+  // modifies the state afterwards, and on the rotating path (ghosts refilled before the reference scans) the refilled high
+  // faces are bit-identical periodic copies
+  const rgpu_params& p = c->p;
+  bool scan = !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
+  if (scan && g.rot) scan = p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC;
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  if (no_fused_dt) scan = false;
+  unsigned long long* slots = scan ? c->d_red : 0;
+  if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   {
     Phase ph(c, RGPU_T_UPDATE);
-    K_mhd_update2d<false> k = {g, rc, in, out, c->F, dt, dtdx, dtdy};
-    K_mhd_update2d<true> kg = {g, rc, in, out, c->F, dt, dtdx, dtdy};
+    K_mhd_update2d<false> k = {g, rc, in, out, c->F, dt, dtdx, dtdy, slots};
+    K_mhd_update2d<true> kg = {g, rc, in, out, c->F, dt, dtdx, dtdy, slots};
     if (gf ? rg_launch<kBlock>(c->stream, c->n32, kg) : rg_launch<kBlock>(c->stream, c->n32, k)) return -1;
   }
+  if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
   return 0;
 }
 

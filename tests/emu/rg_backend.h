@@ -39,6 +39,7 @@ inline void rg_slot_max(unsigned long long* slot, double v) {
   std::memcpy(&cur, slot, sizeof(double));
   if (v > cur) std::memcpy(slot, &v, sizeof(double));
 }
+inline void rg_slot_max_wave(unsigned long long* slot, double v) { rg_slot_max(slot, v); }
 enum { RG_DT_SLOTS = 1024 };
 
 template <int BLOCK, int MINW = 1, class K>
