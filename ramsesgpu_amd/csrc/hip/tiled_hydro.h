@@ -412,12 +412,12 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
     const int SP = SPEC_HYDRO_HLLC | SPEC_SLOPE1 | SPEC_NO_GRAVITY;
     if (tile && spec_matches(SP, g)) {
       const std::string ts = tile;
-      if (ts == "32x16") return launch_hydro3d_sweep<32, 16, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
-      if (ts == "64x8") return launch_hydro3d_sweep<64, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
-      if (ts == "64x4") return launch_hydro3d_sweep<64, 4, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
-      if (ts == "32x8") return launch_hydro3d_sweep<32, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
-      if (ts == "32x8w3") return launch_hydro3d_sweep<32, 8, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
-      if (ts == "64x4w3") return launch_hydro3d_sweep<64, 4, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb);
+      if (ts == "32x16") return launch_hydro3d_sweep<32, 16, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+      if (ts == "64x8") return launch_hydro3d_sweep<64, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+      if (ts == "64x4") return launch_hydro3d_sweep<64, 4, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+      if (ts == "32x8") return launch_hydro3d_sweep<32, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+      if (ts == "32x8w3") return launch_hydro3d_sweep<32, 8, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+      if (ts == "64x4w3") return launch_hydro3d_sweep<64, 4, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
     }
   }
 #endif
