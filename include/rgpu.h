@@ -234,7 +234,15 @@ int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
  * pipeline fill instead of one per plane range), RGPU_CORE_UPDATE then completes planes [k_lo,k_hi) -- any sub-ranges of a
  * FLUXES range, in any order.  For every other solver FLUXES does nothing and UPDATE is rgpu_step_core_planes, so the
  * schedule  FLUXES [0,ksize) ; UPDATE boundary ranges ; exchange || UPDATE inner range  is valid for all of them. */
-enum { RGPU_CORE_FLUXES = 1, RGPU_CORE_UPDATE = 2 };
+enum { RGPU_CORE_FLUXES = 1, RGPU_CORE_UPDATE = 2, RGPU_CORE_SCAN = 4 };
+/* | RGPU_CORE_SCAN: the CFL scan of the new state rides in the update kernels of the pieces (no pass over U for the next
+ * compute_dt): FLUXES | SCAN resets the context's RGPU_DT_SLOTS device slots, every UPDATE | SCAN accumulates the maxima of the
+ * cells it updates, rgpu_inv_dt_fused_commit(ctx, parity of the new state) closes the accumulation and returns the number of
+ * slots to all-reduce (rgpu_inv_dt_device_slot) before rgpu_inv_dt_result.  rgpu_inv_dt_fused_active tells right after the
+ * FLUXES call whether the step can carry the scan; if not (dissipative stage, forcing, open faces on the rotating path, flat
+ * kernels) scan with rgpu_inv_dt_accumulate as before. */
+int rgpu_inv_dt_fused_active(rgpu_ctx* c, int parity);   /* after FLUXES | SCAN: 1 when this step's pieces carry the scan */
+int rgpu_inv_dt_fused_commit(rgpu_ctx* c, int parity);
 int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int what);
 /* The dissipative stage of the step ([hydro] nu / [MHD] eta > 0; no-op otherwise) on U[(nStep+1)%2], WITHOUT the ghost
  * fill that precedes it in rgpu_godunov_unsplit: a slab driver calls it between rgpu_step_core and rgpu_step_post_a after

@@ -28,6 +28,7 @@ struct rgpu_comm {
   int primed;     // parity of the state whose ghosts are all valid, -1 = none
   int scanned;    // parity of the state whose 1/dt sits in the context's device slot, -1 = none
   std::vector<P2P> ops[2];
+  int scan_slots;   // > 0: the 1/dt maxima of the last step sit in that many device slots (fused scan), else in slot 0
   std::string err;
 };
 
@@ -106,9 +107,12 @@ int compute_dt(rgpu_comm* cm, int useU, double* dt) {
   if (cm->scanned != useU) {   // not accumulated plane range by plane range during the last step: full scan
     const int ks = cm->p.nz + 2 * cm->p.ghostWidth;
     RG_TRY(rgpu_inv_dt_accumulate(c, useU, 0, ks, 1), "inv_dt_accumulate");
+    cm->scan_slots = 0;
   }
   cm->scanned = -1;
-  if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), 1, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
+  const int nslots = cm->scan_slots > 0 ? cm->scan_slots : 1;   // the update kernels left their maxima in several slots
+  cm->scan_slots = 0;
+  if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), nslots, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
   double inv = 0.0;
   RG_TRY(rgpu_inv_dt_result(c, &inv), "inv_dt_result");
   *dt = cm->p.cfl / inv;
@@ -175,20 +179,29 @@ int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
   const bool scan = !rot;   // rotating path: the reference's compute_dt sees the refilled ghosts -> full scan next step
   // fluxes / EMFs of the whole slab in one z-marching launch (3D MHD; a no-op for the solvers whose sweep is the whole step),
   // then the update range by range: the boundary-planes-first order costs no extra pipeline fill of the sweep
-  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES), "step_core_planes(fluxes)");
-  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE), "step_core_planes(update)");
-  if (scan) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
+  // ... and the CFL scan of the new state rides in the update kernels (RGPU_CORE_SCAN) when the step allows it: no pass over
+  // the output for the next compute_dt.  Otherwise, plain path: scan plane range by plane range before each fill.
+  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | RGPU_CORE_SCAN), "step_core_planes(fluxes)");
+  bool fused = rgpu_inv_dt_fused_active(c, pout) != 0;
+  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE | RGPU_CORE_SCAN), "step_core_planes(update)");
+  if (scan && !fused) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
   for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
   if (int rc = exchange_start(cm, pout)) return rc;
   if (has_inner) {
-    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE), "step_core_planes(update)");
-    if (scan) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE | RGPU_CORE_SCAN), "step_core_planes(update)");
+    if (scan && !fused) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
     RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, 2 * gw, nz), "step_fill_planes");
   }
   if (int rc = exchange_wait(cm)) return rc;
   RG_TRY(rgpu_make_boundaries(c, pout, RGPU_ZDIR), "make_boundaries(Z)");   // physical z faces (+ 3D jet)
   cm->primed = pout;
-  cm->scanned = scan ? pout : -1;
+  int nslots = 0;
+  if (fused) {
+    nslots = rgpu_inv_dt_fused_commit(c, pout);
+    if (nslots <= 0) return fail(cm, RGPU_EHIP, "the accumulated CFL scan was lost between the update pieces");
+  }
+  cm->scanned = (fused || scan) ? pout : -1;
+  cm->scan_slots = nslots;
   return 0;
 }
 
@@ -204,7 +217,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   rgpu_comm* cm = new (std::nothrow) rgpu_comm();
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
-  cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1;
+  cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
   if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");

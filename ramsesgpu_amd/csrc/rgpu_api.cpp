@@ -56,6 +56,7 @@ struct rgpu_ctx {
   unsigned xcd_sub;     // sub-band size (cells) of the XCD-aware workgroup order of THIS context, 0 = linear
   int fused_dt_parity;  // parity of the state whose CFL maximum the last sweep left in d_red (-1: none)
   int fused_dt_slots;   // how many slots of d_red hold it (1: hydro sweep; RG_DT_SLOTS: MHD update kernel)
+  int scan_acc_parity;  // parity of the state whose CFL maximum is being accumulated piece by piece (RGPU_CORE_SCAN), -1: none
   std::string err;
 };
 
@@ -212,6 +213,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->xcd_sub = 4096;
   c->fused_dt_parity = -1;
   c->fused_dt_slots = 1;
+  c->scan_acc_parity = -1;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
   c->device = rg_current_device();
@@ -447,19 +449,23 @@ int hydro_flux_trace_spec(rgpu_ctx* c, double dtdx, double dtdy, double dtdz, in
 }
 
 template <int ND, int NV>
-int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int b) {
+int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int b, bool acc_piece = false) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
   const int ks = g.ksize;
   if (ND == 3) {   // LDS-tiled z-marching sweep: the whole step in one kernel (hip/tiled_hydro.h)
     Phase ph(c, RGPU_T_SWEEP);
-    // whole-domain steps whose output nothing modifies afterwards carry the CFL scan of the new state along
-    const bool scan = a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
-                      rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on != 2;
+    // whole-domain steps whose output nothing modifies afterwards carry the CFL scan of the new state along; slab pieces
+    // (acc_piece: RGPU_CORE_UPDATE | RGPU_CORE_SCAN after a reset by the FLUXES call) accumulate into the same slot
+    const bool cond = !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled && rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on != 2;
+    const bool scan = a <= 0 && b >= ks && cond && !acc_piece;
+    const bool piece = acc_piece && cond && c->scan_acc_parity == ((out == c->U[0]) ? 0 : 1);
+    if (acc_piece && !piece) c->scan_acc_parity = -1;
     if (scan && rg_memset_async(c->d_red, 0, sizeof(unsigned long long), c->stream)) return -1;
-    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, scan ? c->d_red : 0);
+    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0);
     if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }
     if (rc <= 0) return rc;
+    if (acc_piece) c->scan_acc_parity = -1;   // flat kernels took over: no accumulated scan for this step
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
@@ -583,7 +589,8 @@ template <int S> using K_upd_t = K_mhd_update3d<false, false, S>;
 // phase timers on (or RGPU_CHUNKS=1) everything is issued on the context stream in one chunk.
 // what: 0 = the whole update of planes [a,b); RGPU_CORE_FLUXES = only F, emf (+ the shear remap buffers) that update needs;
 // RGPU_CORE_UPDATE = only the update, from F, emf computed by an earlier RGPU_CORE_FLUXES call covering [a,b)
-int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what = 0) {
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what_flags = 0) {
+  int what = what_flags;
   const DevParams& g = c->g;
   const rgpu_params& p = c->p;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
@@ -647,14 +654,28 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // field on the three high boundary faces keeps its CT value -- always true on the plain path (the reference scans
   // before the ghosts are refilled), on the rotating path when y, z are periodic (the refilled faces are bit-identical
   // copies) and x is periodic or the shearing box (its ghost fill skips the first outer Bx face).
-  bool scan = what == 0 && a <= 0 && b >= ks && !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
-  if (scan && g.rot) {
+  // Slab pieces (RGPU_CORE_SCAN with the split calls): the same scan accumulated over the update launches of a step -- the
+  // slots are reset by the FLUXES call; a z face shared with a neighbour slab (RGPU_BC_COPY) counts like a periodic one: the
+  // exchanged faces are the doubles this slab's own CT update gives them.
+  const bool acc = (what & RGPU_CORE_SCAN) != 0;
+  what &= ~RGPU_CORE_SCAN;
+  bool cond = !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
+  if (cond && g.rot) {
     const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
-    scan = xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && p.bc[4] == RGPU_BC_PERIODIC && p.bc[5] == RGPU_BC_PERIODIC;
+    auto zok = [](int b) { return b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY; };
+    cond = xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && zok(p.bc[4]) && zok(p.bc[5]);
   }
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  if (no_fused_dt) scan = false;
-  unsigned long long* slots = scan ? c->d_red : 0;
+  if (no_fused_dt) cond = false;
+  const int out_parity = (out == c->U[0]) ? 0 : 1;
+  bool scan = what == 0 && a <= 0 && b >= ks && cond;
+  if (scan && g.rot && (p.bc[4] == RGPU_BC_COPY || p.bc[5] == RGPU_BC_COPY)) scan = false;   // whole-slab call of a slab: the driver scans
+  if (acc && what == RGPU_CORE_FLUXES) {
+    c->scan_acc_parity = cond ? out_parity : -1;
+    if (cond && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  }
+  const bool scan_piece = acc && what == RGPU_CORE_UPDATE && cond && c->scan_acc_parity == out_parity;
+  unsigned long long* slots = (scan || scan_piece) ? c->d_red : 0;
   if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   // after the sweep the update is a pure stream over F, emf and U (nothing of it is left in L2): the linear workgroup order
   // measured 8.16 ms against 8.6-9.0 with the XCD sub-band order at 512^3 (which pays for the stencil re-reads of the flat
@@ -736,7 +757,22 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 // for every other solver FLUXES is a no-op and UPDATE the whole piece, so a driver may use the split schedule blindly
 int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int what = 0) {
   const bool splittable = c->g.three_d && c->p.mhdEnabled;
-  if (what != 0 && !splittable) { if (what == RGPU_CORE_FLUXES) return 0; what = 0; }
+  const bool acc = (what & RGPU_CORE_SCAN) != 0;
+  bool hydro_piece = false;
+  if ((what & ~RGPU_CORE_SCAN) != 0 && !splittable) {
+    static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+    if ((what & ~RGPU_CORE_SCAN) == RGPU_CORE_FLUXES) {   // nothing to compute; with SCAN: reset the slot for the pieces that follow
+      c->scan_acc_parity = -1;
+      if (acc && c->g.three_d && !c->p.mhdEnabled && !no_fused_dt && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
+          rgpu_tiled::hydro3d_sweep_covers(c->g) && c->p.gravityEnabled != 2) {
+        if (rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+        c->scan_acc_parity = (nStep + 1) % 2;
+      }
+      return 0;
+    }
+    hydro_piece = acc && c->g.three_d && !c->p.mhdEnabled;
+    what = 0;
+  }
   c->fused_dt_parity = -1;   // the output array is about to change (a whole-domain hydro sweep sets it again)
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
@@ -756,7 +792,7 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   if (a < 0) a = 0;
   if (b > c->g.ksize) b = c->g.ksize;
   if (b <= a) return 0;
-  if (!c->p.mhdEnabled) return hydro_core<3, 5>(c, in, out, dt, a, b);
+  if (!c->p.mhdEnabled) return hydro_core<3, 5>(c, in, out, dt, a, b, hydro_piece);
   return mhd3d_core(c, in, out, dt, totalTime, a, b, what);
 }
 
@@ -789,6 +825,7 @@ int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime, bool f
   const double nu = c->p.nu, eta = c->p.mhdEnabled ? c->p.eta : 0.0;
   if (!(nu > 0 || eta > 0)) return 0;
   c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
   Phase ph(c, RGPU_T_DISSIPATIVE);
   double* U = c->U[(nStep + 1) % 2];
   int rc = 0;
@@ -811,6 +848,7 @@ int step_core(rgpu_ctx* c, int nStep, double dt, double totalTime) {
 // max of the per-cell 1/dt over the flat index range [idx0, idx0+n) into the device slot (reset or accumulate)
 int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) {
   c->fused_dt_parity = -1;   // the slot is rewritten
+  c->scan_acc_parity = -1;
   Phase ph(c, RGPU_T_DT);
   const double* U = c->U[parity & 1];
   if (c->p.mhdEnabled) {
@@ -903,6 +941,7 @@ double forcing_norm(const rgpu_params& p, const double* s, double dt) {   // Hyd
 
 int add_forcing(rgpu_ctx* c, int parity, double norm) {
   c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
   K_add_forcing k = {c->g, c->U[parity & 1], c->Frc, norm};
   return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
 }
@@ -911,6 +950,7 @@ int add_forcing(rgpu_ctx* c, int parity, double norm) {
 int step_ou_forcing(rgpu_ctx* c, int parity, double dt) {
   if (!c->ou) return 0;
   c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
   Phase ph(c, RGPU_T_UPDATE);
   c->ou->update(dt, c->p.cIso);
   K_ou_forcing k = {c->g, c->U[parity & 1], c->ou->m, dt, c->p.yMin, c->p.zMin, c->p.slab_rank * c->p.nz};
@@ -983,6 +1023,7 @@ const char* rgpu_last_error(rgpu_ctx* c) { return c ? c->err.c_str() : "null con
 int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
   RG_CHECK_CTX(c);
   c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
   if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "upload: null pointer / context without state");
   const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
   if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");
@@ -1131,8 +1172,17 @@ int rgpu_inv_dt_accumulate(rgpu_ctx* c, int parity, int k_lo, int k_hi, int rese
 int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt) {
   RG_CHECK_CTX(c);
   if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "inv_dt_result: null pointer / context without state");
-  if (inv_dt_fetch(c, invDt)) return RG_HIPFAIL(c, "inv_dt_result");
+  if (inv_dt_fetch(c, invDt, c->fused_dt_parity >= 0 ? c->fused_dt_slots : 1)) return RG_HIPFAIL(c, "inv_dt_result");
   return RGPU_OK;
+}
+int rgpu_inv_dt_fused_active(rgpu_ctx* c, int parity) { return (c && c->U[0] && c->scan_acc_parity == (parity & 1)) ? 1 : 0; }
+int rgpu_inv_dt_fused_commit(rgpu_ctx* c, int parity) {
+  if (!c || !c->U[0]) return 0;
+  if (c->scan_acc_parity != (parity & 1)) { c->scan_acc_parity = -1; return 0; }
+  c->scan_acc_parity = -1;
+  c->fused_dt_parity = parity & 1;
+  c->fused_dt_slots = RG_DT_SLOTS;
+  return RG_DT_SLOTS;
 }
 
 int rgpu_history_columns(rgpu_ctx* c, int parity, double* cols) {
@@ -1240,7 +1290,8 @@ int rgpu_step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
 int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int what) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
-  if (what != RGPU_CORE_FLUXES && what != RGPU_CORE_UPDATE) return fail(c, RGPU_EINVAL, "step_core_planes_split: what must be RGPU_CORE_FLUXES or RGPU_CORE_UPDATE");
+  if ((what & ~RGPU_CORE_SCAN) != RGPU_CORE_FLUXES && (what & ~RGPU_CORE_SCAN) != RGPU_CORE_UPDATE)
+    return fail(c, RGPU_EINVAL, "step_core_planes_split: what must be RGPU_CORE_FLUXES or RGPU_CORE_UPDATE (| RGPU_CORE_SCAN)");
   if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi, what)) return RG_HIPFAIL(c, "step_core_planes_split");
   return RGPU_OK;
 }

@@ -6,7 +6,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 def short(n):
-    m = re.search(r"K_\w+(<[^>]*>)?", n)
+    m = re.search(r"K_\w+(<[^>]*>)?", n) or re.search(r"(mhd3d|hydro3d)_sweep_kernel", n) or re.search(r"nccl\w*|rccl\w*", n)
     return m.group(0) if m else n[:30]
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows]
 ks.sort()
