@@ -62,10 +62,63 @@ struct HydroTile {
 // map the flat block index to (tile x, tile y, z segment) so that each XCD (block b runs on XCD b % 8) owns a
 // contiguous run of tiles -- x fastest, then y, then z segment: overlapping tile edges are then re-read from that
 // XCD's own L2
+// Work items = (tile, z segment), tile fastest, dealt to the XCDs in contiguous runs of ipx items.  All workgroups of a launch
+// take the same time per plane, so an XCD works through its run in rounds of `slots` resident workgroups and a partly filled
+// last round would cost a whole segment.  Therefore the items of the last, incomplete round are cut once more, each into
+// `tail` sub-segments: up to `slots` short workgroups that finish in 1/tail of a round.  Block b -> XCD b & 7, local index
+// b >> 3: the first `full` local indices are whole items, the rest sub-segments of the remaining items.
 struct TileGrid {
-  int nbx, nby, nseg, per_xcd;
-  int flags;   // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
+  int nbx, nby, nseg;      // tiles and base z segments per tile
+  int ipx, full, tail;     // items per XCD; whole items per XCD; sub-segments per item of the last round (>= 1)
+  int per_xcd;             // workgroups per XCD = full + (ipx - full) * tail
+  int flags;               // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
 };
+struct TileItem { int bx, by, sa, sb; bool valid; };
+// planes [sa, sb) of [za, zb) and the tile of block b
+RG_DEVFN TileItem tile_item(const TileGrid& tg, int b, int za, int zb) {
+  TileItem it;
+  const int xcd = b & 7, l = b >> 3;
+  int item, sub = 0, nsub = 1;
+  if (l < tg.full) item = xcd * tg.ipx + l;
+  else { const int q = l - tg.full; item = xcd * tg.ipx + tg.full + q / tg.tail; sub = q % tg.tail; nsub = tg.tail; }
+  const int tiles = tg.nbx * tg.nby;
+  it.valid = l < tg.per_xcd && item < (xcd + 1) * tg.ipx && item < tiles * tg.nseg;
+  const int t = it.valid ? item % tiles : 0, seg = it.valid ? item / tiles : 0;
+  it.bx = t % tg.nbx;
+  it.by = t / tg.nbx;
+  const int span = zb - za;
+  const int a0 = za + (int)(((long long)span * seg) / tg.nseg), b0 = za + (int)(((long long)span * (seg + 1)) / tg.nseg);
+  it.sa = a0 + (int)(((long long)(b0 - a0) * sub) / nsub);
+  it.sb = a0 + (int)(((long long)(b0 - a0) * (sub + 1)) / nsub);
+  if (it.sb <= it.sa) it.valid = false;
+  return it;
+}
+// host: base segment count and tail split minimising the modelled duration (iterations of the z march; a segment costs
+// `fill` extra iterations), for `slots` resident workgroups per XCD
+inline void tile_grid_plan(TileGrid& tg, int span, int slots, int min_planes, int fill, int zseg_env) {
+  const int tiles = tg.nbx * tg.nby;
+  int best_n = 1, best_tail = 1;
+  double best = 1e300;
+  const int nmax = zseg_env > 0 ? 1 : (span / min_planes < 1 ? 1 : (span / min_planes > 64 ? 64 : span / min_planes));
+  for (int n0 = 1; n0 <= nmax; ++n0) {
+    const int n = zseg_env > 0 ? (span + zseg_env - 1) / zseg_env : n0;
+    const int items = tiles * n, ipx = (items + 7) / 8;
+    const int full = (ipx / slots) * slots, rem = ipx - full;
+    const double len = (double)span / n;
+    int tail = 1;
+    if (rem > 0) { tail = slots / rem; const int cap = (int)(len / min_planes); if (tail > cap) tail = cap; if (tail < 1) tail = 1; }
+    const double t = (full / slots) * (len + fill) + (rem > 0 ? (len / tail + fill) * ((rem * tail + slots - 1) / slots) : 0.0);
+    if (t < best * 0.995) { best = t; best_n = n; best_tail = tail; }   // ties: the fewer, longer segments
+  }
+  if (best_n > span) best_n = span;
+  if (best_n < 1) best_n = 1;
+  tg.nseg = best_n;
+  const int items = tiles * tg.nseg;
+  tg.ipx = (items + 7) / 8;
+  tg.full = (tg.ipx / slots) * slots;
+  tg.tail = (tg.ipx - tg.full) > 0 ? best_tail : 1;
+  tg.per_xcd = tg.full + (tg.ipx - tg.full) * tg.tail;
+}
 
 // dslot != 0: the CFL scan of the NEW state rides along -- every updated cell contributes sum_d (c + |v_d|) / delta_d
 // (hydro_invdt_cell) to a 64-bit atomicMax on *dslot, so that the next compute_dt needs no pass over U (all values are
@@ -81,17 +134,9 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
   static_assert(RING <= NT, "ring cells are handled by the first RING threads");
   __shared__ HydroTile<TX, TY> L;
 
-  const int b = (int)blockIdx.x;
-  const int lin = (b & 7) * tg.per_xcd + (b >> 3);
-  if ((b >> 3) >= tg.per_xcd || lin >= tg.nbx * tg.nby * tg.nseg) return;   // whole workgroup leaves: no barrier is skipped
-  const int bx = lin % tg.nbx;
-  const int by = (lin / tg.nbx) % tg.nby;
-  const int seg = lin / (tg.nbx * tg.nby);
-  // this workgroup's planes [sa, sb) of the update range [za, zb)
-  const int span = zb - za;
-  const int sa = za + (int)(((long long)span * seg) / tg.nseg);
-  const int sb = za + (int)(((long long)span * (seg + 1)) / tg.nseg);
-  if (sb <= sa) return;
+  const TileItem item = tile_item(tg, (int)blockIdx.x, za, zb);   // this workgroup's tile and its planes [sa, sb) of [za, zb)
+  if (!item.valid) return;   // whole workgroup leaves: no barrier is skipped
+  const int bx = item.bx, by = item.by, sa = item.sa, sb = item.sb;
 
   const int t = (int)threadIdx.x;
   const int ti = t % TX, tj = t / TX;
@@ -356,28 +401,8 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   tg.nby = (g.jsize - 1 + (TY - 2) - 1) / (TY - 2);
   const int span = zb - za;
   static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
-  int nseg;
-  if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
-  else {
-    // Two workgroups are resident per CU (190 VGPRs), all of them take the same time: the launch proceeds in rounds of
-    // 512 workgroups and the last round should be full.  A segment costs two extra iterations (pipeline fill).  Pick the
-    // segment count with the best (occupancy of the last round) x (useful iterations): at 256^3 (19 x 19 tiles) that is
-    // 7 segments of ~37 planes, 4.94 rounds (measured: 1.075 ms per sweep against 1.125 with 5 segments, 3.5 rounds).
-    const int tiles = tg.nbx * tg.nby, slots = 512;
-    double best = -1.0;
-    nseg = 1;
-    for (int n = 1; n <= span / 12 && n <= 64; ++n) {
-      const int total = tiles * n, rounds = (total + slots - 1) / slots;
-      const double len = (double)span / n;
-      const double eff = (double)total / ((double)rounds * slots) * (len / (len + 2.0));
-      if (eff > best * 1.005) { best = eff; nseg = n; }   // ties: the fewer, longer segments
-    }
-  }
-  if (nseg < 1) nseg = 1;
-  if (nseg > span) nseg = span;
-  tg.nseg = nseg;
-  const int total = tg.nbx * tg.nby * tg.nseg;
-  tg.per_xcd = (total + 7) / 8;
+  // two workgroups are resident per CU (~200 VGPRs): 64 per XCD; a segment costs two extra iterations (pipeline fill)
+  tile_grid_plan(tg, span, 64, 12, 2, zseg_env);
   hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC, MINW>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
                      dtdx, dtdy, dtdz, za, zb, dslot);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -137,16 +137,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   __shared__ int Lsync;                      // arrival counter of the producer pair
   __shared__ int Lesync;                     // arrival counter of the Riemann waves: E planes completed x 6
 
-  const int b = (int)blockIdx.x;
-  const int lin = (b & 7) * tg.per_xcd + (b >> 3);
-  if ((b >> 3) >= tg.per_xcd || lin >= tg.nbx * tg.nby * tg.nseg) return;
-  const int bx = lin % tg.nbx;
-  const int by = (lin / tg.nbx) % tg.nby;
-  const int seg = lin / (tg.nbx * tg.nby);
-  const int span = rb - ra;
-  const int sa = ra + (int)(((long long)span * seg) / tg.nseg);
-  const int sb = ra + (int)(((long long)span * (seg + 1)) / tg.nseg);
-  if (sb <= sa) return;
+  const TileItem item = tile_item(tg, (int)blockIdx.x, ra, rb);   // this workgroup's tile and its planes [sa, sb) of [ra, rb)
+  if (!item.valid) return;
+  const int bx = item.bx, by = item.by, sa = item.sa, sb = item.sb;
 
   const int gw = g.gw;
   const int i0 = gw + bx * MH_OX, j0 = gw + by * MH_OY;   // first cell of the tile
@@ -379,28 +372,9 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   if (copy_y) tg.nby -= 1;
   const int span = rb - ra;
   static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
-  int nseg;
-  if (zseg_env > 0) nseg = (span + zseg_env - 1) / zseg_env;
-  else {
-    // One workgroup per CU is resident and all take the same time: the launch proceeds in rounds of 256 workgroups.  A
-    // segment costs two extra iterations (pipeline fill).  Pick the segment count with the best (occupancy of the last
-    // round) x (useful iterations), segments of >= 8 planes: 5 segments at 512^3 (2145 tiles, 41.9 rounds), 2 for a
-    // 64-plane slab (16.8 rounds instead of 8.4).
-    const int tiles = tg.nbx * tg.nby, slots = 256;
-    double best = -1.0;
-    nseg = 1;
-    for (int n = 1; n <= span / 8 && n <= 64; ++n) {
-      const int total = tiles * n, rounds = (total + slots - 1) / slots;
-      const double len = (double)span / n;
-      const double eff = (double)total / ((double)rounds * slots) * (len / (len + 2.0));
-      if (eff > best * 1.005) { best = eff; nseg = n; }   // ties: the fewer, longer segments
-    }
-  }
-  if (nseg < 1) nseg = 1;
-  if (nseg > span) nseg = span;
-  tg.nseg = nseg;
-  const int total = tg.nbx * tg.nby * tg.nseg;
-  tg.per_xcd = (total + 7) / 8;
+  // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3: one base
+  // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
+  tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
   hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
                      dt, dtdx, dtdy, dtdz, ra, rb);
   if (hipGetLastError() != hipSuccess) return -1;
