@@ -2,7 +2,7 @@
 # Profile run on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats, three separate --pmc passes -- for the
 # headline workload (512^3 MRI) and for the 256^3 hydro implosion.  Results land in gpurun_out/prof_$TAG; summarise with
 # scripts/summarize_prof.py $TAG into profiles/.
-TAG=${1:-r02f}
+TAG=${1:-r02g}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
