@@ -166,6 +166,36 @@ def test_rccl_driver_single_rank_on_gpu(base, ov, nsteps, overlap, gpu_lib, orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=32;mesh.ny=48;mesh.nz=40"), ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40"),
+                                     ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=32;hydro.riemannSolver=hllc")], ids=["mri", "ot3d", "implode3d"])
+def test_overlapped_slab_steps_need_no_scan_kernel(base, ov, tmp_path):
+    """the CFL scan of the overlapped slab schedule rides in the update kernels (RGPU_CORE_SCAN): after the first step the
+    phase timers show no stand-alone scan, and the time steps equal those of the single-device run.  In a subprocess (RCCL)."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from ramsesgpu_amd import comm as rcomm
+from ramsesgpu_amd.solver import Solver, load_library
+L = load_library(); CL = rcomm.load_comm_library()
+ini = os.path.join(%r, "configs", %r + ".ini"); ov = %r
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True)
+run.init_simulation()
+dts = [run.oneStepIntegration()]
+run.solver.enable_timers(True); run.solver.reset_timers()
+dts += [run.oneStepIntegration() for _ in range(4)]
+tm = run.solver.timers(); run.close()
+assert tm["dt"] == 0.0 and (tm["update"] > 0 or tm["sweep"] > 0), tm
+p = L.params_from_ini(ini, ov); sv = Solver(p, L); ref = sv.start(L.init_condition(ini, ov, p), 5); sv.close()
+assert list(dts) == list(ref), (dts, ref)
+print("OK")
+''' % (ROOT, ROOT, base, ov)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_euler_hip_slabs_front_end_single_rank(gpu_lib, tmp_path):
     """euler_hip --slabs 1: rendezvous file, rgpuh_run_slabs, RCCL self ring -- same step count and dt log as the single-GPU run"""
     exe = os.path.join(ROOT, "ramsesgpu_amd", "euler_hip")
