@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Phase timers of one rank of the z-slab schedule at N = 8 (a 512 x 512 x 64 slab, its own z neighbour) through the C++
+driver: where a rank's step goes (sweep / update / ghost fill; no stand-alone CFL scan: it rides in the update kernels)."""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 from ramsesgpu_amd import comm as rcomm
