@@ -167,9 +167,12 @@ UPSCALE_CASES = [
 
 def check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt="rgr"):
     """fmt: "rgr" = the raw dump, "h5" = the reference's HDF5 format (needs libhdf5)"""
+    old = os.getcwd()
+    os.chdir(tmp_path)      # (the .xmf index of HDF5 outputs goes to the current directory)
     try:
         _check_upscale(lib, base, ovf, dims, ghosts, tmp_path, fmt)
     finally:
+        os.chdir(old)
         os.environ.pop("RGPU_RESTART_FORMAT", None)
 
 
