@@ -200,6 +200,13 @@ int rgpu_make_all_boundaries(rgpu_ctx* c, int parity, double totalTime, double d
  * compute_dt_mhd (MHDRunBase.cpp:140-250) BEFORE "cfl / invDt"; with slabs the caller max-reduces it. */
 int rgpu_compute_inv_dt(rgpu_ctx* c, int parity, double* invDt);
 
+/* Tell the context that the caller changed U[0] / U[1] behind its back (arrays adopted with rgpu_create_external and
+ * written by the host program; the reference has no counterpart: its compute_dt always rescans).  Where nothing modifies the
+ * new state between the step and the next compute_dt, the step's last kernel carries the CFL scan and rgpu_compute_dt only
+ * reads the result back; after this call the next rgpu_compute_dt scans the arrays again.  The ghost-fill entry points above
+ * do it themselves when they can change what the scan reads (any face that is not periodic / copy / shearing, the jet). */
+int rgpu_invalidate_dt(rgpu_ctx* c);
+
 /* == compute_dt[_mhd](useU): cfl / invDt.  Returns NaN on error (see rgpu_last_error). */
 double rgpu_compute_dt(rgpu_ctx* c, int useU);
 
@@ -241,6 +248,10 @@ enum { RGPU_CORE_FLUXES = 1, RGPU_CORE_UPDATE = 2, RGPU_CORE_SCAN = 4 };
  * slots to all-reduce (rgpu_inv_dt_device_slot) before rgpu_inv_dt_result.  rgpu_inv_dt_fused_active tells right after the
  * FLUXES call whether the step can carry the scan; if not (dissipative stage, forcing, open faces on the rotating path, flat
  * kernels) scan with rgpu_inv_dt_accumulate as before. */
+/* 1 when THIS context's configuration lets its update pieces carry the scan (depends on its boundary types: the end slabs of
+ * a run may differ from the inner ones).  All ranks must pass the same flag combination and all-reduce the same number of
+ * slots: the slab driver takes the minimum over the ranks once and drops RGPU_CORE_SCAN everywhere if any rank says 0. */
+int rgpu_inv_dt_fusable(rgpu_ctx* c);
 int rgpu_inv_dt_fused_active(rgpu_ctx* c, int parity);   /* after FLUXES | SCAN: 1 when this step's pieces carry the scan */
 int rgpu_inv_dt_fused_commit(rgpu_ctx* c, int parity);
 int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int what);
@@ -372,6 +383,10 @@ typedef struct rgpuh_step_hooks {
   int (*barrier)(void* self);
   const char* (*last_error)(void* self);
   int (*history_mri)(void* self, int parity, double* out8);   /* optional (may be 0): rgpu_history_mri over the whole box */
+  /* optional (may be 0; then barrier is used): collective over all ranks, returns the NUMBER of ranks that passed
+   * local_failed != 0 (or a negative code when the transport itself failed).  The run loop calls it where one rank alone
+   * can fail -- file output -- so that every rank throws together instead of one leaving the others in a collective. */
+  int (*agree)(void* self, int local_failed);
 } rgpuh_step_hooks;
 typedef int (*rgpuh_attach_fn)(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* hooks);
 typedef void (*rgpuh_detach_fn)(void* user);

@@ -79,6 +79,12 @@ int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
 /* hipSetDevice for launchers without a HIP binding of their own: call before rgpu_create / rgpu_comm_create */
 int rgpu_comm_set_device(int device);
 
+/* What the transport itself reports about the communicator -- RCCL: ncclCommCount, ncclCommUserRank, ncclCommCuDevice and
+ * hipDeviceGetPCIBusId of that device -- as opposed to what the caller passed to rgpu_comm_create.  One rank drives one
+ * device (the reference: HydroMpiParameters.cpp:196-201, cudaSetDevice(rank % deviceCount)); a launcher proves its binding
+ * with these (bench.py prints them per rank, euler_hip --slabs logs them).  Any pointer may be NULL. */
+int rgpu_comm_info(rgpu_comm* cm, int* transport_ranks, int* transport_rank, int* device, char* pci_bus_id, int pci_len);
+
 /* name of the transport the library was built with ("rccl") */
 const char* rgpu_comm_transport_name(void);
 

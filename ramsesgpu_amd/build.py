@@ -63,7 +63,9 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             objs.append(obj)
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
+        # -Bsymbolic-functions: calls between the library's own exported functions bind inside the library (librgpu.so and
+        # librgpu_fast.so export the same names and may share a process)
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic-functions"] + objs + ["-ldl", "-o", out]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -73,7 +75,7 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
     if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
                "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", comm_out]
         if verbose:
             print(" ".join(cmd))

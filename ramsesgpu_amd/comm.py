@@ -21,7 +21,10 @@ def comm_lib_path(arithmetic="exact"):
 
 
 def load_comm_library(path=None):
-    lib = C.CDLL(path or comm_lib_path(), mode=C.RTLD_GLOBAL)
+    # RTLD_LOCAL: DT_NEEDED + rpath ($ORIGIN) bind the driver to ITS librgpu*.so; a global load would promote every rgpu_*
+    # symbol and let another library of the same ABI in the process (the contracted variant, a test build) interpose them
+    lib = C.CDLL(path or comm_lib_path())
+    lib._rgpu_path = os.path.abspath(path or comm_lib_path())
     cm = C.c_void_p
     lib.rgpu_comm_unique_id.restype = C.c_int
     lib.rgpu_comm_unique_id.argtypes = [C.c_char_p]
@@ -34,6 +37,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_transport_name.restype = C.c_char_p
     lib.rgpu_comm_set_device.restype = C.c_int
     lib.rgpu_comm_set_device.argtypes = [C.c_int]
+    lib.rgpu_comm_info.restype = C.c_int
+    lib.rgpu_comm_info.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
     lib.rgpu_comm_set_overlap.restype = C.c_int
     lib.rgpu_comm_set_overlap.argtypes = [cm, C.c_int]
     for name in ("rgpu_comm_exchange_z_wait",):
@@ -59,7 +64,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -75,7 +80,14 @@ class CommRun:
 
     def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=True):
         self.L = library or load_library()
-        self.CL = comm_library or load_comm_library()
+        # the driver library must be the one linked against self.L (librgpu_comm.so <-> librgpu.so, _fast <-> _fast):
+        # a context created by one library must not be stepped by the other
+        self.CL = comm_library or load_comm_library(comm_lib_path(self.L.arithmetic))
+        here = os.path.dirname(os.path.abspath(__file__))
+        cpath = getattr(self.CL, "_rgpu_path", "")
+        if os.path.dirname(cpath) == here and os.path.dirname(os.path.abspath(self.L.path)) == here:
+            if os.path.basename(cpath) != os.path.basename(comm_lib_path(self.L.arithmetic)):
+                raise RgpuError("CommRun: %s does not drive %s (arithmetic %s)" % (os.path.basename(cpath), os.path.basename(self.L.path), self.L.arithmetic))
         self.rank, self.world = rank, world
         self.ini_path, self.overrides = ini_path, overrides
         self.p = self.L.params_from_ini(ini_path, overrides, slab=(rank, world))
@@ -93,6 +105,14 @@ class CommRun:
     def _chk(self, rc, what):
         if rc != 0:
             raise RgpuError("%s: %s (%d)" % (what, self.CL.rgpu_comm_last_error(self.cm).decode(), rc))
+
+    def info(self):
+        """what the transport (RCCL) reports: {"ranks", "rank", "device", "pci_bus_id", "transport"}"""
+        n, r, d = C.c_int(0), C.c_int(-1), C.c_int(-1)
+        pci = C.create_string_buffer(64)
+        self._chk(self.CL.rgpu_comm_info(self.cm, C.byref(n), C.byref(r), C.byref(d), pci, 64), "comm_info")
+        return {"ranks": n.value, "rank": r.value, "device": d.value, "pci_bus_id": pci.value.decode(),
+                "transport": self.CL.rgpu_comm_transport_name().decode()}
 
     def init_simulation(self):
         """each rank builds its own slab of the initial condition (no scatter from rank 0)"""

@@ -29,6 +29,13 @@ struct rgpu_comm {
   int scanned;    // parity of the state whose 1/dt sits in the context's device slot, -1 = none
   std::vector<P2P> ops[2];
   int scan_slots;   // > 0: the 1/dt maxima of the last step sit in that many device slots (fused scan), else in slot 0
+  // != 0: a step piece failed on THIS rank (code kept here).  The rank keeps taking part in the exchanges (best effort, so
+  // that no neighbour waits for planes that never come) and poisons the next 1/dt all-reduce with +inf: every rank then
+  // returns an error from the same rgpu_comm_compute_dt instead of one rank leaving the others in a collective.
+  bool fuse_scan;   // every rank's configuration lets the update pieces carry the CFL scan (agreed at create)
+  int poisoned;
+  int last_nslots;  // slot count of the last 1/dt all-reduce (what the peers will use again in the steady state)
+  int exchanges_posted, exchanges_expected;   // halo exchanges of the current step: posted so far / what the neighbours will post
   std::string err;
 };
 
@@ -70,6 +77,7 @@ void build_ops(rgpu_comm* cm, int parity) {
 
 int exchange_start(rgpu_comm* cm, int parity) {
   const std::vector<P2P>& ops = cm->ops[parity & 1];
+  cm->exchanges_posted += 1;
   if (ops.empty()) return 0;
   if (rgpu_transport::exchange_start(cm->tc, rgpu_stream_handle(cm->ctx), ops.data(), (int)ops.size())) return tr_fail(cm, "exchange_z_start");
   return 0;
@@ -104,17 +112,25 @@ int make_all_boundaries(rgpu_comm* cm, int parity, double t, double dt) {
 // max over the slabs of the inverse time step: all-reduce of the device slot in place, ONE read-back
 int compute_dt(rgpu_comm* cm, int useU, double* dt) {
   rgpu_ctx* c = cm->ctx;
-  if (cm->scanned != useU) {   // not accumulated plane range by plane range during the last step: full scan
+  if (cm->scanned != useU && !cm->poisoned) {   // not accumulated plane range by plane range during the last step: full scan
     const int ks = cm->p.nz + 2 * cm->p.ghostWidth;
-    RG_TRY(rgpu_inv_dt_accumulate(c, useU, 0, ks, 1), "inv_dt_accumulate");
+    const int rc = rgpu_inv_dt_accumulate(c, useU, 0, ks, 1);
+    if (rc) { ctx_fail(cm, rc, "inv_dt_accumulate"); cm->poisoned = rc; }
     cm->scan_slots = 0;
   }
   cm->scanned = -1;
-  const int nslots = cm->scan_slots > 0 ? cm->scan_slots : 1;   // the update kernels left their maxima in several slots
+  const int nslots = cm->poisoned ? cm->last_nslots : (cm->scan_slots > 0 ? cm->scan_slots : 1);   // the update kernels left their maxima in several slots
   cm->scan_slots = 0;
-  if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), nslots, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
+  cm->last_nslots = nslots;
+  if (cm->nranks > 1) {
+    if (cm->poisoned) (void)rgpu_transport::poison_slot(cm->tc, rgpu_inv_dt_device_slot(c), rgpu_stream_handle(c));
+    if (rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), nslots, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
+  }
+  if (cm->poisoned) return cm->poisoned;   // message of the failed piece is in cm->err
   double inv = 0.0;
   RG_TRY(rgpu_inv_dt_result(c, &inv), "inv_dt_result");
+  if (cm->nranks > 1 && !(inv < HUGE_VAL))
+    return fail(cm, RGPU_EHIP, "1/dt is not finite after the all-reduce: another rank reported a failure (see its message), or the solution blew up");
   *dt = cm->p.cfl / inv;
   return 0;
 }
@@ -138,6 +154,7 @@ int random_forcing(rgpu_comm* cm, int nStep, double dt) {
 int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
   rgpu_ctx* c = cm->ctx;
   const bool rot = rotating(cm);
+  cm->exchanges_expected = 1 + (dissipative(cm) ? 1 : 0);
   RG_TRY(rgpu_step_pre(c, nStep, dt, t), "step_pre");
   if (!rot) { if (int rc = exchange(cm, nStep % 2)) return rc; }          // plain path: ghosts of the INPUT
   RG_TRY(rgpu_step_core(c, nStep, dt, t), "step_core");
@@ -156,13 +173,32 @@ int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
   return 0;
 }
 
+int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t);
+
+// A piece of the step that fails on this rank alone (a launch error) must not strand the neighbours in their ncclRecv: post
+// the exchange of the output anyway (contents irrelevant: the run is over), remember the failure, report it through the next
+// 1/dt all-reduce (compute_dt above).  exchanges_posted counts what the failed attempt had already posted.
 int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
+  if (cm->poisoned) return cm->poisoned;
+  cm->exchanges_posted = 0;
+  const int rc = godunov_unsplit_pieces(cm, nStep, dt, t);
+  if (rc && cm->nranks > 1) {
+    const std::string msg = cm->err;
+    for (int n = cm->exchanges_posted; n < cm->exchanges_expected; ++n) (void)exchange(cm, (nStep + 1) % 2);
+    cm->err = msg;
+    cm->poisoned = rc;
+  }
+  return rc;
+}
+
+int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // the dissipative stage needs a second exchange inside the step, the random forcing a global sum and a change of the
   // whole updated state: both use the serial schedule
   if (!cm->overlap || dissipative(cm) || cm->p.randomForcingEnabled || cm->p.ouForcingEnabled) return godunov_unsplit_serial(cm, nStep, dt, t);
   rgpu_ctx* c = cm->ctx;
   const int pin = nStep % 2, pout = (nStep + 1) % 2;
   const bool rot = rotating(cm);
+  cm->exchanges_expected = 1 + ((cm->primed != pin && !rot) ? 1 : 0);
   if (cm->primed != pin && !rot) {   // ghosts of the input not known to be valid (first step): fill them like the reference
     RG_TRY(rgpu_step_pre(c, nStep, dt, t), "step_pre");
     if (int rc = exchange(cm, pin)) return rc;
@@ -181,14 +217,15 @@ int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
   // then the update range by range: the boundary-planes-first order costs no extra pipeline fill of the sweep
   // ... and the CFL scan of the new state rides in the update kernels (RGPU_CORE_SCAN) when the step allows it: no pass over
   // the output for the next compute_dt.  Otherwise, plain path: scan plane range by plane range before each fill.
-  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | RGPU_CORE_SCAN), "step_core_planes(fluxes)");
-  bool fused = rgpu_inv_dt_fused_active(c, pout) != 0;
-  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE | RGPU_CORE_SCAN), "step_core_planes(update)");
+  const int scan_flag = cm->fuse_scan ? RGPU_CORE_SCAN : 0;
+  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes)");
+  bool fused = cm->fuse_scan && rgpu_inv_dt_fused_active(c, pout) != 0;
+  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update)");
   if (scan && !fused) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
   for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
   if (int rc = exchange_start(cm, pout)) return rc;
   if (has_inner) {
-    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE | RGPU_CORE_SCAN), "step_core_planes(update)");
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update)");
     if (scan && !fused) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
     RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, 2 * gw, nz), "step_fill_planes");
   }
@@ -218,6 +255,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
   cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
+  cm->fuse_scan = false; cm->last_nslots = 1; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
   if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");
@@ -226,6 +264,11 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   if (rgpu_transport::create(&cm->tc, rank, nranks, id)) return fail(cm, RGPU_EHIP, "transport: " + (cm->tc ? cm->tc->err : std::string("allocation")));
   build_ops(cm, 0);
   build_ops(cm, 1);
+  // the fused CFL scan changes how many device slots the 1/dt all-reduce carries: all ranks or none (an end slab with an open
+  // / stratified z face on the rotating path cannot fuse it, the inner slabs could)
+  double cannot = rgpu_inv_dt_fusable(ctx) ? 0.0 : 1.0;
+  if (nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, &cannot, 1, rgpu_stream_handle(ctx))) return tr_fail(cm, "comm_create: allreduce");
+  cm->fuse_scan = cannot < 0.5;
   return RGPU_OK;
 }
 
@@ -238,6 +281,11 @@ void rgpu_comm_destroy(rgpu_comm* cm) {
 const char* rgpu_comm_last_error(rgpu_comm* cm) { return cm ? cm->err.c_str() : "null communicator"; }
 const char* rgpu_comm_transport_name(void) { return RG_TRANSPORT_NAME; }
 int rgpu_comm_set_device(int device) { rgpu_transport::set_device(device); return RGPU_OK; }
+int rgpu_comm_info(rgpu_comm* cm, int* transport_ranks, int* transport_rank, int* device, char* pci_bus_id, int pci_len) {
+  if (!cm || !cm->tc) return RGPU_EINVAL;
+  if (rgpu_transport::info(cm->tc, transport_ranks, transport_rank, device, pci_bus_id, pci_len)) return tr_fail(cm, "comm_info");
+  return RGPU_OK;
+}
 
 #define RG_CHECK_CM(cm) do { if (!(cm) || !(cm)->tc) return RGPU_EINVAL; } while (0)
 
@@ -254,7 +302,11 @@ int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double*
   double d = 0.0;
   if (int rc = compute_dt(cm, *nStep % 2, &d)) return rc;
   *dt = d;
-  if (int rc = godunov_unsplit(cm, *nStep, d, *t)) return rc;
+  if (int rc = godunov_unsplit(cm, *nStep, d, *t)) {
+    // tell the other ranks now (their next collective is the 1/dt all-reduce of the next step): see `poisoned`
+    if (cm->nranks > 1 && cm->poisoned) { double dummy; (void)compute_dt(cm, (*nStep + 1) % 2, &dummy); }
+    return rc;
+  }
   *nStep += 1;
   *t += d;
   return RGPU_OK;
@@ -303,6 +355,14 @@ int hook_barrier(void* self) {
   if (rgpu_synchronize(cm->ctx)) return RGPU_EHIP;
   return rgpu_transport::barrier(cm->tc, rgpu_stream_handle(cm->ctx)) ? RGPU_EHIP : 0;
 }
+// number of ranks with local_failed != 0: a SUM all-reduce of the flags (host values through the transport's scratch)
+int hook_agree(void* self, int local_failed) {
+  rgpu_comm* cm = static_cast<SlabAttach*>(self)->cm;
+  if (rgpu_synchronize(cm->ctx)) return RGPU_EHIP;
+  double f = local_failed ? 1.0 : 0.0;
+  if (cm->nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, &f, 1, rgpu_stream_handle(cm->ctx))) return RGPU_EHIP;
+  return (int)(f + 0.5);
+}
 const char* hook_last_error(void* self) {
   SlabAttach* a = static_cast<SlabAttach*>(self);
   if (!a->cm) return a->err.c_str();
@@ -318,6 +378,7 @@ int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
   h->compute_dt = hook_compute_dt;
   h->one_step_integration = hook_one_step;
   h->barrier = hook_barrier;
+  h->agree = hook_agree;
   h->history_mri = hook_history_mri;
   return 0;
 }

@@ -99,6 +99,29 @@ inline int allreduce_sum_host(Comm* c, double* h, int n, void* stream) {
   return 0;
 }
 inline void set_device(int d) { if (d >= 0) (void)hipSetDevice(d); }
+// +inf into a device double (a rank in an error state poisons its 1/dt before the MAX all-reduce: every rank then sees it)
+inline int poison_slot(Comm* c, double* d, void* stream) {
+  const unsigned long long inf_bits = 0x7ff0000000000000ull;
+  if (hipMemcpyAsync(d, &inf_bits, sizeof(inf_bits), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return fail(c, "poison_slot");
+  return 0;
+}
+// what RCCL itself says about the communicator (not what the caller asked for): ranks, this rank, the HIP device the
+// communicator is bound to, and that device's PCI bus id.  The reference binds one MPI rank to one device
+// (HydroMpiParameters.cpp:196-201); a scaling run can prove it did from these.
+inline int info(Comm* c, int* nranks, int* rank, int* device, char* pci, int pci_len) {
+  int n = 0, r = -1, d = -1;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess || ncclCommUserRank(c->comm, &r) != ncclSuccess || ncclCommCuDevice(c->comm, &d) != ncclSuccess)
+    return fail(c, "ncclCommCount / ncclCommUserRank / ncclCommCuDevice");
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  if (pci && pci_len > 0) { pci[0] = 0; if (hipDeviceGetPCIBusId(pci, pci_len, d) != hipSuccess) pci[0] = 0; }
+  return 0;
+}
+// a rank that failed outside a collective tells the others by aborting the communicator: their pending / next RCCL call
+// returns an error instead of waiting for ever
+inline void abort_comm(Comm* c) { if (c && c->comm) { (void)ncclCommAbort(c->comm); c->comm = 0; } }
 inline int barrier(Comm* c, void* stream) {
   double z = 0.0;
   return allreduce_sum_host(c, &z, 1, stream);

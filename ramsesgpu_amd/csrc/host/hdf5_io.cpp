@@ -10,6 +10,8 @@
 #include <iomanip>
 #include <sstream>
 #include <stdexcept>
+#include <utility>
+#include <vector>
 
 namespace rgpu_host {
 
@@ -137,6 +139,21 @@ void chk(long long rc, const std::string& what) {
   if (rc < 0) throw std::runtime_error("HDF5: " + what + " failed");
 }
 
+// ids opened in a scope, closed in reverse order when the scope is left -- by return or by exception.  (A half-written .h5
+// whose file id leaks stays open, and with HDF5 file locking LOCKED, in this process: the next output to that path fails too.)
+struct Ids {
+  typedef herr_t (*close_fn)(hid_t);
+  std::vector<std::pair<close_fn, hid_t> > open;
+  hid_t add(close_fn f, hid_t id) { if (id >= 0) open.push_back(std::make_pair(f, id)); return id; }
+  // close now (checked by the caller); the destructor skips it
+  herr_t close(hid_t id) {
+    for (size_t i = open.size(); i-- > 0;)
+      if (open[i].second == id) { const close_fn f = open[i].first; open.erase(open.begin() + (long)i); return f(id); }
+    return -1;
+  }
+  ~Ids() { for (size_t i = open.size(); i-- > 0;) (void)open[i].first(open[i].second); }
+};
+
 struct Field { const char* name; int var; };
 // datasets of a file in the order the reference writes them (HydroRunBase.cpp:3424-3510); component indices of the state
 // arrays: ID, IP, IU, IV, IW, IA, IB, IC = 0..7
@@ -151,7 +168,7 @@ std::vector<Field> fields_of(const H5Box& b) {
 // without); file space = the whole box on disk (nz_file planes of the same x-y extent) with the same number of planes
 // selected from plane kfile0 on.  2D: one "plane".
 struct Spaces { hid_t mem, file; int rank; };
-Spaces make_spaces(Api& a, const H5Box& b, bool ghosts, hsize_t nz_file, hsize_t kmem0, hsize_t kmem1, hsize_t kfile0) {
+Spaces make_spaces(Api& a, Ids& ids, const H5Box& b, bool ghosts, hsize_t nz_file, hsize_t kmem0, hsize_t kmem1, hsize_t kfile0) {
   const hsize_t gw = (hsize_t)b.ghostWidth;
   const hsize_t full[3] = {(hsize_t)b.nz + 2 * gw, (hsize_t)b.ny + 2 * gw, (hsize_t)b.nx + 2 * gw};
   const hsize_t inner[3] = {(hsize_t)b.nz, (hsize_t)b.ny, (hsize_t)b.nx};
@@ -162,8 +179,8 @@ Spaces make_spaces(Api& a, const H5Box& b, bool ghosts, hsize_t nz_file, hsize_t
   const hsize_t mstart[3] = {kmem0, ghosts ? 0 : gw, ghosts ? 0 : gw}, fstart[3] = {kfile0, 0, 0}, one[3] = {1, 1, 1};
   Spaces s;
   s.rank = rank;
-  s.mem = a.Screate_simple(rank, full + o, 0);
-  s.file = a.Screate_simple(rank, fdims + o, 0);
+  s.mem = ids.add(a.Sclose, a.Screate_simple(rank, full + o, 0));
+  s.file = ids.add(a.Sclose, a.Screate_simple(rank, fdims + o, 0));
   chk(s.mem, "H5Screate_simple"); chk(s.file, "H5Screate_simple");
   chk(a.Sselect_hyperslab(s.mem, kSelectSet, mstart + o, one, count + o, one), "H5Sselect_hyperslab");
   chk(a.Sselect_hyperslab(s.file, kSelectSet, fstart + o, one, count + o, one), "H5Sselect_hyperslab");
@@ -188,12 +205,12 @@ ZRange slab_range(const H5Box& b, int nz_global, int r, int n, bool ghosts, bool
 
 template <class T>
 void write_scalar_attr(Api& a, hid_t file, const char* name, hid_t type, const T& v) {
-  const hid_t sp = a.Screate(kScalar);
-  const hid_t at = a.Acreate2(file, name, type, sp, kDefault, kDefault);
+  Ids ids;
+  const hid_t sp = ids.add(a.Sclose, a.Screate(kScalar));
+  chk(sp, "H5Screate");
+  const hid_t at = ids.add(a.Aclose, a.Acreate2(file, name, type, sp, kDefault, kDefault));
   chk(at, std::string("H5Acreate2 ") + name);
   chk(a.Awrite(at, type, &v), std::string("H5Awrite ") + name);
-  a.Sclose(sp);
-  a.Aclose(at);
 }
 
 std::string current_date_utc() {
@@ -222,13 +239,14 @@ void hdf5_write_slab(const std::string& path, const double* U, const H5Box& b, i
   if (compressionLevel < 0 || compressionLevel > 9) compressionLevel = 0;   // the reference warns and falls back to 0
   const size_t gw = (size_t)b.ghostWidth;
   const size_t ncell = (b.nx + 2 * gw) * (b.ny + 2 * gw) * (b.three_d ? b.nz + 2 * gw : 1);
-  const hid_t file = create ? a.Fcreate(path.c_str(), kAccTrunc, kDefault, kDefault) : a.Fopen(path.c_str(), kAccRdwr, kDefault);
+  Ids ids;   // everything opened below is closed when this function is left, also by an exception
+  const hid_t file = ids.add(a.Fclose, create ? a.Fcreate(path.c_str(), kAccTrunc, kDefault, kDefault) : a.Fopen(path.c_str(), kAccRdwr, kDefault));
   chk(file, (create ? "H5Fcreate " : "H5Fopen (read-write) ") + path);
   const ZRange z = slab_range(b, nz_global, slab_rank, slab_count, ghostIncluded, false);
-  const Spaces sp = make_spaces(a, b, ghostIncluded, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
+  const Spaces sp = make_spaces(a, ids, b, ghostIncluded, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
   hid_t dcpl = -1;
   if (create) {
-    dcpl = a.Pcreate(a.cls_dataset_create);
+    dcpl = ids.add(a.Pclose, a.Pcreate(a.cls_dataset_create));
     chk(dcpl, "H5Pcreate");
     const hsize_t chunk[3] = {(hsize_t)(b.three_d ? nz_global : 1), (hsize_t)b.ny, (hsize_t)b.nx};
     chk(a.Pset_chunk(dcpl, sp.rank, chunk + (b.three_d ? 0 : 1)), "H5Pset_chunk");
@@ -237,10 +255,10 @@ void hdf5_write_slab(const std::string& path, const double* U, const H5Box& b, i
   }
   // the extent of a dataset is that of the file space (the selection only says which part is written now)
   for (const Field& f : fields_of(b)) {
-    const hid_t ds = create ? a.Dcreate2(file, f.name, a.native_double, sp.file, kDefault, dcpl, kDefault) : a.Dopen2(file, f.name, kDefault);
+    const hid_t ds = ids.add(a.Dclose, create ? a.Dcreate2(file, f.name, a.native_double, sp.file, kDefault, dcpl, kDefault) : a.Dopen2(file, f.name, kDefault));
     chk(ds, std::string(create ? "H5Dcreate2 " : "H5Dopen2 ") + f.name);
     chk(a.Dwrite(ds, a.native_double, sp.mem, sp.file, kDefault, U + (size_t)f.var * ncell), std::string("H5Dwrite ") + f.name);
-    a.Dclose(ds);
+    chk(ids.close(ds), std::string("H5Dclose ") + f.name);
   }
   if (create) {
     write_scalar_attr(a, file, "time step", a.native_int, nStep);
@@ -254,21 +272,22 @@ void hdf5_write_slab(const std::string& path, const double* U, const H5Box& b, i
     // "creation date": one variable-length string
     const std::string date = current_date_utc();
     const char* ptr = date.c_str();
-    const hid_t st = a.Tcopy(a.c_s1);
+    const hid_t st = ids.add(a.Tclose, a.Tcopy(a.c_s1));
     chk(st, "H5Tcopy");
     chk(a.Tset_size(st, kVariable), "H5Tset_size");
     const hsize_t one = 1;
-    const hid_t dsp = a.Screate_simple(1, &one, 0);
-    const hid_t at = a.Acreate2(file, "creation date", st, dsp, kDefault, kDefault);
+    const hid_t dsp = ids.add(a.Sclose, a.Screate_simple(1, &one, 0));
+    chk(dsp, "H5Screate_simple");
+    const hid_t at = ids.add(a.Aclose, a.Acreate2(file, "creation date", st, dsp, kDefault, kDefault));
     chk(at, "H5Acreate2 creation date");
     chk(a.Awrite(at, st, &ptr), "H5Awrite creation date");
-    a.Aclose(at); a.Sclose(dsp); a.Tclose(st);
-    a.Pclose(dcpl);
+    ids.close(at); ids.close(dsp); ids.close(st);
+    ids.close(dcpl);
   }
-  a.Sclose(sp.mem);
-  a.Sclose(sp.file);
-  a.Fflush(file, kScopeLocal);
-  chk(a.Fclose(file), "H5Fclose " + path);
+  ids.close(sp.mem);
+  ids.close(sp.file);
+  chk(a.Fflush(file, kScopeLocal), "H5Fflush " + path);
+  chk(ids.close(file), "H5Fclose " + path);
 }
 
 int hdf5_read_state(const std::string& path, double* U, const H5Box& b, double* totalTime, bool* ghostsInFile) {
@@ -280,19 +299,21 @@ int hdf5_read_slab(const std::string& path, double* U, const H5Box& b, int nz_gl
   Api& a = api();
   const size_t gw = (size_t)b.ghostWidth;
   const size_t ncell = (b.nx + 2 * gw) * (b.ny + 2 * gw) * (b.three_d ? b.nz + 2 * gw : 1);
-  const hid_t file = a.Fopen(path.c_str(), kAccRdonly, kDefault);
+  Ids ids;
+  const hid_t file = ids.add(a.Fclose, a.Fopen(path.c_str(), kAccRdonly, kDefault));
   if (file < 0) throw std::runtime_error("restart: cannot open " + path + " as an HDF5 file");
   // with or without ghosts: decided by the extent of the first dataset (the reference trusts [output] ghostIncluded instead)
   bool ghosts = false;
   {
-    const hid_t ds = a.Dopen2(file, "/density", kDefault);
-    if (ds < 0) { a.Fclose(file); throw std::runtime_error("restart: " + path + " has no /density dataset"); }
-    const hid_t fs = a.Dget_space(ds);
+    const hid_t ds = ids.add(a.Dclose, a.Dopen2(file, "/density", kDefault));
+    if (ds < 0) throw std::runtime_error("restart: " + path + " has no /density dataset");
+    const hid_t fs = ids.add(a.Sclose, a.Dget_space(ds));
+    chk(fs, "H5Dget_space /density");
     hsize_t dims[3] = {0, 0, 0};
     const int rank = a.Sget_simple_extent_ndims(fs);
-    if (rank == (b.three_d ? 3 : 2)) a.Sget_simple_extent_dims(fs, dims, 0);
-    a.Sclose(fs);
-    a.Dclose(ds);
+    if (rank == (b.three_d ? 3 : 2)) chk(a.Sget_simple_extent_dims(fs, dims, 0), "H5Sget_simple_extent_dims /density");
+    ids.close(fs);
+    ids.close(ds);
     const hsize_t inner[3] = {(hsize_t)(b.three_d ? nz_global : 1), (hsize_t)b.ny, (hsize_t)b.nx};
     const int o = b.three_d ? 0 : 1, n = b.three_d ? 3 : 2;
     bool is_inner = rank == n, is_full = rank == n;
@@ -301,7 +322,6 @@ int hdf5_read_slab(const std::string& path, double* U, const H5Box& b, int nz_gl
       is_full = is_full && dims[d] == inner[o + d] + 2 * gw;
     }
     if (!is_inner && !is_full) {
-      a.Fclose(file);
       std::ostringstream m;
       m << "restart: " << path << " holds another box than expected from [mesh] nx, ny, nz (/density is";
       for (int d = 0; d < rank && d < 3; ++d) m << " " << dims[d];
@@ -311,25 +331,23 @@ int hdf5_read_slab(const std::string& path, double* U, const H5Box& b, int nz_gl
     ghosts = is_full;
   }
   const ZRange z = slab_range(b, nz_global, slab_rank, slab_count, ghosts, true);
-  const Spaces sp = make_spaces(a, b, ghosts, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
+  const Spaces sp = make_spaces(a, ids, b, ghosts, z.nz_file, z.kmem0, z.kmem1, z.kfile0);
   for (const Field& f : fields_of(b)) {
-    const hid_t ds = a.Dopen2(file, f.name, kDefault);
-    if (ds < 0) { a.Fclose(file); throw std::runtime_error("restart: " + path + " has no dataset " + f.name); }
+    const hid_t ds = ids.add(a.Dclose, a.Dopen2(file, f.name, kDefault));
+    if (ds < 0) throw std::runtime_error("restart: " + path + " has no dataset " + f.name);
     const herr_t rc = a.Dread(ds, a.native_double, sp.mem, sp.file, kDefault, U + (size_t)f.var * ncell);
-    a.Dclose(ds);
-    if (rc < 0) { a.Fclose(file); throw std::runtime_error("restart: reading " + std::string(f.name) + " of " + path + " failed"); }
+    ids.close(ds);
+    if (rc < 0) throw std::runtime_error("restart: reading " + std::string(f.name) + " of " + path + " failed");
   }
   int step = 0;
   double t = 0.0;
   {
-    hid_t at = a.Aopen(file, "time step", kDefault);
-    if (at >= 0) { a.Aread(at, a.native_int, &step); a.Aclose(at); }
-    at = a.Aopen(file, "total time", kDefault);
-    if (at >= 0) { a.Aread(at, a.native_double, &t); a.Aclose(at); }
+    // (files without these attributes resume at step 0, time 0; an attribute that is there must be readable)
+    hid_t at = ids.add(a.Aclose, a.Aopen(file, "time step", kDefault));
+    if (at >= 0) { chk(a.Aread(at, a.native_int, &step), "H5Aread time step"); ids.close(at); }
+    at = ids.add(a.Aclose, a.Aopen(file, "total time", kDefault));
+    if (at >= 0) { chk(a.Aread(at, a.native_double, &t), "H5Aread total time"); ids.close(at); }
   }
-  a.Sclose(sp.mem);
-  a.Sclose(sp.file);
-  a.Fclose(file);
   if (totalTime) *totalTime = t;
   if (ghostsInFile) *ghostsInFile = ghosts;
   return step;

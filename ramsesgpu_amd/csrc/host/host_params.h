@@ -20,7 +20,7 @@ struct RunSettings {
   std::string outputDir, outputPrefix;
   bool outputVtk;
   // [run] restart / restart_filename / restart_reset_totaltime (HydroRunBase.cpp:7033-7066, MHDRunGodunov.cpp:3805, 3866-3880)
-  bool outputRestart, ghostIncluded;   // [output] outputHdf5 (served by the raw restart dump, no HDF5 library here), ghostIncluded
+  bool outputRestart, ghostIncluded;   // [output] outputHdf5 (the reference's HDF5 file through a dlopen'ed libhdf5, else the raw restart dump), ghostIncluded
   bool restartEnabled, restartResetTotalTime;
   bool outputVtkAscii;          // [output] outputVtkAscii: the .vti as text (12 significant digits) instead of appended raw doubles
   bool outputXsm, outputNrrd;   // [output] outputXsm / outputNrrd (HydroParameters.h:478,485)

@@ -46,8 +46,8 @@ int GodunovRun::init_simulation() {
   if (rs_.restartEnabled) {
     // restart run (HydroRunBase.cpp:7033-7066): the state comes from a file of an earlier run instead of the problem's
     // initial condition; the static gravity / forcing fields below are rebuilt as in a fresh run.  The reference reads
-    // HDF5 (inputHdf5, :4818-5160); this image has no HDF5 library, so the file is the .vti this driver writes: interior
-    // cells, raw doubles -- a lossless copy of the state -- plus the step count and the time in its header.
+    // HDF5 (inputHdf5, :4818-5160): so does this driver for a .h5 name (hdf5_io.h, libhdf5 bound at run time); it also resumes
+    // from its raw .rgr dump and from the .vti it writes (interior cells, raw doubles, step count and time in the header).
     std::fill(h_U_.begin(), h_U_.end(), 0.0);
     const std::string path = rs_.outputDir + "/" + rs_.restartFilename;
     restart_has_ghosts_ = false;
@@ -76,6 +76,24 @@ int GodunovRun::init_simulation() {
     if (init_forcing_field(cfg_, p_, hF.data())) check(rgpu_set_forcing_field(ctx_, hF.data()), "set_forcing_field");
   }
   return timeStep;
+}
+
+// collective outcome of a step that can fail on one rank alone: every rank throws if any rank failed
+void GodunovRun::agree_or_throw(const std::string& local_error, const char* what) {
+  if (!hooked_) { if (!local_error.empty()) throw std::runtime_error(local_error); return; }
+  if (!hooks_.agree) {   // an older slab driver: barrier only (a failing rank then throws alone)
+    if (!local_error.empty()) throw std::runtime_error(local_error);
+    hook_check(hooks_.barrier(hooks_.self), "barrier");
+    return;
+  }
+  const int failed = hooks_.agree(hooks_.self, local_error.empty() ? 0 : 1);
+  if (failed < 0) hook_check(failed, what);
+  if (failed > 0) {
+    std::ostringstream m;
+    m << what << ": " << failed << " of " << p_.slab_count << " ranks failed";
+    if (!local_error.empty()) m << "; this rank (" << p_.slab_rank << "): " << local_error;
+    throw std::runtime_error(m.str());
+  }
 }
 
 void GodunovRun::hook_check(int rc, const char* what) {
@@ -231,8 +249,12 @@ H5Box GodunovRun::h5_box(int nx, int ny, int nz) const {
 void GodunovRun::outputHdf5(int nStep) {
   const char* fmt = std::getenv("RGPU_RESTART_FORMAT");   // "rgr": the raw dump even when HDF5 is there
   std::string why;
-  if (slab() && ((fmt && std::string(fmt) == "rgr") || !hdf5_available(&why)))
-    throw std::runtime_error("outputs of a z-slab run go to one HDF5 file for the whole box: " + (why.empty() ? std::string("RGPU_RESTART_FORMAT=rgr is single-domain only") : why));
+  if (slab()) {   // (agreed by all ranks: libhdf5 may be missing on one node only)
+    std::string local_error;
+    if ((fmt && std::string(fmt) == "rgr") || !hdf5_available(&why))
+      local_error = "outputs of a z-slab run go to one HDF5 file for the whole box: " + (why.empty() ? std::string("RGPU_RESTART_FORMAT=rgr is single-domain only") : why);
+    agree_or_throw(local_error, "outputHdf5");
+  }
   if (fmt && std::string(fmt) == "rgr") { outputRestart(nStep); return; }
   if (!hdf5_available(&why)) {
     if (!warned_no_hdf5_) { std::cerr << "outputHdf5: " << why << " -- writing raw .rgr dumps instead\n"; warned_no_hdf5_ = true; }
@@ -243,11 +265,18 @@ void GodunovRun::outputHdf5(int nStep) {
   fn << rs_.outputDir << "/" << rs_.outputPrefix << "_" << std::setw(7) << std::setfill('0') << nStep << ".h5";
   const bool three_d = p_.nz_global != 1;
   if (slab()) {   // one file for the whole box: the slabs take turns, rank 0 creates it (hdf5_io.h)
+    // A write can fail on ONE rank (disk full, file lock, libhdf5 missing on that node): the ranks agree on the outcome of
+    // every turn (hooks.agree: a sum all-reduce of the failure flags in place of the bare barrier) and throw TOGETHER --
+    // a rank that left this loop alone would leave the others waiting in the collective for ever.
     for (int r = 0; r < p_.slab_count; ++r) {
-      if (r == p_.slab_rank)
-        hdf5_write_slab(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, p_.nz), p_.nz_global, p_.slab_rank, p_.slab_count, r == 0, rs_.ghostIncluded, nStep,
-                        totalTime_, rs_.hdf5CompressionLevel);
-      hook_check(hooks_.barrier(hooks_.self), "barrier");
+      std::string local_error;
+      if (r == p_.slab_rank) {
+        try {
+          hdf5_write_slab(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, p_.nz), p_.nz_global, p_.slab_rank, p_.slab_count, r == 0, rs_.ghostIncluded, nStep,
+                          totalTime_, rs_.hdf5CompressionLevel);
+        } catch (const std::exception& e) { local_error = e.what(); }
+      }
+      agree_or_throw(local_error, "outputHdf5");
     }
   } else {
     hdf5_write_state(fn.str(), h_U_.data(), h5_box(p_.nx, p_.ny, three_d ? p_.nz : 1), rs_.ghostIncluded, nStep, totalTime_, rs_.hdf5CompressionLevel);

@@ -41,7 +41,7 @@ class GodunovRun {
   void outputNrrd(int nStep);
   // restart=yes: read the interior fields, the step count and the time back from a .vti this driver wrote
   int inputVtk(const std::string& path);
-  // [output] outputHdf5=yes is served by a raw dump <prefix>_NNNNNNN.rgr (this image has no HDF5 library): the role of the
+  // raw dump <prefix>_NNNNNNN.rgr: what [output] outputHdf5=yes falls back to when no libhdf5 can be loaded; the role of the
   // reference's HDF5 files -- lossless state, optionally with the ghost cells ([output] ghostIncluded), step count and time
   void outputRestart(int nStep);
   // [output] outputHdf5=yes with a loadable libhdf5: the reference's file format (hdf5_io.h), interchangeable with its files
@@ -70,6 +70,7 @@ class GodunovRun {
   rgpuh_step_hooks hooks_;
   bool slab() const { return p_.slab_count > 1; }
   void hook_check(int rc, const char* what);
+  void agree_or_throw(const std::string& local_error, const char* what);
   void note_once(bool* flag, const char* msg);
   bool noted_vtk_, noted_hist_;
   void check(int rc, const char* what);

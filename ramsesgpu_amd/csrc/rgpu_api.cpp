@@ -437,6 +437,26 @@ int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
   return rg_launch_planes<BLOCK, MINW>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k, (unsigned)g.xcd_sub);
 }
 
+// Can the update kernels of a 3D MHD step carry the CFL scan of the new state (see mhd3d_core)?  Depends on this
+// context's boundary types: slabs of one run may answer differently (the slab driver agrees on the minimum once, at
+// rgpu_comm_create, through rgpu_inv_dt_fusable).
+bool mhd3d_scan_cond(const rgpu_ctx* c) {
+  const rgpu_params& p = c->p;
+  const DevParams& g = c->g;
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  if (no_fused_dt || g.grav_on == 2 || p.nu > 0 || p.eta > 0 || p.randomForcingEnabled || p.ouForcingEnabled) return false;
+  if (g.rot) {
+    const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
+    auto zok = [](int b) { return b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY; };
+    return xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && zok(p.bc[4]) && zok(p.bc[5]);
+  }
+  return true;
+}
+bool hydro3d_scan_cond(const rgpu_ctx* c) {
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  return !no_fused_dt && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled && rgpu_tiled::hydro3d_sweep_covers(c->g) && c->g.grav_on != 2;
+}
+
 // hydro: launch-time specialisation on the Riemann solver and the slope type (launchers.h); the no-gravity instantiations
 // only, everything else runs the generic kernels
 template <int ND, int NV, int SPEC>
@@ -457,7 +477,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     Phase ph(c, RGPU_T_SWEEP);
     // whole-domain steps whose output nothing modifies afterwards carry the CFL scan of the new state along; slab pieces
     // (acc_piece: RGPU_CORE_UPDATE | RGPU_CORE_SCAN after a reset by the FLUXES call) accumulate into the same slot
-    const bool cond = !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled && rgpu_tiled::hydro3d_sweep_covers(g) && g.grav_on != 2;
+    const bool cond = hydro3d_scan_cond(c);
     const bool scan = a <= 0 && b >= ks && cond && !acc_piece;
     const bool piece = acc_piece && cond && c->scan_acc_parity == ((out == c->U[0]) ? 0 : 1);
     if (acc_piece && !piece) c->scan_acc_parity = -1;
@@ -659,14 +679,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // exchanged faces are the doubles this slab's own CT update gives them.
   const bool acc = (what & RGPU_CORE_SCAN) != 0;
   what &= ~RGPU_CORE_SCAN;
-  bool cond = !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
-  if (cond && g.rot) {
-    const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
-    auto zok = [](int b) { return b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY; };
-    cond = xy_ok && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC && zok(p.bc[4]) && zok(p.bc[5]);
-  }
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  if (no_fused_dt) cond = false;
+  const bool cond = mhd3d_scan_cond(c);
   const int out_parity = (out == c->U[0]) ? 0 : 1;
   bool scan = what == 0 && a <= 0 && b >= ks && cond;
   if (scan && g.rot && (p.bc[4] == RGPU_BC_COPY || p.bc[5] == RGPU_BC_COPY)) scan = false;   // whole-slab call of a slab: the driver scans
@@ -1116,10 +1129,37 @@ int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out) {
   return RGPU_OK;
 }
 
+// A ghost fill called from OUTSIDE the step may change what the CFL scan reads: with a non-periodic MHD face it overwrites
+// the field the CT update left on the first high ghost face (compute_dt_mhd reads it as the high-face field of the last
+// interior cell).  The 1/dt a fused scan left in the device slot is then stale: drop it, the next compute_dt scans again.
+// Periodic / copy / shearing faces rewrite ghosts with bit-identical images of interior values (or leave that face
+// alone), so the scan result stands.
+static void boundary_call_invalidates_dt(rgpu_ctx* c, int parity, int dim_lo, int dim_hi) {
+  if (c->fused_dt_parity != (parity & 1)) return;   // (a scan being accumulated piece by piece belongs to the slab driver's own schedule)
+  bool keeps = true;
+  for (int d = dim_lo; d <= dim_hi; ++d) {
+    if (d == RGPU_ZDIR && !c->g.three_d) continue;
+    for (int side = 0; side < 2; ++side) {
+      const int bc = c->p.bc[2 * (d - 1) + side];
+      if (bc != RGPU_BC_PERIODIC && bc != RGPU_BC_COPY && bc != RGPU_BC_SHEARINGBOX) keeps = false;
+    }
+  }
+  if (c->p.enableJet) keeps = false;
+  if (!keeps) c->fused_dt_parity = -1;
+}
+
+int rgpu_invalidate_dt(rgpu_ctx* c) {
+  if (!c) return RGPU_EINVAL;
+  c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
+  return RGPU_OK;
+}
+
 int rgpu_make_boundaries(rgpu_ctx* c, int parity, int idim) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (idim < RGPU_XDIR || idim > RGPU_ZDIR) return fail(c, RGPU_EINVAL, "idim must be 1,2,3");
+  boundary_call_invalidates_dt(c, parity, idim, idim);
   Phase ph(c, RGPU_T_BOUNDARIES);
   if (do_make_boundaries(c, c->U[parity & 1], idim)) return RG_HIPFAIL(c, "make_boundaries");
   return RGPU_OK;
@@ -1129,6 +1169,7 @@ int rgpu_make_boundaries_shear(rgpu_ctx* c, int parity, double totalTime, double
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
   if (!(c->g.shearbox && c->g.three_d)) return fail(c, RGPU_EINVAL, "shearing box is not enabled");
+  boundary_call_invalidates_dt(c, parity, RGPU_XDIR, RGPU_XDIR);
   Phase ph(c, RGPU_T_BOUNDARIES);
   if (do_make_boundaries_shear(c, c->U[parity & 1], totalTime, dt)) return RG_HIPFAIL(c, "make_boundaries_shear");
   return RGPU_OK;
@@ -1137,6 +1178,7 @@ int rgpu_make_boundaries_shear(rgpu_ctx* c, int parity, double totalTime, double
 int rgpu_make_all_boundaries(rgpu_ctx* c, int parity, double totalTime, double dt) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  boundary_call_invalidates_dt(c, parity, RGPU_XDIR, RGPU_ZDIR);
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* U = c->U[parity & 1];
   int rc;
@@ -1174,6 +1216,10 @@ int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt) {
   if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "inv_dt_result: null pointer / context without state");
   if (inv_dt_fetch(c, invDt, c->fused_dt_parity >= 0 ? c->fused_dt_slots : 1)) return RG_HIPFAIL(c, "inv_dt_result");
   return RGPU_OK;
+}
+int rgpu_inv_dt_fusable(rgpu_ctx* c) {
+  if (!c || !c->U[0] || !c->g.three_d) return 0;
+  return (c->p.mhdEnabled ? mhd3d_scan_cond(c) : hydro3d_scan_cond(c)) ? 1 : 0;
 }
 int rgpu_inv_dt_fused_active(rgpu_ctx* c, int parity) { return (c && c->U[0] && c->scan_acc_parity == (parity & 1)) ? 1 : 0; }
 int rgpu_inv_dt_fused_commit(rgpu_ctx* c, int parity) {

@@ -70,6 +70,10 @@ def frontend():
     base, ov, outdir, out = sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    # COMM_BREAK_HDF5_ON_RANK=r: rank r alone cannot load libhdf5 -- every rank must come back with an error (no hang)
+    broken = os.environ.get("COMM_BREAK_HDF5_ON_RANK")
+    if broken is not None and int(broken) == rank:
+        os.environ["RGPU_HDF5_LIB"] = "/nonexistent/libhdf5.so"
     lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
     CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
     keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
@@ -87,6 +91,16 @@ def frontend():
     CL.rgpuh_run_slabs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
     n = CL.rgpuh_run_slabs(ini.encode(), (ov + ";output.outputDir=%s" % slabs).encode(), rank, world, 0, ids[0], C.byref(mc), err, 512)
     ok, msg = n >= 0, err.value.decode()
+    if broken is not None:   # expected outcome: EVERY rank failed, together, with a message that names the count
+        flags = [None] * world
+        dist.all_gather_object(flags, (n < 0, msg))
+        good = all(f[0] for f in flags) and all("ranks failed" in f[1] for f in flags) and "libhdf5" in flags[int(broken)][1]
+        if rank == 0:
+            with open(out, "w") as f:
+                f.write("OK\n" if good else "FAILED %r\n" % (flags,))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if good else 1)
     dist.barrier()
     if rank == 0 and ok:
         os.chdir(single)

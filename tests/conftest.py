@@ -87,7 +87,7 @@ def emu_lib():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
         host = [os.path.join(csrc, "host", f) for f in ("ini_config.cpp", "host_params.cpp", "init_conditions.cpp", "host_capi.cpp", "run_driver.cpp", "hdf5_io.cpp")]
-        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "tests", "emu"), "-I", csrc,
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "tests", "emu"), "-I", csrc,
               os.path.join(csrc, "rgpu_api.cpp")] + host + ["-ldl", "-o", so])
     lib = Library(so)
     assert "emulation" in lib.backend

@@ -70,7 +70,18 @@ inline int barrier(Comm* c, void* s) { double z = 0; return allreduce_sum_host(c
 
 }  // namespace rgpu_transport
 
-namespace rgpu_transport { inline void set_device(int) {} }
+namespace rgpu_transport {
+inline void set_device(int) {}
+inline int info(Comm* c, int* nranks, int* rank, int* device, char* pci, int pci_len) {
+  if (nranks) *nranks = c->nranks;
+  if (rank) *rank = c->rank;
+  if (device) *device = -1;
+  if (pci && pci_len > 0) pci[0] = 0;
+  return 0;
+}
+inline void abort_comm(Comm*) {}
+inline int poison_slot(Comm*, double* d, void*) { const unsigned long long b = 0x7ff0000000000000ull; std::memcpy(d, &b, sizeof(b)); return 0; }
+}
 
 // registered once per process by the test worker before rgpu_comm_create (single translation unit: defined here)
 extern "C" void rgpu_comm_test_set_callbacks(rgpu_transport::exchange_fn e, rgpu_transport::allreduce_fn a) {

@@ -43,7 +43,7 @@ def comm_emu_lib(emu_lib):
     deps = [src, os.path.join(ROOT, "tests", "emu", "rg_transport.h"), os.path.join(ROOT, "include", "rgpu_comm.h"),
             os.path.join(out_dir, "librgpu_emu.so")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "tests", "emu"), src,
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-I", os.path.join(ROOT, "tests", "emu"), src,
                                "-L", out_dir, "-lrgpu_emu", "-Wl,-rpath,$ORIGIN", "-o", so])
     return so
 
@@ -66,6 +66,9 @@ CASES = [
     ("orszag-tang3d", "mesh.nx=6;mesh.ny=6;mesh.nz=18;hydro.nu=0.005;MHD.eta=0.01", 3, 3, 1),   # dissipative stage: second exchange
     ("turbulence_hydro", "mesh.nx=8;mesh.ny=8;mesh.nz=12", 3, 2, 1),                   # random forcing: SUM all-reduce
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=24;hydro.slope_type=2.0;MRI.amp=0.3", 3, 2, 1),
+    # three slabs of the stratified box: the end slabs cannot carry the CFL scan in their update kernels (stratified z face on
+    # the rotating path), the inner one could -- the ranks must agree (rgpu_inv_dt_fusable) or the 1/dt all-reduce mismatches
+    ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=27;hydro.slope_type=2.0;MRI.amp=0.3", 3, 3, 1),
     ("turbulence_hydro_ou", "mesh.nx=8;mesh.ny=8;mesh.nz=12;turbulence-Ornstein-Uhlenbeck.initialDensityPerturbationAmplitude=0.1", 3, 2, 1),   # Ornstein-Uhlenbeck forcing: same process on every rank
     ("turbulence_mhd_ou", "mesh.nx=6;mesh.ny=6;mesh.nz=18", 3, 3, 1),
 ]
@@ -108,12 +111,12 @@ FRONTEND_CASES = [
 ]
 
 
-def run_frontend(base, ov, world, outdir, tmp_path, timeout=300):
+def run_frontend(base, ov, world, outdir, tmp_path, timeout=300, env_extra=None):
     out = str(tmp_path / "result.txt")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "comm_worker.py"), "--frontend", base, ov, str(outdir), out]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(env_extra or {}))
     env.pop("RGPU_RESTART_FORMAT", None)
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-3000:]
@@ -126,6 +129,17 @@ def test_slab_front_end_writes_the_single_domain_files(base, ov, world, comm_emu
     if not h5util.available():
         pytest.skip("no loadable libhdf5 on this machine")
     run_frontend(base, ov, world, tmp_path / "run", tmp_path)
+
+
+@pytest.mark.parametrize("broken_rank", [0, 2])
+def test_slab_front_end_fails_on_every_rank_when_one_rank_cannot_write(broken_rank, comm_emu_lib, tmp_path):
+    """one rank alone cannot load libhdf5: the ranks agree on the outcome of the output step (hooks.agree) and all return
+    an error -- nobody is left waiting in a collective (the subprocess timeout would catch a hang)"""
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    base, ov, world = FRONTEND_CASES[1]
+    run_frontend(base, ov, world, tmp_path / "run", tmp_path, timeout=120, env_extra={"COMM_BREAK_HDF5_ON_RANK": str(broken_rank)})
 
 
 def test_slab_front_end_restarts_from_the_file_of_the_whole_box(comm_emu_lib, tmp_path):
