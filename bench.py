@@ -123,9 +123,9 @@ def cpu_sample(w, dims, budget_s=25.0):
     return n, steps
 
 
-def cpu_baseline(w, dims):
+def cpu_baseline(w, dims, budget_s=25.0):
     """time the CPU path on a bounded sample (same physics, smaller box; the metric is intensive)"""
-    n, steps = cpu_sample(w, dims)
+    n, steps = cpu_sample(w, dims, budget_s)
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "euler_cpu")
     sample = "%s at %dx%dx%d, %d steps, 1 thread" % (w["base"], n[0], n[1], n[2], steps)
     if os.path.exists(ref_bin):
@@ -206,6 +206,149 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
             "note": "fraction of the fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq) the kernel fills at its measured duration"}
 
 
+class Control:
+    """torch.distributed as the CONTROL plane of a multi-rank run: the 128-byte RCCL id, the barriers of the timing contract,
+    the max over ranks of the wall time.  Backend "nccl" (= RCCL; the driver's launch) or, RGPU_BENCH_BACKEND=gloo, gloo -- the
+    data plane (halo planes, 1/dt) is the C++ slab driver's own RCCL communicator either way."""
+
+    def __init__(self, world, rank, local_rank):
+        import torch
+        self.torch, self.world, self.rank = torch, world, rank
+        self.dist = None
+        self.backend = None
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            self.backend = os.environ.get("RGPU_BENCH_BACKEND", "nccl")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(self.backend)
+
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_int(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def bcast(self, obj):
+        if not self.dist:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def gather(self, obj):
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def device_facts(torch, local_rank):
+    pr = torch.cuda.get_device_properties(local_rank)
+    pci = None
+    if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    return {"device": local_rank, "name": pr.name, "pci_bus_id": pci}
+
+
+def timed_steps(step, timers_src, ctl, steps, warmup):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  Then the same
+    steps again with HIP events around every launch on the kernels' stream -> (elapsed_s, phase seconds, dominant kernel)"""
+    for _ in range(warmup):
+        step()
+    timers_src.enable_timers(False)
+    ctl.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctl.sync()
+    elapsed = ctl.max(time.perf_counter() - t0)
+    return elapsed
+
+
+def phase_profile(step, timers_src, ctl, steps):
+    """per-kernel durations: the same steps again with HIP events around every launch on the kernels' stream (separate from
+    the timed region: the events serialise host and device)"""
+    timers_src.enable_timers(True)
+    timers_src.reset_timers()
+    nprof = min(5, max(steps, 1))
+    for _ in range(nprof):
+        step()
+    ctl.sync()
+    tm = timers_src.timers()
+    dom_name, dom_ms, dom_launches = timers_src.dominant_kernel()
+    timers_src.enable_timers(False)
+    return nprof, tm, dom_name, dom_ms, dom_launches
+
+
+def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
+    nprof, tm, dom_name, dom_ms, dom_launches = prof
+    # per step: a slab run launches the kernel once per plane range (two boundary ranges + the inner one)
+    dom_ms = dom_ms * dom_launches / nprof
+    achieved = step_bytes / (dom_ms * 1e-3)
+    roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(wname, dom_name) if arith == "exact" else pmc_traffic(wname + "_contracted", dom_name),
+            "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
+            "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
+                     "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
+            "valu_ceiling": valu_ceiling(wname, dom_name, dom_ms / max(dom_launches / nprof, 1.0)) if arith == "exact" else None}
+    step = {"bound": "hbm", "achieved": step_bytes / (elapsed / steps) / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": step_bytes / (elapsed / steps) / HBM_PEAK,
+            "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": sum(tm.values()) / nprof * 1e3}
+    return roof, step
+
+
+def single_gpu_record(wname, dims, arith, steps, warmup, ctl):
+    """one workload on ONE GPU through librgpu.so (exact) or librgpu_fast.so (contracted): value, ms/step, rooflines"""
+    from ramsesgpu_amd.solver import Library, Solver, lib_path
+    w = WORKLOADS[wname]
+    nx, ny, nz = dims
+    L = Library(lib_path(arith))
+    assert L.arithmetic == arith
+    ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+    ov = overrides_for(w, nx, ny, nz)
+    p = L.params_from_ini(ini, ov)
+    U0 = L.init_condition(ini, ov, p)
+    run = Solver(p, L)
+    run.upload(U0, both=False)
+    del U0
+    run.make_all_boundaries(0, 0.0, 0.0)
+    # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
+    elapsed = timed_steps(run.oneStepIntegration, run, ctl, steps, warmup)
+    prof = phase_profile(run.oneStepIntegration, run, ctl, steps)
+    run.close()
+    cells = float(nx) * ny * nz
+    roof, roof_step = roofline_of(wname, w, arith, w["bytes"] * cells, elapsed, steps, prof)
+    return {"value": steps * cells / elapsed / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+            "roofline": roof, "roofline_step": roof_step, "library": os.path.basename(L.path), "arithmetic": arith, "parity": PARITY[arith]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,11 +363,14 @@ def main():
     ap.add_argument("--arith", choices=["exact", "contracted"], default=os.environ.get("RGPU_ARITH", "exact"),
                     help="exact: librgpu.so, bit-identical to the reference (default, the headline); contracted: librgpu_fast.so")
     ap.add_argument("--no-contracted", action="store_true", help="skip the second measurement with librgpu_fast.so (N=1, --arith exact)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default N=1 headline run only: skip the short implode3d 256^3 / orszag-tang 512^2 measurements nested under other_workloads")
     ap.add_argument("--timeline-only", action="store_true", help="stop after the timed region (for rocprofv3 --kernel-trace concurrency analysis)")
     args = ap.parse_args()
 
     w = WORKLOADS[args.workload]
     nx, ny, nz = w["size"]
+    custom_size = bool(args.size or args.nx or args.ny or args.nz)
     if args.size:
         nx, ny, nz = args.size, args.size, (args.size if nz != 1 else 1)
     nx, ny = args.nx or nx, args.ny or ny
@@ -233,8 +379,6 @@ def main():
     two_d = nz == 1
 
     import torch
-    import torch.distributed as dist
-    from ramsesgpu_amd.slab import SlabRun
     from ramsesgpu_amd.solver import Library, Solver, lib_path
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,177 +391,152 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; the product has no CPU fallback\n")
         sys.exit(3)
-    # test hooks (not used by the driver): RGPU_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 and RGPU_BENCH_BACKEND=gloo
-    # replaces RCCL, which refuses two ranks on one device -- lets the N>1 code path be exercised on a 1-GPU box
+    # test hook (not used by the driver): RGPU_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 (with RGPU_BENCH_BACKEND=gloo for the
+    # control plane) -- on a 1-GPU box this exercises the launch line up to RCCL's refusal of two ranks on one device
     if os.environ.get("RGPU_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        # one rank drives one device (the reference: HydroMpiParameters.cpp:196-201)
+        sys.stderr.write("bench.py: rank %d is to drive GPU %d but only %d device(s) are visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(4)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("RGPU_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    ctl = Control(world, rank, local_rank)
 
-    L = Library(lib_path(args.arith))
-    assert L.arithmetic == args.arith
-    ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
-    ov = overrides_for(w, nx, ny, nz)
     replicas = two_d and world > 1      # 2D boxes do not shard: independent replicas
-
-    driver = ""
-    if world == 1 or replicas:
-        p = L.params_from_ini(ini, ov)
-        U0 = L.init_condition(ini, ov, p)
-        run = Solver(p, L)
-        run.upload(U0, both=False)
-        del U0
-        run.make_all_boundaries(0, 0.0, 0.0)
-        # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
-        step = run.oneStepIntegration
-        timers_src = run
-    else:
-        # default: the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the
-        # device; torch.distributed only carries the 128-byte unique id and the barriers of the timing contract.
-        # RGPU_BENCH_DRIVER=python (or a non-nccl backend: the RGPU_BENCH_ONE_DEVICE / RGPU_BENCH_BACKEND=gloo test hook, the
-        # only way to put two ranks on ONE GPU, which RCCL refuses) selects the same schedule in Python over torch.distributed.
-        use_cpp = os.environ.get("RGPU_BENCH_DRIVER", "cpp") != "python" and os.environ.get("RGPU_BENCH_BACKEND", "nccl") == "nccl"
-        srun, driver = None, "python harness over torch.distributed (ramsesgpu_amd/slab.py)"
-        if use_cpp:
-            CL, cid = None, None
-            try:
-                from ramsesgpu_amd import comm as rcomm
-                CL = rcomm.load_comm_library(rcomm.comm_lib_path(args.arith))
-                cid = rcomm.unique_id(CL) if rank == 0 else None
-            except Exception as e:  # noqa: BLE001 -- keep the scaling run alive; the line says which driver ran
-                sys.stderr.write("bench.py: C++ slab driver unavailable on rank %d (%r)\n" % (rank, e))
-                CL = None
-            ids = [cid]
-            dist.broadcast_object_list(ids, src=0)       # every rank takes part, whatever happened above
-            if CL is not None and ids[0] is not None:
-                try:
-                    srun = rcomm.CommRun(ini, ov, rank, world, ids[0], library=L, comm_library=CL)
-                    driver = "C++ RCCL driver, include/rgpu_comm.h"
-                except Exception as e:  # noqa: BLE001
-                    sys.stderr.write("bench.py: rgpu_comm_create failed on rank %d (%r); falling back to the Python harness\n" % (rank, e))
-                    srun = None
-            ok = torch.tensor([1 if srun is not None else 0], device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # all ranks must agree on the driver
-            if int(ok.item()) == 0:
-                if srun is not None:
-                    srun.close()
-                srun = None
-        if srun is None:
-            driver = "python harness over torch.distributed (ramsesgpu_amd/slab.py)"
-            srun = SlabRun(ini, ov, library=L, device="cuda:%d" % local_rank)
-        srun.init_simulation()
-        step = srun.oneStepIntegration
-        timers_src = srun.solver
-        p = srun.p
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    timers_src.enable_timers(False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if args.timeline_only:
-        if rank == 0:
-            print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
-        return
-    # per-kernel durations: the same steps again with HIP events around every launch on the kernels' stream
-    # (separate from the timed region: the events serialise host and device)
-    timers_src.enable_timers(True)
-    timers_src.reset_timers()
-    nprof = min(5, max(args.steps, 1))
-    for _ in range(nprof):
-        step()
-    sync()
-    tm = timers_src.timers()
-    dom_name, dom_ms, dom_launches = timers_src.dominant_kernel()
-    timers_src.enable_timers(False)
-
     cells_box = float(nx) * ny * nz
     cells_global = cells_box * (world if replicas else 1)
     cells_local = cells_global / world
-    value = args.steps * cells_global / elapsed / 1e6
+    dims = "%dx%d" % (nx, ny) if two_d else "%dx%dx%d" % (nx, ny, nz)
+
+    if world == 1:
+        if args.timeline_only:
+            L = Library(lib_path(args.arith))
+            ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+            ov = overrides_for(w, nx, ny, nz)
+            p = L.params_from_ini(ini, ov)
+            run = Solver(p, L)
+            run.upload(L.init_condition(ini, ov, p), both=False)
+            run.make_all_boundaries(0, 0.0, 0.0)
+            elapsed = timed_steps(run.oneStepIntegration, run, ctl, args.steps, args.warmup)
+            print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
+            return
+        rec = single_gpu_record(args.workload, (nx, ny, nz), args.arith, args.steps, args.warmup, ctl)
+        driver, rccl_ranks = "single device: librgpu.so, no communicator", None
+        ranks = [dict(device_facts(torch, local_rank), rank=0)]
+    else:
+        # the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the device;
+        # torch.distributed only carries the 128-byte unique id and the barriers of the timing contract.  There is NO fallback:
+        # if the driver cannot be created on any rank, every rank exits non-zero with the RCCL error.  RGPU_BENCH_DRIVER=python
+        # explicitly selects the test harness (tests/slab_harness.py, the same schedule over torch.distributed) instead.
+        L = Library(lib_path(args.arith))
+        ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+        ov = overrides_for(w, nx, ny, nz)
+        want_python = os.environ.get("RGPU_BENCH_DRIVER", "cpp") == "python"
+        info = None
+        if replicas:
+            p = L.params_from_ini(ini, ov)
+            srun = Solver(p, L)
+            srun.upload(L.init_condition(ini, ov, p), both=False)
+            srun.make_all_boundaries(0, 0.0, 0.0)
+            step, timers_src = srun.oneStepIntegration, srun
+            driver = "independent replicas: librgpu.so per rank, no communicator"
+        elif want_python:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from slab_harness import SlabRun
+            srun = SlabRun(ini, ov, library=L, device="cuda:%d" % local_rank)
+            srun.init_simulation()
+            step, timers_src = srun.oneStepIntegration, srun.solver
+            driver = "TEST HARNESS (RGPU_BENCH_DRIVER=python): tests/slab_harness.py over torch.distributed/%s -- not the product's driver" % ctl.backend
+        else:
+            from ramsesgpu_amd import comm as rcomm
+            err, srun = None, None
+            try:
+                CL = rcomm.load_comm_library(rcomm.comm_lib_path(args.arith))
+                cid = ctl.bcast(rcomm.unique_id(CL) if rank == 0 else None)
+                srun = rcomm.CommRun(ini, ov, rank, world, cid, library=L, comm_library=CL)
+            except Exception as e:  # noqa: BLE001 -- reported below, on every rank, then exit
+                err = e
+            if ctl.min_int(1 if srun is not None else 0) == 0:
+                sys.stderr.write("bench.py: rank %d/%d on GPU %d: %s\n" % (rank, world, local_rank,
+                                 ("the C++ RCCL slab driver could not be created: %r" % (err,)) if err is not None else "another rank failed to create the C++ RCCL slab driver"))
+                sys.stderr.write("bench.py: no fallback (set RGPU_BENCH_DRIVER=python for the torch.distributed test harness)\n")
+                sys.stderr.flush()
+                sys.exit(5)
+            info = srun.info()
+            srun.init_simulation()
+            step, timers_src = srun.oneStepIntegration, srun.solver
+            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h)" % ("" if args.arith == "exact" else "_fast", info["transport"])
+        elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
+        if args.timeline_only:
+            if rank == 0:
+                print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
+            ctl.close()
+            return
+        prof = phase_profile(step, timers_src, ctl, args.steps)
+        roof, roof_step = roofline_of(args.workload, w, args.arith, w["bytes"] * cells_local, elapsed, args.steps, prof)
+        rec = {"value": args.steps * cells_global / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "roofline": roof, "roofline_step": roof_step}
+        mine = dict(device_facts(torch, local_rank), rank=rank)
+        if info is not None:
+            mine.update(rccl_rank=info["rank"], rccl_ranks=info["ranks"], rccl_device=info["device"], rccl_pci_bus_id=info["pci_bus_id"])
+        ranks = ctl.gather(mine)
+        rccl_ranks = info["ranks"] if info is not None else None
+        if info is not None:   # every rank must have seen the same communicator size, and one device each
+            sizes = sorted(set(r.get("rccl_ranks") for r in ranks))
+            buses = [r.get("rccl_pci_bus_id") for r in ranks]
+            if sizes != [world] or len(set(buses)) != world:
+                if rank == 0:
+                    sys.stderr.write("bench.py: RCCL saw communicator sizes %s for WORLD_SIZE=%d, devices %s\n" % (sizes, world, buses))
+                ctl.close()
+                sys.exit(6)
+
     if rank == 0:
-        dims = "%dx%d" % (nx, ny) if two_d else "%dx%dx%d" % (nx, ny, nz)
-        step_bytes = w["bytes"] * cells_local
-        # per step: a slab run launches the kernel once per plane range (two boundary ranges + the inner one)
-        dom_ms = dom_ms * dom_launches / nprof
-        achieved = step_bytes / (dom_ms * 1e-3)
-        step_ms_events = sum(tm.values()) / nprof * 1e3
         out = {
-            "metric": "Mcell-updates/s", "value": value, "unit": "Mcell-updates/s",
+            "metric": "Mcell-updates/s", "value": rec["value"], "unit": "Mcell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["desc"] % dims,
                        "nx": nx, "ny": ny, "nz": nz,
-                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d%s" % (world, " (%s)" % driver if world > 1 and not replicas else ""),
+                       "decomposition": ("%d independent replicas" % world) if replicas else "z-slabs x%d" % world,
+                       "driver": driver, "rccl_ranks": rccl_ranks, "ranks": ranks,
                        "path": w["path"],
-                       "arithmetic": L.arithmetic,
-                       "parity": PARITY[L.arithmetic]},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(args.workload, dom_name),
-                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
-                         "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
-                                  "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
-                         "valu_ceiling": valu_ceiling(args.workload, dom_name, dom_ms / max(dom_launches / nprof, 1.0)) if L.arithmetic == "exact" else None},
-            "roofline_step": {"bound": "hbm", "achieved": step_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": step_bytes / (elapsed / args.steps) / HBM_PEAK,
-                              "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": step_ms_events},
+                       "arithmetic": args.arith,
+                       "parity": PARITY[args.arith]},
+            "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],
         }
         if world == 1 and args.arith == "exact" and not args.no_contracted:
-            # the same workload through the opt-in contracted-arithmetic variant (never the headline value)
+            # the same workload through the tolerance-grade library (relative L2 < 1e-12 to euler_cpu, north_star's own bar; gated by
+            # tests/test_contracted.py): a second record with its own roofline -- never `value`, which stays the bit-identical library
             try:
-                run.close()
-                L2 = Library(lib_path("contracted"))
-                p2 = L2.params_from_ini(ini, ov)
-                U0 = L2.init_condition(ini, ov, p2)
-                run2 = Solver(p2, L2)
-                run2.upload(U0, both=False)
-                del U0
-                run2.make_all_boundaries(0, 0.0, 0.0)
-                for _ in range(args.warmup):
-                    run2.oneStepIntegration()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    run2.oneStepIntegration()
-                torch.cuda.synchronize()
-                e2 = time.perf_counter() - t1
-                run2.close()
-                out["contracted_arithmetic"] = {"value": args.steps * cells_global / e2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": e2 / args.steps * 1e3,
-                                                "library": "ramsesgpu_amd/librgpu_fast.so", "parity": PARITY["contracted"]}
+                c = single_gpu_record(args.workload, (nx, ny, nz), "contracted", args.steps, args.warmup, ctl)
+                out["value_tolerance"] = c
+                out["contracted_arithmetic"] = {k: c[k] for k in ("value", "unit", "ms_per_step", "parity")}   # (round-2 key, kept)
+                out["contracted_arithmetic"]["library"] = "ramsesgpu_amd/librgpu_fast.so"
             except Exception as e:  # noqa: BLE001 -- a secondary number: report why it is missing
+                out["value_tolerance"] = {"value": None, "error": repr(e)}
                 out["contracted_arithmetic"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, (nx, ny, nz))
             allc = cpu_baseline_all_cores(w)
             if allc:
                 out["cpu_baseline_all_cores"] = allc
+        if world == 1 and args.workload == "mri" and not custom_size and args.arith == "exact" and not args.no_other_workloads:
+            # BASELINE.json configs[1] and configs[2], short, so that their numbers are the driver's too (not builder-only claims)
+            others = {}
+            for name, st, wu, budget in (("implode3d", 50, 5, 8.0), ("orszag-tang", 50, 5, 6.0)):
+                try:
+                    ow = WORKLOADS[name]
+                    o = single_gpu_record(name, ow["size"], "exact", st, wu, ctl)
+                    o["config"] = {"workload": ow["desc"] % ("%dx%d" % ow["size"][:2] if ow["size"][2] == 1 else "%dx%dx%d" % ow["size"]), "path": ow["path"]}
+                    if not args.no_cpu_baseline:
+                        o["cpu_baseline"] = cpu_baseline(ow, ow["size"], budget_s=budget)
+                    others[name] = o
+                except Exception as e:  # noqa: BLE001
+                    others[name] = {"value": None, "error": repr(e)}
+            out["other_workloads"] = others
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctl.close()
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """ctypes binding of the C++ z-slab driver (include/rgpu_comm.h, librgpu_comm.so): one process per GPU, RCCL halo
 exchange on a side stream, 1/dt all-reduced in the context's device slot.  CommRun mirrors the method names of the
-reference's Mpi run classes (init_simulation, make_all_boundaries, compute_dt, godunov_unsplit, oneStepIntegration) like
-ramsesgpu_amd.slab.SlabRun does for the torch.distributed harness; here Python only launches -- the schedule, the
+reference's Mpi run classes (init_simulation, make_all_boundaries, compute_dt, godunov_unsplit, oneStepIntegration) (tests/slab_harness.py
+is the same schedule over torch.distributed, a test harness); here Python only launches -- the schedule, the
 exchange and the reduction are C++."""
 import ctypes as C
 import os

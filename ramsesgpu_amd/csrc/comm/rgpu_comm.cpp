@@ -374,6 +374,16 @@ int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
   h->last_error = hook_last_error;
   const int rc = rgpu_comm_create(ctx, a->rank, a->nranks, a->id, &a->cm);
   if (rc) { a->err = a->cm ? a->cm->err : "rgpu_comm_create failed"; if (a->cm) { rgpu_comm_destroy(a->cm); a->cm = 0; } return rc; }
+  {   // one rank <-> one device (HydroMpiParameters.cpp:196-201): say what the transport itself reports
+    int n = 0, r = -1, d = -1;
+    char pci[64] = {0};
+    if (rgpu_comm_info(a->cm, &n, &r, &d, pci, (int)sizeof(pci)) == RGPU_OK) {
+      std::printf("rank %d/%d -> HIP device %d (PCI %s), %s communicator of %d rank%s\n", r, a->nranks, d, pci[0] ? pci : "?",
+                  std::strcmp(RG_TRANSPORT_NAME, "rccl") ? RG_TRANSPORT_NAME : "RCCL", n, n == 1 ? "" : "s");
+      std::fflush(stdout);
+      if (n != a->nranks || r != a->rank) { a->err = "the transport reports another communicator size / rank than the launch asked for"; rgpu_comm_destroy(a->cm); a->cm = 0; return RGPU_EINVAL; }
+    }
+  }
   h->make_all_boundaries = hook_make_all_boundaries;
   h->compute_dt = hook_compute_dt;
   h->one_step_integration = hook_one_step;

@@ -1,4 +1,8 @@
-"""z-slab decomposition of the 3D step across the GPUs of one node (one process per GPU).
+"""TEST HARNESS (not part of the product package): the z-slab schedule of csrc/comm/rgpu_comm.cpp written a second time, in
+Python over torch.distributed, so that the plane-ranged entry points of include/rgpu.h can be driven with gloo on CPU and
+with two ranks on one GPU.  The product's slab driver is the C++ one behind include/rgpu_comm.h.
+
+z-slab decomposition of the 3D step across the GPUs of one node (one process per GPU).
 
 Replaces the reference's MPI cartesian decomposition + host-staged MPI_Sendrecv (HydroRunBaseMpi.cpp:3529-3661,
 HydroMpiParameters.cpp:44-80) for the one layout the scope contract needs: mx = my = 1, mz = world_size.
@@ -33,8 +37,8 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from ._capi import BC_COPY, BC_PERIODIC
-from .solver import Solver, load_library
+from ramsesgpu_amd._capi import BC_COPY, BC_PERIODIC
+from ramsesgpu_amd.solver import Solver, load_library
 
 
 class SlabRun:

@@ -1,5 +1,5 @@
 """Worker of tests/test_slab_gloo.py: one rank of a world_size-N z-slab run on CPU (gloo + TEST-ONLY emulation
-library).  Each rank steps its slab with halo exchange through ramsesgpu_amd.slab.SlabRun, then the slabs are
+library).  Each rank steps its slab with halo exchange through tests/slab_harness.py SlabRun, then the slabs are
 gathered on rank 0 and compared, bit for bit, with the single-domain oracle run."""
 import os
 import sys
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 from oracle_api import Oracle  # noqa: E402
-from ramsesgpu_amd.slab import SlabRun  # noqa: E402
+from slab_harness import SlabRun  # noqa: E402
 from ramsesgpu_amd.solver import Library, interior  # noqa: E402
 
 

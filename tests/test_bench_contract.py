@@ -1,7 +1,9 @@
 """bench.py's contract on the GPU box at toy sizes: one JSON line with the driver's keys plus `roofline` and (N=1)
 `cpu_baseline`, for every workload; the N>1 launch line of the driver (torch.distributed.run, one rank per GPU) exercised
-with two ranks sharing the one GPU of the box through the test hook (gloo + the Python slab harness: RCCL refuses two ranks
-on one device; the C++ RCCL driver itself is covered by tests/test_comm_driver.py)."""
+with two ranks sharing the one GPU of the box: (i) through the explicitly selected test harness (RGPU_BENCH_DRIVER=python over gloo),
+(ii) through the default C++ RCCL driver, which must FAIL CLEANLY there (RCCL refuses two ranks on one device; there is no
+fallback), (iii) with only one device visible, where rank 1 must say so.  The C++ RCCL driver itself is covered by
+tests/test_comm_driver.py."""
 import json
 import os
 import socket
@@ -38,6 +40,11 @@ def test_bench_line_single_gpu(args, gpu_lib):
     assert d["config"]["arithmetic"] == "exact" and "bit-identical" in d["config"]["parity"]
     c = d["contracted_arithmetic"]
     assert c["value"] > 0 and "librgpu_fast.so" in c["library"] and "not bit-identical" in c["parity"]
+    # the tolerance-grade record: a value with its own roofline from the same kind of measurement
+    t = d["value_tolerance"]
+    assert t["value"] == c["value"] and t["arithmetic"] == "contracted" and t["roofline"]["frac"] > 0 and t["roofline"]["avg_launch_ms"] > 0
+    assert d["config"]["rccl_ranks"] is None and len(d["config"]["ranks"]) == 1 and "single device" in d["config"]["driver"]
+    assert "other_workloads" not in d        # only the default headline run carries them
 
 
 def test_bench_line_contracted_on_request(gpu_lib):
@@ -49,13 +56,40 @@ def test_bench_line_contracted_on_request(gpu_lib):
     assert d["config"]["arithmetic"] == "contracted" and "not bit-identical" in d["config"]["parity"] and "contracted_arithmetic" not in d
 
 
-def test_bench_two_ranks_through_the_launch_line(gpu_lib):
+def launch_two_ranks(env_extra, extra_args=()):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--nx", "32", "--ny", "48", "--nz", "32"]
-    env = dict(os.environ, RGPU_BENCH_ONE_DEVICE="1", RGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+           "--nx", "32", "--ny", "48", "--nz", "32"] + list(extra_args)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+
+
+def test_bench_two_ranks_through_the_launch_line(gpu_lib):
+    """the N > 1 code path of bench.py (launch line, barriers, max over ranks, the JSON line) with the test harness selected
+    EXPLICITLY -- the line says so"""
+    res = launch_two_ranks(dict(RGPU_BENCH_ONE_DEVICE="1", RGPU_BENCH_BACKEND="gloo", RGPU_BENCH_DRIVER="python"))
     assert res.returncode == 0, res.stderr[-3000:]
     d = last_json(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "cpu_baseline" not in d
+    assert "TEST HARNESS" in d["config"]["driver"] and d["config"]["rccl_ranks"] is None and len(d["config"]["ranks"]) == 2
+
+
+def test_bench_default_driver_fails_cleanly_with_two_ranks_on_one_device(gpu_lib):
+    """default driver = the C++ RCCL one, no fallback: two ranks on the box's one GPU make ncclCommInitRank fail; every rank
+    reports it and exits non-zero, no JSON line is printed (what a misconfigured 8-GPU launch would look like)"""
+    res = launch_two_ranks(dict(RGPU_BENCH_ONE_DEVICE="1", RGPU_BENCH_BACKEND="gloo"))
+    assert res.returncode != 0
+    assert "C++ RCCL slab driver could not be created" in res.stderr and "no fallback" in res.stderr, res.stderr[-3000:]
+    assert "ncclCommInitRank" in res.stderr, res.stderr[-3000:]
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_rank_without_a_device_says_so(gpu_lib):
+    """one rank <-> one device (the reference: HydroMpiParameters.cpp:196-201): with one visible GPU rank 1 has none"""
+    res = launch_two_ranks(dict(HIP_VISIBLE_DEVICES="0", CUDA_VISIBLE_DEVICES="0"))
+    if "only 1 device(s) are visible" not in res.stderr:
+        import torch
+        if torch.cuda.device_count() > 1:
+            pytest.skip("the visibility mask did not take effect on this multi-GPU box")
+    assert res.returncode != 0 and "rank 1 is to drive GPU 1 but only 1 device(s) are visible" in res.stderr, res.stderr[-3000:]

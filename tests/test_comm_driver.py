@@ -210,6 +210,52 @@ print("OK")
 
 
 @pytest.mark.gpu
+def test_config5_rank_geometry_through_the_rccl_driver(tmp_path):
+    """BASELINE config 5 = 512 x 1024 x 512 MRI over 8 GPUs: every rank owns a 512 x 1024 x 64 slab (+ 3 ghost planes per side).
+    That per-rank box through the product's slab driver (rgpu_comm, RCCL ring of one rank: the slab is its own z neighbour,
+    2 x 102 MB per exchange on the halo stream) for 4 overlapped steps: (i) every double and every dt equal to the
+    single-device run of the same box, (ii) div B at round-off and mass conserved to round-off (size-independent
+    properties: the oracle cannot run this size in seconds), (iii) RCCL itself reports 1 rank on the device the context uses."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from ramsesgpu_amd import comm as rcomm
+from ramsesgpu_amd.solver import Solver, load_library, interior
+L = load_library(); CL = rcomm.load_comm_library()
+ini = os.path.join(%r, "configs", "mhd_mri_3d.ini"); ov = "mesh.nx=512;mesh.ny=1024;mesh.nz=64"
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True)
+info = run.info()
+assert info["ranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["transport"] == "rccl" and info["pci_bus_id"], info
+run.init_simulation()
+p = run.p
+gw = p.ghostWidth
+A0 = run.solver.getDataHost(0)
+mass0 = float(A0[0, gw:-gw, gw:-gw, gw:-gw].sum(dtype=np.longdouble))
+dts = [run.oneStepIntegration() for _ in range(4)]
+got = run.solver.getDataHost(run.nStep %% 2).copy()
+run.close()
+ps = L.params_from_ini(ini, ov); sv = Solver(ps, L); ref_dts = sv.start(L.init_condition(ini, ov, ps), 4); ref = sv.getDataHost(); sv.close()
+assert list(dts) == list(ref_dts), (dts, ref_dts)
+gi, ri = interior(got, p), interior(ref, ps)
+nbad = int((gi != ri).sum())
+assert nbad == 0, "%%d of %%d doubles differ from the single-device run" %% (nbad, ri.size)
+bx, by, bz = got[5], got[6], got[7]
+s = (slice(gw, -gw),) * 3
+d = (bx[gw:-gw, gw:-gw, gw + 1:-gw + 1] - bx[s]) / p.dx + (by[gw:-gw, gw + 1:-gw + 1, gw:-gw] - by[s]) / p.dy + (bz[gw + 1:-gw + 1, gw:-gw, gw:-gw] - bz[s]) / p.dz
+bscale = float(np.abs(bz[s]).max()) / min(p.dx, p.dy, p.dz)
+assert float(np.abs(d).max()) < 1e-11 * bscale, (float(np.abs(d).max()), bscale)
+mass1 = float(gi[0].sum(dtype=np.longdouble))
+assert abs(mass1 - mass0) < 1e-12 * abs(mass0), (mass0, mass1)
+assert np.isfinite(gi).all()
+print("OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-3000:]
+
+
+@pytest.mark.gpu
 def test_euler_hip_slabs_front_end_single_rank(gpu_lib, tmp_path):
     """euler_hip --slabs 1: rendezvous file, rgpuh_run_slabs, RCCL self ring -- same step count and dt log as the single-GPU run"""
     exe = os.path.join(ROOT, "ramsesgpu_amd", "euler_hip")
@@ -224,5 +270,7 @@ def test_euler_hip_slabs_front_end_single_rank(gpu_lib, tmp_path):
     dts = lambda txt: re.findall(r"step=\s*(\d+) t=\s*([0-9.eE+-]+) dt=\s*([0-9.eE+-]+)", txt)
     da, db = dts(a.stdout), dts(b.stdout)
     assert "steps 6" in a.stdout and da, a.stdout[-1000:]
+    # the front end binds LOCAL_RANK -> HIP device before the context exists and logs what RCCL itself reports
+    assert re.search(r"rank 0/1 -> HIP device 0 \(PCI [0-9a-fA-F:.]+\), RCCL communicator of 1 rank", a.stdout), a.stdout[:1500]
     # the slab front end prints after each step, the single-GPU one before: compare the (t, dt) pairs they share
     assert set(x[1:] for x in da) & set(x[1:] for x in db), (da, db)

@@ -62,6 +62,8 @@ def test_medium_sizes_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
 # the LDS-tiled kernels' full-width tile rows.  Few planes keep the oracle at seconds per step.
 BENCH_GEOMETRY = [
     ("mhd_mri_3d", "mesh.nx=512;mesh.ny=512;mesh.nz=16", 2),
+    # the x-y cross-section of BASELINE config 5 (512 x 1024 x 512 over 8 GPUs): 33 x 129 tiles of the MHD sweep
+    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=1024;mesh.nz=16", 2),
     ("orszag-tang3d", "mesh.nx=256;mesh.ny=256;mesh.nz=24", 2),
     ("implode3d", "mesh.nx=512;mesh.ny=512;mesh.nz=8;hydro.riemannSolver=hllc", 2),
 ]
@@ -170,7 +172,7 @@ def test_external_state_and_stream(gpu_lib):
     """rgpu_create_external: state arrays owned by torch, work issued on torch's current stream (the slab driver's
     plumbing), same result as the self-allocating context."""
     import torch
-    from ramsesgpu_amd.slab import SlabRun
+    from slab_harness import SlabRun
     ov = "mesh.nx=16;mesh.ny=24;mesh.nz=12"
     run = SlabRun(ini("mhd_mri_3d"), ov, library=gpu_lib, device="cuda:0")
     run.init_simulation()
@@ -200,7 +202,7 @@ def test_slab_schedule_world1(base, ov, nsteps, overlap, gpu_lib, oracle):
     """SlabRun's step (boundary planes first, plane-wise ghost fill, 1/dt scanned per plane range; world 1, so the z
     faces are the physical ones) == the single-call oracle run."""
     import torch
-    from ramsesgpu_amd.slab import SlabRun
+    from slab_harness import SlabRun
     run = SlabRun(ini(base), ov, library=gpu_lib, device="cuda:0", overlap=overlap)
     run.init_simulation()
     dts = [run.oneStepIntegration() for _ in range(nsteps)]

@@ -1,5 +1,5 @@
 """N>1 path on CPU: world_size 2 (and 3) z-slab runs over gloo, halo planes exchanged in place by
-ramsesgpu_amd.slab.SlabRun, stepping through the TEST-ONLY emulation library; result == single-domain oracle,
+tests/slab_harness.py SlabRun, stepping through the TEST-ONLY emulation library; result == single-domain oracle,
 bit for bit (plain path: ghosts of the input; rotating path: ghosts of the output; Dirichlet ends; dt all-reduce).
 Both schedules of SlabRun are covered: the overlapped one (boundary planes first, exchange in flight during the
 inner planes, 1/dt scanned plane range by plane range) and the serial one (exchange between the step pieces)."""
