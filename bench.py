@@ -27,6 +27,14 @@ Extra objects on the JSON line:
   cpu_baseline  N=1, rank 0 only: the reference binary oracle/_ref/euler_cpu ("reference") -- or the oracle's
                 restatement ("port") -- on ONE host core, on a bounded sample of the same workload (256^3 for the 3D
                 workloads when the host has the memory).
+  cpu_baseline_all_cores  ONE 256^3 box on all host cores: the restatement threaded over z-slabs (deterministic gather
+                update); `upper_bound_replicas` = independent 64^3 replicas of the reference binary, rates summed.
+  value_tolerance  the same workload through librgpu_fast.so (relative L2 < 1e-12 to euler_cpu: north_star's bar) with its own
+                roofline; `value` stays the bit-identical library.
+  other_workloads  default headline run only: short measurements of BASELINE configs[1] (implode3d 256^3) and [2]
+                (orszag-tang 512^2) with their own roofline / cpu_baseline.
+  config.driver / rccl_ranks / ranks  which slab driver ran, what RCCL itself reports (ncclCommCount), device + PCI bus id per
+                rank.  --gpus N > 1 has NO fallback: it is the C++ RCCL driver or a non-zero exit.
 """
 import argparse
 import json
@@ -152,10 +160,10 @@ def cpu_baseline(w, dims, budget_s=25.0):
             "sample": sample + " (oracle/liboracle.so, g++ -O2, %.1f s)" % wall}
 
 
-def cpu_baseline_all_cores(w, steps=10):
-    """the reference binary is single-threaded (its OpenMP build races): occupy the host with one
-    independent replica per core and add the rates up -- an upper bound for any domain-decomposed CPU run.  NOT a
-    decomposed run of one box: independent 64^3 replicas."""
+def cpu_baseline_replicas(w, steps=10):
+    """UPPER BOUND for any domain-decomposed CPU run of the reference: the reference binary is single-threaded (its OpenMP
+    build races), so occupy the host with one independent 64^3 replica per core and add the rates up.  NOT a
+    decomposed run of one box (no halo traffic, every replica cache-resident)."""
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "euler_cpu")
     if not os.path.exists(ref_bin) or w["base"] != "mhd_mri_3d":
         return None
@@ -166,9 +174,50 @@ def cpu_baseline_all_cores(w, steps=10):
     rates, wall = _ref_rates(ref_bin, w, (size, size, size), steps, copies)
     if len(rates) != copies:
         return None
-    return {"value": sum(rates) / 1e6, "unit": "Mcell-updates/s", "cores": copies, "kind": "reference",
+    return {"value": sum(rates) / 1e6, "unit": "Mcell-updates/s", "cores": copies, "kind": "reference", "label": "upper_bound",
             "sample": "%d INDEPENDENT replicas of %s at %d^3, %d steps, one single-threaded euler_cpu per core, rates summed (%.1f s)"
                       % (copies, w["base"], size, steps, wall)}
+
+
+def cpu_baseline_all_cores(w, dims, budget_s=20.0):
+    """ONE box of the workload on all host cores -- the oracle's restatement threaded over z-slabs (orc_run_mt:
+    every loop nest of the 3D MHD step cut into contiguous slabs of planes, one std::thread each; the flux loop stores its
+    fluxes and each cell gathers them in the order the reference's scatter loop delivers them, so the result is deterministic
+    and bit-identical to the 1-thread run -- the reference's own OpenMP loops, mhd_godunov_unsplit_cpu_v3.cpp:32-35, 368-371,
+    race on that scatter).  g++ -O2, no -march, threads not pinned (OS scheduler).  3D MHD workloads only."""
+    if w["bytes"] != 128.0 or dims[2] == 1:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_api import Oracle
+    from ramsesgpu_amd.solver import load_library
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    e = 256 if _avail_gb() > 1.5 * 1.55e-6 * 262 ** 3 else 128      # ~1.55 kB per cell: 167 work doubles + the two state arrays
+    n = (min(e, dims[0]), min(e, dims[1]), min(e, dims[2]))
+    L = load_library()
+    ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
+    ov = overrides_for(w, *n)
+    p = L.params_from_ini(ini, ov)
+    U0 = L.init_condition(ini, ov, p)
+    O = Oracle(so)
+    cells = n[0] * n[1] * n[2]
+    t0 = time.time()
+    O.run_mt(p, U0, 1, cores)                   # allocation + first touch of the work arrays + one step
+    t1 = time.time() - t0
+    steps = int(max(2, min(20, budget_s / max(t1, 1e-3))))
+    t0 = time.time()
+    O.run_mt(p, U0, steps, cores)
+    t2 = time.time() - t0
+    per_step = (t2 - t1) / (steps - 1)          # the set-up (allocation, ghost fill) is in both runs
+    out = {"value": cells / per_step / 1e6, "unit": "Mcell-updates/s", "cores": cores, "kind": "port",
+           "sample": "ONE %s box at %dx%dx%d, %d steps on %d threads (z-slabs of planes; oracle/liboracle.so orc_run_mt, g++ -O2, not pinned; "
+                     "%.2f s per step after %.1f s of set-up + first step)" % (w["base"], n[0], n[1], n[2], steps, cores, per_step, t1)}
+    ub = cpu_baseline_replicas(w)
+    if ub:
+        out["upper_bound_replicas"] = ub
+    return out
 
 
 def pmc_traffic(workload, kernel_phase):
@@ -518,7 +567,7 @@ def main():
                 out["contracted_arithmetic"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, (nx, ny, nz))
-            allc = cpu_baseline_all_cores(w)
+            allc = cpu_baseline_all_cores(w, (nx, ny, nz))
             if allc:
                 out["cpu_baseline_all_cores"] = allc
         if world == 1 and args.workload == "mri" and not custom_size and args.arith == "exact" and not args.no_other_workloads:

@@ -242,4 +242,36 @@ int orc_run(const rgpu_params* p, double* U, int nStepmax, double tEnd, int* nst
   return 0;
 }
 
+// orc_run with every loop nest of the 3D MHD step cut into z-slabs over `nthreads` threads (mhd_step_3d_mt): the all-cores
+// CPU baseline of bench.py.  Same results as orc_run, bit for bit.  Scope: 3D MHD without gravity, dissipative stage, forcing,
+// slope_type 3 (what the bench workloads use); anything else returns RGPU_EUNSUPPORTED.
+int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int nthreads, int* nsteps_done, double* t_final, double* dts) {
+  const int rc = check_scope(p);
+  if (rc) return rc;
+  Ctx c(*p);
+  if (!p->mhdEnabled || !c.three_d || p->gravityEnabled || p->nu > 0 || p->eta > 0 || p->randomForcingEnabled || p->ouForcingEnabled ||
+      p->slope_type == 3)
+    return RGPU_EUNSUPPORTED;
+  const size_t n = c.ncell * c.nvar;
+  std::vector<double> U2(n);
+  make_all_boundaries(c, U, 0.0, 0.0);
+  std::memcpy(U2.data(), U, sizeof(double) * n);
+  MtWork work(c, nthreads);
+  double t = 0.0;
+  int nStep = 0;
+  while (t < tEnd && nStep < nStepmax) {
+    double* cur = (nStep % 2 == 0) ? U : U2.data();
+    double* nxt = (nStep % 2 == 0) ? U2.data() : U;
+    const double dt = p->cfl / compute_inv_dt_mhd3d_mt(c, cur, nthreads);
+    mhd_step_3d_mt(c, work, cur, nxt, dt, t, nthreads);
+    if (dts) dts[nStep] = dt;
+    nStep++;
+    t += dt;
+  }
+  if (nStep % 2 == 1) std::memcpy(U, U2.data(), sizeof(double) * n);
+  if (nsteps_done) *nsteps_done = nStep;
+  if (t_final) *t_final = t;
+  return 0;
+}
+
 }  // extern "C"

@@ -84,5 +84,15 @@ void hydro_step(const Ctx& c, double* Uold, double* Unew, double dt);           
 void mhd_step_2d(const Ctx& c, double* Uold, double* Unew, double dt);                 // orc_mhd2d.cpp
 void mhd_step_3d(const Ctx& c, double* Uold, double* Unew, double dt, double totalTime);  // orc_mhd3d.cpp
 void dissipative_stage(const Ctx& c, double* U, double dt, double totalTime);          // orc_dissipative.cpp
+// threaded variants for the all-cores CPU baseline (z-slab threading, gather update; bit-identical to the sequential ones)
+struct MtWork {   // the step's intermediate arrays, kept across the steps of a run
+  double* buf; size_t doubles;
+  MtWork(const Ctx& c, int nthreads);
+  ~MtWork();
+ private:
+  MtWork(const MtWork&); MtWork& operator=(const MtWork&);
+};
+void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold, double* Unew, double dt, double totalTime, int nthreads);   // orc_mhd3d.cpp
+double compute_inv_dt_mhd3d_mt(const Ctx& c, const double* U, int nthreads);                                // orc_mhd3d.cpp
 
 }  // namespace orc

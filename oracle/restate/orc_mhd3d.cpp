@@ -7,6 +7,10 @@
 //   convertToPrimitives (3D)          MHDRunGodunov.cpp:519-560
 #include "orc_pointwise.h"
 
+#include <cstdlib>
+#include <new>
+#include <thread>
+
 namespace orc {
 
 namespace {
@@ -111,6 +115,28 @@ void trace_mhd_3d(const rgpu_params& g, const double q[8], double dq[3][8], cons
   qLB_Z[ID] = r + (-drx - dry); qLB_Z[IU] = u + (-dux - duy); qLB_Z[IV] = v + (-dvx - dvy); qLB_Z[IW] = w + (-dwx - dwy);
   qLB_Z[IP] = p + (-dpx - dpy); qLB_Z[IA] = AL + (-dALy); qLB_Z[IB] = BL + (-dBLx); qLB_Z[IC] = C + (-dCx - dCy); ORC_FLOOR3(qLB_Z);
 #undef ORC_FLOOR3
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Threaded variant of the same step for the all-cores CPU baseline: every loop nest is cut into
+// contiguous z-slabs, one per thread.  The reference's own OpenMP build parallelises these loops too
+// (mhd_godunov_unsplit_cpu_v3.cpp:32-35, 368-371) but its flux loop SCATTERS into the neighbours' cells and races; here the
+// fluxes are stored and each cell GATHERS its six contributions in the order the sequential scatter loop delivers them
+// (Coriolis, +Fx, +Fy, +Fz of its own iteration, then -Fx(i+1), -Fy(j+1), -Fz(k+1)): deterministic, and bit-identical to
+// mhd_step_3d for any thread count (tests/test_oracle_golden.py::test_threaded_step_equals_sequential).  Scope: the
+// configurations of the bench (no gravity, no dissipative stage, no forcing) -- orc_run_mt refuses the others.
+template <class F>
+void slabs(int k0, int k1, int nthreads, F fn) {   // fn(ka, kb) on [k0, k1) cut into nthreads contiguous pieces
+  const int n = k1 - k0;
+  if (nthreads <= 1 || n <= 1) { fn(k0, k1); return; }
+  if (nthreads > n) nthreads = n;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t) {
+    const int a = k0 + (int)((long long)n * t / nthreads), b = k0 + (int)((long long)n * (t + 1) / nthreads);
+    th.emplace_back([=]() { fn(a, b); });
+  }
+  for (auto& x : th) x.join();
 }
 
 }  // namespace
@@ -441,5 +467,334 @@ void mhd_step_3d(const Ctx& c, double* Uold_d, double* Unew_d, double dt, double
   if (!rot) ou_forcing(c, Unew_d, dt);           // problem "turbulence-Ornstein-Uhlenbeck" (..._cpu_v3.cpp:706-710)
   if (rot) make_all_boundaries(c, Unew_d, totalTime, dt);  // rotating path: ghosts of the OUTPUT at step end
 }
+
+MtWork::MtWork(const Ctx& c, int nthreads) : buf(0), doubles(0) {
+  const size_t N = c.ncell;
+  doubles = N * (size_t)(8 + 3 * 5 + 3 * (8 + 8 + 5) + 12 * 8);
+  buf = static_cast<double*>(std::malloc(doubles * sizeof(double)));
+  if (!buf) throw std::bad_alloc();
+  const size_t plane = (size_t)c.isize * c.jsize;
+  const size_t comps = doubles / N;
+  slabs(0, c.ksize, nthreads, [&](int ka, int kb) {
+    for (size_t v = 0; v < comps; ++v) std::memset(buf + v * N + plane * ka, 0, sizeof(double) * plane * (kb - ka));
+  });
+}
+MtWork::~MtWork() { std::free(buf); }
+
+void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, double dt, double totalTime, int nthreads) {
+  const rgpu_params& p = c.p;
+  const bool rot = p.Omega0 > 0;
+  const bool shearbox = p.shearingBoxEnabled != 0;
+  const int gw = c.gw, isize = c.isize, jsize = c.jsize, ksize = c.ksize, nx = c.nx, ny = c.ny;
+  const double dx = c.dx, dy = c.dy;
+  const double dtdx = dt / c.dx, dtdy = dt / c.dy, dtdz = dt / c.dz;
+  const size_t N = c.ncell;
+  const double Omega0 = p.Omega0;
+  double lambda = 0, ratio = 1, alpha1 = 1, alpha2 = 0;
+  if (rot) {
+    lambda = Omega0 * dt;
+    lambda = 0.25 * lambda * lambda;
+    ratio = (1.0 - lambda) / (1.0 + lambda);
+    alpha1 = 1.0 / (1.0 + lambda);
+    alpha2 = Omega0 * dt / (1.0 + lambda);
+  } else {
+    make_all_boundaries(c, Uold_d, 0.0, 0.0);
+  }
+  slabs(0, ksize, nthreads, [&](int ka, int kb) {
+    const size_t plane = (size_t)isize * jsize;
+    for (int v = 0; v < 8; ++v) std::memcpy(Unew_d + v * N + plane * ka, Uold_d + v * N + plane * ka, sizeof(double) * plane * (kb - ka));
+  });
+
+  // work arrays: allocated once per run and zeroed by the threads that will use each slab (first touch); a step overwrites the
+  // same cells every time, the cells no loop writes keep the zeros the sequential step's fresh arrays have
+  Field U, Unew, Q, elec, dA, dB, dC, qm[3], qp[3], qE[4][3], emf, Fl[3];
+  U.wrap(c, Uold_d, 8); Unew.wrap(c, Unew_d, 8);
+  {
+    size_t o = 0;
+    auto take = [&](Field& f, int nv) { f.wrap(c, w.buf + o, nv); o += N * nv; };
+    take(Q, 8); take(elec, 3); take(dA, 3); take(dB, 3); take(dC, 3); take(emf, 3);
+    for (int d = 0; d < 3; ++d) { take(qm[d], 8); take(qp[d], 8); take(Fl[d], 5); }
+    for (int e = 0; e < 4; ++e) for (int d = 0; d < 3; ++d) take(qE[e][d], 8);
+  }
+
+  slabs(0, ksize - 1, nthreads, [&](int ka, int kb) {   // primitive variables
+    for (int k = ka; k < kb; k++)
+      for (int j = 0; j < jsize - 1; j++)
+        for (int i = 0; i < isize - 1; i++) {
+          double u[8], q[8], cs;
+          for (int v = 0; v < 8; ++v) u[v] = U(i, j, k, v);
+          const double bnb[3] = {U(i + 1, j, k, IA), U(i, j + 1, k, IB), U(i, j, k + 1, IC)};
+          mhd_constoprim(p, u, bnb, q, cs, dt);
+          for (int v = 0; v < 8; ++v) Q(i, j, k, v) = q[v];
+        }
+  });
+  const double st_face = fmin(p.slope_type, 2.0);
+  slabs(1, ksize - 1, nthreads, [&](int ka, int kb) {   // edge electric field + transverse slopes of the face field
+    for (int k = ka; k < kb; k++)
+      for (int j = 1; j < jsize - 1; j++)
+        for (int i = 1; i < isize - 1; i++) {
+          double u, v, w, A, B, C;
+          const double xPos = p.xMin + dx / 2 + (i - gw) * dx;
+          v = 0.25 * (Q(i, j - 1, k - 1, IV) + Q(i, j - 1, k, IV) + Q(i, j, k - 1, IV) + Q(i, j, k, IV));
+          w = 0.25 * (Q(i, j - 1, k - 1, IW) + Q(i, j - 1, k, IW) + Q(i, j, k - 1, IW) + Q(i, j, k, IW));
+          B = 0.5 * (U(i, j, k - 1, IB) + U(i, j, k, IB));
+          C = 0.5 * (U(i, j - 1, k, IC) + U(i, j, k, IC));
+          elec(i, j, k, IX) = v * C - w * B;
+          if (rot) { const double shear = -1.5 * Omega0 * xPos; elec(i, j, k, IX) += shear * C; }
+          u = 0.25 * (Q(i - 1, j, k - 1, IU) + Q(i - 1, j, k, IU) + Q(i, j, k - 1, IU) + Q(i, j, k, IU));
+          w = 0.25 * (Q(i - 1, j, k - 1, IW) + Q(i - 1, j, k, IW) + Q(i, j, k - 1, IW) + Q(i, j, k, IW));
+          A = 0.5 * (U(i, j, k - 1, IA) + U(i, j, k, IA));
+          C = 0.5 * (U(i - 1, j, k, IC) + U(i, j, k, IC));
+          elec(i, j, k, IY) = w * A - u * C;
+          u = 0.25 * (Q(i - 1, j - 1, k, IU) + Q(i - 1, j, k, IU) + Q(i, j - 1, k, IU) + Q(i, j, k, IU));
+          v = 0.25 * (Q(i - 1, j - 1, k, IV) + Q(i - 1, j, k, IV) + Q(i, j - 1, k, IV) + Q(i, j, k, IV));
+          A = 0.5 * (U(i, j - 1, k, IA) + U(i, j, k, IA));
+          B = 0.5 * (U(i - 1, j, k, IB) + U(i, j, k, IB));
+          elec(i, j, k, IZ) = u * B - v * A;
+          if (rot) { const double shear = -1.5 * Omega0 * (xPos - dx / 2); elec(i, j, k, IZ) -= shear * A; }
+          dA(i, j, k, IX) = 0.0;
+          dA(i, j, k, IY) = tvd_slope(st_face, U(i, j - 1, k, IA), U(i, j, k, IA), U(i, j + 1, k, IA));
+          dA(i, j, k, IZ) = tvd_slope(st_face, U(i, j, k - 1, IA), U(i, j, k, IA), U(i, j, k + 1, IA));
+          dB(i, j, k, IX) = tvd_slope(st_face, U(i - 1, j, k, IB), U(i, j, k, IB), U(i + 1, j, k, IB));
+          dB(i, j, k, IY) = 0.0;
+          dB(i, j, k, IZ) = tvd_slope(st_face, U(i, j, k - 1, IB), U(i, j, k, IB), U(i, j, k + 1, IB));
+          dC(i, j, k, IX) = tvd_slope(st_face, U(i - 1, j, k, IC), U(i, j, k, IC), U(i + 1, j, k, IC));
+          dC(i, j, k, IY) = tvd_slope(st_face, U(i, j - 1, k, IC), U(i, j, k, IC), U(i, j + 1, k, IC));
+          dC(i, j, k, IZ) = 0.0;
+        }
+  });
+  slabs(gw - 2, ksize - gw + 1, nthreads, [&](int ka, int kb) {   // trace
+    for (int k = ka; k < kb; k++)
+      for (int j = gw - 2; j < jsize - gw + 1; j++)
+        for (int i = gw - 2; i < isize - gw + 1; i++) {
+          double q[8], dq[3][8], bfNb[6], dbf[12], E[3][2][2], tqm[3][8], tqp[3][8], tqe[4][3][8];
+          const double xPos = p.xMin + dx / 2 + (i - gw) * dx;
+          for (int v = 0; v < 8; ++v) {
+            q[v] = Q(i, j, k, v);
+            if (p.slope_type == 0) { dq[IX][v] = 0.0; dq[IY][v] = 0.0; dq[IZ][v] = 0.0; }
+            else {
+              dq[IX][v] = tvd_slope(p.slope_type, Q(i - 1, j, k, v), q[v], Q(i + 1, j, k, v));
+              dq[IY][v] = tvd_slope(p.slope_type, Q(i, j - 1, k, v), q[v], Q(i, j + 1, k, v));
+              dq[IZ][v] = tvd_slope(p.slope_type, Q(i, j, k - 1, v), q[v], Q(i, j, k + 1, v));
+            }
+          }
+          bfNb[0] = U(i, j, k, IA); bfNb[1] = U(i + 1, j, k, IA); bfNb[2] = U(i, j, k, IB); bfNb[3] = U(i, j + 1, k, IB);
+          bfNb[4] = U(i, j, k, IC); bfNb[5] = U(i, j, k + 1, IC);
+          dbf[0] = dA(i, j, k, IY); dbf[1] = dA(i, j, k, IZ); dbf[2] = dB(i, j, k, IX); dbf[3] = dB(i, j, k, IZ);
+          dbf[4] = dC(i, j, k, IX); dbf[5] = dC(i, j, k, IY);
+          dbf[6] = dA(i + 1, j, k, IY); dbf[7] = dA(i + 1, j, k, IZ); dbf[8] = dB(i, j + 1, k, IX); dbf[9] = dB(i, j + 1, k, IZ);
+          dbf[10] = dC(i, j, k + 1, IX); dbf[11] = dC(i, j, k + 1, IY);
+          E[IX][0][0] = elec(i, j, k, IX); E[IX][0][1] = elec(i, j, k + 1, IX); E[IX][1][0] = elec(i, j + 1, k, IX); E[IX][1][1] = elec(i, j + 1, k + 1, IX);
+          E[IY][0][0] = elec(i, j, k, IY); E[IY][0][1] = elec(i, j, k + 1, IY); E[IY][1][0] = elec(i + 1, j, k, IY); E[IY][1][1] = elec(i + 1, j, k + 1, IY);
+          E[IZ][0][0] = elec(i, j, k, IZ); E[IZ][0][1] = elec(i, j + 1, k, IZ); E[IZ][1][0] = elec(i + 1, j, k, IZ); E[IZ][1][1] = elec(i + 1, j + 1, k, IZ);
+          trace_mhd_3d(p, q, dq, bfNb, dbf, E, dtdx, dtdy, dtdz, xPos, tqm, tqp, tqe);
+          for (int v = 0; v < 8; ++v) {
+            for (int d = 0; d < 3; ++d) { qm[d](i, j, k, v) = tqm[d][v]; qp[d](i, j, k, v) = tqp[d][v]; }
+            for (int e = 0; e < 4; ++e) for (int d = 0; d < 3; ++d) qE[e][d](i, j, k, v) = tqe[e][d][v];
+          }
+        }
+  });
+
+  std::vector<double> sf_min((size_t)jsize * ksize * 2, 0.0), sf_max((size_t)jsize * ksize * 2, 0.0);
+  std::vector<double> sf_min_remap((size_t)jsize * ksize, 0.0), sf_max_remap((size_t)jsize * ksize, 0.0);
+  auto SF = [&](std::vector<double>& b, int j, int k, int comp) -> double& { return b[(size_t)j + (size_t)jsize * (k + (size_t)ksize * comp)]; };
+  static const int perm_y[8] = {ID, IP, IV, IU, IW, IB, IA, IC};
+  static const int perm_z[8] = {ID, IP, IW, IV, IU, IC, IB, IA};
+  slabs(gw, ksize - gw + 1, nthreads, [&](int ka, int kb) {   // Riemann problems: fluxes and emfs STORED (no scatter)
+    for (int k = ka; k < kb; k++)
+      for (int j = gw; j < jsize - gw + 1; j++)
+        for (int i = gw; i < isize - gw + 1; i++) {
+          double ql[8], qr[8], flux_x[8], flux_y[8], flux_z[8];
+          const double xPos = p.xMin + dx / 2 + (i - gw) * dx;
+          for (int v = 0; v < 8; ++v) { flux_x[v] = 0.0; flux_y[v] = 0.0; flux_z[v] = 0.0; }
+          for (int v = 0; v < 8; ++v) { ql[v] = qm[0](i - 1, j, k, v); qr[v] = qp[0](i, j, k, v); }
+          mhd_riemann(p, ql, qr, flux_x);
+          for (int v = 0; v < 8; ++v) { ql[v] = qm[1](i, j - 1, k, perm_y[v]); qr[v] = qp[1](i, j, k, perm_y[v]); }
+          mhd_riemann(p, ql, qr, flux_y);
+          if (rot) {
+            const double shear_y = -1.5 * Omega0 * xPos;
+            double eMag, eKin, eTot;
+            const double bn_mean = 0.5 * (ql[IA] + qr[IA]);
+            const double gamma = p.gamma0;
+            const double* s = (shear_y > 0) ? ql : qr;
+            eMag = 0.5 * (s[IA] * s[IA] + s[IB] * s[IB] + s[IC] * s[IC]);
+            eKin = 0.5 * (s[IU] * s[IU] + s[IV] * s[IV] + s[IW] * s[IW]);
+            eTot = eKin + eMag + s[IP] / (gamma - 1.0);
+            flux_y[ID] = flux_y[ID] + shear_y * s[ID];
+            flux_y[IP] = flux_y[IP] + shear_y * (eTot + eMag - bn_mean * bn_mean);
+            flux_y[IU] = flux_y[IU] + shear_y * s[ID] * s[IU];
+            flux_y[IV] = flux_y[IV] + shear_y * s[ID] * s[IV];
+            flux_y[IW] = flux_y[IW] + shear_y * s[ID] * s[IW];
+          }
+          for (int v = 0; v < 8; ++v) { ql[v] = qm[2](i, j, k - 1, perm_z[v]); qr[v] = qp[2](i, j, k, perm_z[v]); }
+          mhd_riemann(p, ql, qr, flux_z);
+          for (int v = 0; v < 5; ++v) { Fl[0](i, j, k, v) = flux_x[v]; Fl[1](i, j, k, v) = flux_y[v]; Fl[2](i, j, k, v) = flux_z[v]; }
+          const bool in_i = i < isize - gw, in_j = j < jsize - gw, in_k = k < ksize - gw;
+          if (rot && shearbox && in_j && in_k) {   // density flux through the two sheared x borders (taken out of the update below)
+            if (i == (nx + gw)) SF(sf_max, j, k, 0) = flux_x[ID] * dtdx;
+            if (i == gw) SF(sf_min, j, k, 0) = flux_x[ID] * dtdx;
+          }
+          double qe[4][8];
+          for (int v = 0; v < 8; ++v) {
+            qe[0][v] = qE[0][2](i - 1, j - 1, k, v); qe[1][v] = qE[1][2](i - 1, j, k, v);
+            qe[2][v] = qE[2][2](i, j - 1, k, v);     qe[3][v] = qE[3][2](i, j, k, v);
+          }
+          const double emfZ = compute_emf<2>(p, qe, xPos);
+          if (!rot || in_k) emf(i, j, k, I_EMFZ) = emfZ;
+          for (int v = 0; v < 8; ++v) {
+            qe[0][v] = qE[0][1](i - 1, j, k - 1, v); qe[1][v] = qE[2][1](i, j, k - 1, v);
+            qe[2][v] = qE[1][1](i - 1, j, k, v);     qe[3][v] = qE[3][1](i, j, k, v);
+          }
+          const double emfY = compute_emf<1>(p, qe, xPos);
+          if (!rot || in_j) {
+            emf(i, j, k, I_EMFY) = emfY;
+            if (rot && shearbox) {
+              if (i == gw) SF(sf_min, j, k, 1) = emfY;
+              if (i == (nx + gw)) SF(sf_max, j, k, 1) = emfY;
+            }
+          }
+          for (int v = 0; v < 8; ++v) {
+            qe[0][v] = qE[0][0](i, j - 1, k - 1, v); qe[1][v] = qE[1][0](i, j - 1, k, v);
+            qe[2][v] = qE[2][0](i, j, k - 1, v);     qe[3][v] = qE[3][0](i, j, k, v);
+          }
+          const double emfX = compute_emf<0>(p, qe, xPos);
+          if (!rot || in_i) emf(i, j, k, I_EMFX) = emfX;
+        }
+  });
+  slabs(gw, ksize - gw, nthreads, [&](int ka, int kb) {   // gather update of the interior cells, contributions in scatter order
+    for (int k = ka; k < kb; k++)
+      for (int j = gw; j < jsize - gw; j++)
+        for (int i = gw; i < isize - gw; i++) {
+          if (rot) {
+            const double dsx = 2.0 * Omega0 * dt * Unew(i, j, k, IV) / (1.0 + lambda);
+            const double dsy = -0.5 * Omega0 * dt * Unew(i, j, k, IU) / (1.0 + lambda);
+            Unew(i, j, k, IU) = Unew(i, j, k, IU) * ratio + dsx;
+            Unew(i, j, k, IV) = Unew(i, j, k, IV) * ratio + dsy;
+          }
+          const Field& fx = Fl[0]; const Field& fy = Fl[1]; const Field& fz = Fl[2];
+          if (!(rot && shearbox && i == gw)) Unew(i, j, k, ID) += fx(i, j, k, ID) * dtdx;
+          Unew(i, j, k, IP) += fx(i, j, k, IP) * dtdx;
+          Unew(i, j, k, IU) += (alpha1 * fx(i, j, k, IU) + alpha2 * fx(i, j, k, IV)) * dtdx;
+          Unew(i, j, k, IV) += (alpha1 * fx(i, j, k, IV) - 0.25 * alpha2 * fx(i, j, k, IU)) * dtdx;
+          Unew(i, j, k, IW) += fx(i, j, k, IW) * dtdx;
+          Unew(i, j, k, ID) += fy(i, j, k, ID) * dtdy;
+          Unew(i, j, k, IP) += fy(i, j, k, IP) * dtdy;
+          Unew(i, j, k, IU) += (alpha1 * fy(i, j, k, IV) + alpha2 * fy(i, j, k, IU)) * dtdy;
+          Unew(i, j, k, IV) += (alpha1 * fy(i, j, k, IU) - 0.25 * alpha2 * fy(i, j, k, IV)) * dtdy;
+          Unew(i, j, k, IW) += fy(i, j, k, IW) * dtdy;
+          Unew(i, j, k, ID) += fz(i, j, k, ID) * dtdz;
+          Unew(i, j, k, IP) += fz(i, j, k, IP) * dtdz;
+          Unew(i, j, k, IU) += (alpha1 * fz(i, j, k, IW) + alpha2 * fz(i, j, k, IV)) * dtdz;
+          Unew(i, j, k, IV) += (alpha1 * fz(i, j, k, IV) - 0.25 * alpha2 * fz(i, j, k, IW)) * dtdz;
+          Unew(i, j, k, IW) += fz(i, j, k, IU) * dtdz;
+          if (!(rot && shearbox && (i + 1) == (nx + gw))) Unew(i, j, k, ID) -= fx(i + 1, j, k, ID) * dtdx;
+          Unew(i, j, k, IP) -= fx(i + 1, j, k, IP) * dtdx;
+          Unew(i, j, k, IU) -= (alpha1 * fx(i + 1, j, k, IU) + alpha2 * fx(i + 1, j, k, IV)) * dtdx;
+          Unew(i, j, k, IV) -= (alpha1 * fx(i + 1, j, k, IV) - 0.25 * alpha2 * fx(i + 1, j, k, IU)) * dtdx;
+          Unew(i, j, k, IW) -= fx(i + 1, j, k, IW) * dtdx;
+          Unew(i, j, k, ID) -= fy(i, j + 1, k, ID) * dtdy;
+          Unew(i, j, k, IP) -= fy(i, j + 1, k, IP) * dtdy;
+          Unew(i, j, k, IU) -= (alpha1 * fy(i, j + 1, k, IV) + alpha2 * fy(i, j + 1, k, IU)) * dtdy;
+          Unew(i, j, k, IV) -= (alpha1 * fy(i, j + 1, k, IU) - 0.25 * alpha2 * fy(i, j + 1, k, IV)) * dtdy;
+          Unew(i, j, k, IW) -= fy(i, j + 1, k, IW) * dtdy;
+          Unew(i, j, k, ID) -= fz(i, j, k + 1, ID) * dtdz;
+          Unew(i, j, k, IP) -= fz(i, j, k + 1, IP) * dtdz;
+          Unew(i, j, k, IU) -= (alpha1 * fz(i, j, k + 1, IW) + alpha2 * fz(i, j, k + 1, IV)) * dtdz;
+          Unew(i, j, k, IV) -= (alpha1 * fz(i, j, k + 1, IV) - 0.25 * alpha2 * fz(i, j, k + 1, IW)) * dtdz;
+          Unew(i, j, k, IW) -= fz(i, j, k + 1, IU) * dtdz;
+        }
+  });
+
+  if (rot && shearbox) {   // O(N^2): sequential, as in mhd_step_3d
+    double deltay, epsi, eps;
+    int jplus, jremap, jremapp1;
+    deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt / 2);
+    deltay = fmod(deltay, (p.dy * p.ny));
+    jplus = (int)(deltay / dy);
+    epsi = fmod(deltay, dy);
+    for (int k = 0; k < ksize; k++)
+      for (int j = 0; j < jsize; j++) {
+        jremap = j - jplus - 1;
+        jremapp1 = jremap + 1;
+        eps = 1.0 - epsi / dy;
+        if (jremap < gw) jremap += ny;
+        if (jremapp1 < gw) jremapp1 += ny;
+        if (j >= gw && j < jsize - gw + 1 && k >= gw && k < ksize - gw + 1) {
+          sf_min_remap[(size_t)j + (size_t)jsize * k] =
+              SF(sf_min, j, k, 0) + (1.0 - eps) * SF(sf_max, jremap, k, 0) + eps * SF(sf_max, jremapp1, k, 0);
+          sf_min_remap[(size_t)j + (size_t)jsize * k] *= 0.5;
+        }
+        emf(gw, j, k, I_EMFY) += (1.0 - eps) * SF(sf_max, jremap, k, 1) + eps * SF(sf_max, jremapp1, k, 1);
+        emf(gw, j, k, I_EMFY) *= 0.5;
+        jremap = j + jplus;
+        jremapp1 = jremap + 1;
+        eps = epsi / dy;
+        if (jremap > ny + gw - 1) jremap -= ny;
+        if (jremapp1 > ny + gw - 1) jremapp1 -= ny;
+        if (j >= gw && j < jsize - gw + 1 && k >= gw && k < ksize - gw + 1) {
+          sf_max_remap[(size_t)j + (size_t)jsize * k] =
+              SF(sf_max, j, k, 0) + (1.0 - eps) * SF(sf_min, jremap, k, 0) + eps * SF(sf_min, jremapp1, k, 0);
+          sf_max_remap[(size_t)j + (size_t)jsize * k] *= 0.5;
+        }
+        emf(nx + gw, j, k, I_EMFY) += (1.0 - eps) * SF(sf_min, jremap, k, 1) + eps * SF(sf_min, jremapp1, k, 1);
+        emf(nx + gw, j, k, I_EMFY) *= 0.5;
+      }
+    for (int k = gw; k < ksize - gw + 1; k++)
+      for (int j = gw; j < jsize - gw + 1; j++) {
+        Unew(gw, j, k, ID) += sf_min_remap[(size_t)j + (size_t)jsize * k];
+        Unew(nx + gw - 1, j, k, ID) -= sf_max_remap[(size_t)j + (size_t)jsize * k];
+        Unew(gw, j, k, ID) = fmax(Unew(gw, j, k, ID), p.smallr);
+        Unew(nx + gw - 1, j, k, ID) = fmax(Unew(nx + gw - 1, j, k, ID), p.smallr);
+      }
+  }
+  slabs(gw, ksize - gw + 1, nthreads, [&](int ka, int kb) {   // constrained transport
+    for (int k = ka; k < kb; k++)
+      for (int j = gw; j < jsize - gw + 1; j++)
+        for (int i = gw; i < isize - gw + 1; i++) {
+          if (k < ksize - gw) {
+            Unew(i, j, k, IA) += (emf(i, j + 1, k, I_EMFZ) - emf(i, j, k, I_EMFZ)) * dtdy;
+            Unew(i, j, k, IB) -= (emf(i + 1, j, k, I_EMFZ) - emf(i, j, k, I_EMFZ)) * dtdx;
+          }
+          Unew(i, j, k, IA) -= (emf(i, j, k + 1, I_EMFY) - emf(i, j, k, I_EMFY)) * dtdz;
+          Unew(i, j, k, IB) += (emf(i, j, k + 1, I_EMFX) - emf(i, j, k, I_EMFX)) * dtdz;
+          Unew(i, j, k, IC) += (emf(i + 1, j, k, I_EMFY) - emf(i, j, k, I_EMFY)) * dtdx;
+          Unew(i, j, k, IC) -= (emf(i, j + 1, k, I_EMFX) - emf(i, j, k, I_EMFX)) * dtdy;
+        }
+  });
+  if (rot) make_all_boundaries(c, Unew_d, totalTime, dt);
+}
+
+// compute_dt_mhd (3D) with the scan cut into z-slabs: max is order independent, hence the sequential value
+double compute_inv_dt_mhd3d_mt(const Ctx& c, const double* U, int nthreads) {
+  const rgpu_params& p = c.p;
+  const int gw = c.gw;
+  const size_t N = c.ncell;
+  const double deltaX = p.xMax - p.xMin;
+  const size_t sj = c.isize, sk = (size_t)c.isize * c.jsize;
+  std::vector<double> part((size_t)(nthreads > 0 ? nthreads : 1) + c.ksize, p.smallc / fmin(c.dx, c.dy));
+  slabs(gw, c.ksize - gw, nthreads, [&](int ka, int kb) {
+    double invDt = p.smallc / fmin(c.dx, c.dy);
+    for (int k = ka; k < kb; k++)
+      for (int j = gw; j < c.jsize - gw; j++)
+        for (int i = gw; i < c.isize - gw; i++) {
+          const size_t o = c.idx(i, j, k);
+          double u[8];
+          for (int v = 0; v < 8; ++v) u[v] = U[o + v * N];
+          const double bnb[3] = {U[o + 1 + IA * N], U[o + sj + IB * N], U[o + sk + IC * N]};
+          double q[8], cs;
+          mhd_constoprim(p, u, bnb, q, cs, 0.0);
+          double s[3];
+          find_speed_info<3>(p, q, s);
+          double vy = s[IY];
+          if (p.Omega0 > 0) vy += 1.5 * p.Omega0 * deltaX / 2;
+          invDt = fmax(invDt, s[IX] / c.dx + vy / c.dy + s[IZ] / c.dz);
+        }
+    part[ka] = invDt;   // one slot per slab start plane: disjoint
+  });
+  double invDt = p.smallc / fmin(c.dx, c.dy);
+  for (double v : part) invDt = fmax(invDt, v);
+  return invDt;
+}
+
 
 }  // namespace orc

@@ -313,11 +313,18 @@ RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double 
 // find_speed_fast<IX> (mhd_utils.h:28-52), bn = the field component along the wanted direction
 // inv_r = rg_recip(q.r): the three divisions by the density (and those of a second call for another direction
 // of the same state) share one reciprocal
-RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
+// fast_speed_sq: the radicand, cf = sqrt(fast_speed_sq).  The square root is monotonic and (exact arithmetic) correctly
+// rounded, so the MAXIMUM of several fast speeds is the root of the maximum radicand, bit for bit: where the reference only
+// consumes max(cf_1 .. cf_n) -- the wave-speed bounds of riemann_hlld / riemann_hll, mag_riemann2d_hlld / _hllf -- one root
+// is taken instead of n (a NaN radicand is dropped by fmax exactly like the NaN root would be).
+RG_DEVFN double fast_speed_sq(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
   const double c2 = rg_div(g.gamma0 * q.p, inv_r);
   const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
-  return rg_sqrt_pos(d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r)));   // d2 > 0: p > 0
+  return d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r));
+}
+RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
+  return rg_sqrt_pos(fast_speed_sq(g, q, bn, inv_r));   // d2 > 0: p > 0
 }
 RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn) { return fast_speed(g, q, bn, rg_recip(q.r)); }
 
@@ -381,9 +388,9 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double etotr = pr * entho + ecinr + emagr;
   const double ptotr = pr + emagr;
   const double vdotbr = ur * a + vr * br + wr * cr;
-  const double cfastl = fast_speed(g, L, L.a, rg_recip(L.r)), cfastr = fast_speed(g, R, R.a, rg_recip(R.r));
-  const double sl = fmin(ul, ur) - fmax(cfastl, cfastr);
-  const double sr = fmax(ul, ur) + fmax(cfastl, cfastr);
+  const double cfast = rg_sqrt_pos(fmax(fast_speed_sq(g, L, L.a, rg_recip(L.r)), fast_speed_sq(g, R, R.a, rg_recip(R.r))));   // = max(cfastl, cfastr)
+  const double sl = fmin(ul, ur) - cfast;
+  const double sr = fmax(ul, ur) + cfast;
   const double rcl = rl * (ul - sl), rcr = rr * (sr - ur);
   const rg_recip_t inv_rc = rg_recip(rcr + rcl);
   const double ustar = rg_div(rcr * ur + rcl * ul + (ptotl - ptotr), inv_rc);
@@ -455,9 +462,9 @@ RG_DEVFN void mhd_hll(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   double uL[8], fL[8], uR[8], fR[8];
   mhd_physical_flux(g, L, uL, fL);
   mhd_physical_flux(g, R, uR, fR);
-  const double cfl = fast_speed(g, L, L.a), cfr = fast_speed(g, R, R.a);
-  const double sl = fmin(fmin(L.u, R.u) - fmax(cfl, cfr), 0.0);
-  const double sr = fmax(fmax(L.u, R.u) + fmax(cfl, cfr), 0.0);
+  const double cf = rg_sqrt_pos(fmax(fast_speed_sq(g, L, L.a, rg_recip(L.r)), fast_speed_sq(g, R, R.a, rg_recip(R.r))));   // = max(cfl, cfr)
+  const double sl = fmin(fmin(L.u, R.u) - cf, 0.0);
+  const double sr = fmax(fmax(L.u, R.u) + cf, 0.0);
 #pragma unroll
   for (int n = 0; n < 8; ++n) flux[n] = (sr * fL[n] - sl * fR[n] + sr * sl * (uR[n] - uL[n])) / (sr - sl);
 }
@@ -510,12 +517,11 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   // 66 divisions by 24 distinct denominators: every denominator gets one shared reciprocal (rg_recip), see
   // rg_backend.h; numerators and operand order are the reference's
   const rg_recip_t iLLr = rg_recip(LL.r), iLRr = rg_recip(LR.r), iRLr = rg_recip(RL.r), iRRr = rg_recip(RR.r);
-  const double cFastLLx = fast_speed(g, LL, LL.a, iLLr), cFastLRx = fast_speed(g, LR, LR.a, iLRr);
-  const double cFastRLx = fast_speed(g, RL, RL.a, iRLr), cFastRRx = fast_speed(g, RR, RR.a, iRRr);
-  const double cFastLLy = fast_speed(g, LL, LL.b, iLLr), cFastLRy = fast_speed(g, LR, LR.b, iLRr);
-  const double cFastRLy = fast_speed(g, RL, RL.b, iRLr), cFastRRy = fast_speed(g, RR, RR.b, iRRr);
-  const double cxmax = max_of4(cFastLLx, cFastLRx, cFastRLx, cFastRRx);
-  const double cymax = max_of4(cFastLLy, cFastLRy, cFastRLy, cFastRRy);
+  // the eight fast speeds are only consumed through their maxima per direction: two roots instead of eight (fast_speed_sq)
+  const double cxmax = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.a, iLLr), fast_speed_sq(g, LR, LR.a, iLRr),
+                                           fast_speed_sq(g, RL, RL.a, iRLr), fast_speed_sq(g, RR, RR.a, iRRr)));
+  const double cymax = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.b, iLLr), fast_speed_sq(g, LR, LR.b, iLRr),
+                                           fast_speed_sq(g, RL, RL.b, iRLr), fast_speed_sq(g, RR, RR.b, iRRr)));
   const double SL = min_of4(LL.u, LR.u, RL.u, RR.u) - cxmax;
   const double SR = max_of4(LL.u, LR.u, RL.u, RR.u) + cxmax;
   const double SB = min_of4(LL.v, LR.v, RL.v, RR.v) - cymax;
@@ -650,8 +656,8 @@ RG_DEVFN double mag_hlla_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
 RG_DEVFN double mag_hllf_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
                             double ELL, double ERL, double ELR, double ERR) {
   const rg_recip_t iLL = rg_recip(LL.r), iLR = rg_recip(LR.r), iRL = rg_recip(RL.r), iRR = rg_recip(RR.r);
-  const double cMaxx = max_of4(fast_speed(g, LL, LL.a, iLL), fast_speed(g, LR, LR.a, iLR), fast_speed(g, RL, RL.a, iRL), fast_speed(g, RR, RR.a, iRR));
-  const double cMaxy = max_of4(fast_speed(g, LL, LL.b, iLL), fast_speed(g, LR, LR.b, iLR), fast_speed(g, RL, RL.b, iRL), fast_speed(g, RR, RR.b, iRR));
+  const double cMaxx = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.a, iLL), fast_speed_sq(g, LR, LR.a, iLR), fast_speed_sq(g, RL, RL.a, iRL), fast_speed_sq(g, RR, RR.a, iRR)));
+  const double cMaxy = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.b, iLL), fast_speed_sq(g, LR, LR.b, iLR), fast_speed_sq(g, RL, RL.b, iRL), fast_speed_sq(g, RR, RR.b, iRR)));
   const double SL = fmin(min_of4(LL.u, LR.u, RL.u, RR.u) - cMaxx, 0.0);
   const double SR = fmax(max_of4(LL.u, LR.u, RL.u, RR.u) + cMaxx, 0.0);
   const double SB = fmin(min_of4(LL.v, LR.v, RL.v, RR.v) - cMaxy, 0.0);

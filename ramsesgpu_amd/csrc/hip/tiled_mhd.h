@@ -39,11 +39,26 @@ constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E
 constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
 constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
+// Experiment (RG_EXP_TILE_STRIDE): tiles placed every 15 x 7 cells although each still solves 16 x 8 problems -- the Riemann
+// work of a sweep whose tiles FINISH the cells they own (a fused flux + update kernel must own both faces of a cell in x and
+// y, i.e. (OX - 1) x (OY - 1) cells per tile).  Overlapping tiles write the same doubles twice; results are unchanged.
+#ifdef RG_EXP_TILE_STRIDE
+constexpr int MH_SX = MH_OX - 1, MH_SY = MH_OY - 1;
+#else
+constexpr int MH_SX = MH_OX, MH_SY = MH_OY;
+#endif
 
+#ifdef RG_T_AOS
+struct TLdsWrite {   // cell-major: the 38 components of a traced cell are contiguous (stride 76 dwords: conflict-free 16-byte accesses)
+  double* cell;
+  RG_DEVFN void put(int slot, double v) const { cell[slot] = v; }
+};
+#else
 struct TLdsWrite {
   double* cell;
   RG_DEVFN void put(int slot, double v) const { cell[slot * MH_CELLS] = v; }
 };
+#endif
 struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B, planes kk, kk+1 of E
   const double* qb[3]; const double* eb[2];
   const int* flag; int want;   // E of plane kk+1 is complete once *flag >= want (written by the Riemann waves)
@@ -64,7 +79,11 @@ struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q 
 // component when the plane above has been traced (see "carried states" below).
 struct TLdsPlane {
   const double* base;
+#ifdef RG_T_AOS
+  RG_DEVFN double get(int slot, unsigned m) const { return base[(int)m * T_COUNT + slot]; }
+#else
   RG_DEVFN double get(int slot, unsigned m) const { return base[slot * MH_CELLS + m]; }
+#endif
   RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)MH_PX : 0u; }
 };
 
@@ -79,48 +98,62 @@ struct TLdsPlane {
 // first 70 % of its work both finish together.
 template <int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
-                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop, bool flux_first) {
   const size_t N = g.ncell;
   const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  // flux_first (wave-uniform): the face problem before the edge problem.  The two Riemann waves of a SIMD then start a plane
+  // with different LDS appetites (2 face states against 4 edge states) instead of both queueing at the LDS at once.
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
     if (solve) {
+      auto face = [&]() {
+        Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<XD>(g, L, R, xPos, fl);
+        store_flux<XD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);        // b2 = CL(m2) + s1 * dCLy(m2), s1 = +1, m2 = the cell above
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<XD>(g, L, R, xPos, fl);
-      store_flux<XD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = edge_state3d<0, +1, +1, false>(g, Tk, m - sj, idx);
     c1 = edge_state3d<0, -1, +1, false>(g, Tk, m, idx);
   } else if (DIR == YD) {   // edge along y: t1 = z, t2 = x.  rt = (+,+) from c-z-x, rb = (+,-) from c-z, lt = (-,+) from c-x, lb from c
     if (solve) {
+      auto face = [&]() {
+        Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<YD>(g, L, R, xPos, fl);
+        store_flux<YD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       c0.a = Tk.get(T_CL, m - sx) + Tk.get(T_DCLX, m - sx);        // b1 = CL(m1) + s2 * dCLx(m1), s2 = +1
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<YD>(g, L, R, xPos, fl);
-      store_flux<YD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = edge_state3d<1, +1, +1, false>(g, Tk, m - sx, idx);
     c1 = edge_state3d<1, +1, -1, false>(g, Tk, m, idx);
   } else {   // edge along z: all four states on plane kk; z face: left state from plane kk-1
     if (solve) {
+      auto face = [&]() {
+        c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
+        Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<ZD>(g, c0, R, xPos, fl);
+        store_flux<ZD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
-      Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<ZD>(g, c0, R, xPos, fl);
-      store_flux<ZD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = face_state3d<ZD, +1, false>(g, Tk, m, idx);
   }
@@ -131,7 +164,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   spec_assume<SPEC>(g);
-  __shared__ double LT[2 * MH_BUF];          // T of planes kk (read) and kk+1 (written)   (buffer = plane & 1)
+  __shared__ __attribute__((aligned(16))) double LT[2 * MH_BUF];          // T of planes kk (read) and kk+1 (written)   (buffer = plane & 1)
   __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk .. kk+2                  (slot = plane % 3)
   __shared__ double LE[2 * MH_ESLOT];        // E of planes kk+1, kk+2                      (slot = plane & 1)
   __shared__ int Lsync;                      // arrival counter of the producer pair
@@ -142,7 +175,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int bx = item.bx, by = item.by, sa = item.sa, sb = item.sb;
 
   const int gw = g.gw;
-  const int i0 = gw + bx * MH_OX, j0 = gw + by * MH_OY;   // first cell of the tile
+  const int i0 = gw + bx * MH_SX, j0 = gw + by * MH_SY;   // first cell of the tile
   const int t = (int)threadIdx.x;
   const size_t N = g.ncell;
   const unsigned sk = g.sk;
@@ -245,7 +278,11 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
     if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
       const IJK c = {ti, tj, k};
+#ifdef RG_T_AOS
+      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell * T_COUNT};
+#else
       const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
+#endif
       const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
                              {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
       mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
@@ -319,9 +356,14 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         if (raise) __builtin_amdgcn_s_setprio(1);
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
-        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+#ifdef RG_FLUX_FIRST   // experiment: 1 = the younger wave of each SIMD, 2 = the older one, 3 = both solve the face problem first
+        const bool ff = ((RG_FLUX_FIRST) & (wave >= 4 ? 1 : 2)) != 0;
+#else
+        const bool ff = false;
+#endif
+        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
+        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
+        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }
@@ -365,8 +407,9 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   TileGrid tg;
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
-  tg.nbx = (g.isize - 2 * g.gw + 1 + MH_OX - 1) / MH_OX;   // cells gw .. isize-gw
-  tg.nby = (g.jsize - 2 * g.gw + 1 + MH_OY - 1) / MH_OY;
+  tg.nbx = (g.isize - 2 * g.gw + 1 + MH_SX - 1) / MH_SX;   // cells gw .. isize-gw
+  tg.nby = (g.jsize - 2 * g.gw + 1 + MH_SY - 1) / MH_SY;
+  if (MH_SX != MH_OX) reuse = 0;
   const bool copy_x = (reuse & 1) && g.nx % MH_OX == 0 && g.nx >= MH_OX, copy_y = (reuse & 2) && g.ny % MH_OY == 0 && g.ny >= MH_OY;
   if (copy_x) tg.nbx -= 1;
   if (copy_y) tg.nby -= 1;

@@ -80,6 +80,17 @@ class Oracle:
         assert rc == 0, rc
         return Unew
 
+    def run_mt(self, p, U0, nsteps, nthreads, tEnd=1e300):
+        """orc_run with the 3D MHD step threaded over z-slabs (the all-cores CPU baseline); same results as run()"""
+        U = np.array(U0, dtype=np.float64, order="C", copy=True)
+        nd, tf = C.c_int(), C.c_double()
+        dts = np.zeros(max(nsteps, 1))
+        self.lib.orc_run_mt.restype = C.c_int
+        self.lib.orc_run_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.orc_run_mt(C.byref(p), U.ctypes.data, nsteps, tEnd, nthreads, C.byref(nd), C.byref(tf), dts.ctypes.data)
+        assert rc == 0, rc
+        return U, dts[:nd.value], tf.value
+
     def run(self, p, U0, nsteps, tEnd=1e300):
         """start(): returns (U_final incl. ghosts, dts, t_final)"""
         U = np.array(U0, dtype=np.float64, order="C", copy=True)

@@ -338,3 +338,107 @@ def check_history_turbulence(lib, oracle, base, ov, nsteps):
     for q, (a, b) in enumerate(zip(got, ref)):
         tol = 1e-11 * max(abs(b), mag.get(q, 0.0))
         assert abs(a - b) <= tol, "history_turbulence column %d: device %r oracle %r tol %g" % (q, a, b, tol)
+
+
+# ---- gates at the BASELINE sizes, for the exact library (equal bits) and for the tolerance-grade one (relative L2 < 1e-12) ----
+OT_VARS = ["density", "energy", "mx", "my", "mz", "bx", "by", "bz"]
+
+
+def orszag_tang_gate(lib, oracle, exact):
+    """data/orszag-tang.ini as shipped (512^2, nstepmax = 50) against the oracle: north_star's gate, relative L2 < 1e-12 per
+    variable; exact=True additionally demands every double and every dt equal.  Returns {variable: relative L2}."""
+    p = lib.params_from_ini(ini("orszag-tang"))
+    assert (p.nx, p.ny) == (512, 512)
+    U0 = lib.init_condition(ini("orszag-tang"), "", p)
+    ref, dts_ref, _ = oracle.run(p, U0, 50)
+    sv = Solver(p, lib)
+    try:
+        dts = sv.start(U0, 50)
+        got, ref = interior(sv.getDataHost(), p), interior(ref, p)
+    finally:
+        sv.close()
+    errs = {}
+    for v, name in enumerate(OT_VARS):
+        errs[name] = float(rel_l2(got[v], ref[v]))
+        assert errs[name] < L2_TOLERANCE, "Orszag-Tang %s: relative L2 %.3e" % (name, errs[name])
+    if exact:
+        assert np.array_equal(got, ref) and np.array_equal(np.array(dts), dts_ref)
+    else:
+        assert np.abs(np.array(dts) / dts_ref - 1.0).max() < 1e-11
+    return errs
+
+
+def divB_max(U, p):
+    gw = p.ghostWidth
+    bx, by, bz = U[5], U[6], U[7]
+    s = (slice(gw, -gw),) * 3
+    sx = (slice(gw, -gw), slice(gw, -gw), slice(gw + 1, -gw + 1 if gw > 1 else None))
+    sy = (slice(gw, -gw), slice(gw + 1, -gw + 1 if gw > 1 else None), slice(gw, -gw))
+    sz = (slice(gw + 1, -gw + 1 if gw > 1 else None), slice(gw, -gw), slice(gw, -gw))
+    d = (bx[sx] - bx[s]) / p.dx + (by[sy] - by[s]) / p.dy + (bz[sz] - bz[s]) / p.dz
+    return float(np.abs(d).max())
+
+
+def mri_headline_size_properties(lib):
+    """512^3 MRI (the bench workload): div B at round-off, mass conserved to round-off, finite fields"""
+    ov = "mesh.nx=512;mesh.ny=512;mesh.nz=512"
+    p = lib.params_from_ini(ini("mhd_mri_3d"), ov)
+    U0 = lib.init_condition(ini("mhd_mri_3d"), ov, p)
+    sv = Solver(p, lib)
+    try:
+        sv.start(U0, 0)
+        A = sv.getDataHost()
+        m0 = interior(A, p)[0].sum(dtype=np.longdouble)
+        b_scale = float(np.abs(A[7]).max()) / p.dx
+        d0 = divB_max(A, p)
+        del U0, A
+        for _ in range(3):
+            sv.oneStepIntegration()
+        B = sv.getDataHost()
+    finally:
+        sv.close()
+    assert np.isfinite(B).all()
+    m1 = interior(B, p)[0].sum(dtype=np.longdouble)
+    assert abs(float((m1 - m0) / m0)) < 1e-13
+    assert divB_max(B, p) <= max(d0, 1e-13 * b_scale) + 1e-12 * b_scale
+
+
+def implode_bench_size_properties(lib):
+    """256^3 implode, HLLC, reflecting walls: mass and energy conserved to round-off, x <-> y symmetry of the solution"""
+    ov = "mesh.nx=256;mesh.ny=256;mesh.nz=256;hydro.riemannSolver=hllc"
+    p = lib.params_from_ini(ini("implode3d"), ov)
+    U0 = lib.init_condition(ini("implode3d"), ov, p)
+    sv = Solver(p, lib)
+    try:
+        sv.start(U0, 5)
+        A = interior(sv.getDataHost(), p)
+    finally:
+        sv.close()
+    I0 = interior(U0, p)
+    for v in (0, 1):
+        a, b = A[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
+        assert abs(float((a - b) / b)) < 1e-13
+    # x <-> y transposition symmetry: density invariant, mx <-> my
+    assert np.allclose(A[0], A[0].transpose(0, 2, 1), rtol=0, atol=1e-12)
+    assert np.allclose(A[2], A[3].transpose(0, 2, 1), rtol=0, atol=1e-12)
+
+
+def long_run_error_growth(lib, oracle, base, ov, nsteps, every):
+    """relative L2 (all variables together) of `lib` against the oracle after every `every` steps of one run -- how round-off
+    differences of the tolerance-grade arithmetic grow on a long run.  Returns [(step, relative L2, max |dt / dt_ref - 1|)]."""
+    p = lib.params_from_ini(ini(base), ov)
+    U0 = lib.init_condition(ini(base), ov, p)
+    out = []
+    sv = Solver(p, lib)
+    try:
+        sv.start(U0, 0)      # the init part of start(): ghost fill of the initial state, both arrays
+        dts = []
+        for n in range(1, nsteps + 1):
+            dts.append(sv.oneStepIntegration())
+            if n % every == 0 or n == nsteps:
+                ref, dts_ref, _ = oracle.run(p, U0, n)
+                got = interior(sv.getDataHost(), p)
+                out.append((n, float(rel_l2(got, interior(ref, p))), float(np.abs(np.array(dts) / np.asarray(dts_ref)[:n] - 1.0).max())))
+    finally:
+        sv.close()
+    return out

@@ -100,72 +100,20 @@ def test_xcd_sub_band_sizes_vs_oracle(base, ov, sub, gpu_lib, oracle, monkeypatc
 def test_orszag_tang_gate_full_size(gpu_lib, oracle):
     """BASELINE config: data/orszag-tang.ini as shipped (512^2, nstepmax=50).  Gate of north_star:
     L2 error vs euler_cpu < 1e-12 per variable; here the reference's CPU arithmetic is reproduced exactly."""
-    p = gpu_lib.params_from_ini(ini("orszag-tang"))
-    assert (p.nx, p.ny) == (512, 512)
-    U0 = gpu_lib.init_condition(ini("orszag-tang"), "", p)
-    ref, dts_ref, _ = oracle.run(p, U0, 50)
-    sv = Solver(p, gpu_lib)
-    dts = sv.start(U0, 50)
-    got, ref = interior(sv.getDataHost(), p), interior(ref, p)
-    sv.close()
-    for v, name in enumerate(["density", "energy", "mx", "my", "mz", "bx", "by", "bz"]):
-        err = pc.rel_l2(got[v], ref[v])
-        assert err < 1e-12, "Orszag-Tang %s: relative L2 %.3e" % (name, err)
-    assert np.array_equal(got, ref) and np.array_equal(np.array(dts), dts_ref)
-
-
-def divB_max(U, p):
-    gw = p.ghostWidth
-    bx, by, bz = U[5], U[6], U[7]
-    s = (slice(gw, -gw),) * 3
-    sx = (slice(gw, -gw), slice(gw, -gw), slice(gw + 1, -gw + 1 if gw > 1 else None))
-    sy = (slice(gw, -gw), slice(gw + 1, -gw + 1 if gw > 1 else None), slice(gw, -gw))
-    sz = (slice(gw + 1, -gw + 1 if gw > 1 else None), slice(gw, -gw), slice(gw, -gw))
-    d = (bx[sx] - bx[s]) / p.dx + (by[sy] - by[s]) / p.dy + (bz[sz] - bz[s]) / p.dz
-    return float(np.abs(d).max())
+    pc.orszag_tang_gate(gpu_lib, oracle, exact=True)
 
 
 def test_mri_headline_size_properties(gpu_lib):
     """BASELINE config: data/mhd_mri_3d.ini scaled to 512^3 (the bench workload).  The oracle cannot run this
     size in seconds, so size-independent properties are checked: constrained transport keeps div B at round-off,
     the shearing box conserves mass to round-off (the remapped x-border fluxes cancel), fields stay finite."""
-    ov = "mesh.nx=512;mesh.ny=512;mesh.nz=512"
-    p = gpu_lib.params_from_ini(ini("mhd_mri_3d"), ov)
-    U0 = gpu_lib.init_condition(ini("mhd_mri_3d"), ov, p)
-    sv = Solver(p, gpu_lib)
-    sv.start(U0, 0)
-    A = sv.getDataHost()
-    m0 = interior(A, p)[0].sum(dtype=np.longdouble)
-    b_scale = float(np.abs(A[7]).max()) / p.dx
-    d0 = divB_max(A, p)
-    del U0, A
-    for _ in range(3):
-        sv.oneStepIntegration()
-    B = sv.getDataHost()
-    sv.close()
-    assert np.isfinite(B).all()
-    m1 = interior(B, p)[0].sum(dtype=np.longdouble)
-    assert abs(float((m1 - m0) / m0)) < 1e-13
-    assert divB_max(B, p) <= max(d0, 1e-13 * b_scale) + 1e-12 * b_scale
+    pc.mri_headline_size_properties(gpu_lib)
 
 
 def test_implode_bench_size_properties(gpu_lib):
     """BASELINE config: data/implode3d.ini at 256^3 with HLLC.  Reflecting walls: mass and energy are conserved to
     round-off; the initial condition is symmetric under any permutation of (x,y,z) and so must the solution be."""
-    ov = "mesh.nx=256;mesh.ny=256;mesh.nz=256;hydro.riemannSolver=hllc"
-    p = gpu_lib.params_from_ini(ini("implode3d"), ov)
-    U0 = gpu_lib.init_condition(ini("implode3d"), ov, p)
-    sv = Solver(p, gpu_lib)
-    sv.start(U0, 5)
-    A = interior(sv.getDataHost(), p)
-    sv.close()
-    I0 = interior(U0, p)
-    for v in (0, 1):
-        a, b = A[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
-        assert abs(float((a - b) / b)) < 1e-13
-    # x <-> y transposition symmetry: density invariant, mx <-> my
-    assert np.allclose(A[0], A[0].transpose(0, 2, 1), rtol=0, atol=1e-12)
-    assert np.allclose(A[2], A[3].transpose(0, 2, 1), rtol=0, atol=1e-12)
+    pc.implode_bench_size_properties(gpu_lib)
 
 
 def test_external_state_and_stream(gpu_lib):

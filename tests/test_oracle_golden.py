@@ -82,3 +82,19 @@ def test_oracle_turbulence_history_matches_reference_history_file(oracle, produc
                 assert abs(a - b) <= 1e-12 * scale[q] * p.nx * p.ny * p.nz + 6e-6 * abs(b), (n, q, a, b)   # 6 printed digits
             else:
                 assert float("%.5e" % a) == float("%.5e" % b) or abs(a - b) <= 2e-6 * abs(b), (n, q, a, b)
+
+
+@pytest.mark.parametrize("base,ov,nsteps,nthreads", [
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=32;mesh.nz=16", 6, 3),                  # rotating + shearing box (the headline workload)
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=10;MHD.omega0=0.02", 4, 16),  # more threads than planes per slab
+    ("orszag-tang3d", "mesh.nx=12;mesh.ny=10;mesh.nz=14", 4, 4),               # plain 3D MHD
+])
+def test_threaded_step_equals_sequential(base, ov, nsteps, nthreads, oracle, product_lib):
+    """the all-cores CPU baseline (orc_run_mt: z-slab threads, fluxes stored, gather update in scatter order) reproduces the
+    sequential restatement -- which the golden fixtures pin to the reference binary -- bit for bit, dt sequence included"""
+    p = product_lib.params_from_ini(ini(base), ov)
+    U0 = product_lib.init_condition(ini(base), ov, p)
+    a, da, ta = oracle.run(p, U0, nsteps)
+    b, db, tb = oracle.run_mt(p, U0, nsteps, nthreads)
+    assert np.array_equal(da, db) and ta == tb
+    assert np.array_equal(interior(a, p), interior(b, p))
