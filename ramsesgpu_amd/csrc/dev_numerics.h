@@ -243,10 +243,11 @@ RG_DEVFN void riemann_hllc(const DevParams& g, const double* ql, const double* q
   ecinr += 0.5 * rr * qr[IV] * qr[IV];
   if (NV == 5) ecinr += 0.5 * rr * qr[IW] * qr[IW];
   const double etotr = pr * entho + ecinr;
-  const double cfastl = rg_sqrt(fmax(rg_div(g.gamma0 * pl, rg_recip(rl)), g.smallc * g.smallc));
-  const double cfastr = rg_sqrt(fmax(rg_div(g.gamma0 * pr, rg_recip(rr)), g.smallc * g.smallc));
-  const double SL = fmin(ul, ur) - fmax(cfastl, cfastr);
-  const double SR = fmax(ul, ur) + fmax(cfastl, cfastr);
+  // max(cfastl, cfastr) = sqrt(max of the radicands): the root is monotonic and correctly rounded (see fast_speed_sq)
+  const double cfast = rg_sqrt(fmax(fmax(rg_div(g.gamma0 * pl, rg_recip(rl)), g.smallc * g.smallc),
+                                    fmax(rg_div(g.gamma0 * pr, rg_recip(rr)), g.smallc * g.smallc)));
+  const double SL = fmin(ul, ur) - cfast;
+  const double SR = fmax(ul, ur) + cfast;
   const double rcl = rl * (ul - SL), rcr = rr * (SR - ur);
   const rg_recip_t inv_rc = rg_recip(rcr + rcl);
   const double ustar = rg_div(rcr * ur + rcl * ul + (pl - pr), inv_rc);

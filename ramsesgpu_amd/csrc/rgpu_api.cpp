@@ -538,10 +538,43 @@ RotCoef rot_coef(const rgpu_ctx* c, double dt) {
   return rc;
 }
 
+// Launch-time specialisations of the 3D MHD kernels (launchers.h): the isothermal rotating box (MRI) and the adiabatic
+// inertial one, both with the HLLD pair, slope type 2 and no gravity; everything else runs the generic kernels.
+const int kSpecMri = SPEC_HLLD | SPEC_ISOTHERMAL | SPEC_ROTATING | SPEC_NO_GRAVITY | SPEC_SLOPE2;
+const int kSpecPlain = SPEC_HLLD | SPEC_ADIABATIC | SPEC_INERTIAL | SPEC_NO_GRAVITY | SPEC_SLOPE2;
+inline int pick_spec(const DevParams& g) {
+  static const bool off = std::getenv("RGPU_NO_SPEC") != 0;
+  return off ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
+}
+
 int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   const DevParams& g = c->g;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   const RotCoef rc = rot_coef(c, dt);
+  {
+    // LDS-tiled fused step (hip/tiled_mhd2d.h): U -> Unew in one kernel, the CFL term of the new state included under the
+    // conditions of the flat update kernel below.  Not with a Dirichlet face (its ghost fill leaves B alone, so the output's
+    // ghost cells must be copies of the input's: the flat update copies them, the fused kernel writes its own cells only).
+    const rgpu_params& p = c->p;
+    bool faces_ok = true;
+    for (int f = 0; f < 4; ++f) faces_ok = faces_ok && (p.bc[f] == RGPU_BC_PERIODIC || p.bc[f] == RGPU_BC_NEUMANN);
+    if (faces_ok && g.grav_on != 2) {
+      bool scan = !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
+      if (scan && g.rot) scan = p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC;
+      static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+      if (no_fused_dt) scan = false;
+      if (rgpu_tiled::mhd2d_step_covers(g)) {
+        if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+        Phase ph(c, RGPU_T_SWEEP);
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0);
+        if (rct < 0) return -1;
+        if (rct == 0) {
+          if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
+          return 0;
+        }
+      }
+    }
+  }
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim<> k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   const bool gf = g.grav_on == 2;
@@ -571,14 +604,6 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   return 0;
 }
 
-// Launch-time specialisations of the 3D MHD kernels (launchers.h): the isothermal rotating box (MRI) and the adiabatic
-// inertial one, both with the HLLD pair, slope type 2 and no gravity; everything else runs the generic kernels.
-const int kSpecMri = SPEC_HLLD | SPEC_ISOTHERMAL | SPEC_ROTATING | SPEC_NO_GRAVITY | SPEC_SLOPE2;
-const int kSpecPlain = SPEC_HLLD | SPEC_ADIABATIC | SPEC_INERTIAL | SPEC_NO_GRAVITY | SPEC_SLOPE2;
-inline int pick_spec(const DevParams& g) {
-  static const bool off = std::getenv("RGPU_NO_SPEC") != 0;
-  return off ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
-}
 // linear workgroup order (pure streaming kernels; two cells per thread measured 2x slower: the loads do not merge)
 template <int BLOCK, class K>
 int launch_planes_stream(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {

@@ -6,7 +6,11 @@ namespace rgpu_tiled {
 inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int, unsigned long long* = 0) { return 1; }
 inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
+inline bool mhd2d_step_covers(const rgpu_dev::DevParams&) { return false; }
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const double*, double*, double*,
                        double, double, double, double, int, int, int = 0) { return 1; }
+template <int SPEC_PLAIN>
+inline int mhd2d_step(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const rgpu_dev::RotCoef&, bool, const double*, double*, double,
+                      unsigned long long*) { return 1; }
 }  // namespace rgpu_tiled
