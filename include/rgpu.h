@@ -288,6 +288,10 @@ int rgpu_history_mri(rgpu_ctx* c, int parity, double* out);
  * coef_x coef_y coef_z (the three high-k DFT amplitudes of Bx it monitors).  Single-domain contexts; fixed summation order,
  * device cos / sin: agreement with the reference to round-off. */
 int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out);
+/* The 18 raw sums behind rgpu_history_turbulence over the interior cells of this context -- also a slab's (its own planes):
+ * the z-slab driver adds them up across the ranks (rgpu_comm_history_turbulence, the reference's history_mhd_turbulence of the
+ * MPI classes, HydroRunBaseMpi.cpp:11346-11530). */
+int rgpu_history_turbulence_sums(rgpu_ctx* c, int parity, double* sums18);
 /* One cell of the state, out[nbVar] = U(i,j,k,:) with ghost-inclusive local indices: what history_inertial_wave
  * (MHDRunBase.cpp:3414-3469) probes -- U(ghostWidth + nx/2, ghostWidth) in 2D, U(ghostWidth + nx/2, 1, ghostWidth) in 3D --
  * without copying the whole array back (the reference calls copyGpuToCpu first). */
@@ -387,6 +391,8 @@ typedef struct rgpuh_step_hooks {
    * local_failed != 0 (or a negative code when the transport itself failed).  The run loop calls it where one rank alone
    * can fail -- file output -- so that every rank throws together instead of one leaving the others in a collective. */
   int (*agree)(void* self, int local_failed);
+  /* optional: the 14 numbers after "totalTime dt" of the MPI classes' turbulence history row (rgpu_comm_history_turbulence) */
+  int (*history_turbulence)(void* self, int parity, double* out14);
 } rgpuh_step_hooks;
 typedef int (*rgpuh_attach_fn)(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* hooks);
 typedef void (*rgpuh_detach_fn)(void* user);

@@ -73,6 +73,13 @@ int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double*
  * before the Reynolds stress can be formed, rgpu_history_reynolds), the same value on every rank. */
 int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out);
 
+/* HydroRunBaseMpi::history_mhd_turbulence (HydroRunBaseMpi.cpp:11346-11530): out[14] = the columns after "totalTime dt" of its
+ * row -- mass, divB, eKin, eMag, helicity, mean_B, mean_Bx, mean_By, mean_Bz, mean_rhovx, mean_rhovy, mean_rhovz, Ma_s, Ma_alfven.
+ * Reproduced as the reference computes them: mass, eKin, eMag, mean_v2 and the mean field are summed over the ranks; mean_B is
+ * the SUM of the ranks' |mean B| (not the norm of the sum); divB, helicity and mean_rhov are the values of THIS rank alone (the
+ * reference reduces them and then prints rank 0's local variables).  Collective; rank 0's result is the file's row. */
+int rgpu_comm_history_turbulence(rgpu_comm* cm, int parity, double* out14);
+
 /* 0: serial schedule (exchange between the step pieces), 1: overlapped (default) */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
 

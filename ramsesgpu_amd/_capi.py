@@ -190,7 +190,7 @@ def declare_device_api(lib):
 DECLARED_SYMBOLS = [
     "rgpu_create", "rgpu_create_external", "rgpu_destroy", "rgpu_state_elems", "rgpu_device_bytes", "rgpu_last_error",
     "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_get_params", "rgpu_stream_handle", "rgpu_inv_dt_device_slot", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
-    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_history_turbulence", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_invalidate_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
+    "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_history_turbulence", "rgpu_history_turbulence_sums", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_invalidate_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_core_planes_split", "rgpu_inv_dt_fused_commit", "rgpu_inv_dt_fused_active", "rgpu_inv_dt_fusable", "rgpu_step_fill_planes", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
     "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",

@@ -54,6 +54,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_godunov_unsplit.argtypes = [cm, C.c_int, C.c_double, C.c_double]
     lib.rgpu_comm_history_mri.restype = C.c_int
     lib.rgpu_comm_history_mri.argtypes = [cm, C.c_int, C.POINTER(C.c_double)]
+    lib.rgpu_comm_history_turbulence.restype = C.c_int
+    lib.rgpu_comm_history_turbulence.argtypes = [cm, C.c_int, C.POINTER(C.c_double)]
     lib.rgpu_comm_one_step_integration.restype = C.c_int
     lib.rgpu_comm_one_step_integration.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rgpuh_run_slabs.restype = C.c_int
@@ -64,7 +66,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 

@@ -337,6 +337,27 @@ int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out) {
   return RGPU_OK;
 }
 
+int rgpu_comm_history_turbulence(rgpu_comm* cm, int parity, double* out) {
+  RG_CHECK_CM(cm);
+  if (!out) return fail(cm, RGPU_EINVAL, "history_turbulence: null pointer");
+  const rgpu_params& p = cm->p;
+  double s[18];
+  RG_TRY(rgpu_history_turbulence_sums(cm->ctx, parity, s), "history_turbulence_sums");
+  const double dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin);   // zMax - zMin: the whole box
+  // this rank's values, scaled like the reference does before its MPI_Reduce calls
+  const double mass = s[0] * dTau, eKin = s[1] * dTau, mean_v2 = s[2] * dTau, eMag = s[3] * dTau, helicity = s[4] * dTau, divB = s[17];
+  const double mB[3] = {s[5] * dTau, s[6] * dTau, s[7] * dTau}, mrv[3] = {s[8] * dTau, s[9] * dTau, s[10] * dTau};
+  const double mB_norm = std::sqrt(mB[0] * mB[0] + mB[1] * mB[1] + mB[2] * mB[2]);
+  double t[8] = {mass, mean_v2, eKin, eMag, mB_norm, mB[0], mB[1], mB[2]};
+  if (cm->nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, t, 8, rgpu_stream_handle(cm->ctx))) return tr_fail(cm, "allreduce(history turbulence)");
+  const double pi = 2 * std::asin(1.0);
+  out[0] = t[0]; out[1] = divB; out[2] = t[2]; out[3] = t[3]; out[4] = helicity; out[5] = t[4];
+  out[6] = t[5]; out[7] = t[6]; out[8] = t[7]; out[9] = mrv[0]; out[10] = mrv[1]; out[11] = mrv[2];
+  out[12] = std::sqrt(t[1]) / p.cIso;                                   // Ma_s
+  out[13] = std::sqrt(t[1]) / (t[4] / std::sqrt(4 * pi * t[0]));        // Ma_alfven
+  return RGPU_OK;
+}
+
 // euler_hip --slabs: the run loop of the single-GPU front end (rgpuh_run_hooked in librgpu: initial condition or restart of this
 // slab, the reference's time loop, HDF5 outputs of the whole box written slab after slab) stepping through this driver
 namespace {
@@ -350,6 +371,7 @@ int hook_make_all_boundaries(void* self, int parity, double t, double dt) { retu
 int hook_compute_dt(void* self, int useU, double* dt) { return rgpu_comm_compute_dt(static_cast<SlabAttach*>(self)->cm, useU, dt); }
 int hook_one_step(void* self, int* nStep, double* t, double* dt) { return rgpu_comm_one_step_integration(static_cast<SlabAttach*>(self)->cm, nStep, t, dt); }
 int hook_history_mri(void* self, int parity, double* out) { return rgpu_comm_history_mri(static_cast<SlabAttach*>(self)->cm, parity, out); }
+int hook_history_turbulence(void* self, int parity, double* out) { return rgpu_comm_history_turbulence(static_cast<SlabAttach*>(self)->cm, parity, out); }
 int hook_barrier(void* self) {
   rgpu_comm* cm = static_cast<SlabAttach*>(self)->cm;
   if (rgpu_synchronize(cm->ctx)) return RGPU_EHIP;
@@ -390,6 +412,7 @@ int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
   h->barrier = hook_barrier;
   h->agree = hook_agree;
   h->history_mri = hook_history_mri;
+  h->history_turbulence = hook_history_turbulence;
   return 0;
 }
 void slab_detach(void* user) {

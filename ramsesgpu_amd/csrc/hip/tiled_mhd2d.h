@@ -63,7 +63,7 @@ struct F2LdsRead {
 template <int SPEC>
 __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, RotCoef rc, int nbx, const double* __restrict__ U,
                                                                    double* __restrict__ Unew, double dt, double dtdx, double dtdy,
-                                                                   unsigned long long* dt_slots) {
+                                                                   unsigned long long* dt_slots, int images) {
   spec_assume<SPEC>(g);
   __shared__ double LQ[8 * M2_ICELLS];          // primitives of the input tile; from phase 2 on: the fluxes F (13 x 128)
   __shared__ double LA[M2_ICELLS], LB[M2_ICELLS];   // face field Bx, By of the input tile
@@ -163,8 +163,26 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, 
       const F2LdsRead fa = {LF};
       mhd_update2d_at<false>(g, rc, fa, u, u[ID], dt, dtdx, dtdy, fm, gm, interior, true);
       if (dt_slots && interior) inv = mhd_invdt2d_new(g, fa, u, U[gm + 1 + (size_t)IA * N], U[gm + sj + (size_t)IB * N], dtdx, dtdy, fm);
+      if (!images) {
 #pragma unroll
-      for (int v = 0; v < 8; ++v) Unew[gm + (size_t)v * N] = u[v];
+        for (int v = 0; v < 8; ++v) Unew[gm + (size_t)v * N] = u[v];
+      } else if (interior) {
+        // all four faces periodic: the cell also writes its periodic images into the ghost cells (what the next step's ghost fill
+        // would copy there: the same doubles), so that fill is not launched.  Every ghost cell -- the CT layer included, whose
+        // own value the fill overwrites -- is the image of exactly one interior cell: one writer per location.
+        const int nx = g.nx, ny = g.ny;
+        const int xi[3] = {ci, ci + nx, ci - nx}, yj[3] = {cj, cj + ny, cj - ny};
+        const bool xok[3] = {true, ci < 2 * gw, ci >= nx}, yok[3] = {true, cj < 2 * gw, cj >= ny};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            if (xok[a] && yok[b]) {
+              double* o = Unew + (size_t)xi[a] + (size_t)yj[b] * sj;
+#pragma unroll
+              for (int v = 0; v < 8; ++v) o[(size_t)v * N] = u[v];
+            }
+      }
     }
     if (dt_slots) rgpu::rg_slot_max_wave(dt_slots + (((unsigned)blockIdx.x * 2u + (unsigned)(t >> 6)) & (rgpu::RG_DT_SLOTS - 1)), inv);
   }
@@ -177,16 +195,18 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, 
 inline bool mhd2d_step_covers(const DevParams& g) { return tiled_enabled() && !g.three_d && g.mhd && g.grav_on != 2; }
 
 template <int SPEC_PLAIN>
+// images != 0 (caller: all four faces periodic, nx, ny >= ghost width, nothing modifies the new state after this kernel): the
+// interior cells also write their periodic images, i.e. the output's ghost cells are valid on return
 inline int mhd2d_step(rg_stream_t s, const DevParams& g, const RotCoef& rc, bool spec_plain, const double* U, double* Unew, double dt,
-                      unsigned long long* dt_slots) {
+                      unsigned long long* dt_slots, int images) {
   if (!mhd2d_step_covers(g)) return 1;
   const int nbx = (g.isize - 2 * g.gw + 1 + M2_OX - 1) / M2_OX;   // cells gw .. isize-gw (the CT layer included)
   const int nby = (g.jsize - 2 * g.gw + 1 + M2_OY - 1) / M2_OY;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   if (spec_plain)
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images);
   else
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -189,6 +189,81 @@ void GodunovRun::outputVtk(int nStep) {
   out << tail;
 }
 
+// z-slab runs: HydroRunBaseMpi::outputVtk, hand-written branch (HydroRunBaseMpi.cpp:4167-4790) for the 1 x 1 x N topology of the
+// slab driver -- every rank writes <prefix>_time<step>_mpi<rank>.vti with its own planes (ranks > 0: plus the plane below, the
+// one-cell overlap the parallel image-data format wants), rank 0 the index <prefix>_time<step>.pvti.  Appended raw doubles or,
+// [output] outputVtkAscii, text with the stream's default precision (the MPI writer sets none).
+void GodunovRun::outputVtkSlab(int nStep) {
+  static const char* names[8] = {"density", "energy", "mx", "my", "mz", "bx", "by", "bz"};
+  const int gw = p_.ghostWidth, nx = p_.nx, ny = p_.ny, nz = p_.nz, rank = p_.slab_rank, count = p_.slab_count;
+  const size_t isize = nx + 2 * gw, jsize = ny + 2 * gw, ksize = nz + 2 * gw;
+  const size_t ncell = isize * jsize * ksize;
+  std::ostringstream ts, rk;
+  ts << std::setw(7) << std::setfill('0') << nStep;
+  rk << std::setw(5) << std::setfill('0') << rank;
+  const std::string stem = rs_.outputPrefix + "_time" + ts.str();
+  std::string local_error;
+  try {
+    if (rank == 0) {
+      const std::string hn = rs_.outputDir + "/" + stem + ".pvti";
+      std::ofstream h(hn.c_str());
+      if (!h) throw std::runtime_error("cannot write " + hn);
+      h << "<?xml version=\"1.0\"?>\n<VTKFile type=\"PImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
+      h << "  <PImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << count * nz - 1
+        << "\" GhostLevel=\"0\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n    <PPointData Scalars=\"Scalars_\">\n";
+      for (int v = 0; v < p_.nbVar; ++v) h << "      <PDataArray type=\"Float64\" Name=\"" << names[v] << "\"/>\n";
+      h << "    </PPointData>\n";
+      for (int r = 0; r < count; ++r) {
+        std::ostringstream pr;
+        pr << std::setw(5) << std::setfill('0') << r;
+        h << " <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " ";
+        if (r == 0) h << 0 << " " << nz - 1 << " ";
+        else h << r * nz - 1 << " " << r * nz + nz - 1 << " ";
+        h << "\" Source=\"" << stem << "_mpi" << pr.str() << ".vti\"/>\n";
+      }
+      h << "</PImageData>\n</VTKFile>\n";
+    }
+    const std::string fn = rs_.outputDir + "/" + stem + "_mpi" + rk.str() + ".vti";
+    std::ofstream out(fn.c_str(), std::ios::binary);
+    if (!out) throw std::runtime_error("cannot write " + fn);
+    const int zlo = (rank == 0) ? 0 : rank * nz - 1, zhi = (rank == 0) ? nz - 1 : rank * nz + nz - 1;
+    const int k0 = (rank == 0) ? gw : gw - 1, k1 = (int)ksize - gw;   // array planes [k0, k1)
+    if (rs_.outputVtkAscii) out << "<?xml version=\"1.0\"?>\n";
+    out << "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
+    out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " " << zlo << " " << zhi << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
+    out << "  <Piece Extent=\"0 " << nx - 1 << " 0 " << ny - 1 << " " << zlo << " " << zhi << "\">\n    <PointData>\n";
+    if (rs_.outputVtkAscii) {
+      for (int v = 0; v < p_.nbVar; ++v) {
+        out << "      <DataArray type=\"Float64\" Name=\"" << names[v] << "\" format=\"ascii\">\n";
+        for (int k = k0; k < k1; ++k)
+          for (int j = gw; j < (int)jsize - gw; ++j) {
+            const double* src = &h_U_[gw + isize * (j + jsize * (size_t)k) + ncell * v];
+            for (int i = 0; i < nx; ++i) out << src[i] << " ";
+            out << "\n";
+          }
+        out << "      </DataArray>\n";
+      }
+      out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n</VTKFile>\n";
+    } else {
+      const size_t tuples = (size_t)nx * ny * (size_t)(k1 - k0);
+      const uint32_t nbytes = static_cast<uint32_t>(tuples * sizeof(double));
+      for (int v = 0; v < p_.nbVar; ++v)
+        out << "     <DataArray type=\"Float64\" Name=\"" << names[v] << "\" format=\"appended\" offset=\""
+            << (size_t)v * tuples * sizeof(double) + (size_t)v * sizeof(uint32_t) << "\" />\n";
+      out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n  <AppendedData encoding=\"raw\">\n_";
+      for (int v = 0; v < p_.nbVar; ++v) {
+        out.write(reinterpret_cast<const char*>(&nbytes), sizeof(nbytes));
+        for (int k = k0; k < k1; ++k)
+          for (int j = gw; j < (int)jsize - gw; ++j)
+            out.write(reinterpret_cast<const char*>(&h_U_[gw + isize * (j + jsize * (size_t)k) + ncell * v]), sizeof(double) * nx);
+      }
+      out << "  </AppendedData>\n</VTKFile>\n";
+    }
+    if (!out) throw std::runtime_error("writing " + fn + " failed");
+  } catch (const std::exception& e) { local_error = e.what(); }
+  agree_or_throw(local_error, "outputVtk");
+}
+
 // Xsmurf: one ASCII header line + the interior of ONE variable (the density: the reference's default argument) as raw doubles,
 // written to the current directory (no outputDir in the name, HydroRunBase.cpp:2535)
 void GodunovRun::outputXsm(int nStep) {
@@ -496,10 +571,32 @@ void GodunovRun::history(int nStep, double dt) {
   if (!p_.mhdEnabled) return;
   const std::string problem = cfg_.get_string("hydro", "problem", "unknown");
   const bool mri = problem == "MRI" || problem == "Mri" || problem == "mri";
-  const bool dflt = problem == "Orszag-Tang" || problem == "OrszagTang";
+  bool dflt = problem == "Orszag-Tang" || problem == "OrszagTang";
+  if (slab()) {
+    // z-slab runs follow the history set-up of the MPI classes (HydroRunBaseMpi.cpp:10667-10730): MRI -> history_mhd_mri,
+    // turbulence -> history_mhd_turbulence (16 columns, no DFT amplitudes), every other MHD problem -> history_mhd_default
+    const bool turb = (problem == "turbulence" || problem == "turbulence-Ornstein-Uhlenbeck") && p_.nz_global != 1;
+    if (turb && hooks_.history_turbulence) {
+      double h[14];
+      hook_check(hooks_.history_turbulence(hooks_.self, nStep % 2, h), "history");   // collective; rank 0's values are the row
+      if (p_.slab_rank != 0) return;
+      const std::string fileName = cfg_.get_string("output", "outputDir", "./") + "/" + cfg_.get_string("output", "outputPrefix", "output") +
+                                   "_" + cfg_.get_string("history", "filename", "history.txt");
+      std::ofstream histo(fileName.c_str(), std::ios::out | std::ios::app | std::ios::ate);
+      if (totalTime_ <= 0) {
+        histo << "# history" << std::endl;
+        histo << "# totalTime dt mass divB eKin eMag helicity mean_B mean_Bx mean_By mean_Bz mean_rhovx mean_rhovy mean_rhovz Ma_s Ma_alfven\n";
+      }
+      histo << totalTime_ << "\t" << dt;
+      for (int q = 0; q < 14; ++q) histo << "\t" << h[q];
+      histo << "\n";
+      return;
+    }
+    if (!mri) dflt = true;
+  }
   const bool iwave = problem == "InertialWave" || problem == "inertialwave" || problem == "Inertial-Wave" ||
                      problem == "inertial-wave" || problem == "Inertialwave";
-  if (iwave) {
+  if (iwave && !slab()) {
     double u[8];
     const int iPos = p_.ghostWidth + p_.nx / 2, kPos = p_.ghostWidth;
     if (p_.nz_global == 1) check(rgpu_read_cell(ctx_, nStep % 2, iPos, kPos, 0, u), "history");
@@ -520,7 +617,7 @@ void GodunovRun::history(int nStep, double dt) {
     histo << "\n";
     return;
   }
-  if (problem == "turbulence" || problem == "turbulence-Ornstein-Uhlenbeck") {   // history_turbulence (MHDRunBase.cpp:3626-3810)
+  if (!slab() && (problem == "turbulence" || problem == "turbulence-Ornstein-Uhlenbeck")) {   // history_turbulence (MHDRunBase.cpp:3626-3810)
     if (p_.nz_global == 1) return;
     double h[18];
     check(rgpu_history_turbulence(ctx_, nStep % 2, h), "history");
@@ -582,11 +679,7 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
   const double dtHist = cfg_.get_float("history", "dtHist", static_cast<float>(10 * dt));
   double tHist = totalTime_;   // MHDRunGodunov.cpp:3916
   // z-slab runs: the MRI / Orszag-Tang history goes through the slab driver's global sums; the other problems' do not
-  bool slab_history_ok = false;
-  if (slab() && hooks_.history_mri) {
-    const std::string problem = cfg_.get_string("hydro", "problem", "unknown");
-    slab_history_ok = problem == "MRI" || problem == "Mri" || problem == "mri" || problem == "Orszag-Tang" || problem == "OrszagTang";
-  }
+  const bool slab_history_ok = slab() && hooks_.history_mri;   // (every MHD problem has a history in the MPI classes)
   const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   while (totalTime_ < rs_.tEnd && nStep < rs_.nStepmax) {
     if (rs_.nLog > 0 && (nStep % rs_.nLog) == 0 && p_.slab_rank == 0)
@@ -598,7 +691,7 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
       if (raw && rs_.outputXsm) outputXsm(nStep);
       if (raw && rs_.outputNrrd) outputNrrd(nStep);
       if (rs_.outputVtk && !slab()) outputVtk(nStep);
-      if (rs_.outputVtk && slab()) note_once(&noted_vtk_, "z-slab run: outputs go to HDF5 ([output] outputHdf5=yes), no .vti is written");
+      if (rs_.outputVtk && slab()) outputVtkSlab(nStep);
       if (rs_.outputRestart) outputHdf5(nStep);
       if ((rs_.outputVtk || rs_.outputRestart) && p_.slab_rank == 0) save_forcing_process(nStep);
       io_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
@@ -620,6 +713,7 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
     if (raw && rs_.outputXsm) outputXsm(nStep);
     if (raw && rs_.outputNrrd) outputNrrd(nStep);
     if (rs_.outputVtk && !slab()) outputVtk(nStep);
+    if (rs_.outputVtk && slab()) outputVtkSlab(nStep);
     if (rs_.outputRestart) outputHdf5(nStep);
     if ((rs_.outputVtk || rs_.outputRestart) && p_.slab_rank == 0) save_forcing_process(nStep);
     // the XDMF index of the .h5 files of this run, in the current directory (MHDRunGodunov.cpp:4004)

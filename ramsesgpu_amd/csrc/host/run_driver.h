@@ -35,6 +35,7 @@ class GodunovRun {
   // attach (may be 0): called once the context holds its initial state, before the first ghost fill (rgpuh_run_hooked)
   int start(double* mcell_per_s, rgpuh_attach_fn attach = 0, void* user = 0);
   void outputVtk(int nStep);
+  void outputVtkSlab(int nStep);   // z-slab runs: per-rank .vti + the .pvti index (HydroRunBaseMpi::outputVtk)
   // the reference's two raw single-variable formats: Xsmurf (density, doubles, current directory; HydroRunBase.cpp:2520-2562)
   // and NRRD (every variable as 32-bit floats, output directory; :4266-4335)
   void outputXsm(int nStep);

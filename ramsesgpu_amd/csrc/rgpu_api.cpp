@@ -56,6 +56,8 @@ struct rgpu_ctx {
   unsigned xcd_sub;     // sub-band size (cells) of the XCD-aware workgroup order of THIS context, 0 = linear
   int fused_dt_parity;  // parity of the state whose CFL maximum the last sweep left in d_red (-1: none)
   int fused_dt_slots;   // how many slots of d_red hold it (1: hydro sweep; RG_DT_SLOTS: MHD update kernel)
+  int ghost_ok_parity;  // parity of the state whose ghost cells the step kernel itself left valid (2D MHD, periodic box: images written
+                        // by the fused kernel), -1: none -- the plain path then skips the ghost fill of that state at the next step's entry
   int scan_acc_parity;  // parity of the state whose CFL maximum is being accumulated piece by piece (RGPU_CORE_SCAN), -1: none
   std::string err;
 };
@@ -214,6 +216,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->fused_dt_parity = -1;
   c->fused_dt_slots = 1;
   c->scan_acc_parity = -1;
+  c->ghost_ok_parity = -1;
   if (vr) return fail(c, vr, why);
   if (rg_device_count() < 1) return fail(c, RGPU_ENODEVICE, "no HIP device: this library has no CPU fallback (backend " RG_BACKEND_NAME ")");
   c->device = rg_current_device();
@@ -375,6 +378,7 @@ int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt
 // ---- the step -------------------------------------------------------------------------------------------------
 int step_pre(rgpu_ctx* c, int nStep) {
   if (c->g.rot) return 0;
+  if (c->ghost_ok_parity == nStep % 2) return 0;   // the kernel that wrote this state filled its ghost cells too (periodic images)
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* in = c->U[nStep % 2];
   if (do_make_boundaries(c, in, RGPU_XDIR) || do_make_boundaries(c, in, RGPU_YDIR)) return -1;
@@ -566,10 +570,16 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
       if (rgpu_tiled::mhd2d_step_covers(g)) {
         if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
         Phase ph(c, RGPU_T_SWEEP);
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0);
+        // periodic box on the plain path, nothing modifying the new state after this kernel: it writes the periodic images too and
+        // the next step's ghost fill is skipped (step_pre)
+        static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
+        bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
+        for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0);
         if (rct < 0) return -1;
         if (rct == 0) {
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
+          if (images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
           return 0;
         }
       }
@@ -812,6 +822,7 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
     what = 0;
   }
   c->fused_dt_parity = -1;   // the output array is about to change (a whole-domain hydro sweep sets it again)
+  c->ghost_ok_parity = -1;
   // static gravity of this step: (0.5 * dt) * g, the reference's "HALF_F * dt * h_gravity"; of the 2D MHD steps only
   // implementation version 0 has it
   c->g.grav_on = (c->p.gravityEnabled && !(c->p.mhdEnabled && !c->g.three_d && (c->p.implementationVersion != 0 || c->g.rot))) ? 1 : 0;
@@ -1062,6 +1073,7 @@ int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
   RG_CHECK_CTX(c);
   c->fused_dt_parity = -1;
   c->scan_acc_parity = -1;
+  c->ghost_ok_parity = -1;
   if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "upload: null pointer / context without state");
   const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
   if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");
@@ -1177,6 +1189,7 @@ int rgpu_invalidate_dt(rgpu_ctx* c) {
   if (!c) return RGPU_EINVAL;
   c->fused_dt_parity = -1;
   c->scan_acc_parity = -1;
+  c->ghost_ok_parity = -1;
   return RGPU_OK;
 }
 
@@ -1299,12 +1312,12 @@ int rgpu_history_mri(rgpu_ctx* c, int parity, double* out) {
   return RGPU_OK;
 }
 
-int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out) {
+// the 18 raw sums of history_turbulence over the interior cells of THIS context (a slab: its own planes): 0 rho, 1 rho v^2,
+// 2 v^2, 3 B^2, 4 m.B / sqrt(rho), 5-7 B, 8-10 m, 11-16 the DFT sums of Bx (local plane index in the z term), 17 div B
+int rgpu_history_turbulence_sums(rgpu_ctx* c, int parity, double* s) {
   RG_CHECK_CTX(c);
-  if (!out || !c->U[0]) return fail(c, RGPU_EINVAL, "history_turbulence: null pointer / context without state");
+  if (!s || !c->U[0]) return fail(c, RGPU_EINVAL, "history_turbulence: null pointer / context without state");
   if (!c->p.mhdEnabled || !c->g.three_d) return fail(c, RGPU_EUNSUPPORTED, "history_turbulence is defined for 3D MHD runs (it does nothing in 2D)");
-  if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "history_turbulence: single-domain contexts only");
-  const rgpu_params& p = c->p;
   const int is = c->g.isize, gw = c->g.gw;
   // rows [NQ][nz][isize] and columns [NQ][isize] in the flux array, dead between steps (F has 15 components per cell)
   const size_t R = (size_t)is * c->g.nz;
@@ -1315,8 +1328,17 @@ int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out) {
   std::vector<double> h((size_t)HIST_TURB_NQ * is);
   if (rg_launch<kBlock>(c->stream, (unsigned)R, kr) || rg_launch<kBlock>(c->stream, (unsigned)(HIST_TURB_NQ * is), kc) ||
       rg_copy_d2h(h.data(), cols, sizeof(double) * h.size(), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "history_turbulence");
-  double s[HIST_TURB_NQ];
   for (int q = 0; q < HIST_TURB_NQ; ++q) { s[q] = 0.0; for (int i = gw; i < is - gw; ++i) s[q] += h[(size_t)q * is + i]; }
+  return RGPU_OK;
+}
+
+int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out) {
+  RG_CHECK_CTX(c);
+  if (!out) return fail(c, RGPU_EINVAL, "history_turbulence: null pointer");
+  if (c->p.slab_count > 1) return fail(c, RGPU_EINVAL, "history_turbulence: single-domain contexts only (slabs: rgpu_comm_history_turbulence)");
+  double s[HIST_TURB_NQ];
+  if (const int rc = rgpu_history_turbulence_sums(c, parity, s)) return rc;
+  const rgpu_params& p = c->p;
   const double dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin);
   const double pi = 2 * std::asin(1.0);
   const double mass = s[0] * dTau, eKin = s[1] * dTau, mean_v2 = s[2] * dTau, eMag = s[3] * dTau, helicity = s[4] * dTau;

@@ -62,6 +62,93 @@ def _allreduce(data, n, op):
         return 1
 
 
+def check_pvti(lib, ini, ov, slabs, single, world):
+    """per-rank .vti pieces + .pvti index of the slab run (HydroRunBaseMpi::outputVtk) against the single-domain .vti files: every
+    piece holds its own planes (ranks > 0 one plane more, below: the format's overlap), the index names them with those extents"""
+    import re
+    from vtiutil import read_vti
+    p = lib.params_from_ini(ini, ov)
+    nx, ny, nzg = p.nx, p.ny, p.nz
+    nzl = nzg // world
+    steps = sorted(f for f in os.listdir(single) if f.endswith(".vti"))
+    if len(steps) < 2:
+        return False, "single-domain run wrote %d .vti files" % len(steps)
+    for f in steps:
+        num = re.search(r"_(\d{7})\.vti$", f).group(1)
+        prefix = f[:-len("_%s.vti" % num)]
+        ref, _ = read_vti(os.path.join(single, f))
+        index = os.path.join(slabs, "%s_time%s.pvti" % (prefix, num))
+        if not os.path.exists(index):
+            return False, "no %s" % index
+        text = open(index).read()
+        if '<PImageData WholeExtent="0 %d 0 %d 0 %d" GhostLevel="0" Origin="0 0 0" Spacing="1 1 1">' % (nx - 1, ny - 1, nzg - 1) not in text:
+            return False, "pvti header: %s" % text[:300]
+        for r in range(world):
+            name = "%s_time%s_mpi%05d.vti" % (prefix, num, r)
+            zlo, zhi = (0, nzl - 1) if r == 0 else (r * nzl - 1, r * nzl + nzl - 1)
+            if ' <Piece Extent="0 %d 0 %d %d %d " Source="%s"/>' % (nx - 1, ny - 1, zlo, zhi, name) not in text:
+                return False, "pvti piece %d: %s" % (r, text)
+            got, ext = read_vti(os.path.join(slabs, name))
+            if ext != [0, nx - 1, 0, ny - 1, zlo, zhi] or sorted(got) != sorted(ref):
+                return False, "%s: extent %s, arrays %s" % (name, ext, sorted(got))
+            for k in ref:
+                if not np.array_equal(got[k], ref[k][zlo:zhi + 1]):
+                    return False, "%s: %s differs from the single-domain file in %d doubles" % (name, k, int((got[k] != ref[k][zlo:zhi + 1]).sum()))
+    return True, ""
+
+
+def check_turbulence_history(lib, ini, ov, slabs, single, world):
+    """history file of a z-slab turbulence run = the row of HydroRunBaseMpi::history_mhd_turbulence, its quirks included (sum of
+    the ranks' |mean B|; divB, helicity and mean_rhov of rank 0 alone), evaluated here with numpy on the single-domain .h5 states"""
+    import h5util
+    p = lib.params_from_ini(ini, ov)
+    nzl = p.nz // world
+    rows = [l.split() for l in open([os.path.join(slabs, f) for f in os.listdir(slabs) if f.endswith("history.txt")][0]) if not l.startswith("#")]
+    head = [l for l in open([os.path.join(slabs, f) for f in os.listdir(slabs) if f.endswith("history.txt")][0]) if l.startswith("# totalTime")]
+    if not head or len(head[0].split()) != 17:
+        return False, "history header %r" % head
+    files = sorted(f for f in os.listdir(single) if f.endswith(".h5"))
+    if len(rows) < 2 or len(files) < len(rows):
+        return False, "%d history rows, %d .h5 files" % (len(rows), len(files))
+    dTau = p.dx * p.dy * p.dz / (p.xMax - p.xMin) / (p.yMax - p.yMin) / (p.zMax - p.zMin)
+    for n, row in enumerate(rows):
+        d, a = h5util.read(os.path.join(single, files[n]))
+        if abs(float(row[0]) - a["total time"]) > 1e-5 * max(abs(a["total time"]), 1e-30) + 1e-30:
+            return False, "row %d is for t = %s, file %s for t = %r" % (n, row[0], files[n], a["total time"])
+        gw = p.ghostWidth
+        U = {k: d[k] for k in d}     # ghost-inclusive arrays [z, y, x] ([output] ghostIncluded=yes)
+        I = (slice(gw, -gw),) * 3
+        def slab(x, r):
+            return x[I][r * nzl:(r + 1) * nzl]
+        tot = dict(mass=0.0, v2=0.0, ek=0.0, em=0.0, bn=0.0, b=np.zeros(3))
+        loc = None
+        for r in range(world):
+            rho = slab(U["density"], r)
+            m = [slab(U["momentum_" + c], r) for c in "xyz"]
+            b = [slab(U["magnetic_field_" + c], r) for c in "xyz"]
+            mb = np.array([x.sum() for x in b]) * dTau
+            tot["mass"] += rho.sum() * dTau
+            tot["v2"] += sum(((x / rho) ** 2).sum() for x in m) * dTau
+            tot["ek"] += sum((x * x / rho).sum() for x in m) * dTau
+            tot["em"] += sum((x * x).sum() for x in b) * dTau
+            tot["bn"] += float(np.sqrt((mb ** 2).sum()))
+            tot["b"] += mb
+            if r == 0:
+                bx, by, bz = (U["magnetic_field_" + c] for c in "xyz")
+                k0, k1 = gw, gw + nzl
+                div = ((bx[k0:k1, gw:-gw, gw + 1:-gw + 1] - bx[k0:k1, gw:-gw, gw:-gw]) / p.dx + (by[k0:k1, gw + 1:-gw + 1, gw:-gw] - by[k0:k1, gw:-gw, gw:-gw]) / p.dy +
+                       (bz[k0 + 1:k1 + 1, gw:-gw, gw:-gw] - bz[k0:k1, gw:-gw, gw:-gw]) / p.dz).sum()
+                loc = dict(div=div, hel=sum((x * y / np.sqrt(rho)).sum() for x, y in zip(m, b)) * dTau, rv=[x.sum() * dTau for x in m])
+        exp = [tot["mass"], loc["div"], tot["ek"], tot["em"], loc["hel"], tot["bn"], tot["b"][0], tot["b"][1], tot["b"][2], loc["rv"][0], loc["rv"][1],
+               loc["rv"][2], np.sqrt(tot["v2"]) / p.cIso, np.sqrt(tot["v2"]) / (tot["bn"] / np.sqrt(4 * np.pi * tot["mass"]))]
+        got = [float(x) for x in row[2:]]
+        for q, (g, e) in enumerate(zip(got, exp)):
+            noise = 1e-9 if q == 1 else 1e-14 if q in (4, 9, 10, 11) else 0.0   # div B, helicity, mean momentum: round-off noise around 0
+            if abs(g - e) > 2e-5 * abs(e) + noise:    # 6 printed digits
+                return False, "history row %d column %d: %r, expected %r" % (n, q + 2, g, e)
+    return True, ""
+
+
 def frontend():
     """--frontend base overrides outdir resultfile: the z-slab FRONT END (rgpuh_run_slabs: run loop, HDF5 outputs of the whole box
     written slab after slab, restart) on the emulation libraries; rank 0 then runs the single-domain front end (rgpuh_run) with
@@ -107,13 +194,15 @@ def frontend():
         m = lib.lib.rgpuh_run(ini.encode(), (ov.replace(slabs, single) + ";output.outputDir=%s" % single).encode(), C.byref(mc), err, 512)
         ok, msg = m == n, "steps %d vs %d %s" % (n, m, err.value.decode())
         files = sorted(f for f in os.listdir(single) if f.endswith(".h5"))
-        ok = ok and len(files) >= 2 and files == sorted(f for f in os.listdir(slabs) if f.endswith(".h5"))
+        want_h5 = "output.outputHdf5=yes" in ov
+        ok = ok and (len(files) >= 2 or not want_h5) and files == sorted(f for f in os.listdir(slabs) if f.endswith(".h5"))
         for f in files if ok else []:
             da, aa = h5util.read(os.path.join(slabs, f)); db, ab = h5util.read(os.path.join(single, f))
             same = aa == ab and sorted(da) == sorted(db) and all(np.array_equal(da[k], db[k]) for k in db)
             if not same:
                 ok, msg = False, "%s differs: attrs %s / %s, %s" % (f, aa, ab, {k: int((da[k] != db[k]).sum()) for k in db if da[k].shape == db[k].shape})
-        for f in [f for f in os.listdir(single) if f.endswith("history.txt")] if ok else []:   # global sums: round-off agreement, 6 printed digits
+        turb = bool(os.environ.get("COMM_CHECK_TURB_HISTORY"))   # (the MPI classes' turbulence row has other columns: checked below)
+        for f in [f for f in os.listdir(single) if f.endswith("history.txt")] if ok and not turb else []:   # global sums: round-off agreement, 6 printed digits
             ra = [l.split() for l in open(os.path.join(slabs, f)) if not l.startswith("#")]
             rb = [l.split() for l in open(os.path.join(single, f)) if not l.startswith("#")]
             same = len(ra) == len(rb) and len(rb) >= 2 and all(
@@ -121,7 +210,12 @@ def frontend():
             if not same:
                 ok, msg = False, "history differs: %r / %r" % (ra, rb)
         xa = [f for f in os.listdir(slabs) if f.endswith(".xmf")]
-        ok = ok and len(xa) == 1 and open(os.path.join(slabs, xa[0])).read() == open(os.path.join(single, xa[0])).read()
+        if files:
+            ok = ok and len(xa) == 1 and open(os.path.join(slabs, xa[0])).read() == open(os.path.join(single, xa[0])).read()
+    if rank == 0 and ok and "output.outputVtk=yes" in ov:
+        ok, msg = check_pvti(lib, ini, ov, slabs, single, world)
+    if rank == 0 and ok and os.environ.get("COMM_CHECK_TURB_HISTORY"):
+        ok, msg = check_turbulence_history(lib, ini, ov, slabs, single, world)
     if rank == 0:
         with open(out, "w") as f:
             f.write("OK\n" if ok else "FAILED %s\n" % msg)

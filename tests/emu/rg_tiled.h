@@ -12,5 +12,5 @@ inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const
                        double, double, double, double, int, int, int = 0) { return 1; }
 template <int SPEC_PLAIN>
 inline int mhd2d_step(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const rgpu_dev::RotCoef&, bool, const double*, double*, double,
-                      unsigned long long*) { return 1; }
+                      unsigned long long*, int) { return 1; }
 }  // namespace rgpu_tiled

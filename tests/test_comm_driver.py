@@ -142,6 +142,24 @@ def test_slab_front_end_fails_on_every_rank_when_one_rank_cannot_write(broken_ra
     run_frontend(base, ov, world, tmp_path / "run", tmp_path, timeout=120, env_extra={"COMM_BREAK_HDF5_ON_RANK": str(broken_rank)})
 
 
+def test_slab_front_end_writes_pvti_and_pieces(comm_emu_lib, tmp_path):
+    """[output] outputVtk=yes in a z-slab run: per-rank .vti (own planes + the overlap plane) and the .pvti index of
+    HydroRunBaseMpi::outputVtk; the pieces hold the doubles of the single-domain .vti files"""
+    ov = "mesh.nx=6;mesh.ny=8;mesh.nz=18;MRI.amp=0.2;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=yes;output.outputHdf5=no"
+    run_frontend("mhd_mri_3d", ov, 3, tmp_path / "run", tmp_path)
+
+
+def test_slab_front_end_writes_the_mpi_turbulence_history(comm_emu_lib, tmp_path):
+    """history file of a z-slab run of the MHD turbulence problem: the 16-column row of the MPI classes (global sums through
+    rgpu_comm_history_turbulence), checked against a numpy statement of that row on the single-domain states"""
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    ov = ("mesh.nx=6;mesh.ny=6;mesh.nz=12;run.nstepmax=3;run.noutput=1;run.tend=1e9;output.outputVtk=no;output.outputHdf5=yes;"
+          "output.ghostIncluded=yes;history.enabled=yes;history.dtHist=1e-12")
+    run_frontend("turbulence_mhd_ou", ov, 2, tmp_path / "run", tmp_path, env_extra={"COMM_CHECK_TURB_HISTORY": "1"})
+
+
 def test_slab_front_end_restarts_from_the_file_of_the_whole_box(comm_emu_lib, tmp_path):
     """3 slabs resume at step 3 from the ghost-inclusive .h5 a 2-slab run wrote and end in the files of the uninterrupted
     single-domain run (the worker compares the restarted slabs with a restarted single-domain run; both are compared with the
