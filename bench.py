@@ -250,9 +250,15 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
         return None
     cycles = 4.0 * insts + 12.0 * trans
     cap = 1024 * 2.4e9 * launch_ms * 1e-3
+    # what a pure stream of independent v_fma_f64 / v_rcp_f64 reaches on this chip at the kernel's occupancy (2 waves per SIMD):
+    # 5.3 / 17.4 cycles per wave instruction at the nominal clock (scripts/ubench/valu_rate2.cpp, profiles/r03_valu_rate*.txt)
+    measured = 5.3 * (insts - trans) + 17.4 * trans
     return {"valu_wave_insts_per_launch": insts, "trans_f64_wave_insts_per_launch": trans, "issue_cycles": cycles,
             "capacity_cycles": cap, "frac": cycles / cap, "clock_ghz": 2.4, "simds": 1024,
-            "note": "fraction of the fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq) the kernel fills at its measured duration"}
+            "frac_of_measured_issue_rate": measured / cap,
+            "note": "frac: share of the nominal fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq, 2.4 GHz) the kernel fills at its "
+                    "measured duration; frac_of_measured_issue_rate: the same against the rate a pure FMA / rcp stream reaches at 2 waves per SIMD "
+                    "(5.3 / 17.4 cycles, profiles/r03_valu_rate2.txt) -- the practical ceiling of this kernel's occupancy"}
 
 
 class Control:
