@@ -18,7 +18,15 @@
  *
  * Step schedule (overlap, the default): update the planes the neighbours read -> finish their x / y ghosts -> start the
  * exchange of the output state -> update the inner planes while it is in flight -> wait (device side) -> physical z faces.
- * Results are bit-identical to the single-domain run (tests/test_comm_driver.py, world sizes 1, 2, 3).
+ * State and dt sequence are bit-identical to the single-domain run for every configuration whose step has no global sum
+ * (tests/test_comm_driver.py, world sizes 1, 2, 3: hydro, plain and rotating MHD, shearing box, stratified box, dissipative
+ * stage, Ornstein-Uhlenbeck forcing).  NOT bit-identical, by construction: the static random forcing of the "turbulence"
+ * problem -- its normalisation is a sum over the whole box, formed here as an ncclSum of per-slab partial sums, i.e. in
+ * another association order than the single-domain column sums, so `norm` and with it the state agree to round-off (and may
+ * vary with the number of ranks; the tests hold relative L2 < 1e-12) -- and every history column, which is printed to six
+ * digits anyway.  Ghost cells of the plain path: the overlapped schedule has refilled the x / y ghosts of the new state when a
+ * step returns, the single-domain step leaves them for the next step's fill -- ghost-inclusive HDF5 files agree on the
+ * interior and on the ghost cells the reference itself defines (rotating path: all of them).
  *
  * Bootstrap: rank 0 calls rgpu_comm_unique_id and hands the 128 bytes to the other ranks by any out-of-band channel
  * (a file, an environment variable, torch.distributed's store: the library does not care).
@@ -99,8 +107,11 @@ const char* rgpu_comm_transport_name(void);
  * `device` (-1: the current one).  id as above.  Returns the steps done or a negative error; *mcell_per_s = whole-box
  * cell updates per second.  This is the single-GPU run loop (rgpuh_run_hooked, rgpu.h) stepping through this driver: each rank
  * builds -- or, [run] restart, reads from the .h5 of the whole box -- its own slab; [output] outputHdf5 writes ONE file per
- * output step for the whole box (the ranks take turns), identical to the single-domain file, plus the .xmf index; the MRI /
- * Orszag-Tang history file is written by rank 0 from all-reduced sums.  (.vti, Xsmurf and NRRD outputs: single-domain runs.) */
+ * output step for the whole box (the ranks take turns and agree on the outcome of every turn: a write error on one rank ends
+ * the run on all of them), equal to the single-domain file on the interior (see the top of this header), plus the .xmf index;
+ * [output] outputVtk writes one .vti per rank and the .pvti index (HydroRunBaseMpi::outputVtk, HydroRunBaseMpi.cpp:4167-4790);
+ * the history file is written by rank 0 from all-reduced sums in the formats of the MPI classes (history_mhd_mri,
+ * history_mhd_turbulence, history_mhd_default; HydroRunBaseMpi.cpp:10667-11530).  (Xsmurf and NRRD: single-domain runs.) */
 int rgpuh_run_slabs(const char* ini_path, const char* overrides, int rank, int nranks, int device,
                     const char id[RGPU_COMM_ID_BYTES], double* mcell_per_s, char* err, int err_len);
 

@@ -39,6 +39,9 @@ constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E
 constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
 constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
+#ifndef RG_SWEEP_LB   // experiment (ISA inspection only): 768 = the register budget of three waves per SIMD (168 VGPRs)
+#define RG_SWEEP_LB MH_THREADS
+#endif
 // Experiment (RG_EXP_TILE_STRIDE): tiles placed every 15 x 7 cells although each still solves 16 x 8 problems -- the Riemann
 // work of a sweep whose tiles FINISH the cells they own (a fused flux + update kernel must own both faces of a cell in x and
 // y, i.e. (OX - 1) x (OY - 1) cells per tile).  Overlapping tiles write the same doubles twice; results are unchanged.
@@ -160,7 +163,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
 }
 
 template <int SPEC>
-__global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
+__global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   spec_assume<SPEC>(g);
