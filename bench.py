@@ -179,7 +179,7 @@ def cpu_baseline_replicas(w, steps=10):
                       % (copies, w["base"], size, steps, wall)}
 
 
-def cpu_baseline_all_cores(w, dims, budget_s=20.0):
+def cpu_baseline_all_cores(w, dims):
     """ONE box of the workload on all host cores -- the oracle's restatement threaded over z-slabs (orc_run_mt:
     every loop nest of the 3D MHD step cut into contiguous slabs of planes, one std::thread each; the flux loop stores its
     fluxes and each cell gathers them in the order the reference's scatter loop delivers them, so the result is deterministic
@@ -203,17 +203,20 @@ def cpu_baseline_all_cores(w, dims, budget_s=20.0):
     U0 = L.init_condition(ini, ov, p)
     O = Oracle(so)
     cells = n[0] * n[1] * n[2]
-    t0 = time.time()
-    O.run_mt(p, U0, 1, cores)                   # allocation + first touch of the work arrays + one step
-    t1 = time.time() - t0
-    steps = int(max(2, min(20, budget_s / max(t1, 1e-3))))
-    t0 = time.time()
-    O.run_mt(p, U0, steps, cores)
-    t2 = time.time() - t0
-    per_step = (t2 - t1) / (steps - 1)          # the set-up (allocation, ghost fill) is in both runs
-    out = {"value": cells / per_step / 1e6, "unit": "Mcell-updates/s", "cores": cores, "kind": "port",
-           "sample": "ONE %s box at %dx%dx%d, %d steps on %d threads (z-slabs of planes; oracle/liboracle.so orc_run_mt, g++ -O2, not pinned; "
-                     "%.2f s per step after %.1f s of set-up + first step)" % (w["base"], n[0], n[1], n[2], steps, cores, per_step, t1)}
+    # thread counts: all hardware threads down to 16 in halves, one step each; then `more` steps with the fastest
+    scan = []
+    t = cores
+    while t >= 16 or not scan:
+        scan.append(t)
+        t //= 2
+    scan = [scan[0]] + scan      # (the first step of a run is cold: page tables, caches -- let it not decide)
+    more = 5
+    secs, used = O.run_mt_scan(p, U0, len(scan) + more, scan, cores)
+    per_step = float(sum(secs[len(scan):]) / max(len(secs) - len(scan), 1))
+    out = {"value": cells / per_step / 1e6, "unit": "Mcell-updates/s", "cores": used, "kind": "port",
+           "sample": "ONE %s box at %dx%dx%d on %d threads of %d (z-slabs of planes; oracle/liboracle.so orc_run_mt_scan, g++ -O2, not pinned): %.2f s per step "
+                     "over %d steps; thread-count scan, one step each: %s" % (w["base"], n[0], n[1], n[2], used, cores, per_step, more,
+                                                                            ", ".join("%d -> %.2f s" % (a, b) for a, b in zip(scan, secs)))}
     ub = cpu_baseline_replicas(w)
     if ub:
         out["upper_bound_replicas"] = ub

@@ -1,5 +1,6 @@
 // orc_api.cpp -- ORACLE (test infrastructure).  C entry points of the CPU restatement, loaded with ctypes by
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The product never links this.
+#include <chrono>
 #include <cstdio>
 
 #include <vector>
@@ -245,7 +246,11 @@ int orc_run(const rgpu_params* p, double* U, int nStepmax, double tEnd, int* nst
 // orc_run with every loop nest of the 3D MHD step cut into z-slabs over `nthreads` threads (mhd_step_3d_mt): the all-cores
 // CPU baseline of bench.py.  Same results as orc_run, bit for bit.  Scope: 3D MHD without gravity, dissipative stage, forcing,
 // slope_type 3 (what the bench workloads use); anything else returns RGPU_EUNSUPPORTED.
-int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int nthreads, int* nsteps_done, double* t_final, double* dts) {
+// scan / nscan (may be 0): thread counts to try, one step each, at the start of the run -- the rest of the steps use the fastest
+// (the step streams ~1.3 kB of intermediates per cell through 144 arrays: on a two-socket host the best count is well below
+// the number of hardware threads).  step_seconds (may be 0): wall time of every step; *threads_used: the count the run settled on.
+int orc_run_mt_scan(const rgpu_params* p, double* U, int nStepmax, double tEnd, int nthreads, const int* scan, int nscan, int* nsteps_done,
+                    double* t_final, double* dts, double* step_seconds, int* threads_used) {
   const int rc = check_scope(p);
   if (rc) return rc;
   Ctx c(*p);
@@ -256,14 +261,21 @@ int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int n
   std::vector<double> U2(n);
   make_all_boundaries(c, U, 0.0, 0.0);
   std::memcpy(U2.data(), U, sizeof(double) * n);
-  MtWork work(c, nthreads);
-  double t = 0.0;
-  int nStep = 0;
+  int most = nthreads;
+  for (int i = 0; i < nscan; ++i) most = scan[i] > most ? scan[i] : most;
+  MtWork work(c, most);
+  double t = 0.0, best = 1e300;
+  int nStep = 0, use = nthreads;
   while (t < tEnd && nStep < nStepmax) {
     double* cur = (nStep % 2 == 0) ? U : U2.data();
     double* nxt = (nStep % 2 == 0) ? U2.data() : U;
-    const double dt = p->cfl / compute_inv_dt_mhd3d_mt(c, cur, nthreads);
-    mhd_step_3d_mt(c, work, cur, nxt, dt, t, nthreads);
+    const int nt = nStep < nscan ? scan[nStep] : use;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    const double dt = p->cfl / compute_inv_dt_mhd3d_mt(c, cur, nt);
+    mhd_step_3d_mt(c, work, cur, nxt, dt, t, nt);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (step_seconds) step_seconds[nStep] = secs;
+    if (nStep < nscan && secs < best) { best = secs; use = nt; }
     if (dts) dts[nStep] = dt;
     nStep++;
     t += dt;
@@ -271,7 +283,11 @@ int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int n
   if (nStep % 2 == 1) std::memcpy(U, U2.data(), sizeof(double) * n);
   if (nsteps_done) *nsteps_done = nStep;
   if (t_final) *t_final = t;
+  if (threads_used) *threads_used = use;
   return 0;
+}
+int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int nthreads, int* nsteps_done, double* t_final, double* dts) {
+  return orc_run_mt_scan(p, U, nStepmax, tEnd, nthreads, 0, 0, nsteps_done, t_final, dts, 0, 0);
 }
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 //   convertToPrimitives (3D)          MHDRunGodunov.cpp:519-560
 #include "orc_pointwise.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 #include <thread>
@@ -482,6 +484,14 @@ MtWork::MtWork(const Ctx& c, int nthreads) : buf(0), doubles(0) {
 MtWork::~MtWork() { std::free(buf); }
 
 void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, double dt, double totalTime, int nthreads) {
+  static const bool timing = std::getenv("ORC_MT_TIMING") != 0;
+  std::chrono::steady_clock::time_point tprev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  orc_mt %-10s %.3f s\n", what, std::chrono::duration<double>(now - tprev).count());
+    tprev = now;
+  };
   const rgpu_params& p = c.p;
   const bool rot = p.Omega0 > 0;
   const bool shearbox = p.shearingBoxEnabled != 0;
@@ -517,6 +527,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
     for (int e = 0; e < 4; ++e) for (int d = 0; d < 3; ++d) take(qE[e][d], 8);
   }
 
+  lap("copy");
   slabs(0, ksize - 1, nthreads, [&](int ka, int kb) {   // primitive variables
     for (int k = ka; k < kb; k++)
       for (int j = 0; j < jsize - 1; j++)
@@ -528,6 +539,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
           for (int v = 0; v < 8; ++v) Q(i, j, k, v) = q[v];
         }
   });
+  lap("prim");
   const double st_face = fmin(p.slope_type, 2.0);
   slabs(1, ksize - 1, nthreads, [&](int ka, int kb) {   // edge electric field + transverse slopes of the face field
     for (int k = ka; k < kb; k++)
@@ -563,6 +575,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
           dC(i, j, k, IZ) = 0.0;
         }
   });
+  lap("elec");
   slabs(gw - 2, ksize - gw + 1, nthreads, [&](int ka, int kb) {   // trace
     for (int k = ka; k < kb; k++)
       for (int j = gw - 2; j < jsize - gw + 1; j++)
@@ -595,6 +608,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
         }
   });
 
+  lap("trace");
   std::vector<double> sf_min((size_t)jsize * ksize * 2, 0.0), sf_max((size_t)jsize * ksize * 2, 0.0);
   std::vector<double> sf_min_remap((size_t)jsize * ksize, 0.0), sf_max_remap((size_t)jsize * ksize, 0.0);
   auto SF = [&](std::vector<double>& b, int j, int k, int comp) -> double& { return b[(size_t)j + (size_t)jsize * (k + (size_t)ksize * comp)]; };
@@ -661,6 +675,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
           if (!rot || in_i) emf(i, j, k, I_EMFX) = emfX;
         }
   });
+  lap("riemann");
   slabs(gw, ksize - gw, nthreads, [&](int ka, int kb) {   // gather update of the interior cells, contributions in scatter order
     for (int k = ka; k < kb; k++)
       for (int j = gw; j < jsize - gw; j++)
@@ -705,6 +720,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
         }
   });
 
+  lap("update");
   if (rot && shearbox) {   // O(N^2): sequential, as in mhd_step_3d
     double deltay, epsi, eps;
     int jplus, jremap, jremapp1;
@@ -747,6 +763,7 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
         Unew(nx + gw - 1, j, k, ID) = fmax(Unew(nx + gw - 1, j, k, ID), p.smallr);
       }
   }
+  lap("shear");
   slabs(gw, ksize - gw + 1, nthreads, [&](int ka, int kb) {   // constrained transport
     for (int k = ka; k < kb; k++)
       for (int j = gw; j < jsize - gw + 1; j++)
@@ -761,7 +778,9 @@ void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, dou
           Unew(i, j, k, IC) -= (emf(i, j + 1, k, I_EMFX) - emf(i, j, k, I_EMFX)) * dtdy;
         }
   });
+  lap("ct");
   if (rot) make_all_boundaries(c, Unew_d, totalTime, dt);
+  lap("ghosts");
 }
 
 // compute_dt_mhd (3D) with the scan cut into z-slabs: max is order independent, hence the sequential value

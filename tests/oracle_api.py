@@ -91,6 +91,21 @@ class Oracle:
         assert rc == 0, rc
         return U, dts[:nd.value], tf.value
 
+    def run_mt_scan(self, p, U0, nsteps, scan, nthreads=1):
+        """orc_run_mt_scan: the first len(scan) steps try the thread counts of `scan`, the rest use the fastest.
+        Returns (per-step seconds, thread count the run settled on)"""
+        U = np.array(U0, dtype=np.float64, order="C", copy=True)
+        nd, tf, used = C.c_int(), C.c_double(), C.c_int()
+        secs = np.zeros(max(nsteps, 1))
+        arr = (C.c_int * max(len(scan), 1))(*scan)
+        self.lib.orc_run_mt_scan.restype = C.c_int
+        self.lib.orc_run_mt_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        rc = self.lib.orc_run_mt_scan(C.byref(p), U.ctypes.data, nsteps, 1e300, nthreads, arr, len(scan), C.byref(nd), C.byref(tf), None,
+                                      secs.ctypes.data, C.byref(used))
+        assert rc == 0, rc
+        return secs[:nd.value], used.value
+
     def run(self, p, U0, nsteps, tEnd=1e300):
         """start(): returns (U_final incl. ghosts, dts, t_final)"""
         U = np.array(U0, dtype=np.float64, order="C", copy=True)
