@@ -442,3 +442,38 @@ def long_run_error_growth(lib, oracle, base, ov, nsteps, every):
     finally:
         sv.close()
     return out
+
+
+def check_public_ghost_fill_invalidates_fused_dt(lib, oracle, base, ov):
+    """ADVICE (round 2): the step's last kernel leaves the CFL maximum of the new state in a device slot and the next compute_dt
+    only reads it back.  A ghost fill called from OUTSIDE the step with a non-periodic MHD face overwrites the field the CT update
+    left on the first high ghost face, which compute_dt_mhd reads: the slot is then stale.  After rgpu_make_all_boundaries the
+    library must scan again -- the value must equal the oracle's compute_dt of the downloaded state -- and rgpu_invalidate_dt must
+    do the same for a host program that wrote into the arrays itself."""
+    p = lib.params_from_ini(ini(base), ov)
+    U0 = lib.init_condition(ini(base), ov, p)
+    sv = Solver(p, lib)
+    try:
+        sv.start(U0, 3)                               # three steps: the slot holds the scan of the state after step 3
+        par = sv.nStep % 2
+        sv.make_all_boundaries(par, sv.totalTime, 0.0)   # public ghost fill of the CURRENT state
+        got = sv.compute_inv_dt(par)
+        ref = oracle.compute_inv_dt(p, sv.getDataHost(par))
+        assert got == ref, (got, ref)
+        # rgpu_invalidate_dt (a host program that wrote into adopted arrays calls it): the next compute_dt scans again
+        sv.oneStepIntegration()
+        par = sv.nStep % 2
+        ref = oracle.compute_inv_dt(p, sv.getDataHost(par))
+        sv.enable_timers(True)
+        sv.reset_timers()
+        fused = sv.compute_inv_dt(par)                 # read back from the slot the update kernel filled: no scan kernel
+        t_fused = sv.timers().get("dt", 0.0)
+        assert lib.lib.rgpu_invalidate_dt(sv.ctx) == 0
+        rescanned = sv.compute_inv_dt(par)
+        t_scan = sv.timers().get("dt", 0.0)
+        sv.enable_timers(False)
+        assert fused == ref and rescanned == ref, (fused, rescanned, ref)
+        if "emulation" not in lib.backend:             # (the emulation backend has no phase timers)
+            assert t_fused == 0.0 and t_scan > 0.0, (t_fused, t_scan)
+    finally:
+        sv.close()

@@ -314,3 +314,9 @@ def test_run_driver_writes_turbulence_history_file(gpu_lib, tmp_path):
     assert np.allclose(rows[:, [18, 19]], H[:, [18, 19]], rtol=1e-3, atol=1e-15)  # coef_y, coef_z: Bx picks up structure along y, z
     assert np.abs(rows[:, 3]).max() <= 1e-12                                       # divB: round-off
     assert np.abs(rows[:, 17]).max() <= 1e-18                                      # coef_x: Bx stays uniform along x to round-off
+
+
+@pytest.mark.parametrize("base,ov", [("mhd_BrioWu", "mesh.nx=48;mesh.ny=32"),
+                                     ("mhd_BrioWu", "mesh.nx=24;mesh.ny=16;mesh.nz=16;BrioWu.direction=0;MHD.implementationVersion=4")])
+def test_public_ghost_fill_invalidates_fused_dt(base, ov, gpu_lib, oracle):
+    pc.check_public_ghost_fill_invalidates_fused_dt(gpu_lib, oracle, base, ov)

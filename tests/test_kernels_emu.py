@@ -63,3 +63,9 @@ def test_run_driver_inertial_wave_history_file(emu_lib, tmp_path):
 @pytest.mark.parametrize("base,ov,nsteps", pc.TURB_HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.TURB_HISTORY_CASES])
 def test_turbulence_history(base, ov, nsteps, emu_lib, oracle):
     pc.check_history_turbulence(emu_lib, oracle, base, ov, nsteps)
+
+
+@pytest.mark.parametrize("base,ov", [("mhd_BrioWu", "mesh.nx=24;mesh.ny=16"),                       # Neumann faces, 2D MHD
+                                     ("mhd_BrioWu", "mesh.nx=12;mesh.ny=10;mesh.nz=8;BrioWu.direction=0;MHD.implementationVersion=4")])
+def test_public_ghost_fill_invalidates_fused_dt(base, ov, emu_lib, oracle):
+    pc.check_public_ghost_fill_invalidates_fused_dt(emu_lib, oracle, base, ov)
