@@ -116,7 +116,12 @@ typedef struct rgpu_ctx rgpu_ctx;
 
 /* Allocates U, U2 and all scratch on the current HIP device.  Replaces the allocations of the HydroRunBase /
  * MHDRunGodunov constructors (HydroRunBase.cpp:92-300, MHDRunGodunov.cpp:128-418).  Fails with RGPU_ENODEVICE when
- * no GPU is present: there is NO CPU fallback. */
+ * no GPU is present: there is NO CPU fallback.
+ * Size limit: the kernels address a cell of one context with a 32-bit flat index (byte offsets and component strides are
+ * 64-bit), so (nx + 2 gw)(ny + 2 gw)(nz + 2 gw) must stay below 2^32 - 1 cells PER CONTEXT -- 1619^3 with gw = 3; at the 34
+ * doubles per cell of the 3D MHD step that is 1.17 TB, four times the 288 GB of one MI355X, so the memory is exhausted long
+ * before the index.  rgpu_create checks it and fails with RGPU_EUNSUPPORTED ("more than 2^32 cells per device"); larger boxes
+ * run as z-slabs (rgpu_comm.h), every slab its own context.  (The reference's 32-bit BYTE offsets overflow at 518^3 x 8.) */
 int rgpu_create(const rgpu_params* p, rgpu_ctx** out);
 
 /* Same, but U and U2 are device buffers owned by the caller (e.g. torch tensors) of rgpu_state_elems() doubles
