@@ -344,6 +344,8 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
         prim_store(kk + 3);              // -> the Q / B slot of plane kk
       }
     } else {
+      // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
+      //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
       if (tracing) elec_plane(kk + 2, rthread, 384);   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
