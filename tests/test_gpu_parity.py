@@ -320,3 +320,36 @@ def test_run_driver_writes_turbulence_history_file(gpu_lib, tmp_path):
                                      ("mhd_BrioWu", "mesh.nx=24;mesh.ny=16;mesh.nz=16;BrioWu.direction=0;MHD.implementationVersion=4")])
 def test_public_ghost_fill_invalidates_fused_dt(base, ov, gpu_lib, oracle):
     pc.check_public_ghost_fill_invalidates_fused_dt(gpu_lib, oracle, base, ov)
+
+
+def test_orszag_tang_large_box_properties(gpu_lib):
+    """the fused 2D MHD kernel at a size the oracle does not run in seconds (2048^2: 137 x 293 tiles, the periodic ghost images
+    written by the kernel itself): div B stays at round-off, mass / energy / momentum are conserved to round-off in the periodic
+    box, and the flat kernels (RGPU_TILED=0 is read per process, so: a second context through the plane API is not available
+    in 2D) -- instead the run is repeated with the ghost images off (RGPU_NO_GHOST_IMAGES is read once per process too), hence
+    only the properties here; bit-identity of the tiled path is pinned by the 512^2 gate and the fixtures."""
+    ov = "mesh.nx=2048;mesh.ny=2048"
+    p = gpu_lib.params_from_ini(ini("orszag-tang"), ov)
+    U0 = gpu_lib.init_condition(ini("orszag-tang"), ov, p)
+    sv = Solver(p, gpu_lib)
+    try:
+        sv.start(U0, 8)
+        A = sv.getDataHost()
+    finally:
+        sv.close()
+    gw = p.ghostWidth
+    I0, I1 = interior(U0, p), interior(A, p)
+    assert np.isfinite(A).all()
+    for v in (0, 1, 2, 3):     # density, energy, x and y momentum: conserved by the flux form in a periodic box
+        a, b = I1[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
+        scale = max(abs(float(b)), float(np.abs(I0[v]).sum(dtype=np.longdouble)))
+        assert abs(float(a - b)) < 1e-12 * scale, (v, float(a), float(b))
+    bx, by = A[5], A[6]        # 2D arrays [y, x] with ghosts
+    s = (slice(gw, -gw), slice(gw, -gw))
+    div = (bx[gw:-gw, gw + 1:-gw + 1] - bx[s]) / p.dx + (by[gw + 1:-gw + 1, gw:-gw] - by[s]) / p.dy
+    bscale = float(np.abs(bx[s]).max()) / min(p.dx, p.dy)
+    assert float(np.abs(div).max()) < 1e-11 * bscale
+    # the ghost cells the kernel wrote are the periodic images of the interior
+    nx, ny = p.nx, p.ny
+    assert np.array_equal(A[:, gw:-gw, :gw], A[:, gw:-gw, nx:nx + gw]) and np.array_equal(A[:, gw:-gw, nx + gw:], A[:, gw:-gw, gw:2 * gw])
+    assert np.array_equal(A[:, :gw, :], A[:, ny:ny + gw, :]) and np.array_equal(A[:, ny + gw:, :], A[:, gw:2 * gw, :])
