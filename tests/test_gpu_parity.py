@@ -344,7 +344,8 @@ def test_orszag_tang_large_box_properties(gpu_lib):
         a, b = I1[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
         scale = max(abs(float(b)), float(np.abs(I0[v]).sum(dtype=np.longdouble)))
         assert abs(float(a - b)) < 1e-12 * scale, (v, float(a), float(b))
-    bx, by = A[5], A[6]        # 2D arrays [y, x] with ghosts
+    A = A[:, 0]                # 2D: [variable, y, x] with ghosts
+    bx, by = A[5], A[6]
     s = (slice(gw, -gw), slice(gw, -gw))
     div = (bx[gw:-gw, gw + 1:-gw + 1] - bx[s]) / p.dx + (by[gw + 1:-gw + 1, gw:-gw] - by[s]) / p.dy
     bscale = float(np.abs(bx[s]).max()) / min(p.dx, p.dy)
