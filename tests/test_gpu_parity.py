@@ -350,7 +350,10 @@ def test_orszag_tang_large_box_properties(gpu_lib):
     div = (bx[gw:-gw, gw + 1:-gw + 1] - bx[s]) / p.dx + (by[gw + 1:-gw + 1, gw:-gw] - by[s]) / p.dy
     bscale = float(np.abs(bx[s]).max()) / min(p.dx, p.dy)
     assert float(np.abs(div).max()) < 1e-11 * bscale
-    # the ghost cells the kernel wrote are the periodic images of the interior
+    # the ghost cells the kernel wrote are the periodic images of the interior (RGPU_NO_GHOST_IMAGES / RGPU_TILED=0: the next
+    # step's ghost fill does it, so the output array's ghosts are one step old)
+    if os.environ.get("RGPU_NO_GHOST_IMAGES") or os.environ.get("RGPU_TILED") == "0":
+        return
     nx, ny = p.nx, p.ny
     assert np.array_equal(A[:, gw:-gw, :gw], A[:, gw:-gw, nx:nx + gw]) and np.array_equal(A[:, gw:-gw, nx + gw:], A[:, gw:-gw, gw:2 * gw])
     assert np.array_equal(A[:, :gw, :], A[:, ny:ny + gw, :]) and np.array_equal(A[:, ny + gw:, :], A[:, gw:2 * gw, :])
