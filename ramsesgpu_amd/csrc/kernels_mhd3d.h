@@ -7,7 +7,7 @@
 //                                                 (+ shear terms             MHDRunGodunov.cpp:2448-2525)
 //   mhd_trace3d_cell   U,Q,E        -> T   (38)   slopes + CTU trace         ..._cpu_v3.cpp:115-361, trace_mhd.h:1854-2248
 //   mhd_flux3d_cell    T            -> F   (15), emf (3)   3 HLLD + 3 2D-HLLD ..._cpu_v3.cpp:372-583
-//   mhd_update3d_cell  Uold,F,emf   -> Unew (8)   conservative + CT update   ..._cpu_v3.cpp:475-533,600-630
+//   mhd_update3d_column Uold,F,emf  -> Unew (8)   conservative + CT update   ..._cpu_v3.cpp:475-533,600-630
 //
 // T is the COMPACT traced state: instead of the reference's 18 face/edge state arrays (144 doubles per cell,
 // trace_mhd.h:2032-2246) we keep what they are all built from -- the time-advanced cell state, the three
@@ -554,22 +554,31 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
 // ------------------------------------------------------------------------------------------------------------
 struct RotCoef { double lambda, ratio, alpha1, alpha2; };  // MHDRunGodunov.cpp:2039-2053
 
+// What one cell's update reads, by value: the flat kernel loads it all from global memory, the z-marching one carries the
+// plane k+1 entries over to the next plane (where they are the plane k entries).
+struct UpdIn {
+  double u[8];                                      // Uold of the cell
+  double fx0[5], fy0[5], fz0[5];                    // fluxes through the cell's low faces
+  double fx1[5], fy1[5], fz1[5];                    // ... of cells i+1, j+1, k+1 (= through the high faces)
+  double eZ00, eZ10, eZ01, eZ11;                    // emf z at (i,j) (i+1,j) (i,j+1) (i+1,j+1), plane k
+  double eY00, eY10, eY01, eY11;                    // emf y at (i,k) (i+1,k) (i,k+1) (i+1,k+1), row j
+  double eX00, eX10, eX01, eX11;                    // emf x at (j,k) (j+1,k) (j,k+1) (j+1,k+1), column i
+  double uA1, uB1, uC1;                             // Uold: IA of cell i+1, IB of cell j+1, IC of cell k+1 (CFL scan only)
+};
+
 // dt_slots != 0: the CFL scan of the NEW state rides along (compute_dt_mhd of the next step, MHDRunBase.cpp:140-250): an
 // interior cell needs the new field on its three high faces, which belong to its +1 neighbours -- their CT update is
 // repeated here from the same emf values (same expressions as below, hence the same bits) -- then the value of
 // mhd_invdt_cell goes to one of RG_DT_SLOTS maxima.
 template <bool ROT, bool GF>
-RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
-                                double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
-                                const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
-                                unsigned idx, unsigned long long* dt_slots = 0) {
-  const IJK c = unflatten(g, idx);
+RG_DEVFN void mhd_update3d_apply(const DevParams& g, const RotCoef rc, const IJK c, unsigned idx, const UpdIn& in,
+                                 double* __restrict__ Unew, const double* __restrict__ remap, double dt, double dtdx, double dtdy,
+                                 double dtdz, unsigned long long* dt_slots) {
   const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
   const int gw = g.gw;
   double u[8];
 #pragma unroll
-  for (int v = 0; v < 8; ++v) u[v] = Uold[idx + v * N];
+  for (int v = 0; v < 8; ++v) u[v] = in.u[v];
   const bool in_i = c.i >= gw && c.i < g.isize - gw, in_j = c.j >= gw && c.j < g.jsize - gw, in_k = c.k >= gw && c.k < g.ksize - gw;
   const bool shear = ROT && g.shearbox;
   if (in_i && in_j && in_k) {
@@ -581,49 +590,46 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
       u[IV] = u[IV] * rc.ratio + dsy;
     }
     const double a1 = rc.alpha1, a2 = rc.alpha2;
-    double f[5];
     // contributions in the order the reference's k,j,i loop delivers them to this cell:
     // own iteration: +Fx, +Fy, +Fz ; then -Fx(i+1), -Fy(j+1), -Fz(k+1)
-#define RG_LOADF(base, off) _Pragma("unroll") for (int v = 0; v < 5; ++v) f[v] = F[(idx + (off)) + (size_t)((base) + v) * N]
-    RG_LOADF(F_X, 0);
+    const double* f = in.fx0;
     if (!(shear && c.i == gw)) u[ID] += f[ID] * dtdx;
     u[IP] += f[IP] * dtdx;
     if (ROT) { u[IU] += (a1 * f[IU] + a2 * f[IV]) * dtdx; u[IV] += (a1 * f[IV] - 0.25 * a2 * f[IU]) * dtdx; }
     else { u[IU] += f[IU] * dtdx; u[IV] += f[IV] * dtdx; }
     u[IW] += f[IW] * dtdx;
-    RG_LOADF(F_Y, 0);   // y-normal frame: f[IU] is the y momentum flux, f[IV] the x momentum flux
+    f = in.fy0;   // y-normal frame: f[IU] is the y momentum flux, f[IV] the x momentum flux
     u[ID] += f[ID] * dtdy;
     u[IP] += f[IP] * dtdy;
     if (ROT) { u[IU] += (a1 * f[IV] + a2 * f[IU]) * dtdy; u[IV] += (a1 * f[IU] - 0.25 * a2 * f[IV]) * dtdy; }
     else { u[IU] += f[IV] * dtdy; u[IV] += f[IU] * dtdy; }
     u[IW] += f[IW] * dtdy;
-    RG_LOADF(F_Z, 0);   // z-normal frame: f[IU] is the z momentum flux, f[IW] the x momentum flux
+    f = in.fz0;   // z-normal frame: f[IU] is the z momentum flux, f[IW] the x momentum flux
     u[ID] += f[ID] * dtdz;
     u[IP] += f[IP] * dtdz;
     if (ROT) { u[IU] += (a1 * f[IW] + a2 * f[IV]) * dtdz; u[IV] += (a1 * f[IV] - 0.25 * a2 * f[IW]) * dtdz; }
     else { u[IU] += f[IW] * dtdz; u[IV] += f[IV] * dtdz; }
     u[IW] += f[IU] * dtdz;
-    RG_LOADF(F_X, 1);
+    f = in.fx1;
     if (!(shear && (c.i + 1) == (g.nx + gw))) u[ID] -= f[ID] * dtdx;
     u[IP] -= f[IP] * dtdx;
     if (ROT) { u[IU] -= (a1 * f[IU] + a2 * f[IV]) * dtdx; u[IV] -= (a1 * f[IV] - 0.25 * a2 * f[IU]) * dtdx; }
     else { u[IU] -= f[IU] * dtdx; u[IV] -= f[IV] * dtdx; }
     u[IW] -= f[IW] * dtdx;
-    RG_LOADF(F_Y, sj);
+    f = in.fy1;
     u[ID] -= f[ID] * dtdy;
     u[IP] -= f[IP] * dtdy;
     if (ROT) { u[IU] -= (a1 * f[IV] + a2 * f[IU]) * dtdy; u[IV] -= (a1 * f[IU] - 0.25 * a2 * f[IV]) * dtdy; }
     else { u[IU] -= f[IV] * dtdy; u[IV] -= f[IU] * dtdy; }
     u[IW] -= f[IW] * dtdy;
-    RG_LOADF(F_Z, sk);
+    f = in.fz1;
     u[ID] -= f[ID] * dtdz;
     u[IP] -= f[IP] * dtdz;
     if (ROT) { u[IU] -= (a1 * f[IW] + a2 * f[IV]) * dtdz; u[IV] -= (a1 * f[IV] - 0.25 * a2 * f[IW]) * dtdz; }
     else { u[IU] -= f[IW] * dtdz; u[IV] -= f[IV] * dtdz; }
     u[IW] -= f[IU] * dtdz;
-#undef RG_LOADF
     if (GF || g.grav_on) {  // momentum source before the shear remap of the density (MHDRunGodunov.cpp:3190-3192)
-      const double rho_sum = Uold[idx + ID * N] + u[ID];
+      const double rho_sum = in.u[ID] + u[ID];
       double gx, gy, gz;
       half_dt_gravity<GF>(g, idx, gx, gy, gz);
       u[IU] += gx * rho_sum;
@@ -641,37 +647,98 @@ RG_DEVFN void mhd_update3d_cell(const DevParams& g, const RotCoef rc, const doub
   // constrained transport on [gw, size-gw] in every direction (faces of the first high ghost layer included)
   const bool ct_i = c.i >= gw && c.i <= g.isize - gw, ct_j = c.j >= gw && c.j <= g.jsize - gw, ct_k = c.k >= gw && c.k <= g.ksize - gw;
   if (ct_i && ct_j && ct_k) {
-    const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
     if (c.k < g.ksize - gw) {
-      u[IA] += (eZ[idx + sj] - eZ[idx]) * dtdy;
-      u[IB] -= (eZ[idx + 1] - eZ[idx]) * dtdx;
+      u[IA] += (in.eZ01 - in.eZ00) * dtdy;
+      u[IB] -= (in.eZ10 - in.eZ00) * dtdx;
     }
-    u[IA] -= (eY[idx + sk] - eY[idx]) * dtdz;
-    u[IB] += (eX[idx + sk] - eX[idx]) * dtdz;
-    u[IC] += (eY[idx + 1] - eY[idx]) * dtdx;
-    u[IC] -= (eX[idx + sj] - eX[idx]) * dtdy;
+    u[IA] -= (in.eY01 - in.eY00) * dtdz;
+    u[IB] += (in.eX01 - in.eX00) * dtdz;
+    u[IC] += (in.eY10 - in.eY00) * dtdx;
+    u[IC] -= (in.eX10 - in.eX00) * dtdy;
   }
 #pragma unroll
   for (int v = 0; v < 8; ++v) RG_STREAM_STORE(&Unew[idx + v * N], u[v]);
   if (dt_slots && in_i && in_j && in_k) {
-    const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
-    unsigned m = idx + 1;    // low x face of cell i+1
-    double bnx = Uold[m + IA * N];
-    bnx += (eZ[m + sj] - eZ[m]) * dtdy;          // (k < ksize - gw holds for an interior cell)
-    bnx -= (eY[m + sk] - eY[m]) * dtdz;
-    m = idx + sj;            // low y face of cell j+1
-    double bny = Uold[m + IB * N];
-    bny -= (eZ[m + 1] - eZ[m]) * dtdx;
-    bny += (eX[m + sk] - eX[m]) * dtdz;
-    m = idx + sk;            // low z face of cell k+1
-    double bnz = Uold[m + IC * N];
-    bnz += (eY[m + 1] - eY[m]) * dtdx;
-    bnz -= (eX[m + sj] - eX[m]) * dtdy;
+    double bnx = in.uA1;     // low x face of cell i+1
+    bnx += (in.eZ11 - in.eZ10) * dtdy;          // (k < ksize - gw holds for an interior cell)
+    bnx -= (in.eY11 - in.eY10) * dtdz;
+    double bny = in.uB1;     // low y face of cell j+1
+    bny -= (in.eZ11 - in.eZ01) * dtdx;
+    bny += (in.eX11 - in.eX10) * dtdz;
+    double bnz = in.uC1;     // low z face of cell k+1
+    bnz += (in.eY11 - in.eY01) * dtdx;
+    bnz -= (in.eX11 - in.eX01) * dtdy;
     const Prim8 q = mhd_prim(g, u, bnx, bny, bnz, 0.0);
     double sx, sy, sz;
     info_speeds(g, q, sx, sy, sz);
     if (g.Omega0 > 0) sy += 1.5 * g.Omega0 * g.deltaX / 2;  // shear velocity at the box edge (MHDRunBase.cpp:223-225)
     rgpu::rg_slot_max(dt_slots + ((idx >> 6) & (rgpu::RG_DT_SLOTS - 1)), sx / g.dx + sy / g.dy + sz / g.dz);
+  }
+}
+
+// One thread per column (i, j) and z segment: planes [k_lo + seg * seg_len, + seg_len) of [k_lo, k_hi), marching upwards.  The
+// entries of plane k+1 a cell reads -- Fz, emf x and y at two positions each, the z face field for the CFL scan: 10 of its 53
+// loads, and the ones no cache keeps when a one-thread-per-cell kernel walks plane after plane -- are loaded once and carried in
+// registers to the next plane, where they are the cell's own.  Short segments: on gfx950 a wave's loads of plane k+1 return
+// behind its stores of plane k (one in-order counter), so long marches expose the write latency -- 512^3, same box: one cell per
+// thread 8.07 ms, segments of 2 / 3 / 4 / 8 / 32 planes 7.49 / 7.42 / 7.50 / 7.65 / 9.0.  t = seg * (isize * jsize) + column.
+template <bool ROT, bool GF>
+RG_DEVFN void mhd_update3d_column(const DevParams& g, const RotCoef rc, const double* __restrict__ Uold,
+                                  double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
+                                  const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
+                                  unsigned t, int k_lo, int k_hi, int seg_len, unsigned long long* dt_slots = 0) {
+  const size_t N = g.ncell;
+  const unsigned sj = g.sj, sk = g.sk;
+  const int gw = g.gw;
+  const unsigned seg = t / sk, col = t - seg * sk;
+  IJK c = unflatten(g, col);
+  const int ka = k_lo + (int)seg * seg_len;
+  const int kb = (ka + seg_len < k_hi) ? ka + seg_len : k_hi;
+  unsigned idx = col + (unsigned)ka * sk;
+  const bool in_col = c.i >= gw && c.i < g.isize - gw && c.j >= gw && c.j < g.jsize - gw;
+  const bool ct_col = c.i >= gw && c.i <= g.isize - gw && c.j >= gw && c.j <= g.jsize - gw;
+  if (!ct_col) {   // ghost columns: the new array gets the old values (refilled by the next ghost fill)
+    for (int k = ka; k < kb; ++k, idx += sk) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) RG_STREAM_STORE(&Unew[idx + v * N], Uold[idx + v * N]);
+    }
+    return;
+  }
+  const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
+  // this plane's share of the carried entries
+  double fz[5], eX00, eX10, eY00, eY10, uC;
+#pragma unroll
+  for (int v = 0; v < 5; ++v) fz[v] = in_col ? F[idx + (size_t)(F_Z + v) * N] : 0.0;
+  eX00 = eX[idx]; eX10 = eX[idx + sj]; eY00 = eY[idx]; eY10 = eY[idx + 1];
+  uC = Uold[idx + IC * N];
+  for (int k = ka; k < kb; ++k, idx += sk) {
+    c.k = k;
+    UpdIn in;
+    const bool up = k + 1 < g.ksize;   // (the top plane is a ghost plane: nothing of plane k+1 is used there)
+    const unsigned nx_ = idx + sk;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) in.u[v] = (v == IC) ? uC : Uold[idx + v * N];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+      in.fx0[v] = in_col ? F[idx + (size_t)(F_X + v) * N] : 0.0;
+      in.fy0[v] = in_col ? F[idx + (size_t)(F_Y + v) * N] : 0.0;
+      in.fz0[v] = fz[v];
+      in.fx1[v] = in_col ? F[idx + 1 + (size_t)(F_X + v) * N] : 0.0;
+      in.fy1[v] = in_col ? F[idx + sj + (size_t)(F_Y + v) * N] : 0.0;
+      in.fz1[v] = (in_col && up) ? F[nx_ + (size_t)(F_Z + v) * N] : 0.0;
+    }
+    in.eZ00 = eZ[idx]; in.eZ10 = eZ[idx + 1]; in.eZ01 = eZ[idx + sj]; in.eZ11 = eZ[idx + sj + 1];
+    in.eY00 = eY00; in.eY10 = eY10;
+    in.eX00 = eX00; in.eX10 = eX10;
+    in.eY01 = up ? eY[nx_] : 0.0; in.eY11 = up ? eY[nx_ + 1] : 0.0;
+    in.eX01 = up ? eX[nx_] : 0.0; in.eX11 = up ? eX[nx_ + sj] : 0.0;
+    in.uA1 = Uold[idx + 1 + IA * N];
+    in.uB1 = Uold[idx + sj + IB * N];
+    in.uC1 = up ? Uold[nx_ + IC * N] : 0.0;
+    mhd_update3d_apply<ROT, GF>(g, rc, c, idx, in, Unew, remap, dt, dtdx, dtdy, dtdz, dt_slots);
+#pragma unroll
+    for (int v = 0; v < 5; ++v) fz[v] = in.fz1[v];
+    eX00 = in.eX01; eX10 = in.eX11; eY00 = in.eY01; eY10 = in.eY11; uC = in.uC1;
   }
 }
 

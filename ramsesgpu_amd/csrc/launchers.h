@@ -191,11 +191,12 @@ struct K_shear_remap {
   DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx;
   RG_DEVFN void operator()(unsigned idx) const { shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx); }
 };
+// t = z segment * (isize * jsize) + column: one thread marches planes [k_lo + seg * seg_len, + seg_len) of [k_lo, k_hi)
 template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_update3d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
-  double dt, dtdx, dtdy, dtdz; unsigned long long* dt_slots;
-  RG_DEVFN void operator()(unsigned idx) const { spec_assume<SPEC>(g); mhd_update3d_cell<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, idx, dt_slots); }
+  double dt, dtdx, dtdy, dtdz; unsigned long long* dt_slots; int k_lo, k_hi, seg_len;
+  RG_DEVFN void operator()(unsigned t) const { spec_assume<SPEC>(g); mhd_update3d_column<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, t, k_lo, k_hi, seg_len, dt_slots); }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------

@@ -614,19 +614,6 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   return 0;
 }
 
-// linear workgroup order (pure streaming kernels; two cells per thread measured 2x slower: the loads do not merge)
-template <int BLOCK, class K>
-int launch_planes_stream(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
-  if (r.hi <= r.lo) return 0;
-  return rg_launch_planes<BLOCK, 1>(s, (unsigned)r.lo * g.sk, g.sk, (unsigned)(r.hi - r.lo), k, 0u);
-}
-template <template <int> class K, int BLOCK, class... A>
-int launch_spec_stream(int spec, rg_stream_t s, const DevParams& g, PlaneRange r, A... a) {
-  if (spec == 1) { K<kSpecMri> k = {g, a...}; return launch_planes_stream<BLOCK>(s, g, r, k); }
-  if (spec == 2) { K<kSpecPlain> k = {g, a...}; return launch_planes_stream<BLOCK>(s, g, r, k); }
-  K<SPEC_NONE> k = {g, a...};
-  return launch_planes_stream<BLOCK>(s, g, r, k);
-}
 template <template <int> class K, int BLOCK, class... A>
 int launch_spec(int spec, rg_stream_t s, const DevParams& g, PlaneRange r, A... a) {
   if (spec == 1) { K<kSpecMri> k = {g, a...}; return launch_planes<BLOCK, 1>(s, g, r, k); }
@@ -635,8 +622,6 @@ int launch_spec(int spec, rg_stream_t s, const DevParams& g, PlaneRange r, A... 
   return launch_planes<BLOCK, 1>(s, g, r, k);
 }
 template <int S> using K_riemann_t = K_mhd_flux3d<DO_ALL, false, S>;
-template <int S> using K_upd_rot_t = K_mhd_update3d<true, false, S>;
-template <int S> using K_upd_t = K_mhd_update3d<false, false, S>;
 
 // 3D MHD: complete the update of planes [a,b).  The range is swept in chunks of ~8 planes; the HBM-bound stages
 // (prim, elec, trace, update) go to the context stream, the fp64-VALU-bound Riemann stages (flux, emf) to a second
@@ -725,23 +710,18 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   const bool scan_piece = acc && what == RGPU_CORE_UPDATE && cond && c->scan_acc_parity == out_parity;
   unsigned long long* slots = (scan || scan_piece) ? c->d_red : 0;
   if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
-  // after the sweep the update is a pure stream over F, emf and U (nothing of it is left in L2): the linear workgroup order
-  // measured 8.16 ms against 8.6-9.0 with the XCD sub-band order at 512^3 (which pays for the stencil re-reads of the flat
-  // trace / Riemann kernels)
-  DevParams gu = g;
-  if (use_sweep) gu.xcd_sub = 0;
-  auto update_planes = [&, gu](rg_stream_t s, PlaneRange r) -> int {
-    const DevParams& g = gu;
-    if (gf) {
-      K_mhd_update3d<true, true> kr = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots};
-      K_mhd_update3d<false, true> kp = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots};
-      return g.rot ? launch_planes<kBlock, 1>(s, g, r, kr) : launch_planes<kBlock, 1>(s, g, r, kp);
-    }
-    if (use_sweep)
-      return g.rot ? launch_spec_stream<K_upd_rot_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots)
-                   : launch_spec_stream<K_upd_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots);
-    return g.rot ? launch_spec<K_upd_rot_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots)
-                 : launch_spec<K_upd_t, kBlock>(spec, s, g, r, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots);
+  // the update is a pure stream over F, emf and U: one thread per column and short z segment, linear workgroup order, the plane
+  // k+1 entries carried in registers (mhd_update3d_column; 512^3: 8.07 -> 7.42 ms against one thread per cell)
+  static const int upd_seg = std::getenv("RGPU_UPD_SEG") ? std::atoi(std::getenv("RGPU_UPD_SEG")) : 3;
+  auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+    if (r.hi <= r.lo) return 0;
+    const int seg_len = upd_seg > 0 ? upd_seg : 3;
+    const unsigned nt = g.sk * (unsigned)((r.hi - r.lo + seg_len - 1) / seg_len);
+#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
+    if (gf) { if (g.rot) RG_UPD(true, true, SPEC_NONE) else RG_UPD(false, true, SPEC_NONE) }
+    if (g.rot) { if (spec == 1) RG_UPD(true, false, kSpecMri) if (spec == 2) RG_UPD(true, false, kSpecPlain) RG_UPD(true, false, SPEC_NONE) }
+    if (spec == 1) RG_UPD(false, false, kSpecMri) if (spec == 2) RG_UPD(false, false, kSpecPlain) RG_UPD(false, false, SPEC_NONE)
+#undef RG_UPD
   };
 
   // the fused sweep marches along z inside one launch: cutting the range into chunks only adds prologues (measured 60.4
