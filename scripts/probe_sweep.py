@@ -15,7 +15,8 @@ if base == "implode3d":
 prof = "--prof" in sys.argv
 if prof:   # experiment build with per-wave phase cycle counters (RG_SWEEP_PROF)
     from ramsesgpu_amd import build as rb
-    L = Library(rb.build(verbose=False, extra_flags=["-DRG_SWEEP_PROF"], out_name="librgpu_prof.so"))
+    fast = "--fast" in sys.argv   # the contracted-arithmetic variant of the library
+    L = Library(rb.build(verbose=False, extra_flags=["-DRG_SWEEP_PROF"] + (rb.FAST_FLAGS if fast else []), out_name="librgpu_prof_fast.so" if fast else "librgpu_prof.so"))
 else:
     L = Library(os.environ.get('RGPU_LIB') or lib_path())   # RGPU_LIB: an experiment build of the library
 ini = os.path.join(ROOT, "configs", base + ".ini")
