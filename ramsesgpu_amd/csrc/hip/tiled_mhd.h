@@ -39,6 +39,13 @@ constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E
 constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
 constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
+#ifndef RG_SWEEP_SPLIT_LOOPS   // main loop of the sweep once per wave role (1) or once for all waves (0): see mhd3d_sweep_kernel
+#ifdef RG_ARITH_FAST
+#define RG_SWEEP_SPLIT_LOOPS 0
+#else
+#define RG_SWEEP_SPLIT_LOOPS 1
+#endif
+#endif
 #ifndef RG_SWEEP_LB   // experiment (ISA inspection only): 768 = the register budget of three waves per SIMD (168 VGPRs)
 #define RG_SWEEP_LB MH_THREADS
 #endif
@@ -196,13 +203,22 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
     pok[r] = producer && cell < MH_QCELLS && pi < g.isize - 1 && pj < g.jsize - 1;   // range of mhd_prim_cell
     pidx2[r] = pok[r] ? (unsigned)pi + (unsigned)pj * g.sj : 0u;
   }
-  // what a producer keeps from one iteration to the next: pu[2][11] = the loaded U (8), Ua(i+1), Ub(j+1), Uc(k+1) and then the
-  // primitives (8) + the cell's own face field (3) of its two input cells
+  // What a wave keeps from one iteration to the next.  Producers: pu[2][11] = the loaded U (8), Ua(i+1), Ub(j+1), Uc(k+1) and
+  // then the primitives (8) + the cell's own face field (3) of their two input cells.  Riemann waves: the two carried states
+  // c0, c1 (8 doubles each).  With ONE main loop for all waves (RG_SWEEP_SPLIT_LOOPS 0) both live in one array, because the
+  // register allocator cannot know that a wave is either a producer or a Riemann wave for its whole life.
+#if RG_SWEEP_SPLIT_LOOPS
   double pu[2][11];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int v = 0; v < 11; ++v) pu[r][v] = 0.0;
+#else
+  double keep[22];
+#pragma unroll
+  for (int v = 0; v < 22; ++v) keep[v] = 0.0;
+  double (*pu)[11] = reinterpret_cast<double (*)[11]>(keep);
+#endif
   auto prim_load = [&](int k) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -321,21 +337,87 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
   // trace(kk+1) (waits for that announcement just before it reads E), prim(kk+3) -> the slot Q / B (kk) vacated.
   // kk = sa-2 only traces plane sa-1, kk = sa-1 traces plane sa and builds the carried states from T(sa-1); the last
   // planes have nothing left to produce.
-  // One loop per role (the role of a wave never changes): the register allocator then sees two independent live sets -- the
-  // producers' loaded / converted input cells, the Riemann waves' carried states -- instead of their union in every wave
-  // (exact arithmetic: 235 instead of 256 VGPRs, no VGPR spill, sweep -1.5 %).  Every wave passes the same number of barriers.
+  // the two per-plane bodies, as text: the kernel has them either in one loop or in one loop per role (below), and a lambda
+  // capturing the carried arrays by reference kept them in scratch
+#ifdef RG_SWEEP_PROF
+#define RG_TRACE_ON (tracing && !(tg.flags & 4))                    /* RGPU_SWEEP_FLAGS=4 times the kernel without the trace */
+#define RG_RIEMANN_ON (fl_ok && kk >= sa - 1 && !(tg.flags & 2))    /* RGPU_SWEEP_FLAGS=2: without the Riemann problems */
+#else
+#define RG_TRACE_ON tracing
+#define RG_RIEMANN_ON (fl_ok && kk >= sa - 1)
+#endif
+#ifdef RG_FLUX_FIRST   // experiment: 1 = the younger wave of each SIMD, 2 = the older one, 3 = both solve the face problem first
+#define RG_FF (((RG_FLUX_FIRST) & (wave >= 4 ? 1 : 2)) != 0)
+#else
+#define RG_FF false
+#endif
+#define RG_PRODUCER_PLANE(kk, nit) {                                                                                     \
+    const bool more = kk + 3 <= sb;                                                                                      \
+    const bool tracing = kk + 1 < sb;                                                                                    \
+    if (more) prim_load(kk + 3);                                                                                         \
+    if (RG_TRACE_ON) {                                                                                                   \
+      if (wave == 3) { trace_cell(kk + 1, lane, 6 * nit); trace_cell(kk + 1, 128 + lane, 6 * nit); }                     \
+      else trace_cell(kk + 1, 64 + lane, 6 * nit);                                                                       \
+    }                                                                                                                    \
+    if (more) {                                                                                                          \
+      prim_compute();                                                                                                    \
+      pair_sync();                     /* both producers are done reading Q / B (kk) */                                  \
+      prim_store(kk + 3);              /* -> the Q / B slot of plane kk */                                               \
+    }                                                                                                                    \
+  }
+  // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
+  //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
+#define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
+    const bool tracing = kk + 1 < sb;                                                                                    \
+    if (tracing) elec_plane(kk + 2, rthread, 384);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */            \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                               \
+    if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                   \
+    if (RG_RIEMANN_ON) {                                                                                                 \
+      const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
+      const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
+      const bool solve = kk >= sa;                                                                                       \
+      const bool raise = prio_mode && solve && wave >= 4;                                                                \
+      if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
+      const bool ff = RG_FF;                                                                                             \
+      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                             \
+      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                        \
+      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                                      \
+    }                                                                                                                    \
+  }
 #ifdef RG_SWEEP_PROF
 #define RG_PLANE_END() { RG_PROF_T(tB); __syncthreads(); const long long tE = (long long)__builtin_readcyclecounter(); acc[0] += tB - tA; acc[1] += tE - tB; }
 #else
 #define RG_PLANE_END() __syncthreads()   /* T(kk+1) and Q / B (kk+3) complete, T(kk) free */
 #endif
+#if RG_SWEEP_SPLIT_LOOPS
+  // One loop per role (the role of a wave never changes): the register allocator sees two independent live sets -- the
+  // producers' input cells, the Riemann waves' carried states -- instead of their union in every wave.  Exact arithmetic: 235
+  // instead of 256 VGPRs, no VGPR spill, sweep 31.7 against 32.2 ms; contracted arithmetic, whose critical chain is the
+  // producers', 25.7 against 25.3 (same boxes), hence the switch.  Every wave passes the same number of barriers.
   if (producer) {
     int nit = 0;
     for (int kk = sa - 2; kk < sb; ++kk) {
       RG_PROF_T(tA);
       ++nit;
-      const bool more = kk + 3 <= sb;
-      const bool tracing = kk + 1 < sb;
+      RG_PRODUCER_PLANE(kk, nit);
+      RG_PLANE_END();
+    }
+  } else {
+    Prim8 c0 = {0, 0, 0, 0, 0, 0, 0, 0}, c1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kk = sa - 2; kk < sb; ++kk) {
+      RG_PROF_T(tA);
+      RG_RIEMANN_PLANE(kk, c0, c1);
+      RG_PLANE_END();
+    }
+  }
+#else   // (the loop as it was before the split, verbatim: small changes of its text move the register allocation)
+  int nit = 0;
+  for (int kk = sa - 2; kk < sb; ++kk) {
+    RG_PROF_T(tA);
+    ++nit;
+    const bool more = kk + 3 <= sb;
+    const bool tracing = kk + 1 < sb;
+    if (producer) {
       if (more) prim_load(kk + 3);
 #ifdef RG_SWEEP_PROF
       if (tracing && !(tg.flags & 4)) {   // experiment: RGPU_SWEEP_FLAGS=4 times the kernel without the trace
@@ -350,13 +432,7 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
         pair_sync();                     // both producers are done reading Q / B (kk)
         prim_store(kk + 3);              // -> the Q / B slot of plane kk
       }
-      RG_PLANE_END();
-    }
-  } else {
-    Prim8 c0 = {0, 0, 0, 0, 0, 0, 0, 0}, c1 = {0, 0, 0, 0, 0, 0, 0, 0};   // the two carried states
-    for (int kk = sa - 2; kk < sb; ++kk) {
-      RG_PROF_T(tA);
-      const bool tracing = kk + 1 < sb;
+    } else {
       // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
       //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
       if (tracing) elec_plane(kk + 2, rthread, 384);   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
@@ -372,6 +448,8 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
         const bool solve = kk >= sa;
         const bool raise = prio_mode && solve && wave >= 4;
         if (raise) __builtin_amdgcn_s_setprio(1);
+        Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
+        Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
 #ifdef RG_FLUX_FIRST   // experiment: 1 = the younger wave of each SIMD, 2 = the older one, 3 = both solve the face problem first
         const bool ff = ((RG_FLUX_FIRST) & (wave >= 4 ? 1 : 2)) != 0;
 #else
@@ -380,11 +458,24 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
         if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
         else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
         else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
+        keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
+        keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }
-      RG_PLANE_END();
     }
+    RG_PROF_T(tB);
+    __syncthreads();   // T(kk+1) and Q / B (kk+3) complete, T(kk) free
+#ifdef RG_SWEEP_PROF
+    const long long tE = (long long)__builtin_readcyclecounter();
+    acc[0] += tB - tA; acc[1] += tE - tB;
+#endif
   }
+#endif
 #undef RG_PLANE_END
+#undef RG_PRODUCER_PLANE
+#undef RG_RIEMANN_PLANE
+#undef RG_TRACE_ON
+#undef RG_RIEMANN_ON
+#undef RG_FF
 #ifdef RG_SWEEP_PROF
   if ((t & 63) == 0)
     for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)acc[q]);
