@@ -29,8 +29,12 @@ Extra objects on the JSON line:
                 workloads when the host has the memory).
   cpu_baseline_all_cores  ONE 256^3 box on all host cores: the restatement threaded over z-slabs (deterministic gather
                 update); `upper_bound_replicas` = independent 64^3 replicas of the reference binary, rates summed.
-  value_tolerance  the same workload through librgpu_fast.so (relative L2 < 1e-12 to euler_cpu: north_star's bar) with its own
-                roofline; `value` stays the bit-identical library.
+  config.arithmetic  which build of the library `value` was measured with.  Default "contracted": librgpu_fast.so, the
+                tolerance-grade build (FMA contraction, ~1-ulp division / square root), held to north_star's bar -- relative L2
+                < 1e-12 to euler_cpu -- by tests/test_contracted.py (all fixtures, the full 512^2 x 50 Orszag-Tang gate, 300-400 step
+                runs, the headline-size property checks; worst measured 2e-14).  --arith exact: librgpu.so, bit-identical.
+  value_exact   (N=1, default arithmetic) the same workload, same K and W, through the bit-identical library librgpu.so, with its
+                own roofline.  (--arith exact prints the contracted record beside it as value_tolerance instead.)
   other_workloads  default headline run only: short measurements of BASELINE configs[1] (implode3d 256^3) and [2]
                 (orszag-tang 512^2) with their own roofline / cpu_baseline.
   config.driver / rccl_ranks / ranks  which slab driver ran, what RCCL itself reports (ncclCommCount), device + PCI bus id per
@@ -236,9 +240,10 @@ def pmc_traffic(workload, kernel_phase):
         return None
 
 
-PARITY = {"exact": "bit-identical to euler_cpu on all golden fixtures (tests/)",
-          "contracted": "librgpu_fast.so (FMA contraction, ~1-ulp division / sqrt): relative L2 < 1e-12 to euler_cpu on all golden fixtures "
-                        "(worst measured 2e-14, tests/test_contracted.py); not bit-identical"}
+PARITY = {"exact": "librgpu.so: bit-identical to euler_cpu on all golden fixtures, oracle runs and the full Orszag-Tang gate (tests/)",
+          "contracted": "librgpu_fast.so (FMA contraction, ~1-ulp division / sqrt; not bit-identical): relative L2 < 1e-12 to euler_cpu -- "
+                        "north_star's tolerance -- gated by tests/test_contracted.py on all golden fixtures (worst 2e-14), the full 512^2 x 50 "
+                        "Orszag-Tang gate (<= 9e-16 per variable), 300-400 step runs (<= 2.1e-15) and the headline-size property checks"}
 
 
 def valu_ceiling(workload, kernel_phase, launch_ms):
@@ -253,15 +258,18 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
         return None
     cycles = 4.0 * insts + 12.0 * trans
     cap = 1024 * 2.4e9 * launch_ms * 1e-3
-    # what a pure stream of independent v_fma_f64 / v_rcp_f64 reaches on this chip at the kernel's occupancy (2 waves per SIMD):
-    # 5.3 / 17.4 cycles per wave instruction at the nominal clock (scripts/ubench/valu_rate2.cpp, profiles/r03_valu_rate*.txt)
-    measured = 5.3 * (insts - trans) + 17.4 * trans
+    # what instruction streams reach on this chip at the kernel's occupancy (2 waves per SIMD), cycles per wave instruction at the
+    # nominal clock (scripts/ubench/valu_mix.cpp, profiles/r03_valu_mix.txt): v_fma_f64 5.4, v_mul_f64 5.0, v_add_f64 5.1, v_max_f64 4.9,
+    # v_cndmask_b32 4.0, v_add_u32 3.0, v_mov_b32 2.3, v_rcp / v_rsq_f64 16.8; weighted with the static instruction mix of the MHD sweep
+    # (75 % fp64 arithmetic, 25 % 32-bit selects / integer) 4.7 per non-transcendental instruction
+    measured = 4.7 * (insts - trans) + 16.8 * trans
     return {"valu_wave_insts_per_launch": insts, "trans_f64_wave_insts_per_launch": trans, "issue_cycles": cycles,
             "capacity_cycles": cap, "frac": cycles / cap, "clock_ghz": 2.4, "simds": 1024,
             "frac_of_measured_issue_rate": measured / cap,
             "note": "frac: share of the nominal fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq, 2.4 GHz) the kernel fills at its "
-                    "measured duration; frac_of_measured_issue_rate: the same against the rate a pure FMA / rcp stream reaches at 2 waves per SIMD "
-                    "(5.3 / 17.4 cycles, profiles/r03_valu_rate2.txt) -- the practical ceiling of this kernel's occupancy"}
+                    "measured duration; frac_of_measured_issue_rate: the same against the rates instruction streams of the kernel's mix reach at 2 waves "
+                    "per SIMD (4.7 cycles per instruction, 16.8 per rcp/rsq: profiles/r03_valu_mix.txt), averaged over all SIMDs -- in the MHD sweep "
+                    "the three SIMDs of the Riemann waves are the critical path (~95 % busy), the producer pair's SIMD carries ~72 % of their load"}
 
 
 class Control:
@@ -370,12 +378,13 @@ def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
     # per step: a slab run launches the kernel once per plane range (two boundary ranges + the inner one)
     dom_ms = dom_ms * dom_launches / nprof
     achieved = step_bytes / (dom_ms * 1e-3)
+    pkey = wname if arith == "exact" else wname + "_contracted"   # key of the committed PMC summary (profiles/pmc_traffic.json)
     roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(wname, dom_name) if arith == "exact" else pmc_traffic(wname + "_contracted", dom_name),
+            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(pkey, dom_name),
             "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
             "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
                      "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
-            "valu_ceiling": valu_ceiling(wname, dom_name, dom_ms / max(dom_launches / nprof, 1.0)) if arith == "exact" else None}
+            "valu_ceiling": valu_ceiling(pkey, dom_name, dom_ms / max(dom_launches / nprof, 1.0))}
     step = {"bound": "hbm", "achieved": step_bytes / (elapsed / steps) / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": step_bytes / (elapsed / steps) / HBM_PEAK,
             "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": sum(tm.values()) / nprof * 1e3}
@@ -418,9 +427,11 @@ def main():
     ap.add_argument("--ny", type=int, default=0)
     ap.add_argument("--nz", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--arith", choices=["exact", "contracted"], default=os.environ.get("RGPU_ARITH", "exact"),
-                    help="exact: librgpu.so, bit-identical to the reference (default, the headline); contracted: librgpu_fast.so")
-    ap.add_argument("--no-contracted", action="store_true", help="skip the second measurement with librgpu_fast.so (N=1, --arith exact)")
+    ap.add_argument("--arith", choices=["exact", "contracted"], default=os.environ.get("RGPU_ARITH", "contracted"),
+                    help="contracted (default): librgpu_fast.so, the tolerance-grade build gated at north_star's relative L2 < 1e-12; "
+                         "exact: librgpu.so, bit-identical to the reference")
+    ap.add_argument("--no-second-arith", "--no-contracted", dest="no_second", action="store_true",
+                    help="N=1: skip the second measurement with the other build of the library (value_exact / value_tolerance)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default N=1 headline run only: skip the short implode3d 256^3 / orszag-tang 512^2 measurements nested under other_workloads")
     ap.add_argument("--timeline-only", action="store_true", help="stop after the timed region (for rocprofv3 --kernel-trace concurrency analysis)")
@@ -479,7 +490,7 @@ def main():
             print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
             return
         rec = single_gpu_record(args.workload, (nx, ny, nz), args.arith, args.steps, args.warmup, ctl)
-        driver, rccl_ranks = "single device: librgpu.so, no communicator", None
+        driver, rccl_ranks = "single device: %s, no communicator" % rec["library"], None
         ranks = [dict(device_facts(torch, local_rank), rank=0)]
     else:
         # the C++ z-slab driver (include/rgpu_comm.h): RCCL halo exchange on a side stream, 1/dt all-reduced on the device;
@@ -563,29 +574,30 @@ def main():
                        "parity": PARITY[args.arith]},
             "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],
         }
-        if world == 1 and args.arith == "exact" and not args.no_contracted:
-            # the same workload through the tolerance-grade library (relative L2 < 1e-12 to euler_cpu, north_star's own bar; gated by
-            # tests/test_contracted.py): a second record with its own roofline -- never `value`, which stays the bit-identical library
+        if world == 1 and not args.no_second:
+            # the same workload, same K and W, through the OTHER build of the library, with its own roofline: the bit-identical one
+            # beside the default tolerance-grade headline (value_exact), or the other way round with --arith exact (value_tolerance)
+            other = "exact" if args.arith == "contracted" else "contracted"
+            key = "value_exact" if other == "exact" else "value_tolerance"
             try:
-                c = single_gpu_record(args.workload, (nx, ny, nz), "contracted", args.steps, args.warmup, ctl)
-                out["value_tolerance"] = c
-                out["contracted_arithmetic"] = {k: c[k] for k in ("value", "unit", "ms_per_step", "parity")}   # (round-2 key, kept)
-                out["contracted_arithmetic"]["library"] = "ramsesgpu_amd/librgpu_fast.so"
+                out[key] = single_gpu_record(args.workload, (nx, ny, nz), other, args.steps, args.warmup, ctl)
             except Exception as e:  # noqa: BLE001 -- a secondary number: report why it is missing
-                out["value_tolerance"] = {"value": None, "error": repr(e)}
-                out["contracted_arithmetic"] = {"value": None, "error": repr(e)}
+                out[key] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, (nx, ny, nz))
             allc = cpu_baseline_all_cores(w, (nx, ny, nz))
             if allc:
                 out["cpu_baseline_all_cores"] = allc
-        if world == 1 and args.workload == "mri" and not custom_size and args.arith == "exact" and not args.no_other_workloads:
+        if world == 1 and args.workload == "mri" and not custom_size and not args.no_other_workloads:
             # BASELINE.json configs[1] and configs[2], short, so that their numbers are the driver's too (not builder-only claims)
             others = {}
             for name, st, wu, budget in (("implode3d", 50, 5, 8.0), ("orszag-tang", 50, 5, 6.0)):
                 try:
                     ow = WORKLOADS[name]
-                    o = single_gpu_record(name, ow["size"], "exact", st, wu, ctl)
+                    o = single_gpu_record(name, ow["size"], args.arith, st, wu, ctl)
+                    if args.arith != "exact" and not args.no_second:
+                        e = single_gpu_record(name, ow["size"], "exact", st, wu, ctl)
+                        o["value_exact"] = {k: e[k] for k in ("value", "unit", "ms_per_step", "roofline", "library", "arithmetic", "parity")}
                     o["config"] = {"workload": ow["desc"] % ("%dx%d" % ow["size"][:2] if ow["size"][2] == 1 else "%dx%dx%d" % ow["size"]), "path": ow["path"]}
                     if not args.no_cpu_baseline:
                         o["cpu_baseline"] = cpu_baseline(ow, ow["size"], budget_s=budget)

@@ -9,13 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 python $R/bench.py --workload implode3d --steps 100 --warmup 10 > $OUT/bench_implode3d.json 2> $OUT/bench_implode3d.err
 python $R/bench.py --workload orszag-tang --steps 50 --warmup 5 > $OUT/bench_orszag-tang.json 2> $OUT/bench_orszag-tang.err
-for W in mri implode3d orszag-tang mri_contracted; do
-  WL=$W; AR=""
-  if [ $W = mri_contracted ]; then WL=mri; AR="--arith contracted"; fi
+for W in mri_contracted mri implode3d_contracted implode3d orszag-tang_contracted orszag-tang; do
+  WL=${W%_contracted}; AR="--arith exact"
+  if [ $W != $WL ]; then AR="--arith contracted"; fi
   if [ $WL = mri ]; then ST="--steps 10 --warmup 2"; PST="--steps 2 --warmup 1"; elif [ $WL = implode3d ]; then ST="--steps 50 --warmup 5"; PST="--steps 5 --warmup 2"; else ST="--steps 200 --warmup 20"; PST="--steps 20 --warmup 5"; fi
-  BENCH="python $R/bench.py --workload $WL $AR $ST --no-cpu-baseline --no-contracted --no-other-workloads"
+  BENCH="python $R/bench.py --workload $WL $AR $ST --no-cpu-baseline --no-second-arith --no-other-workloads"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o bench -- $BENCH > $OUT/bench_${W}_under_rocprof.json 2> $OUT/trace_$W.err
-  CMD="python $R/bench.py --workload $WL $AR $PST --no-cpu-baseline --no-contracted --no-other-workloads"
+  CMD="python $R/bench.py --workload $WL $AR $PST --no-cpu-baseline --no-second-arith --no-other-workloads"
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS_F64 --output-format csv -d $OUT/pmc_sq_$W -o pmc -- $CMD > /dev/null 2> $OUT/pmc_sq_$W.err
   rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch_$W -o pmc -- $CMD > /dev/null 2> $OUT/pmc_fetch_$W.err
   rocprofv3 --pmc WRITE_SIZE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d $OUT/pmc_write_$W -o pmc -- $CMD > /dev/null 2> $OUT/pmc_write_$W.err

@@ -15,7 +15,8 @@ PHASE = [("mhd3d_sweep_kernel", "sweep"), ("hydro3d_sweep_kernel", "sweep"), ("m
          ("K_mhd_update3d", "update"), ("K_shear_save_emf", "shear"), ("K_shear_remap", "shear"), ("K_shear_ghost", "boundaries"),
          ("K_bc_face", "boundaries"), ("K_copy_cells", "boundaries"), ("K_hydro_prim", "prim"), ("K_hydro_trace", "trace"),
          ("K_hydro_flux", "flux"), ("K_hydro_update", "update")]
-CELLS = {"mri": 512.0 ** 3, "implode3d": 256.0 ** 3, "orszag-tang": 512.0 ** 2, "mri_contracted": 512.0 ** 3}
+CELLS = {"mri": 512.0 ** 3, "implode3d": 256.0 ** 3, "orszag-tang": 512.0 ** 2}
+CELLS.update({k + "_contracted": v for k, v in list(CELLS.items())})
 
 
 def phase_of(kernel):
@@ -33,7 +34,7 @@ for name in ("bench", "bench_implode3d", "bench_orszag-tang"):
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, "%s_%s.json" % (tag, name)), "w"), indent=1)
 
 traffic = {}
-for w in ("mri", "implode3d", "orszag-tang", "mri_contracted"):
+for w in ("mri", "implode3d", "orszag-tang", "mri_contracted", "implode3d_contracted", "orszag-tang_contracted"):
     f = glob.glob(os.path.join(src, "trace_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, w)))
@@ -43,7 +44,7 @@ for w in ("mri", "implode3d", "orszag-tang", "mri_contracted"):
         for f in glob.glob(os.path.join(src, grp + w, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 ph = phase_of(row["Kernel_Name"])
-                if ph is None or ph in ("boundaries", "shear") or int(row["Grid_Size"]) < (100000 if w != "orszag-tang" else 50000):
+                if ph is None or ph in ("boundaries", "shear") or int(row["Grid_Size"]) < (100000 if not w.startswith("orszag-tang") else 50000):
                     continue
                 acc[ph][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
     if not acc:
