@@ -268,8 +268,9 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
             "frac_of_measured_issue_rate": measured / cap,
             "note": "frac: share of the nominal fp64 VALU issue slots (4 cycles per wave instruction, 16 for rcp/rsq, 2.4 GHz) the kernel fills at its "
                     "measured duration; frac_of_measured_issue_rate: the same against the rates instruction streams of the kernel's mix reach at 2 waves "
-                    "per SIMD (4.7 cycles per instruction, 16.8 per rcp/rsq: profiles/r03_valu_mix.txt), averaged over all SIMDs -- in the MHD sweep "
-                    "the three SIMDs of the Riemann waves are the critical path (~95 % busy), the producer pair's SIMD carries ~72 % of their load"}
+                    "per SIMD (4.7 cycles per instruction, 16.8 per rcp/rsq: profiles/r03_valu_mix.txt), averaged over all SIMDs -- in the exact MHD "
+                    "sweep the three SIMDs of the Riemann waves are the critical path (~95 % busy) and the producer pair's SIMD carries ~72 % of their "
+                    "load; in the contracted one the producer pair's chain (loads, trace, barrier) is the critical one: DESIGN.md section 3.2"}
 
 
 class Control:
