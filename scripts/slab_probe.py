@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import load_library
 L = load_library()
-CL = rcomm.load_comm_library()
+CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))   # the driver built for this arithmetic (RGPU_ARITH)
 ini = os.path.join(ROOT, "configs", "mhd_mri_3d.ini")
 cid = rcomm.unique_id(CL)
 for nz in (512, 256, 128, 64):
