@@ -13,8 +13,8 @@ L = load_library()
 CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))   # the driver built for this arithmetic (RGPU_ARITH)
 ini = os.path.join(ROOT, "configs", "mhd_mri_3d.ini")
 cid = rcomm.unique_id(CL)
-for nz in (512, 256, 128, 64):
-    for overlap in (True, False):
+for nz in ([int(os.environ['PROBE_NZ'])] if os.environ.get('PROBE_NZ') else (512, 256, 128, 64)):   # PROBE_NZ: one slab thickness (for rocprofv3)
+    for overlap in ((True,) if os.environ.get('PROBE_NZ') else (True, False)):
         run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=%d" % nz, 0, 1, cid, library=L, comm_library=CL, overlap=overlap)
         run.init_simulation()
         for _ in range(3): run.oneStepIntegration()
