@@ -491,6 +491,30 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     if (rc <= 0) return rc;
     if (acc_piece) c->scan_acc_parity = -1;   // flat kernels took over: no accumulated scan for this step
   }
+  // the CFL scan of the new state rides in the kernel that writes it when the whole domain is updated in this call and nothing
+  // modifies the state afterwards (2D: the fused step or the flat update kernel; 3D with a per-cell gravity field: the flat one)
+  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
+  const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
+  unsigned long long* slots = scan2 ? c->d_red : 0;
+  if (scan2 && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
+    Phase ph(c, RGPU_T_SWEEP);
+    // plain faces, nothing modifying the new state after this kernel: it writes the ghost images too and the next step's fill is skipped
+    static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
+    int images = 0;
+    if (!no_images && scan2 && !c->p.enableJet && g.nx >= g.gw && g.ny >= g.gw) {
+      images = 1 << 12;
+      for (int f = 0; f < 4; ++f) {
+        const int bc = c->p.bc[f];
+        if (bc != RGPU_BC_DIRICHLET && bc != RGPU_BC_NEUMANN && bc != RGPU_BC_PERIODIC) { images = 0; break; }
+        images |= bc << (2 * f);
+      }
+    }
+    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images);
+    if (rc == 0 && scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
+    if (rc == 0 && images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
+    if (rc <= 0) return rc;
+  }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
@@ -512,12 +536,6 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     K_hydro_flux<ND, NV, true> kg = {g, c->T, c->F};
     if (gf ? launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), kg) : launch_planes<kBlockHeavy, 1>(c->stream, g, clip(a, b + 1, ks), k)) return -1;
   }
-  // flat path (2D; 3D with a per-cell gravity field): the CFL scan of the new state rides in the update kernel when the
-  // whole domain is updated in this call and nothing modifies the state afterwards
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
-  unsigned long long* slots = scan2 ? c->d_red : 0;
-  if (scan2 && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   {
     Phase ph(c, RGPU_T_UPDATE);
     K_hydro_update<ND, NV, false> k = {g, in, out, c->F, dtdx, dtdy, dtdz, slots};

@@ -7,6 +7,7 @@ inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const do
 inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool mhd2d_step_covers(const rgpu_dev::DevParams&) { return false; }
+inline int hydro2d_step(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, unsigned long long*, int) { return 1; }
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const double*, double*, double*,
                        double, double, double, double, int, int, int = 0) { return 1; }
