@@ -227,15 +227,21 @@ def cpu_baseline_all_cores(w, dims):
     return out
 
 
-def pmc_traffic(workload, kernel_phase):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary, or None"""
+def pmc_traffic(workload, kernel_phase, doubled_fetch=False):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
+    KiB x 1024), or None.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section: exactly 1/2 for
+    16 B per lane streaming reads, "other widths uncalibrated"); calibrated on this code's own 8 B per lane SoA streams against known byte
+    counts it reports 0.49-0.77 of them.  Hence two figures: FETCH + WRITE as counted (a lower bound) and 2 x FETCH + WRITE (the guide's
+    correction, an upper bound for these kernels)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
         d = json.load(open(path))
-        d = d.get(workload, d)
-        return d.get(kernel_phase, {}).get("hbm_bytes_per_launch")
+        d = d.get(workload, d).get(kernel_phase, {})
+        if doubled_fetch:
+            return 2.0 * d["fetch_bytes"] + d["write_bytes"]
+        return d.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -381,7 +387,10 @@ def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
     achieved = step_bytes / (dom_ms * 1e-3)
     pkey = wname if arith == "exact" else wname + "_contracted"   # key of the committed PMC summary (profiles/pmc_traffic.json)
     roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(pkey, dom_name),
+            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(pkey, dom_name), "traffic_fetch_doubled": pmc_traffic(pkey, dom_name, True),
+            "traffic_note": "HBM bytes per launch from rocprofv3 --pmc (profiles/pmc_traffic.json): FETCH_SIZE + WRITE_SIZE as counted = a lower bound (gfx950 tallies "
+                            "128-B read requests at 64 B; 0.49-0.77 of known byte counts on this code's 8 B per lane streams), and with FETCH_SIZE doubled as "
+                            "MI355X_MICROARCH.md prescribes for wide streaming reads = an upper bound",
             "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
             "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
                      "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),

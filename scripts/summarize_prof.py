@@ -80,7 +80,8 @@ for w in ("mri", "implode3d", "orszag-tang", "mri_contracted", "implode3d_contra
                                           if not k.startswith("_") and 2 * v["launches_sampled"] >= nmax)
 traffic["_note"] = ("rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE), one whole-domain launch per kernel and step; KiB x 1024. "
                     "WRITE_SIZE matches the byte count of the stores; FETCH_SIZE is a LOWER bound on gfx950 (128-B requests tallied as "
-                    "64 B, MI355X_MICROARCH.md HBM section): 0.62-0.78x of the known unique bytes on the pure streaming kernels. "
+                    "64 B, MI355X_MICROARCH.md HBM section, which prescribes doubling it for 16 B per lane streaming reads): 0.49-0.77x of the known unique bytes on this code's 8 B per lane SoA streams "
+                    "(the CFL scan of the initial state reads the whole state array once: 5.32 of 8.90 GB at 518^3 x 8, 0.34 of 0.70 GB at 260^3 x 5); bench.py reports FETCH + WRITE (lower bound) and 2 x FETCH + WRITE (upper bound). "
                     "mri = 512^3 MRI box, implode3d = 256^3 hydro implosion (HLLC)")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))
