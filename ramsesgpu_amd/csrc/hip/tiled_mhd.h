@@ -46,6 +46,9 @@ constexpr int MH_THREADS = 512;
 #define RG_SWEEP_SPLIT_LOOPS 1
 #endif
 #endif
+#ifndef RG_E_LATE   // experiment (split loops only): the edge electric field of plane kk+3 by the producer pair at the END of iteration kk
+#define RG_E_LATE 0
+#endif
 #ifndef RG_SWEEP_LB   // experiment (ISA inspection only): 768 = the register budget of three waves per SIMD (168 VGPRs)
 #define RG_SWEEP_LB MH_THREADS
 #endif
@@ -302,7 +305,11 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
       const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
 #endif
       const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
+#if RG_E_LATE
+                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, 0, e_want};   // E(k+1) was completed before the last barrier
+#else
                              {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
+#endif
       mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
     }
   };
@@ -330,6 +337,9 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
     prim_store(k);
     __syncthreads();
     if (k == sa - 1) elec_plane(k, t, MH_THREADS);
+#if RG_E_LATE
+    if (k == sa) elec_plane(k, t, MH_THREADS);   // the producers compute E(kk+3) at the END of iteration kk: E(sa) is needed before the first one
+#endif
   }
   __syncthreads();
   // iteration kk.  Riemann waves: electric field of plane kk+2 (from Q / B of planes kk+1, kk+2, complete since the last
@@ -351,6 +361,11 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
 #else
 #define RG_FF false
 #endif
+#if RG_E_LATE   /* E(kk+3) by the producer pair, after both have stored Q / B (kk+3): into the slot of E(kk+1), dead since both finished trace(kk+1) */
+#define RG_PRODUCER_E(kk) if (kk + 2 < sb) { pair_sync(); elec_plane(kk + 3, (wave >> 2) * 64 + lane, 128); }
+#else
+#define RG_PRODUCER_E(kk)
+#endif
 #define RG_PRODUCER_PLANE(kk, nit) {                                                                                     \
     const bool more = kk + 3 <= sb;                                                                                      \
     const bool tracing = kk + 1 < sb;                                                                                    \
@@ -363,15 +378,21 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
       prim_compute();                                                                                                    \
       pair_sync();                     /* both producers are done reading Q / B (kk) */                                  \
       prim_store(kk + 3);              /* -> the Q / B slot of plane kk */                                               \
+      RG_PRODUCER_E(kk)                                                                                                  \
     }                                                                                                                    \
   }
   // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
   //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-#define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
-    const bool tracing = kk + 1 < sb;                                                                                    \
+#if RG_E_LATE
+#define RG_RIEMANN_E(kk)
+#else
+#define RG_RIEMANN_E(kk) { const bool tracing = kk + 1 < sb;                                                            \
     if (tracing) elec_plane(kk + 2, rthread, 384);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */            \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                               \
-    if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                   \
+    if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+#define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
+    RG_RIEMANN_E(kk)                                                                                                     \
     if (RG_RIEMANN_ON) {                                                                                                 \
       const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
       const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
@@ -472,6 +493,8 @@ __global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, T
 #endif
 #undef RG_PLANE_END
 #undef RG_PRODUCER_PLANE
+#undef RG_PRODUCER_E
+#undef RG_RIEMANN_E
 #undef RG_RIEMANN_PLANE
 #undef RG_TRACE_ON
 #undef RG_RIEMANN_ON
