@@ -387,3 +387,31 @@ def test_fused_hydro2d_ghost_images(base, ov, gpu_lib, oracle):
         assert np.array_equal(A, B), "%d ghost cells differ from the ghost fill" % int((A != B).sum())
     finally:
         sv.close()
+
+
+def test_kelvin_helmholtz_large_box_properties(gpu_lib):
+    """the fused 2D hydro kernel at a size the oracle does not run in seconds (2048^2: 147 x 147 tiles, periodic ghost images written by
+    the kernel itself): mass, momentum and energy are conserved to round-off by the flux form in the periodic box, and the ghost cells
+    of the output are the periodic images of its interior; bit-identity of the kernel is pinned by the fixtures and oracle runs."""
+    base, ov = "kelvin_helmholtz_gpu_2d", "mesh.nx=2048;mesh.ny=2048"
+    p = gpu_lib.params_from_ini(ini(base), ov)
+    U0 = gpu_lib.init_condition(ini(base), ov, p)
+    sv = Solver(p, gpu_lib)
+    try:
+        sv.start(U0, 10)
+        A = sv.getDataHost()
+    finally:
+        sv.close()
+    gw = p.ghostWidth
+    I0, I1 = interior(U0, p), interior(A, p)
+    assert np.isfinite(A).all() and not np.array_equal(I0, I1)
+    for v in range(4):
+        a, b = I1[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
+        scale = max(abs(float(b)), float(np.abs(I0[v]).sum(dtype=np.longdouble)))
+        assert abs(float(a - b)) < 1e-12 * scale, (v, float(a), float(b))
+    if os.environ.get("RGPU_NO_GHOST_IMAGES") or os.environ.get("RGPU_TILED") == "0":
+        return
+    A = A[:, 0]
+    nx, ny = p.nx, p.ny
+    assert np.array_equal(A[:, gw:-gw, :gw], A[:, gw:-gw, nx:nx + gw]) and np.array_equal(A[:, gw:-gw, nx + gw:], A[:, gw:-gw, gw:2 * gw])
+    assert np.array_equal(A[:, :gw, :], A[:, ny:ny + gw, :]) and np.array_equal(A[:, ny + gw:, :], A[:, gw:2 * gw, :])
