@@ -22,7 +22,8 @@ Extra objects on the JSON line:
   roofline      dominant kernel of the step (by accumulated time): algorithmic bytes per launch (read U once + write U
                 once: 128 B per MHD cell update, 80 B hydro 3D) / its average duration measured
                 with HIP events on the kernel's stream, against the 8 TB/s HBM3E peak.  `traffic` comes from the
-                rocprofv3 --pmc summary under profiles/ (null if absent).
+                rocprofv3 --pmc summary under profiles/ (null if absent): FETCH_SIZE + WRITE_SIZE as counted, a lower
+                bound on gfx950; `traffic_fetch_doubled` = with the guide's x2 on FETCH_SIZE, an upper bound.
   roofline_step the same accounting for the whole step (all kernels).
   cpu_baseline  N=1, rank 0 only: the reference binary oracle/_ref/euler_cpu ("reference") -- or the oracle's
                 restatement ("port") -- on ONE host core, on a bounded sample of the same workload (256^3 for the 3D
