@@ -34,8 +34,9 @@ Extra objects on the JSON line:
                 tolerance-grade build (FMA contraction, ~1-ulp division / square root), held to north_star's bar -- relative L2
                 < 1e-12 to euler_cpu -- by tests/test_contracted.py (all fixtures, the full 512^2 x 50 Orszag-Tang gate, 300-400 step
                 runs, the headline-size property checks; worst measured 2e-14).  --arith exact: librgpu.so, bit-identical.
-  value_exact   (N=1, default arithmetic) the same workload, same K and W, through the bit-identical library librgpu.so, with its
-                own roofline.  (--arith exact prints the contracted record beside it as value_tolerance instead.)
+  value_exact   (every N, default arithmetic) the same workload, same K and W, through the bit-identical library librgpu.so (N=1: with its
+                own roofline; N>1: a second RCCL communicator after the first is destroyed).  --arith exact prints the contracted record
+                beside it as value_tolerance instead.  value_arithmetic / metric_version say which build `value` is.
   other_workloads  default headline run only: short measurements of BASELINE configs[1] (implode3d 256^3) and [2]
                 (orszag-tang 512^2) with their own roofline / cpu_baseline.
   config.driver / rccl_ranks / ranks  which slab driver ran, what RCCL itself reports (ncclCommCount), device + PCI bus id per
@@ -189,7 +190,10 @@ def cpu_baseline_all_cores(w, dims):
     every loop nest of the 3D MHD step cut into contiguous slabs of planes, one std::thread each; the flux loop stores its
     fluxes and each cell gathers them in the order the reference's scatter loop delivers them, so the result is deterministic
     and bit-identical to the 1-thread run -- the reference's own OpenMP loops, mhd_godunov_unsplit_cpu_v3.cpp:32-35, 368-371,
-    race on that scatter).  g++ -O2, no -march, threads not pinned (OS scheduler).  3D MHD workloads only."""
+    race on that scatter).  g++ -O2, no -march.  Threads are PINNED and every z-slab of the state and work arrays is first
+    touched by the thread that works on it (orc_set_thread_placement): placement "all" = every allowed CPU in NUMA-node order,
+    "node0" = the first NUMA node alone (one socket); for each a thread-count scan, the best of all is `value`, the rest is in
+    `placements`.  3D MHD workloads only."""
     if w["bytes"] != 128.0 or dims[2] == 1:
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -199,7 +203,7 @@ def cpu_baseline_all_cores(w, dims):
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    e = 256 if _avail_gb() > 1.5 * 1.55e-6 * 262 ** 3 else 128      # ~1.55 kB per cell: 167 work doubles + the two state arrays
+    e = 256 if _avail_gb() > 1.5 * 1.7e-6 * 262 ** 3 else 128      # ~1.7 kB per cell: 167 work doubles + four state arrays
     n = (min(e, dims[0]), min(e, dims[1]), min(e, dims[2]))
     L = load_library()
     ini = os.path.join(ROOT, "configs", w["base"] + ".ini")
@@ -208,24 +212,59 @@ def cpu_baseline_all_cores(w, dims):
     U0 = L.init_condition(ini, ov, p)
     O = Oracle(so)
     cells = n[0] * n[1] * n[2]
-    # thread counts: all hardware threads down to 16 in halves, one step each; then `more` steps with the fastest
-    scan = []
-    t = cores
-    while t >= 16 or not scan:
-        scan.append(t)
-        t //= 2
-    scan = [scan[0]] + scan      # (the first step of a run is cold: page tables, caches -- let it not decide)
-    more = 5
-    secs, used = O.run_mt_scan(p, U0, len(scan) + more, scan, cores)
-    per_step = float(sum(secs[len(scan):]) / max(len(secs) - len(scan), 1))
-    out = {"value": cells / per_step / 1e6, "unit": "Mcell-updates/s", "cores": used, "kind": "port",
-           "sample": "ONE %s box at %dx%dx%d on %d threads of %d (z-slabs of planes; oracle/liboracle.so orc_run_mt_scan, g++ -O2, not pinned): %.2f s per step "
-                     "over %d steps; thread-count scan, one step each: %s" % (w["base"], n[0], n[1], n[2], used, cores, per_step, more,
-                                                                            ", ".join("%d -> %.2f s" % (a, b) for a, b in zip(scan, secs)))}
+    more = 4
+    runs = []
+    for label, mode in (("all", 1), ("node0", 2)):
+        ncpu = O.set_thread_placement(mode)
+        if ncpu <= 0 or (label == "node0" and ncpu >= cores):   # no NUMA information, or a single node: "all" already is it
+            continue
+        # thread counts: the CPUs of the set down to 16 in halves, one step each; then `more` steps with the fastest
+        scan, t = [], ncpu
+        while t >= 16 or not scan:
+            scan.append(t)
+            t //= 2
+        scan = [scan[0]] + scan      # (the first step of a run is cold: page tables, caches -- let it not decide)
+        secs, used = O.run_mt_scan(p, U0, len(scan) + more, scan, ncpu)
+        per_step = float(sum(secs[len(scan):]) / max(len(secs) - len(scan), 1))
+        runs.append({"placement": label, "cpus_in_set": ncpu, "threads": used, "s_per_step": per_step, "value": cells / per_step / 1e6,
+                     "scan": ", ".join("%d -> %.2f s" % (a, b) for a, b in zip(scan, secs))})
+    O.set_thread_placement(0)
+    if not runs:
+        return None
+    best = max(runs, key=lambda r: r["value"])
+    out = {"value": best["value"], "unit": "Mcell-updates/s", "cores": best["threads"], "kind": "port",
+           "sample": "ONE %s box at %dx%dx%d on %d pinned threads (placement %s: %d CPUs; host has %d), z-slabs of planes first touched by their "
+                     "threads; oracle/liboracle.so orc_run_mt_scan, g++ -O2: %.2f s per step over %d steps; thread-count scan, one step each: %s"
+                     % (w["base"], n[0], n[1], n[2], best["threads"], best["placement"], best["cpus_in_set"], cores, best["s_per_step"], more, best["scan"]),
+           "placements": runs}
     ub = cpu_baseline_replicas(w)
     if ub:
         out["upper_bound_replicas"] = ub
     return out
+
+
+_PMC = {}
+
+
+def pmc_summary():
+    """profiles/pmc_traffic.json, or None when it is absent OR was collected on another state of the kernel sources: the summary
+    carries the hash of the device sources it was measured on (ramsesgpu_amd/build.py: kernel_source_hash, recorded by
+    scripts/prof_round.sh); a kernel change without a PMC refresh must not silently skew `traffic` / `valu_ceiling`."""
+    if "d" not in _PMC:
+        _PMC["d"], _PMC["note"] = None, None
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            from ramsesgpu_amd import build as rb
+            d = json.load(open(path))
+            have, want = d.get("_kernel_source_sha"), rb.kernel_source_hash()
+            if have == want:
+                _PMC["d"] = d
+            else:
+                _PMC["note"] = ("profiles/pmc_traffic.json was collected on kernel sources %s, this build is %s: traffic / valu_ceiling withheld "
+                                "(re-run scripts/prof_round.sh + scripts/summarize_prof.py)" % (have, want))
+        except Exception as e:  # noqa: BLE001
+            _PMC["note"] = "no usable profiles/pmc_traffic.json (%r)" % (e,)
+    return _PMC["d"]
 
 
 def pmc_traffic(workload, kernel_phase, doubled_fetch=False):
@@ -234,11 +273,10 @@ def pmc_traffic(workload, kernel_phase, doubled_fetch=False):
     16 B per lane streaming reads, "other widths uncalibrated"); calibrated on this code's own 8 B per lane SoA streams against known byte
     counts it reports 0.49-0.77 of them.  Hence two figures: FETCH + WRITE as counted (a lower bound) and 2 x FETCH + WRITE (the guide's
     correction, an upper bound for these kernels)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
+    d = pmc_summary()
+    if d is None:
         return None
     try:
-        d = json.load(open(path))
         d = d.get(workload, d).get(kernel_phase, {})
         if doubled_fetch:
             return 2.0 * d["fetch_bytes"] + d["write_bytes"]
@@ -259,7 +297,7 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
     SQ_INSTS_VALU_TRANS_F64); an fp64 instruction occupies a SIMD for 4 cycles (16 lanes per cycle), rcp / rsq / sqrt for 16;
     1024 SIMDs at the 2.4 GHz peak clock.  None without the summary."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload][kernel_phase]
+        d = pmc_summary()[workload][kernel_phase]
         insts, trans = d["valu_wave_insts"], d.get("valu_trans_f64_wave_insts", 0.0)
     except Exception:
         return None
@@ -352,8 +390,8 @@ def device_facts(torch, local_rank):
 
 
 def timed_steps(step, timers_src, ctl, steps, warmup):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  Then the same
-    steps again with HIP events around every launch on the kernels' stream -> (elapsed_s, phase seconds, dominant kernel)"""
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns the max over ranks of the wall
+    time of the K steps [s].  (Per-kernel durations are a separate pass: phase_profile.)"""
     for _ in range(warmup):
         step()
     timers_src.enable_timers(False)
@@ -396,6 +434,8 @@ def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
             "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
                      "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
             "valu_ceiling": valu_ceiling(pkey, dom_name, dom_ms / max(dom_launches / nprof, 1.0))}
+    if _PMC.get("note"):
+        roof["pmc_note"] = _PMC["note"]
     step = {"bound": "hbm", "achieved": step_bytes / (elapsed / steps) / 1e9, "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": step_bytes / (elapsed / steps) / HBM_PEAK,
             "phase_ms": {k: v / nprof * 1e3 for k, v in tm.items() if v > 0}, "sum_phase_ms": sum(tm.values()) / nprof * 1e3}
@@ -425,6 +465,28 @@ def single_gpu_record(wname, dims, arith, steps, warmup, ctl):
     roof, roof_step = roofline_of(wname, w, arith, w["bytes"] * cells, elapsed, steps, prof)
     return {"value": steps * cells / elapsed / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
             "roofline": roof, "roofline_step": roof_step, "library": os.path.basename(L.path), "arithmetic": arith, "parity": PARITY[arith]}
+
+
+def slab_driver_run(arith, ini, ov, rank, world, ctl):
+    """rank `rank` of `world` z-slabs through the C++ RCCL driver (librgpu_comm[_fast].so) with the initial condition built and its
+    ghosts filled; (run, info, None), or (None, None, error) on EVERY rank if any rank failed (the ranks agree through ctl)"""
+    from ramsesgpu_amd import comm as rcomm
+    from ramsesgpu_amd.solver import Library, lib_path
+    err, srun, info = None, None, None
+    try:
+        L = Library(lib_path(arith))
+        CL = rcomm.load_comm_library(rcomm.comm_lib_path(arith))
+        cid = ctl.bcast(rcomm.unique_id(CL) if rank == 0 else None)
+        srun = rcomm.CommRun(ini, ov, rank, world, cid, library=L, comm_library=CL)
+    except Exception as e:  # noqa: BLE001 -- reported by the caller, on every rank
+        err = e
+    if ctl.min_int(1 if srun is not None else 0) == 0:
+        if srun is not None:
+            srun.close()
+        return None, None, err
+    info = srun.info()
+    srun.init_simulation()
+    return srun, info, None
 
 
 def main():
@@ -519,7 +581,7 @@ def main():
             srun.upload(L.init_condition(ini, ov, p), both=False)
             srun.make_all_boundaries(0, 0.0, 0.0)
             step, timers_src = srun.oneStepIntegration, srun
-            driver = "independent replicas: librgpu.so per rank, no communicator"
+            driver = "independent replicas: %s per rank, no communicator" % os.path.basename(L.path)
         elif want_python:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from slab_harness import SlabRun
@@ -528,22 +590,13 @@ def main():
             step, timers_src = srun.oneStepIntegration, srun.solver
             driver = "TEST HARNESS (RGPU_BENCH_DRIVER=python): tests/slab_harness.py over torch.distributed/%s -- not the product's driver" % ctl.backend
         else:
-            from ramsesgpu_amd import comm as rcomm
-            err, srun = None, None
-            try:
-                CL = rcomm.load_comm_library(rcomm.comm_lib_path(args.arith))
-                cid = ctl.bcast(rcomm.unique_id(CL) if rank == 0 else None)
-                srun = rcomm.CommRun(ini, ov, rank, world, cid, library=L, comm_library=CL)
-            except Exception as e:  # noqa: BLE001 -- reported below, on every rank, then exit
-                err = e
-            if ctl.min_int(1 if srun is not None else 0) == 0:
+            srun, info, err = slab_driver_run(args.arith, ini, ov, rank, world, ctl)
+            if srun is None:
                 sys.stderr.write("bench.py: rank %d/%d on GPU %d: %s\n" % (rank, world, local_rank,
                                  ("the C++ RCCL slab driver could not be created: %r" % (err,)) if err is not None else "another rank failed to create the C++ RCCL slab driver"))
                 sys.stderr.write("bench.py: no fallback (set RGPU_BENCH_DRIVER=python for the torch.distributed test harness)\n")
                 sys.stderr.flush()
                 sys.exit(5)
-            info = srun.info()
-            srun.init_simulation()
             step, timers_src = srun.oneStepIntegration, srun.solver
             driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h)" % ("" if args.arith == "exact" else "_fast", info["transport"])
         elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
@@ -555,6 +608,21 @@ def main():
         prof = phase_profile(step, timers_src, ctl, args.steps)
         roof, roof_step = roofline_of(args.workload, w, args.arith, w["bytes"] * cells_local, elapsed, args.steps, prof)
         rec = {"value": args.steps * cells_global / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "roofline": roof, "roofline_step": roof_step}
+        if info is not None and not args.no_second and os.environ.get("RGPU_BENCH_SECOND_ARITH", "1") != "0":
+            # the same slabs, same K and W, through the OTHER build of the library (a second RCCL communicator, after the first is
+            # destroyed): `value` stays comparable round over round whichever build is the headline
+            other = "exact" if args.arith == "contracted" else "contracted"
+            srun.close()
+            srun2, info2, err2 = slab_driver_run(other, ini, ov, rank, world, ctl)
+            if srun2 is None:
+                rec["second"] = (other, {"value": None, "error": repr(err2) if err2 is not None else "another rank failed"})
+            else:
+                el2 = timed_steps(srun2.oneStepIntegration, srun2.solver, ctl, args.steps, args.warmup)
+                rec["second"] = (other, {"value": args.steps * cells_global / el2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": el2 / args.steps * 1e3,
+                                         "steps": args.steps, "warmup": args.warmup, "arithmetic": other, "parity": PARITY[other],
+                                         "library": "librgpu_comm%s.so + %s" % ("" if other == "exact" else "_fast", os.path.basename(srun2.L.path)),
+                                         "rccl_ranks": info2["ranks"]})
+                srun2.close()
         mine = dict(device_facts(torch, local_rank), rank=rank)
         if info is not None:
             mine.update(rccl_rank=info["rank"], rccl_ranks=info["ranks"], rccl_device=info["device"], rccl_pci_bus_id=info["pci_bus_id"])
@@ -572,6 +640,9 @@ def main():
     if rank == 0:
         out = {
             "metric": "Mcell-updates/s", "value": rec["value"], "unit": "Mcell-updates/s",
+            # which build of the library `value` is: since round 3 the tolerance-grade one by default (metric_version 2; rounds 1-2
+            # quoted the bit-identical library -- compare those with value_exact, which rides beside `value` at every N)
+            "value_arithmetic": args.arith, "metric_version": 2,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
@@ -585,6 +656,8 @@ def main():
                        "parity": PARITY[args.arith]},
             "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],
         }
+        if world > 1 and rec.get("second"):
+            out["value_exact" if rec["second"][0] == "exact" else "value_tolerance"] = rec["second"][1]
         if world == 1 and not args.no_second:
             # the same workload, same K and W, through the OTHER build of the library, with its own roofline: the bit-identical one
             # beside the default tolerance-grade headline (value_exact), or the other way round with --arith exact (value_tolerance)

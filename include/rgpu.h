@@ -185,6 +185,11 @@ double* rgpu_device_state(rgpu_ctx* c, int parity);
 int rgpu_get_params(rgpu_ctx* c, rgpu_params* out);
 void* rgpu_stream_handle(rgpu_ctx* c);
 double* rgpu_inv_dt_device_slot(rgpu_ctx* c);
+/* The slot is the first of RGPU_DT_SLOTS doubles (zero at create): the update kernels that carry the CFL scan of the new state
+ * spread their maxima over all of them (rgpu_inv_dt_fused_commit).  A communication layer all-reduces ALL RGPU_DT_SLOTS values,
+ * whatever the step left in them -- a fixed count, so that ranks in different states (first step, a failed step piece) can never
+ * post all-reduces of different sizes; rgpu_inv_dt_result reads the ones that are valid. */
+#define RGPU_DT_SLOTS 1024
 
 /* ---- the path ------------------------------------------------------------------------------------------- */
 

@@ -2,6 +2,7 @@
 // tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg ONLY.  The product never links this.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 
 #include <vector>
 
@@ -258,17 +259,29 @@ int orc_run_mt_scan(const rgpu_params* p, double* U, int nStepmax, double tEnd, 
       p->slope_type == 3)
     return RGPU_EUNSUPPORTED;
   const size_t n = c.ncell * c.nvar;
-  std::vector<double> U2(n);
   make_all_boundaries(c, U, 0.0, 0.0);
-  std::memcpy(U2.data(), U, sizeof(double) * n);
   int most = nthreads;
   for (int i = 0; i < nscan; ++i) most = scan[i] > most ? scan[i] : most;
+  // the two state arrays of the run: pages FIRST TOUCHED slab by slab by the threads that will work on them (the caller's array
+  // lives wherever the caller's one thread put it: on a two-socket host every other slab would stream it across the link)
+  struct Buf { double* p; Buf(size_t k) : p(static_cast<double*>(std::malloc(k * sizeof(double)))) {} ~Buf() { std::free(p); } };
+  Buf Ua(n), Ub(n);
+  if (!Ua.p || !Ub.p) return RGPU_ENOMEM;
+  {
+    const size_t plane = (size_t)c.isize * c.jsize, N = c.ncell;
+    slabs(0, c.ksize, most, [&](int ka, int kb) {
+      for (int v = 0; v < c.nvar; ++v) {
+        std::memcpy(Ua.p + v * N + plane * ka, U + v * N + plane * ka, sizeof(double) * plane * (kb - ka));
+        std::memcpy(Ub.p + v * N + plane * ka, U + v * N + plane * ka, sizeof(double) * plane * (kb - ka));
+      }
+    });
+  }
   MtWork work(c, most);
   double t = 0.0, best = 1e300;
   int nStep = 0, use = nthreads;
   while (t < tEnd && nStep < nStepmax) {
-    double* cur = (nStep % 2 == 0) ? U : U2.data();
-    double* nxt = (nStep % 2 == 0) ? U2.data() : U;
+    double* cur = (nStep % 2 == 0) ? Ua.p : Ub.p;
+    double* nxt = (nStep % 2 == 0) ? Ub.p : Ua.p;
     const int nt = nStep < nscan ? scan[nStep] : use;
     const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     const double dt = p->cfl / compute_inv_dt_mhd3d_mt(c, cur, nt);
@@ -280,12 +293,15 @@ int orc_run_mt_scan(const rgpu_params* p, double* U, int nStepmax, double tEnd, 
     nStep++;
     t += dt;
   }
-  if (nStep % 2 == 1) std::memcpy(U, U2.data(), sizeof(double) * n);
+  std::memcpy(U, (nStep % 2 == 1) ? Ub.p : Ua.p, sizeof(double) * n);
   if (nsteps_done) *nsteps_done = nStep;
   if (t_final) *t_final = t;
   if (threads_used) *threads_used = use;
   return 0;
 }
+// placement of the threads of orc_run_mt / orc_run_mt_scan: 0 = not pinned, 1 = pinned over all allowed CPUs in NUMA-node order,
+// 2 = pinned inside the first NUMA node (one socket); returns the number of CPUs in the set (0: unpinned)
+int orc_set_thread_placement(int mode) { return set_thread_placement(mode); }
 int orc_run_mt(const rgpu_params* p, double* U, int nStepmax, double tEnd, int nthreads, int* nsteps_done, double* t_final, double* dts) {
   return orc_run_mt_scan(p, U, nStepmax, tEnd, nthreads, 0, 0, nsteps_done, t_final, dts, 0, 0);
 }

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/rgpu.h"
@@ -92,6 +93,21 @@ struct MtWork {   // the step's intermediate arrays, kept across the steps of a 
  private:
   MtWork(const MtWork&); MtWork& operator=(const MtWork&);
 };
+// thread placement of the threaded variants (orc_mhd3d.cpp): see set_thread_placement
+int set_thread_placement(int mode);           // 0 unpinned, 1 pinned over all allowed CPUs (NUMA-major order), 2 pinned inside NUMA node 0; returns CPUs in the set
+void pin_slab_thread(int t, int nthreads);    // called by thread t of n at its start
+template <class F>
+void slabs(int k0, int k1, int nthreads, F fn) {   // fn(ka, kb) on [k0, k1) cut into nthreads contiguous pieces, one std::thread each
+  const int n = k1 - k0;
+  if (nthreads <= 1 || n <= 1) { fn(k0, k1); return; }
+  if (nthreads > n) nthreads = n;
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t) {
+    const int a = k0 + (int)((long long)n * t / nthreads), b = k0 + (int)((long long)n * (t + 1) / nthreads);
+    th.emplace_back([=]() { pin_slab_thread(t, nthreads); fn(a, b); });
+  }
+  for (auto& x : th) x.join();
+}
 void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold, double* Unew, double dt, double totalTime, int nthreads);   // orc_mhd3d.cpp
 double compute_inv_dt_mhd3d_mt(const Ctx& c, const double* U, int nthreads);                                // orc_mhd3d.cpp
 

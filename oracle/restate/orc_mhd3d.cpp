@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <new>
 #include <thread>
+#include <algorithm>
+#include <string>
+#include <sched.h>
 
 namespace orc {
 
@@ -128,18 +131,7 @@ void trace_mhd_3d(const rgpu_params& g, const double q[8], double dq[3][8], cons
 // (Coriolis, +Fx, +Fy, +Fz of its own iteration, then -Fx(i+1), -Fy(j+1), -Fz(k+1)): deterministic, and bit-identical to
 // mhd_step_3d for any thread count (tests/test_oracle_golden.py::test_threaded_step_equals_sequential).  Scope: the
 // configurations of the bench (no gravity, no dissipative stage, no forcing) -- orc_run_mt refuses the others.
-template <class F>
-void slabs(int k0, int k1, int nthreads, F fn) {   // fn(ka, kb) on [k0, k1) cut into nthreads contiguous pieces
-  const int n = k1 - k0;
-  if (nthreads <= 1 || n <= 1) { fn(k0, k1); return; }
-  if (nthreads > n) nthreads = n;
-  std::vector<std::thread> th;
-  for (int t = 0; t < nthreads; ++t) {
-    const int a = k0 + (int)((long long)n * t / nthreads), b = k0 + (int)((long long)n * (t + 1) / nthreads);
-    th.emplace_back([=]() { fn(a, b); });
-  }
-  for (auto& x : th) x.join();
-}
+using orc::slabs;   // orc_common.h: [k0, k1) cut into contiguous pieces, one (optionally pinned) std::thread each
 
 }  // namespace
 
@@ -482,6 +474,91 @@ MtWork::MtWork(const Ctx& c, int nthreads) : buf(0), doubles(0) {
   });
 }
 MtWork::~MtWork() { std::free(buf); }
+
+// ---- thread placement of the all-cores baseline (bench.py: cpu_baseline_all_cores) ------------------------------------------
+// mode 0: threads not pinned (OS scheduler).  1: thread t of n is pinned to the CPU at fraction t / n of the list of allowed CPUs
+// ordered NUMA node by NUMA node (and, inside a node, physical core by physical core with its SMT siblings adjacent) -- the
+// planes at fraction f of the box are then worked on by the same NUMA node for every thread count, which is also the node that
+// first touched them (MtWork, the state copies of orc_run_mt_scan).  2: the same inside NUMA node 0 only (one socket).
+namespace {
+struct Placement { int mode; std::vector<int> cpus; };
+Placement& placement() { static Placement p = {0, std::vector<int>()}; return p; }
+bool read_int(const std::string& path, long& v) {
+  FILE* f = std::fopen(path.c_str(), "r");
+  if (!f) return false;
+  const bool ok = std::fscanf(f, "%ld", &v) == 1;
+  std::fclose(f);
+  return ok;
+}
+std::vector<int> parse_cpulist(const std::string& path) {   // "0-63,128-191"
+  std::vector<int> out;
+  FILE* f = std::fopen(path.c_str(), "r");
+  if (!f) return out;
+  char buf[4096];
+  if (std::fgets(buf, sizeof(buf), f)) {
+    const char* s = buf;
+    while (*s) {
+      char* e;
+      const long a = std::strtol(s, &e, 10);
+      if (e == s) break;
+      long b = a;
+      s = e;
+      if (*s == '-') { b = std::strtol(s + 1, &e, 10); s = e; }
+      for (long c = a; c <= b; ++c) out.push_back((int)c);
+      if (*s == ',') ++s; else break;
+    }
+  }
+  std::fclose(f);
+  return out;
+}
+}  // namespace
+
+int set_thread_placement(int mode) {
+  Placement& P = placement();
+  P.mode = 0;
+  P.cpus.clear();
+  if (mode <= 0) return 0;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+  struct Cpu { int node; long pkg, core; int id; };
+  std::vector<Cpu> all;
+  for (int node = 0; node < 64; ++node) {
+    const std::vector<int> l = parse_cpulist("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    for (int id : l) {
+      if (id >= CPU_SETSIZE || !CPU_ISSET(id, &allowed)) continue;
+      long pkg = 0, core = id;
+      read_int("/sys/devices/system/cpu/cpu" + std::to_string(id) + "/topology/physical_package_id", pkg);
+      read_int("/sys/devices/system/cpu/cpu" + std::to_string(id) + "/topology/core_id", core);
+      const Cpu c = {node, pkg, core, id};
+      all.push_back(c);
+    }
+  }
+  if (all.empty())   // no NUMA information: the allowed CPUs in numerical order, one node
+    for (int id = 0; id < CPU_SETSIZE; ++id)
+      if (CPU_ISSET(id, &allowed)) { const Cpu c = {0, 0, id, id}; all.push_back(c); }
+  std::sort(all.begin(), all.end(), [](const Cpu& a, const Cpu& b) {
+    if (a.node != b.node) return a.node < b.node;
+    if (a.pkg != b.pkg) return a.pkg < b.pkg;
+    if (a.core != b.core) return a.core < b.core;
+    return a.id < b.id;
+  });
+  const int first_node = all.empty() ? 0 : all[0].node;
+  for (const Cpu& c : all)
+    if (mode == 1 || c.node == first_node) P.cpus.push_back(c.id);
+  P.mode = P.cpus.empty() ? 0 : mode;
+  return (int)P.cpus.size();
+}
+
+void pin_slab_thread(int t, int nthreads) {
+  const Placement& P = placement();
+  if (P.mode == 0 || P.cpus.empty()) return;
+  const size_t i = (size_t)t * P.cpus.size() / (size_t)(nthreads > 0 ? nthreads : 1);
+  cpu_set_t one;
+  CPU_ZERO(&one);
+  CPU_SET(P.cpus[i < P.cpus.size() ? i : P.cpus.size() - 1], &one);
+  (void)sched_setaffinity(0, sizeof(one), &one);   // tid 0 = the calling thread
+}
 
 void mhd_step_3d_mt(const Ctx& c, MtWork& w, double* Uold_d, double* Unew_d, double dt, double totalTime, int nthreads) {
   static const bool timing = std::getenv("ORC_MT_TIMING") != 0;

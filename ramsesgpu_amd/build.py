@@ -35,6 +35,55 @@ def _newer(target, sources):
 FAST_FLAGS = ["-DRG_ARITH_FAST=2", "-ffp-contract=fast"]
 
 
+def resources_path(out_name="librgpu.so"):
+    """the compiler's kernel-resource-usage remarks of the last device compile of `out_name`"""
+    return os.path.join(HERE, "..", "build", "obj_" + out_name.replace(".", "_"), "kernel_resources.txt")
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the device sources -- csrc/*.h, csrc/hip/*.h, csrc/rgpu_api.cpp with // comments and whitespace runs
+    removed -- so that numbers MEASURED on one state of the kernels (profiles/pmc_traffic.json: instruction counts, HBM bytes) are
+    not quoted for another: scripts/prof_round.sh records it with the counters, bench.py compares before it uses them"""
+    import hashlib
+    import re
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
+        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h")] + [os.path.join(CSRC, "rgpu_api.cpp")]
+    h = hashlib.sha256()
+    for f in files:
+        text = re.sub(r"//[^\n]*", "", open(f).read())
+        h.update(os.path.basename(f).encode())
+        h.update(re.sub(r"\s+", " ", text).encode())
+    return h.hexdigest()[:16]
+
+
+def kernel_resources(out_name="librgpu.so"):
+    """{demangled kernel name: {"vgprs", "agprs", "sgprs", "sgpr_spill", "vgpr_spill", "scratch", "lds", "occupancy"}} parsed from
+    resources_path(out_name); {} when the library was built without it (an older build.py)"""
+    import re
+    path = resources_path(out_name)
+    if not os.path.exists(path):
+        return {}
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "ScratchSize [bytes/lane]": "scratch", "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy"}
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    mangled = list(out)
+    if mangled:
+        try:
+            dem = subprocess.run(["c++filt"], input="\n".join(mangled), stdout=subprocess.PIPE, universal_newlines=True).stdout.split("\n")
+            out = {d: out[m] for m, d in zip(mangled, dem)}
+        except OSError:
+            pass
+    return out
+
+
 def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     """out_name "librgpu.so": the product (+ librgpu_comm.so, euler_hip); "librgpu_fast.so": the contracted-arithmetic
     variant (FAST_FLAGS are added, + librgpu_comm_fast.so); any other name: an experiment build of the library alone"""
@@ -56,12 +105,22 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         for i, src in enumerate(srcs):
             obj = os.path.join(objdir, os.path.basename(src) + ".o")
             if i == 0:
-                cmd = [HIPCC, "--offload-arch=" + ARCH] + COMMON + list(extra_flags) + ["-x", "hip", "-c", src, "-o", obj]
+                # the device compile also reports what every kernel needs (registers, spills, scratch, LDS, occupancy): kept next
+                # to the objects and checked by tests/test_kernel_resources.py -- the speed of the sweeps hangs on these numbers
+                cmd = [HIPCC, "--offload-arch=" + ARCH] + COMMON + list(extra_flags) + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", src, "-o", obj]
             else:
                 cmd = [HIPCC] + COMMON + ["-x", "c++", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            if i == 0:
+                r = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+                with open(resources_path(out_name), "w") as f:
+                    f.write(r.stderr)
+                if r.returncode != 0:
+                    sys.stderr.write(r.stderr[-20000:])
+                    raise subprocess.CalledProcessError(r.returncode, cmd)
+            else:
+                subprocess.check_call(cmd)
             objs.append(obj)
         # -Bsymbolic-functions: calls between the library's own exported functions bind inside the library (librgpu.so and
         # librgpu_fast.so export the same names and may share a process)

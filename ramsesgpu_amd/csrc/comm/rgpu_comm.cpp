@@ -34,7 +34,6 @@ struct rgpu_comm {
   // returns an error from the same rgpu_comm_compute_dt instead of one rank leaving the others in a collective.
   bool fuse_scan;   // every rank's configuration lets the update pieces carry the CFL scan (agreed at create)
   int poisoned;
-  int last_nslots;  // slot count of the last 1/dt all-reduce (what the peers will use again in the steady state)
   int exchanges_posted, exchanges_expected;   // halo exchanges of the current step: posted so far / what the neighbours will post
   std::string err;
 };
@@ -119,12 +118,14 @@ int compute_dt(rgpu_comm* cm, int useU, double* dt) {
     cm->scan_slots = 0;
   }
   cm->scanned = -1;
-  const int nslots = cm->poisoned ? cm->last_nslots : (cm->scan_slots > 0 ? cm->scan_slots : 1);   // the update kernels left their maxima in several slots
   cm->scan_slots = 0;
-  cm->last_nslots = nslots;
   if (cm->nranks > 1) {
+    // ALWAYS all RGPU_DT_SLOTS slots (8 KB: latency-bound like 8 B): how many of them a rank's last step filled depends on its
+    // state -- 1 after a full scan (first step, serial schedule), all of them after the fused scan of the overlapped schedule --
+    // and a rank whose step piece failed has no state its peers share; a fixed count cannot mismatch.  Slot 0 is read in every
+    // state, so +inf there reaches every rank.
     if (cm->poisoned) (void)rgpu_transport::poison_slot(cm->tc, rgpu_inv_dt_device_slot(c), rgpu_stream_handle(c));
-    if (rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), nslots, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
+    if (rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c))) return tr_fail(cm, "allreduce(1/dt)");
   }
   if (cm->poisoned) return cm->poisoned;   // message of the failed piece is in cm->err
   double inv = 0.0;
@@ -255,7 +256,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
   cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
-  cm->fuse_scan = false; cm->last_nslots = 1; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0;
+  cm->fuse_scan = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
   if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");

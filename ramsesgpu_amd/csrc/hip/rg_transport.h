@@ -5,7 +5,9 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 
 #define RG_TRANSPORT_NAME "rccl"
@@ -21,7 +23,17 @@ struct Comm {
   double* scratch;   // device scratch for host-value reductions
   int rank, nranks;
   std::string err;
+  // MEASUREMENT knob (scripts/slab_probe.py; off unless RGPU_COMM_EMULATE_GBPS is set): a one-GPU probe exchanges its halo planes
+  // with itself, device-local, in ~0.03 ms; with the knob the halo stream is held for the time the same bytes would need on ONE
+  // xGMI link at that rate -- RGPU_COMM_EMULATE_PEERS = 2: the two neighbours are different GPUs (N >= 3: two links in parallel,
+  // the per-peer bytes count), 1: both neighbours are the same GPU (N = 2: all bytes over one link)
+  double emulate_gbps; int emulate_peers; long long emulate_ns;
 };
+inline void emulated_link_sleep(void* ns) {   // hipLaunchHostFunc: the stream waits until this returns
+  const long long t = *static_cast<long long*>(ns);
+  timespec ts; ts.tv_sec = (time_t)(t / 1000000000ll); ts.tv_nsec = (long)(t % 1000000000ll);
+  nanosleep(&ts, 0);
+}
 
 inline int fail(Comm* c, const std::string& m) { if (c) c->err = m; return -1; }
 
@@ -37,6 +49,9 @@ inline int unique_id(char* id128) {
 inline int create(Comm** out, int rank, int nranks, const char* id128) {
   Comm* c = new Comm();
   c->comm = 0; c->halo = 0; c->ev_ready = 0; c->ev_done = 0; c->scratch = 0; c->rank = rank; c->nranks = nranks;
+  c->emulate_gbps = std::getenv("RGPU_COMM_EMULATE_GBPS") ? std::atof(std::getenv("RGPU_COMM_EMULATE_GBPS")) : 0.0;
+  c->emulate_peers = std::getenv("RGPU_COMM_EMULATE_PEERS") ? std::atoi(std::getenv("RGPU_COMM_EMULATE_PEERS")) : 2;
+  c->emulate_ns = 0;
   *out = c;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
@@ -72,6 +87,12 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
                     : ncclRecv(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo);
   const ncclResult_t re = ncclGroupEnd();
   if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+  if (c->emulate_gbps > 0) {   // measurement knob, see Comm
+    size_t sent = 0;
+    for (int i = 0; i < nops; ++i) if (ops[i].send) sent += ops[i].count * sizeof(double);
+    c->emulate_ns = (long long)((double)sent / (c->emulate_peers >= 2 ? 2.0 : 1.0) / c->emulate_gbps);   // bytes / (GB/s) = ns
+    if (hipLaunchHostFunc(c->halo, emulated_link_sleep, &c->emulate_ns) != hipSuccess) return fail(c, "hipLaunchHostFunc");
+  }
   if (hipEventRecord(c->ev_done, c->halo) != hipSuccess) return fail(c, "event record");
   return 0;
 }

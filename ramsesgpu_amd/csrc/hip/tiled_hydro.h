@@ -431,21 +431,6 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
   // update a cell)
   constexpr int TX = 16, TY = 16;
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
-#ifdef RG_HYDRO_TILE_EXPERIMENT   // experiment builds only: other thread-tile shapes for the HLLC / slope-1 kernel
-  {
-    static const char* tile = std::getenv("RGPU_HYDRO_TILE");
-    const int SP = SPEC_HYDRO_HLLC | SPEC_SLOPE1 | SPEC_NO_GRAVITY;
-    if (tile && spec_matches(SP, g)) {
-      const std::string ts = tile;
-      if (ts == "32x16") return launch_hydro3d_sweep<32, 16, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-      if (ts == "64x8") return launch_hydro3d_sweep<64, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-      if (ts == "64x4") return launch_hydro3d_sweep<64, 4, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-      if (ts == "32x8") return launch_hydro3d_sweep<32, 8, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-      if (ts == "32x8w3") return launch_hydro3d_sweep<32, 8, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-      if (ts == "64x4w3") return launch_hydro3d_sweep<64, 4, SP, 3>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
-    }
-  }
-#endif
   if (!no_spec) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
 #define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot)

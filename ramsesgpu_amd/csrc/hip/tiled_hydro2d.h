@@ -238,19 +238,6 @@ inline bool hydro2d_step_covers(const DevParams& g) { return tiled_enabled() && 
 inline int hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy, unsigned long long* dt_slots, int images) {
   if (!hydro2d_step_covers(g)) return 1;
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
-#ifdef RG_HYDRO_TILE_EXPERIMENT   // experiment builds only: other thread-tile shapes for the HLLC / slope-1 kernel
-  {
-    static const char* tile = std::getenv("RGPU_HYDRO2D_TILE");
-    const int SP = SPEC_HYDRO_HLLC | SPEC_SLOPE2 | SPEC_NO_GRAVITY;
-    if (tile && spec_matches(SP, g)) {
-      const std::string ts = tile;
-      if (ts == "32x16") return launch_hydro2d_step<32, 16, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images);
-      if (ts == "32x8") return launch_hydro2d_step<32, 8, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images);
-      if (ts == "64x8") return launch_hydro2d_step<64, 8, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images);
-      if (ts == "64x4") return launch_hydro2d_step<64, 4, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images);
-    }
-  }
-#endif
   constexpr int TX = 16, TY = 16;
 #define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro2d_step<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images);
   if (!no_spec) {

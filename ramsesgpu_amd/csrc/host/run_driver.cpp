@@ -163,6 +163,11 @@ void GodunovRun::outputVtk(int nStep) {
   }
   // appended raw doubles: the bytes of the reference's file (no XML declaration in this mode), followed by ONE comment line
   // with what a restart needs besides the fields (the reference keeps them as HDF5 attributes "time step" / "total time")
+  // the format's per-array byte count is a uint32 (the reference's files: HydroRunBase.cpp:2974-2995): >= 4 GiB per variable cannot
+  // be described -- say so instead of writing a corrupt header (HDF5 output has no such limit)
+  if (sizeof(double) * (size_t)nx * ny * nz > UINT32_MAX)
+    throw std::runtime_error("outputVtk: " + std::to_string(sizeof(double) * (size_t)nx * ny * nz) + " bytes per variable exceed the uint32 byte count of the "
+                             "appended-raw .vti format; use [output] outputHdf5=yes (or outputVtkAscii=yes) for this box");
   const uint32_t nbytes = static_cast<uint32_t>(sizeof(double) * nx * ny * nz);
   out << "<VTKFile type=\"ImageData\" version=\"0.1\" byte_order=\"LittleEndian\">\n";
   out << "  <ImageData WholeExtent=\"0 " << nx - 1 << " 0 " << ny - 1 << " 0 " << nz - 1 << "\" Origin=\"0 0 0\" Spacing=\"1 1 1\">\n";
@@ -246,6 +251,9 @@ void GodunovRun::outputVtkSlab(int nStep) {
       out << "    </PointData>\n    <CellData>\n    </CellData>\n  </Piece>\n  </ImageData>\n</VTKFile>\n";
     } else {
       const size_t tuples = (size_t)nx * ny * (size_t)(k1 - k0);
+      if (tuples * sizeof(double) > UINT32_MAX)   // caught below: every rank then fails the output step together (hooks.agree)
+        throw std::runtime_error("outputVtk: " + std::to_string(tuples * sizeof(double)) + " bytes per variable in this rank's piece exceed the uint32 byte "
+                                 "count of the appended-raw .vti format; use [output] outputHdf5=yes for this box");
       const uint32_t nbytes = static_cast<uint32_t>(tuples * sizeof(double));
       for (int v = 0; v < p_.nbVar; ++v)
         out << "     <DataArray type=\"Float64\" Name=\"" << names[v] << "\" format=\"appended\" offset=\""

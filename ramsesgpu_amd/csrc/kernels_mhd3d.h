@@ -30,21 +30,6 @@ RG_DEVFN IJK unflatten(const DevParams& g, unsigned idx) {
 }
 
 // slots of the compact traced state T
-#ifdef RG_T_AOS
-// experiment (hip/tiled_mhd.h keeps T cell-major in LDS): groups on even slots, so that two neighbouring components of one
-// cell are one aligned 16-byte LDS access
-enum {
-  T_R = 0, T_P, T_U, T_V, T_W, T_A, T_B, T_C,       // advanced cell-centred state
-  T_DX = 8,                                          // 8..14: x half slopes of r,p,u,v,w then B, C
-  T_AL = 15,
-  T_DY = 16,                                         // 16..22: y half slopes of r,p,u,v,w then A, C
-  T_BL = 23,
-  T_DZ = 24,                                         // 24..30: z half slopes of r,p,u,v,w then A, B
-  T_CL = 31,
-  T_DALY = 32, T_DALZ, T_DBLX, T_DBLZ, T_DCLX, T_DCLY,   // 32..37: transverse half slopes of the low faces
-  T_COUNT                                            // 38
-};
-#else
 enum {
   T_R = 0, T_P, T_U, T_V, T_W, T_A, T_B, T_C,       // advanced cell-centred state
   T_AL, T_BL, T_CL,                                  // advanced low-face field
@@ -54,7 +39,6 @@ enum {
   T_DALY = T_DZ + 7, T_DALZ, T_DBLX, T_DBLZ, T_DCLX, T_DCLY,   // 32..37: transverse half slopes of the low faces
   T_COUNT                                            // 38
 };
-#endif
 // flux array F: 5 hydro components per direction, in the FACE-NORMAL frame
 enum { F_X = 0, F_Y = 5, F_Z = 10, F_COUNT = 15 };
 enum { EMF_Z = 0, EMF_Y = 1, EMF_X = 2 };            // EmfIndex, constants.h:191-195

@@ -255,8 +255,10 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
     if (alloc_zero(c, &c->shear_save, 2 * P) || alloc_zero(c, &c->shear_remap, 2 * P))
       return fail(c, RGPU_ENOMEM, "device allocation of the shear buffers failed");
   }
-  if (rg_malloc((void**)&c->d_red, RG_DT_SLOTS * sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, RG_DT_SLOTS * sizeof(unsigned long long)))
-    return fail(c, RGPU_ENOMEM, "allocation of the reduction slot failed");
+  static_assert((int)RG_DT_SLOTS == RGPU_DT_SLOTS, "include/rgpu.h promises RGPU_DT_SLOTS device slots");
+  if (rg_malloc((void**)&c->d_red, RG_DT_SLOTS * sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, RG_DT_SLOTS * sizeof(unsigned long long)) ||
+      rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream))
+    return fail(c, RGPU_ENOMEM, "allocation of the reduction slots failed");
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
   // sub-band size (cells) of the XCD-aware workgroup order, 0 = linear order (rg_backend.h: rg_launch_planes)
@@ -868,11 +870,19 @@ int dissipative_nd(rgpu_ctx* c, double* U, double dt, double nu, double eta) {
   return 0;
 }
 
+// Every entry point that WRITES a state array outside the step kernels calls this: what the context remembers about that state --
+// the CFL maximum a kernel left in the device slots (fused_dt_parity), a scan being accumulated piece by piece
+// (scan_acc_parity), ghost cells the step kernel wrote itself (ghost_ok_parity) -- is void from here on.
+inline void state_modified(rgpu_ctx* c) {
+  c->fused_dt_parity = -1;
+  c->scan_acc_parity = -1;
+  c->ghost_ok_parity = -1;
+}
+
 int step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime, bool fill_ghosts = true) {
   const double nu = c->p.nu, eta = c->p.mhdEnabled ? c->p.eta : 0.0;
   if (!(nu > 0 || eta > 0)) return 0;
-  c->fused_dt_parity = -1;
-  c->scan_acc_parity = -1;
+  state_modified(c);
   Phase ph(c, RGPU_T_DISSIPATIVE);
   double* U = c->U[(nStep + 1) % 2];
   int rc = 0;
@@ -987,8 +997,7 @@ double forcing_norm(const rgpu_params& p, const double* s, double dt) {   // Hyd
 }
 
 int add_forcing(rgpu_ctx* c, int parity, double norm) {
-  c->fused_dt_parity = -1;
-  c->scan_acc_parity = -1;
+  state_modified(c);
   K_add_forcing k = {c->g, c->U[parity & 1], c->Frc, norm};
   return launch_planes<kBlock, 1>(c->stream, c->g, clip(c->g.gw, c->g.ksize - c->g.gw, c->g.ksize), k);
 }
@@ -996,8 +1005,7 @@ int add_forcing(rgpu_ctx* c, int parity, double norm) {
 // Ornstein-Uhlenbeck forcing on U[parity]: advance the modes on the host, then one kernel over the interior planes
 int step_ou_forcing(rgpu_ctx* c, int parity, double dt) {
   if (!c->ou) return 0;
-  c->fused_dt_parity = -1;
-  c->scan_acc_parity = -1;
+  state_modified(c);
   Phase ph(c, RGPU_T_UPDATE);
   c->ou->update(dt, c->p.cIso);
   K_ou_forcing k = {c->g, c->U[parity & 1], c->ou->m, dt, c->p.yMin, c->p.zMin, c->p.slab_rank * c->p.nz};
@@ -1069,9 +1077,7 @@ const char* rgpu_last_error(rgpu_ctx* c) { return c ? c->err.c_str() : "null con
 
 int rgpu_upload(rgpu_ctx* c, const double* hU, int both) {
   RG_CHECK_CTX(c);
-  c->fused_dt_parity = -1;
-  c->scan_acc_parity = -1;
-  c->ghost_ok_parity = -1;
+  state_modified(c);
   if (!hU || !c->U[0]) return fail(c, RGPU_EINVAL, "upload: null pointer / context without state");
   const size_t bytes = c->ncell * (size_t)c->p.nbVar * sizeof(double);
   if (rg_copy_h2d(c->U[0], hU, bytes, c->stream)) return RG_HIPFAIL(c, "upload");
@@ -1185,9 +1191,7 @@ static void boundary_call_invalidates_dt(rgpu_ctx* c, int parity, int dim_lo, in
 
 int rgpu_invalidate_dt(rgpu_ctx* c) {
   if (!c) return RGPU_EINVAL;
-  c->fused_dt_parity = -1;
-  c->scan_acc_parity = -1;
-  c->ghost_ok_parity = -1;
+  state_modified(c);
   return RGPU_OK;
 }
 

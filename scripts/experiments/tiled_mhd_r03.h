@@ -46,12 +46,32 @@ constexpr int MH_THREADS = 512;
 #define RG_SWEEP_SPLIT_LOOPS 1
 #endif
 #endif
-constexpr int MH_SX = MH_OX, MH_SY = MH_OY;       // tile pitch = tile size: every Riemann problem is solved by exactly one tile
+#ifndef RG_E_LATE   // experiment (split loops only): the edge electric field of plane kk+3 by the producer pair at the END of iteration kk
+#define RG_E_LATE 0
+#endif
+#ifndef RG_SWEEP_LB   // experiment (ISA inspection only): 768 = the register budget of three waves per SIMD (168 VGPRs)
+#define RG_SWEEP_LB MH_THREADS
+#endif
+// Experiment (RG_EXP_TILE_STRIDE): tiles placed every 15 x 7 cells although each still solves 16 x 8 problems -- the Riemann
+// work of a sweep whose tiles FINISH the cells they own (a fused flux + update kernel must own both faces of a cell in x and
+// y, i.e. (OX - 1) x (OY - 1) cells per tile).  Overlapping tiles write the same doubles twice; results are unchanged.
+#ifdef RG_EXP_TILE_STRIDE
+constexpr int MH_SX = MH_OX - 1, MH_SY = MH_OY - 1;
+#else
+constexpr int MH_SX = MH_OX, MH_SY = MH_OY;
+#endif
 
+#ifdef RG_T_AOS
+struct TLdsWrite {   // cell-major: the 38 components of a traced cell are contiguous (stride 76 dwords: conflict-free 16-byte accesses)
+  double* cell;
+  RG_DEVFN void put(int slot, double v) const { cell[slot] = v; }
+};
+#else
 struct TLdsWrite {
   double* cell;
   RG_DEVFN void put(int slot, double v) const { cell[slot * MH_CELLS] = v; }
 };
+#endif
 struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B, planes kk, kk+1 of E
   const double* qb[3]; const double* eb[2];
   const int* flag; int want;   // E of plane kk+1 is complete once *flag >= want (written by the Riemann waves)
@@ -72,7 +92,11 @@ struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q 
 // component when the plane above has been traced (see "carried states" below).
 struct TLdsPlane {
   const double* base;
+#ifdef RG_T_AOS
+  RG_DEVFN double get(int slot, unsigned m) const { return base[(int)m * T_COUNT + slot]; }
+#else
   RG_DEVFN double get(int slot, unsigned m) const { return base[slot * MH_CELLS + m]; }
+#endif
   RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)MH_PX : 0u; }
 };
 
@@ -87,55 +111,69 @@ struct TLdsPlane {
 // first 70 % of its work both finish together.
 template <int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
-                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop, bool flux_first) {
   const size_t N = g.ncell;
   const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  // flux_first (wave-uniform): the face problem before the edge problem.  The two Riemann waves of a SIMD then start a plane
+  // with different LDS appetites (2 face states against 4 edge states) instead of both queueing at the LDS at once.
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
     if (solve) {
+      auto face = [&]() {
+        Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<XD>(g, L, R, xPos, fl);
+        store_flux<XD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);        // b2 = CL(m2) + s1 * dCLy(m2), s1 = +1, m2 = the cell above
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<XD>(g, L, R, xPos, fl);
-      store_flux<XD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = edge_state3d<0, +1, +1, false>(g, Tk, m - sj, idx);
     c1 = edge_state3d<0, -1, +1, false>(g, Tk, m, idx);
   } else if (DIR == YD) {   // edge along y: t1 = z, t2 = x.  rt = (+,+) from c-z-x, rb = (+,-) from c-z, lt = (-,+) from c-x, lb from c
     if (solve) {
+      auto face = [&]() {
+        Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<YD>(g, L, R, xPos, fl);
+        store_flux<YD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       c0.a = Tk.get(T_CL, m - sx) + Tk.get(T_DCLX, m - sx);        // b1 = CL(m1) + s2 * dCLx(m1), s2 = +1
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<YD>(g, L, R, xPos, fl);
-      store_flux<YD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = edge_state3d<1, +1, +1, false>(g, Tk, m - sx, idx);
     c1 = edge_state3d<1, +1, -1, false>(g, Tk, m, idx);
   } else {   // edge along z: all four states on plane kk; z face: left state from plane kk-1
     if (solve) {
+      auto face = [&]() {
+        c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
+        Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
+        double fl[8];
+        mhd_face_flux<ZD>(g, c0, R, xPos, fl);
+        store_flux<ZD>(g, F, idx, fl);
+      };
+      if (flux_first) face();
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
-      c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
-      Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
-      double fl[8];
-      mhd_face_flux<ZD>(g, c0, R, xPos, fl);
-      store_flux<ZD>(g, F, idx, fl);
+      if (!flux_first) face();
     }
     c0 = face_state3d<ZD, +1, false>(g, Tk, m, idx);
   }
 }
 
 template <int SPEC>
-__global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
+__global__ void __launch_bounds__(RG_SWEEP_LB) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
   spec_assume<SPEC>(g);
@@ -143,7 +181,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk .. kk+2                  (slot = plane % 3)
   __shared__ double LE[2 * MH_ESLOT];        // E of planes kk+1, kk+2                      (slot = plane & 1)
   __shared__ int Lsync;                      // arrival counter of the producer pair
-  __shared__ int Lesync;                     // arrival counter of the waves that compute E: planes completed x E_NWAVES
+  __shared__ int Lesync;                     // arrival counter of the Riemann waves: E planes completed x 6
 
   const TileItem item = tile_item(tg, (int)blockIdx.x, ra, rb);   // this workgroup's tile and its planes [sa, sb) of [ra, rb)
   if (!item.valid) return;
@@ -155,15 +193,10 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const size_t N = g.ncell;
   const unsigned sk = g.sk;
   const int wave = t >> 6, lane = t & 63;
-  // the role of a wave is a function of its index alone: wave-uniform, fixed for the life of the workgroup (the per-role main
-  // loops below rely on it: every wave passes the same number of workgroup barriers, each from one place in its own loop)
-  static_assert(MH_THREADS == 8 * 64, "eight waves: six Riemann waves and two producers");
-  const bool producer = (wave & 3) == 3;                      // waves 3 and 7: a SIMD of their own
-  const int pid = wave >> 2;                                  // producer 0 traces two passes of 64 cells, producer 1 one
-  const int dir = wave & 3, half = wave >> 2;                 // Riemann waves: direction, and which 64 of the tile's 128 cells
+  const bool producer = (wave & 3) == 3;
 
   // ---- producer role: primitives of two input cells per thread (cells pw and pw + 128 of the 19 x 11 input tile) ----
-  const int pw = pid * 64 + lane;
+  const int pw = (wave >> 2) * 64 + lane;
   bool pok[2]; unsigned pidx2[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -266,19 +299,26 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
     if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
       const IJK c = {ti, tj, k};
+#ifdef RG_T_AOS
+      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell * T_COUNT};
+#else
       const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
+#endif
       const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
+#if RG_E_LATE
+                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, 0, e_want};   // E(k+1) was completed before the last barrier
+#else
                              {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
+#endif
       mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
     }
   };
 
   // ---- Riemann role ----
-  // the six Riemann waves compute the edge electric field of plane kk+2 (384 threads, two trips over its 512 values)
-  constexpr int E_NTHREADS = 384, E_NWAVES = E_NTHREADS / 64;
-  const int ethread = producer ? -1 : (dir + 3 * half) * 64 + lane;
+  const int rthread = (wave - (wave >> 2)) * 64 + lane;   // 0..383 over the six Riemann waves (wave 3 skipped)
   const bool prio_mode = (tg.flags & 1) == 0;             // RGPU_SWEEP_FLAGS=1 switches the priority scheme off
-  const int cl = half * 64 + lane;
+  const int dir = wave & 3;
+  const int cl = (wave >> 2) * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
   const bool fl_ok = !producer && ci <= g.isize - gw && cj <= g.jsize - gw;
@@ -297,6 +337,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     prim_store(k);
     __syncthreads();
     if (k == sa - 1) elec_plane(k, t, MH_THREADS);
+#if RG_E_LATE
+    if (k == sa) elec_plane(k, t, MH_THREADS);   // the producers compute E(kk+3) at the END of iteration kk: E(sa) is needed before the first one
+#endif
   }
   __syncthreads();
   // iteration kk.  Riemann waves: electric field of plane kk+2 (from Q / B of planes kk+1, kk+2, complete since the last
@@ -313,37 +356,53 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #define RG_TRACE_ON tracing
 #define RG_RIEMANN_ON (fl_ok && kk >= sa - 1)
 #endif
+#ifdef RG_FLUX_FIRST   // experiment: 1 = the younger wave of each SIMD, 2 = the older one, 3 = both solve the face problem first
+#define RG_FF (((RG_FLUX_FIRST) & (wave >= 4 ? 1 : 2)) != 0)
+#else
+#define RG_FF false
+#endif
+#if RG_E_LATE   /* E(kk+3) by the producer pair, after both have stored Q / B (kk+3): into the slot of E(kk+1), dead since both finished trace(kk+1) */
+#define RG_PRODUCER_E(kk) if (kk + 2 < sb) { pair_sync(); elec_plane(kk + 3, (wave >> 2) * 64 + lane, 128); }
+#else
+#define RG_PRODUCER_E(kk)
+#endif
 #define RG_PRODUCER_PLANE(kk, nit) {                                                                                     \
     const bool more = kk + 3 <= sb;                                                                                      \
     const bool tracing = kk + 1 < sb;                                                                                    \
     if (more) prim_load(kk + 3);                                                                                         \
     if (RG_TRACE_ON) {                                                                                                   \
-      if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }        \
-      else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);                                                                \
+      if (wave == 3) { trace_cell(kk + 1, lane, 6 * nit); trace_cell(kk + 1, 128 + lane, 6 * nit); }                     \
+      else trace_cell(kk + 1, 64 + lane, 6 * nit);                                                                       \
     }                                                                                                                    \
     if (more) {                                                                                                          \
       prim_compute();                                                                                                    \
       pair_sync();                     /* both producers are done reading Q / B (kk) */                                  \
       prim_store(kk + 3);              /* -> the Q / B slot of plane kk */                                               \
+      RG_PRODUCER_E(kk)                                                                                                  \
     }                                                                                                                    \
   }
   // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
   //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-#define RG_E_STEP(kk) if (ethread >= 0) { const bool tracing_e = kk + 1 < sb;                                            \
-    if (tracing_e) elec_plane(kk + 2, ethread, E_NTHREADS);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */   \
+#if RG_E_LATE
+#define RG_RIEMANN_E(kk)
+#else
+#define RG_RIEMANN_E(kk) { const bool tracing = kk + 1 < sb;                                                            \
+    if (tracing) elec_plane(kk + 2, rthread, 384);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */            \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                               \
     if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
 #define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
-    RG_E_STEP(kk)                                                                                                        \
+    RG_RIEMANN_E(kk)                                                                                                     \
     if (RG_RIEMANN_ON) {                                                                                                 \
       const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
       const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
       const bool solve = kk >= sa;                                                                                       \
       const bool raise = prio_mode && solve && wave >= 4;                                                                \
       if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
-      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                             \
-      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                        \
-      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                                      \
+      const bool ff = RG_FF;                                                                                             \
+      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                             \
+      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                        \
+      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);                                      \
     }                                                                                                                    \
   }
 #ifdef RG_SWEEP_PROF
@@ -386,8 +445,8 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #else
       if (tracing) {
 #endif
-        if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }
-        else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);
+        if (wave == 3) { trace_cell(kk + 1, lane, 6 * nit); trace_cell(kk + 1, 128 + lane, 6 * nit); }
+        else trace_cell(kk + 1, 64 + lane, 6 * nit);
       }
       if (more) {
         prim_compute();
@@ -397,7 +456,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     } else {
       // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
       //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-      RG_E_STEP(kk)
+      if (tracing) elec_plane(kk + 2, rthread, 384);   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef RG_SWEEP_PROF
       if (fl_ok && kk >= sa - 1 && !(tg.flags & 2)) {   // experiment: RGPU_SWEEP_FLAGS=2 times the kernel without the Riemann problems
 #else
@@ -410,9 +471,14 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         if (raise) __builtin_amdgcn_s_setprio(1);
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
-        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+#ifdef RG_FLUX_FIRST   // experiment: 1 = the younger wave of each SIMD, 2 = the older one, 3 = both solve the face problem first
+        const bool ff = ((RG_FLUX_FIRST) & (wave >= 4 ? 1 : 2)) != 0;
+#else
+        const bool ff = false;
+#endif
+        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
+        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
+        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise, ff);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }
@@ -427,15 +493,289 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #endif
 #undef RG_PLANE_END
 #undef RG_PRODUCER_PLANE
-#undef RG_E_STEP
+#undef RG_PRODUCER_E
+#undef RG_RIEMANN_E
 #undef RG_RIEMANN_PLANE
 #undef RG_TRACE_ON
 #undef RG_RIEMANN_ON
+#undef RG_FF
 #ifdef RG_SWEEP_PROF
   if ((t & 63) == 0)
     for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)acc[q]);
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Variant with THREE waves per SIMD (768 threads, 168 VGPRs): fp64 issues at 5.0 instead of 5.3 cycles per wave instruction
+// with three waves on a SIMD (scripts/ubench/valu_rate2.cpp), and the twelve waves divide the work of a plane more evenly.
+// Waves w, w + 4, w + 8 share a SIMD.  Roles:
+//   waves 0,1,2 and 4,5,6   edge problem (2D HLLD EMF) of direction w & 3 for the cells [64 (w >> 2), +64) -- with the carried
+//                           edge states of the x / y edges
+//   waves 3, 7, 11          face problem (HLLD flux) of direction w >> 2 for all 128 cells, two passes -- with the carried left
+//                           state of the z faces
+//   waves 8, 9, 10          producers: U(kk+3) -> primitives, trace(kk+1): cells [64 p, +64) of the 153, p = w - 8
+// Same LDS layout, same per-plane barrier, same arithmetic as mhd3d_sweep_kernel; E(kk+2) is computed by the nine
+// non-producer waves (576 threads >= 512 values: one trip).
+// MEASURED (round 3, 512^3 MRI, bit-identical on the parity cases): 40.2 ms against 32.4 for the 8-wave kernel (contracted
+// arithmetic: 44.4 against 24.8).  At 168 VGPRs the kernel keeps 280 B per lane in scratch (the loop-invariant addresses and
+// the carried states no longer fit beside the edge solver), and what the third wave gains in issue rate is lost several times
+// over to the reloads.  Kept as an experiment build only (-DRG_SWEEP12_EXPERIMENT, selected at run time with RGPU_SWEEP12=1).
+#ifdef RG_SWEEP12_EXPERIMENT
+constexpr int MH12_THREADS = 768;
+
+template <int DIR>
+RG_DEVFN void emf_part(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ emf, unsigned idx,
+                       Prim8& c0, Prim8& c1, bool solve) {
+  const size_t N = g.ncell;
+  const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  if (DIR == XD) {
+    if (solve) {
+      c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);
+      c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);
+      const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
+    }
+    c0 = edge_state3d<0, +1, +1, false>(g, Tk, m - sj, idx);
+    c1 = edge_state3d<0, -1, +1, false>(g, Tk, m, idx);
+  } else if (DIR == YD) {
+    if (solve) {
+      c0.a = Tk.get(T_CL, m - sx) + Tk.get(T_DCLX, m - sx);
+      c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
+      const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
+    }
+    c0 = edge_state3d<1, +1, +1, false>(g, Tk, m - sx, idx);
+    c1 = edge_state3d<1, +1, -1, false>(g, Tk, m, idx);
+  } else {
+    if (solve) {
+      const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
+      const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
+    }
+  }
+}
+
+// face problem of direction DIR at cell m; zl: the carried left state of the z face (built from T(kk-1)), rebuilt for the next plane
+template <int DIR>
+RG_DEVFN void flux_part(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F, unsigned idx,
+                        Prim8& zl, bool solve) {
+  const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  if (solve) {
+    double fl[8];
+    if (DIR == XD) {
+      Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
+      mhd_face_flux<XD>(g, L, R, xPos, fl);
+      store_flux<XD>(g, F, idx, fl);
+    } else if (DIR == YD) {
+      Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
+      mhd_face_flux<YD>(g, L, R, xPos, fl);
+      store_flux<YD>(g, F, idx, fl);
+    } else {
+      zl.a = Tk.get(T_CL, m);
+      Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
+      mhd_face_flux<ZD>(g, zl, R, xPos, fl);
+      store_flux<ZD>(g, F, idx, fl);
+    }
+  }
+  if (DIR == ZD) zl = face_state3d<ZD, +1, false>(g, Tk, m, idx);
+}
+
+template <int SPEC>
+__global__ void __launch_bounds__(MH12_THREADS) mhd3d_sweep12_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
+                                                                     double* __restrict__ F, double* __restrict__ emf,
+                                                                     double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
+  spec_assume<SPEC>(g);
+  __shared__ __attribute__((aligned(16))) double LT[2 * MH_BUF];
+  __shared__ double LQ[3 * MH_QBSLOT];
+  __shared__ double LE[2 * MH_ESLOT];
+  __shared__ int Lsync;
+  __shared__ int Lesync;
+
+  const TileItem item = tile_item(tg, (int)blockIdx.x, ra, rb);
+  if (!item.valid) return;
+  const int bx = item.bx, by = item.by, sa = item.sa, sb = item.sb;
+  const int gw = g.gw;
+  const int i0 = gw + bx * MH_SX, j0 = gw + by * MH_SY;
+  const int t = (int)threadIdx.x;
+  const size_t N = g.ncell;
+  const unsigned sk = g.sk;
+  const int wave = t >> 6, lane = t & 63;
+  const int simd = wave & 3, grp = wave >> 2;
+  const bool producer = simd < 3 && grp == 2;
+  const bool fluxer = simd == 3;
+  const bool emfer = simd < 3 && grp < 2;
+
+  // ---- producers: input cells pw and pw + 192 of the 19 x 11 input tile ----
+  const int pw = simd * 64 + lane;
+  bool pok[2]; unsigned pidx2[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int cell = pw + 192 * r;
+    const int qy = cell / MH_QX, qx = cell - qy * MH_QX;
+    const int pi = i0 - 2 + qx, pj = j0 - 2 + qy;
+    pok[r] = producer && cell < MH_QCELLS && pi < g.isize - 1 && pj < g.jsize - 1;
+    pidx2[r] = pok[r] ? (unsigned)pi + (unsigned)pj * g.sj : 0u;
+  }
+  double keep[22];
+#pragma unroll
+  for (int v = 0; v < 22; ++v) keep[v] = 0.0;
+  double (*pu)[11] = reinterpret_cast<double (*)[11]>(keep);
+  auto prim_load = [&](int k) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+        const double* u = U + pidx2[r] + (size_t)k * sk;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) pu[r][v] = u[(size_t)v * N];
+        pu[r][8] = u[(size_t)IA * N + 1];
+        pu[r][9] = u[(size_t)IB * N + g.sj];
+        pu[r][10] = u[(size_t)IC * N + sk];
+      }
+  };
+  auto prim_compute = [&]() {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+        const Prim8 q = mhd_prim(g, pu[r], pu[r][8], pu[r][9], pu[r][10], dt);
+        const double fa = pu[r][IA], fb = pu[r][IB], fc = pu[r][IC];
+        pu[r][ID] = q.r; pu[r][IP] = q.p; pu[r][IU] = q.u; pu[r][IV] = q.v; pu[r][IW] = q.w; pu[r][IA] = q.a; pu[r][IB] = q.b; pu[r][IC] = q.c;
+        pu[r][8] = fa; pu[r][9] = fb; pu[r][10] = fc;
+      }
+  };
+  auto prim_store = [&](int k) {
+    double* qd = LQ + (k % 3) * MH_QBSLOT;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      if (pok[r]) {
+#pragma unroll
+        for (int v = 0; v < MH_NQB; ++v) qd[v * MH_QCELLS + pw + 192 * r] = pu[r][v];
+      }
+  };
+  // edge electric field of plane k: 512 values, value e by thread `first` + n * `stride`
+  auto elec_plane = [&](int k, int first, int stride) {
+    const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT}, {0, 0}, 0, 0};
+    double* ed = LE + (k & 1) * MH_ESLOT;
+    constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY, NEALL = NEX + NEY + (MH_PX + 1) * (MH_PY + 1);
+    for (int e = first; e < NEALL; e += stride) {
+      int comp, ex, ey;
+      if (e < NEX) { comp = 0; ey = e / MH_PX; ex = e - ey * MH_PX; }
+      else if (e < NEX + NEY) { comp = 1; const int c = e - NEX; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+      else { comp = 2; const int c = e - NEX - NEY; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+      const int ei = i0 - 1 + ex, ej = j0 - 1 + ey;
+      if (ei < g.isize - 1 && ej < g.jsize - 1) {
+        const unsigned qm = (unsigned)((ey + 1) * MH_QX + ex + 1);
+        const double xPos = g.xMin + g.dx / 2 + (ei - gw) * g.dx;
+        double v;
+        if (comp == 0) v = mhd_elec_comp<0>(g, in, xPos, qm);
+        else if (comp == 1) v = mhd_elec_comp<1>(g, in, xPos, qm);
+        else v = mhd_elec_comp<2>(g, in, xPos, qm);
+        ed[comp * MH_QCELLS + qm] = v;
+      }
+    }
+  };
+  int nsync = 0;
+  auto producer_sync = [&]() {   // rendezvous of the THREE producer waves
+    nsync += 3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&Lsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(&Lsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nsync) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  auto trace_cell = [&](int k, int cell, int e_want) {
+    const int ty = cell / MH_PX, tx = cell - ty * MH_PX;
+    const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
+    if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {
+      const IJK c = {ti, tj, k};
+#ifdef RG_T_AOS
+      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell * T_COUNT};
+#else
+      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
+#endif
+      const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
+                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
+      mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
+    }
+  };
+
+  // ---- Riemann roles ----
+  // nine non-producer waves: index 0 .. 575 for the electric field
+  const int rwave = emfer ? grp * 3 + simd : 6 + grp;   // 0..5 edge waves, 6..8 face waves
+  const int rthread = rwave * 64 + lane;
+  // edge wave: cell cl of the tile; face wave: cells lane and lane + 64
+  const int ecl = grp * 64 + lane;
+  int oy = ecl / MH_OX, ox = ecl - oy * MH_OX;
+  if (fluxer) { oy = lane / MH_OX; ox = lane - oy * MH_OX; }
+  const int ci = i0 + ox, cj0 = j0 + oy, cj1 = cj0 + 4;          // (second pass of a face wave: 64 cells = 4 rows further)
+  const bool ok0 = !producer && ci <= g.isize - gw && cj0 <= g.jsize - gw;
+  const bool ok1 = fluxer && ci <= g.isize - gw && cj1 <= g.jsize - gw;
+  const unsigned cidx0 = ok0 ? (unsigned)ci + (unsigned)cj0 * g.sj : 0u;
+  const unsigned cidx1 = ok1 ? (unsigned)ci + (unsigned)cj1 * g.sj : 0u;
+  const unsigned cm0 = (unsigned)((oy + 1) * MH_PX + ox + 1), cm1 = cm0 + 4u * (unsigned)MH_PX;
+  const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
+  const int edir = simd, fdir = grp;
+
+  if (t == 0) { Lsync = 0; Lesync = 0; }
+  for (int k = sa - 2; k <= sa; ++k) {
+    prim_load(k);
+    prim_compute();
+    prim_store(k);
+    __syncthreads();
+    if (k == sa - 1) elec_plane(k, t, MH12_THREADS);
+  }
+  __syncthreads();
+  int nit = 0;
+  for (int kk = sa - 2; kk < sb; ++kk) {
+    ++nit;
+    const bool more = kk + 3 <= sb;
+    const bool tracing = kk + 1 < sb;
+    if (producer) {
+      if (more) prim_load(kk + 3);
+      if (tracing) trace_cell(kk + 1, simd * 64 + lane, 9 * nit);
+      if (more) {
+        prim_compute();
+        producer_sync();
+        prim_store(kk + 3);
+      }
+    } else {
+      if (tracing) elec_plane(kk + 2, rthread, 9 * 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (kk >= sa - 1) {
+        const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
+        const bool solve = kk >= sa;
+        if (emfer) {
+          if (ok0) {
+            const unsigned idx = cidx0 + (unsigned)kk * sk;
+            Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
+            Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
+            if (edir == 0) emf_part<XD>(g, Tk, cm0, xPos, emf, idx, c0, c1, solve);
+            else if (edir == 1) emf_part<YD>(g, Tk, cm0, xPos, emf, idx, c0, c1, solve);
+            else emf_part<ZD>(g, Tk, cm0, xPos, emf, idx, c0, c1, solve);
+            keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
+            keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
+          }
+        } else {
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 0 ? ok0 : ok1) {
+              const unsigned idx = (pass == 0 ? cidx0 : cidx1) + (unsigned)kk * sk;
+              const unsigned m = pass == 0 ? cm0 : cm1;
+              Prim8 zl = {keep[8 * pass + 0], keep[8 * pass + 1], keep[8 * pass + 2], keep[8 * pass + 3], keep[8 * pass + 4], keep[8 * pass + 5],
+                          keep[8 * pass + 6], keep[8 * pass + 7]};
+              if (fdir == 0) flux_part<XD>(g, Tk, m, xPos, F, idx, zl, solve);
+              else if (fdir == 1) flux_part<YD>(g, Tk, m, xPos, F, idx, zl, solve);
+              else flux_part<ZD>(g, Tk, m, xPos, F, idx, zl, solve);
+              keep[8 * pass + 0] = zl.r; keep[8 * pass + 1] = zl.p; keep[8 * pass + 2] = zl.u; keep[8 * pass + 3] = zl.v; keep[8 * pass + 4] = zl.w;
+              keep[8 * pass + 5] = zl.a; keep[8 * pass + 6] = zl.b; keep[8 * pass + 7] = zl.c;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // T(kk+1) and Q / B (kk+3) complete, T(kk) free
+  }
+}
+#endif   // RG_SWEEP12_EXPERIMENT
 
 // Periodic faces: every input of the Riemann problems at the layer j = ny + gw (i = nx + gw) is a ghost copy of what the
 // layer j = gw (i = gw) sees, so their fluxes and EMFs are the same doubles.  When that layer would need a tile row (column) of
@@ -465,6 +805,7 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   tg.flags = flags_env;
   tg.nbx = (g.isize - 2 * g.gw + 1 + MH_SX - 1) / MH_SX;   // cells gw .. isize-gw
   tg.nby = (g.jsize - 2 * g.gw + 1 + MH_SY - 1) / MH_SY;
+  if (MH_SX != MH_OX) reuse = 0;
   const bool copy_x = (reuse & 1) && g.nx % MH_OX == 0 && g.nx >= MH_OX, copy_y = (reuse & 2) && g.ny % MH_OY == 0 && g.ny >= MH_OY;
   if (copy_x) tg.nbx -= 1;
   if (copy_y) tg.nby -= 1;
@@ -473,8 +814,15 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3: one base
   // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
   tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
-  hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
-                     dt, dtdx, dtdy, dtdz, ra, rb);
+#ifdef RG_SWEEP12_EXPERIMENT
+  static const bool sweep12 = std::getenv("RGPU_SWEEP12") != 0;
+  if (sweep12)
+    hipLaunchKernelGGL((mhd3d_sweep12_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH12_THREADS), 0, s, g, tg, U, F, emf,
+                       dt, dtdx, dtdy, dtdz, ra, rb);
+  else
+#endif
+    hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
+                       dt, dtdx, dtdy, dtdz, ra, rb);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
   if (copy_x) { const K_copy_periodic_layer k = {g, F, emf, 0, ra}; if (rgpu::rg_launch<256>(s, (unsigned)g.jsize * (unsigned)(rb - ra), k)) return -1; }

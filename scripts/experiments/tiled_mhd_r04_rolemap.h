@@ -46,6 +46,21 @@ constexpr int MH_THREADS = 512;
 #define RG_SWEEP_SPLIT_LOOPS 1
 #endif
 #endif
+// Which waves do what (waves w and w + 4 share a SIMD).  RG_ROLE_MAP 0: producers = waves 3, 7 (one SIMD of their own), Riemann
+// waves (direction, tile half) = (w & 3, w >> 2).  1: producers = waves 3, 6 -- one per SIMD, each next to a z-direction Riemann
+// wave (waves 2 and 7): a producer's chain loads -> trace -> barrier then competes with one busy wave instead of running half of
+// the time alone at single-wave issue rate.  RG_E_BY: who computes the edge electric field of plane kk+2: 0 = the six Riemann
+// waves (384 threads, two trips), 1 = the two z-direction Riemann waves (128 threads, four trips), 2 = the z waves and the producers
+// next to them (RG_ROLE_MAP 1 only: the waves of SIMDs 2, 3).  RG_PROD_PRIO: s_setprio of the producers during their iteration.
+#ifndef RG_ROLE_MAP
+#define RG_ROLE_MAP 0
+#endif
+#ifndef RG_E_BY
+#define RG_E_BY 0
+#endif
+#ifndef RG_PROD_PRIO
+#define RG_PROD_PRIO 0
+#endif
 constexpr int MH_SX = MH_OX, MH_SY = MH_OY;       // tile pitch = tile size: every Riemann problem is solved by exactly one tile
 
 struct TLdsWrite {
@@ -158,9 +173,15 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   // the role of a wave is a function of its index alone: wave-uniform, fixed for the life of the workgroup (the per-role main
   // loops below rely on it: every wave passes the same number of workgroup barriers, each from one place in its own loop)
   static_assert(MH_THREADS == 8 * 64, "eight waves: six Riemann waves and two producers");
-  const bool producer = (wave & 3) == 3;                      // waves 3 and 7: a SIMD of their own
-  const int pid = wave >> 2;                                  // producer 0 traces two passes of 64 cells, producer 1 one
-  const int dir = wave & 3, half = wave >> 2;                 // Riemann waves: direction, and which 64 of the tile's 128 cells
+#if RG_ROLE_MAP == 1
+  const bool producer = wave == 3 || wave == 6;
+  const int pid = wave == 3 ? 0 : 1;                        // producer 0 traces two passes, producer 1 one
+  const int dir = producer ? 0 : (wave == 7 ? 2 : (wave & 3)), half = wave >> 2;
+#else
+  const bool producer = (wave & 3) == 3;
+  const int pid = wave >> 2;
+  const int dir = wave & 3, half = wave >> 2;
+#endif
 
   // ---- producer role: primitives of two input cells per thread (cells pw and pw + 128 of the 19 x 11 input tile) ----
   const int pw = pid * 64 + lane;
@@ -274,9 +295,19 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   };
 
   // ---- Riemann role ----
-  // the six Riemann waves compute the edge electric field of plane kk+2 (384 threads, two trips over its 512 values)
-  constexpr int E_NTHREADS = 384, E_NWAVES = E_NTHREADS / 64;
-  const int ethread = producer ? -1 : (dir + 3 * half) * 64 + lane;
+  // threads that compute the edge electric field of plane kk+2: index 0 .. E_NTHREADS-1, or -1
+#if RG_E_BY == 0
+  constexpr int E_NTHREADS = 384;
+  const int ethread = producer ? -1 : (dir + 3 * half) * 64 + lane;          // the six Riemann waves
+#elif RG_E_BY == 1
+  constexpr int E_NTHREADS = 128;
+  const int ethread = (!producer && dir == 2) ? half * 64 + lane : -1;       // the two z-direction Riemann waves
+#else
+  static_assert(RG_ROLE_MAP == 1, "RG_E_BY 2 needs the producers next to the z waves");
+  constexpr int E_NTHREADS = 256;
+  const int ethread = (wave & 2) ? ((wave >> 2) * 2 + (wave & 1)) * 64 + lane : -1;   // the four waves of SIMDs 2 and 3
+#endif
+  constexpr int E_NWAVES = E_NTHREADS / 64;
   const bool prio_mode = (tg.flags & 1) == 0;             // RGPU_SWEEP_FLAGS=1 switches the priority scheme off
   const int cl = half * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
@@ -289,6 +320,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #ifdef RG_SWEEP_PROF
   long long acc[4] = {0, 0, 0, 0};
 #endif
+  if (RG_PROD_PRIO > 0 && producer) __builtin_amdgcn_s_setprio(RG_PROD_PRIO);
   // prologue: primitives of planes sa-2, sa-1, sa; electric field of plane sa-1
   if (t == 0) { Lsync = 0; Lesync = 0; }
   for (int k = sa - 2; k <= sa; ++k) {
@@ -317,6 +349,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const bool more = kk + 3 <= sb;                                                                                      \
     const bool tracing = kk + 1 < sb;                                                                                    \
     if (more) prim_load(kk + 3);                                                                                         \
+    if (RG_E_BY == 2) { RG_E_STEP(kk) }                                                                                  \
     if (RG_TRACE_ON) {                                                                                                   \
       if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }        \
       else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);                                                                \
@@ -339,7 +372,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
       const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
       const bool solve = kk >= sa;                                                                                       \
-      const bool raise = prio_mode && solve && wave >= 4;                                                                \
+      const bool raise = prio_mode && solve && wave >= 4 && !(RG_ROLE_MAP == 1 && dir == 2);                             \
       if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
       if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                             \
       else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                        \
@@ -381,6 +414,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const bool tracing = kk + 1 < sb;
     if (producer) {
       if (more) prim_load(kk + 3);
+      if (RG_E_BY == 2) { RG_E_STEP(kk) }
 #ifdef RG_SWEEP_PROF
       if (tracing && !(tg.flags & 4)) {   // experiment: RGPU_SWEEP_FLAGS=4 times the kernel without the trace
 #else
@@ -406,7 +440,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;
-        const bool raise = prio_mode && solve && wave >= 4;
+        const bool raise = prio_mode && solve && wave >= 4 && !(RG_ROLE_MAP == 1 && dir == 2);
         if (raise) __builtin_amdgcn_s_setprio(1);
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};

@@ -2,10 +2,12 @@
 # Profile run on the GPU box (through gpurun): bench lines, rocprofv3 kernel stats, three separate --pmc passes -- for the
 # headline workload (512^3 MRI) and for the 256^3 hydro implosion.  Results land in gpurun_out/prof_$TAG; summarise with
 # scripts/summarize_prof.py $TAG into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
 OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# which state of the kernels the counters below belong to (bench.py compares it before quoting pmc_traffic.json)
+python -c "import sys; sys.path.insert(0, '$R'); from ramsesgpu_amd import build as rb; print(rb.kernel_source_hash())" > $OUT/kernel_source_sha.txt
 python $R/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 python $R/bench.py --workload implode3d --steps 100 --warmup 10 > $OUT/bench_implode3d.json 2> $OUT/bench_implode3d.err
 python $R/bench.py --workload orszag-tang --steps 50 --warmup 5 > $OUT/bench_orszag-tang.json 2> $OUT/bench_orszag-tang.err

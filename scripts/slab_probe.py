@@ -2,8 +2,11 @@
 """Per-rank cost of the z-slab schedule on ONE GPU: one rank of a ring of one (periodic z: the rank is its own neighbour,
 the halo planes really travel through RCCL send / recv on the halo stream, device-local instead of over xGMI) stepping a
 512 x 512 x (512/N) box through the C++ driver (include/rgpu_comm.h) with the overlapped and the serial schedule -- what a
-rank of bench.py --gpus N does per step, minus the link time of 2 x 51.5 MB (~0.4 ms at 150 GB/s, hidden behind the
-inner planes by the overlapped schedule)."""
+rank of bench.py --gpus N does per step.  The self-exchange itself costs ~0.03 ms; RGPU_COMM_EMULATE_GBPS=<rate> (a measurement
+knob of csrc/hip/rg_transport.h) holds the halo stream for the time the same bytes need on ONE xGMI link at that rate
+(2 x 51.5 MB per rank and step at 512^2 planes: N >= 3 -> two neighbours, two links in parallel, 51.5 MB each; N = 2 -> one
+neighbour, 103 MB over one link), so that the numbers show what the overlapped schedule really hides.  PROBE_LINK_GBPS="0 60 40"
+runs the whole table once per rate."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +16,14 @@ L = load_library()
 CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))   # the driver built for this arithmetic (RGPU_ARITH)
 ini = os.path.join(ROOT, "configs", "mhd_mri_3d.ini")
 cid = rcomm.unique_id(CL)
-for nz in ([int(os.environ['PROBE_NZ'])] if os.environ.get('PROBE_NZ') else (512, 256, 128, 64)):   # PROBE_NZ: one slab thickness (for rocprofv3)
+rates = [float(x) for x in os.environ.get("PROBE_LINK_GBPS", os.environ.get("RGPU_COMM_EMULATE_GBPS", "0")).split()]
+for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] if os.environ.get('PROBE_NZ') else (512, 256, 128, 64))]:   # PROBE_NZ: one slab thickness (for rocprofv3)
+    if rate > 0 and nz == 512:
+        continue   # N = 1 has no link
+    os.environ.pop("RGPU_COMM_EMULATE_GBPS", None)
+    if rate > 0:
+        os.environ["RGPU_COMM_EMULATE_GBPS"] = "%g" % rate
+        os.environ["RGPU_COMM_EMULATE_PEERS"] = "1" if 512 // nz == 2 else "2"
     for overlap in ((True,) if os.environ.get('PROBE_NZ') else (True, False)):
         run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=%d" % nz, 0, 1, cid, library=L, comm_library=CL, overlap=overlap)
         run.init_simulation()
@@ -22,7 +32,8 @@ for nz in ([int(os.environ['PROBE_NZ'])] if os.environ.get('PROBE_NZ') else (512
         n = 10
         for _ in range(n): run.oneStepIntegration()
         run.solver.synchronize(); dt = (time.time() - t0) / n
-        print("nz=%3d (N=%d) %-8s %7.2f ms/step  -> %6.0f Mcell/s per rank, x%d = %6.0f" % (nz, 512 // nz, "overlap" if overlap else "serial", dt * 1e3,
-              512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6), flush=True)
+        link_ms = 0.0 if rate <= 0 else 8 * 518 * 518 * 3 * 8 * (2 if 512 // nz == 2 else 1) / rate / 1e6
+        print("nz=%3d (N=%d) link %3g GB/s (%.2f ms per exchange) %-8s %7.2f ms/step  -> %6.0f Mcell/s per rank, x%d = %6.0f" % (nz, 512 // nz, rate, link_ms,
+              "overlap" if overlap else "serial", dt * 1e3, 512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6), flush=True)
         run.close()
         cid = rcomm.unique_id(CL)

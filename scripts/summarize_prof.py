@@ -83,5 +83,8 @@ traffic["_note"] = ("rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE),
                     "64 B, MI355X_MICROARCH.md HBM section, which prescribes doubling it for 16 B per lane streaming reads): 0.49-0.77x of the known unique bytes on this code's 8 B per lane SoA streams "
                     "(the CFL scan of the initial state reads the whole state array once: 5.32 of 8.90 GB at 518^3 x 8, 0.34 of 0.70 GB at 260^3 x 5); bench.py reports FETCH + WRITE (lower bound) and 2 x FETCH + WRITE (upper bound). "
                     "mri = 512^3 MRI box, implode3d = 256^3 hydro implosion (HLLC)")
+sha = os.path.join(src, "kernel_source_sha.txt")
+if os.path.exists(sha):   # the state of the kernel sources the counters were collected on (ramsesgpu_amd/build.py: kernel_source_hash)
+    traffic["_kernel_source_sha"] = open(sha).read().strip()
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(dst)))

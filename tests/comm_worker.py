@@ -224,9 +224,51 @@ def frontend():
     sys.exit(0 if ok else 1)
 
 
+def poison():
+    """--poison base overrides fail_rank fail_step resultfile: rank `fail_rank` gets a launch error in the first step piece of step
+    `fail_step` (emulation backend: rgpu_emu_fail_launch_after).  It must still post the halo exchange its neighbours wait for
+    and tell them through the next 1/dt all-reduce -- whose size must be the one the healthy ranks use, whatever state the failing
+    rank is in (step 0: its last all-reduce followed a full scan, theirs follows a fused one).  Expected: EVERY rank comes back
+    with an error, the failing one at `fail_step`, the others one step later; nobody hangs (the test's timeout would tell)."""
+    base, ov, frank, fstep, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+    CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
+    keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+    CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+    ids = [rcomm.unique_id(CL) if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ini = os.path.join(ROOT, "configs", base + ".ini")
+    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0")
+    run.init_simulation()
+    failed_at, msg = None, ""
+    for n in range(fstep + 3):
+        if rank == frank and n == fstep:
+            lib.lib.rgpu_emu_fail_launch_after(1)
+        try:
+            run.oneStepIntegration()
+        except Exception as e:  # noqa: BLE001
+            failed_at, msg = n, str(e)
+            break
+    flags = [None] * world
+    dist.all_gather_object(flags, (failed_at, msg))
+    good = all(f[0] == (fstep if r == frank else fstep + 1) for r, f in enumerate(flags))
+    good = good and all("not finite" in f[1] for r, f in enumerate(flags) if r != frank)
+    if rank == 0:
+        with open(out, "w") as f:
+            f.write("OK\n" if good else "FAILED %r\n" % (flags,))
+    dist.barrier()
+    run.close()
+    dist.destroy_process_group()
+    sys.exit(0 if good else 1)
+
+
 def main():
     if sys.argv[1] == "--frontend":
         return frontend()
+    if sys.argv[1] == "--poison":
+        return poison()
     base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -52,8 +52,12 @@ inline int rg_launch_range(rg_stream_t, unsigned idx0, unsigned n, const K& k) {
   for (unsigned off = 0; off < n; ++off) k(idx0 + off);
   return 0;
 }
+// failure injection (tests/test_comm_driver.py: a step piece that fails on ONE rank): the n-th plane-range launch from now fails
+// once, like a launch error would; 0 = disarmed.  Armed through rgpu_emu_fail_launch_after() below.
+inline int& rg_fail_countdown() { static int n = 0; return n; }
 template <int BLOCK, int MINW = 1, class K>
 inline int rg_launch_planes(rg_stream_t, unsigned idx0, unsigned plane_cells, unsigned nplanes, const K& k, unsigned = 0) {
+  if (rg_fail_countdown() > 0 && --rg_fail_countdown() == 0) return -1;
   for (unsigned off = 0; off < plane_cells * nplanes; ++off) k(idx0 + off);
   return 0;
 }
@@ -91,3 +95,6 @@ inline int rg_event_record(rg_event_t, rg_stream_t) { return 0; }
 inline double rg_event_elapsed_ms(rg_event_t, rg_event_t) { return 0.0; }
 
 }  // namespace rgpu
+
+// TEST-ONLY entry point of the emulation library (single translation unit: defined here)
+extern "C" inline __attribute__((used, visibility("default"))) void rgpu_emu_fail_launch_after(int n) { rgpu::rg_fail_countdown() = n; }

@@ -91,6 +91,13 @@ class Oracle:
         assert rc == 0, rc
         return U, dts[:nd.value], tf.value
 
+    def set_thread_placement(self, mode):
+        """threads of run_mt / run_mt_scan: 0 = not pinned, 1 = pinned over all allowed CPUs in NUMA-node order (each z-slab first
+        touched and always worked on by the same node), 2 = pinned inside the first NUMA node; returns the CPUs in the set"""
+        self.lib.orc_set_thread_placement.restype = C.c_int
+        self.lib.orc_set_thread_placement.argtypes = [C.c_int]
+        return self.lib.orc_set_thread_placement(int(mode))
+
     def run_mt_scan(self, p, U0, nsteps, scan, nthreads=1):
         """orc_run_mt_scan: the first len(scan) steps try the thread counts of `scan`, the rest use the fastest.
         Returns (per-step seconds, thread count the run settled on)"""

@@ -151,7 +151,8 @@ def check_single_step_random(lib, oracle, base, ov, seed=3, mach=1.5, t0=2.0):
         sv.close()
 
 
-def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
+def check_run_vs_oracle(lib, oracle, base, ov, nsteps, exact=True):
+    """exact=False: the contracted-arithmetic variant of the library -- relative L2 < 1e-12 on the state, dt within 1e-11"""
     p = lib.params_from_ini(ini(base), ov)
     U0 = lib.init_condition(ini(base), ov, p)
     attach_gravity(lib, base, ov, p, oracle=oracle)
@@ -160,6 +161,10 @@ def check_run_vs_oracle(lib, oracle, base, ov, nsteps):
     try:
         attach_gravity(lib, base, ov, p, sv=sv)
         dts = sv.start(U0, nsteps)
+        if not exact:
+            assert np.abs(np.array(dts) / np.asarray(dts_ref) - 1.0).max() < 1e-11, "%s: dt sequences differ beyond round-off" % base
+            assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps), exact=False)
+            return p
         if p.randomForcingEnabled or p.ouForcingEnabled:   # round-off level agreement only (see assert_same)
             np.testing.assert_allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
             assert_same(interior(sv.getDataHost(), p), interior(ref, p), "%s [%s] %d steps vs oracle" % (base, ov, nsteps), exact=False)
@@ -242,6 +247,18 @@ BOUNDARY_CASES = [
     ("implode3d", "mesh.nx=6;mesh.ny=5;mesh.nz=4"), ("orszag-tang3d", "mesh.nx=6;mesh.ny=5;mesh.nz=4"),
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=4;MHD.omega0=0.4"),
     ("mhd_BrioWu", "mesh.nx=4;mesh.ny=5;mesh.nz=6;mesh.boundary_xmin=1;mesh.boundary_ymax=1;mesh.boundary_zmin=3;mesh.boundary_zmax=3"),
+]
+
+
+# The bench's launch geometry: planes of > 32768 cells, where the XCD-aware workgroup order splits each XCD's y band
+# into several sub-bands (rg_backend.h: rg_launch_planes, nsub > 1), with >= 2 chunks of the two-stream sweep and
+# the LDS-tiled kernels' full-width tile rows.  Few planes keep the oracle at seconds per step.
+BENCH_GEOMETRY = [
+    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=512;mesh.nz=16", 2),
+    # the x-y cross-section of BASELINE config 5 (512 x 1024 x 512 over 8 GPUs): 33 x 129 tiles of the MHD sweep
+    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=1024;mesh.nz=16", 2),
+    ("orszag-tang3d", "mesh.nx=256;mesh.ny=256;mesh.nz=24", 2),
+    ("implode3d", "mesh.nx=512;mesh.ny=512;mesh.nz=8;hydro.riemannSolver=hllc", 2),
 ]
 
 

@@ -45,6 +45,10 @@ def test_bench_line_single_gpu(args, gpu_lib):
     assert e["steps"] == d["steps"] and e["warmup"] == d["warmup"] and e["roofline"]["frac"] > 0 and e["roofline"]["avg_launch_ms"] > 0
     assert d["config"]["rccl_ranks"] is None and len(d["config"]["ranks"]) == 1 and "single device" in d["config"]["driver"]
     assert "other_workloads" not in d        # only the default headline run carries them
+    # which build `value` is travels at the top level too (round-over-round comparisons: value_exact is the like-for-like number)
+    assert d["value_arithmetic"] == "contracted" and d["metric_version"] == 2
+    # traffic / valu_ceiling come from the committed PMC summary only when it was collected on THIS state of the kernel sources
+    assert ("pmc_note" in r) == (r["traffic"] is None), r.get("pmc_note")
 
 
 def test_bench_line_exact_on_request(gpu_lib):
@@ -95,3 +99,40 @@ def test_bench_rank_without_a_device_says_so(gpu_lib):
         if torch.cuda.device_count() > 1:
             pytest.skip("the visibility mask did not take effect on this multi-GPU box")
     assert res.returncode != 0 and "rank 1 is to drive GPU 1 but only 1 device(s) are visible" in res.stderr, res.stderr[-3000:]
+
+
+def test_both_slab_drivers_in_one_process(gpu_lib):
+    """bench.py --gpus N > 1 measures the slabs through BOTH builds of the driver, one after the other in one process (value +
+    value_exact at every N): librgpu_comm_fast.so + librgpu_fast.so, destroyed, then librgpu_comm.so + librgpu.so.  The libraries
+    export the same symbols, so each pair must stay bound to itself: with one rank (its own z neighbour, real RCCL) the second,
+    exact pair has to reproduce the single-device run of librgpu.so bit for bit, and the first must not."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import bench
+from ramsesgpu_amd.solver import Library, Solver, interior, lib_path
+import torch
+torch.cuda.set_device(0)
+ctl = bench.Control(1, 0, 0)
+ini = os.path.join(%r, "configs", "mhd_mri_3d.ini"); ov = "mesh.nx=16;mesh.ny=32;mesh.nz=16"
+out = {}
+for arith in ("contracted", "exact"):
+    run, info, err = bench.slab_driver_run(arith, ini, ov, 0, 1, ctl)
+    assert run is not None and err is None and info["ranks"] == 1, (arith, err, info)
+    assert run.L.arithmetic == arith
+    el = bench.timed_steps(run.oneStepIntegration, run.solver, ctl, 3, 1)
+    assert el > 0
+    out[arith] = run.local_interior().copy()
+    run.close()
+L = Library(lib_path("exact")); p = L.params_from_ini(ini, ov); sv = Solver(p, L); sv.start(L.init_condition(ini, ov, p), 4)
+ref = interior(sv.getDataHost(), p); sv.close()
+assert np.array_equal(out["exact"], ref), int((out["exact"] != ref).sum())
+assert not np.array_equal(out["contracted"], ref)
+err = float(np.sqrt(((out["contracted"] - ref) ** 2).sum() / (ref ** 2).sum()))
+assert err < 1e-12, err
+print("OK")
+''' % (ROOT, ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"); env.pop("RGPU_LIB", None); env.pop("RGPU_ARITH", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-3000:]

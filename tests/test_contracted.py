@@ -44,6 +44,17 @@ def test_contracted_against_exact(base, ov, nsteps, gpu_lib, gpu_contracted_lib)
     assert not np.array_equal(out[0], out[1]), "the contracted variant returned the exact library's bits: is it the right build?"
 
 
+# The bench's launch geometry (tests/test_gpu_parity.py: BENCH_GEOMETRY -- full-width tile rows, several rounds of workgroups,
+# sub-segmented last round, XCD sub-bands) for THIS build against the oracle: the contracted MHD sweep has one main loop for all
+# wave roles (RG_SWEEP_SPLIT_LOOPS 0), i.e. it is not the kernel the exact library's geometry test covers.
+BENCH_GEOMETRY = pc.BENCH_GEOMETRY
+
+
+@pytest.mark.parametrize("base,ov,nsteps", BENCH_GEOMETRY, ids=["%s[%s]" % (b, o) for b, o, _ in BENCH_GEOMETRY])
+def test_bench_launch_geometry_within_tolerance(base, ov, nsteps, gpu_contracted_lib, oracle):
+    pc.check_run_vs_oracle(gpu_contracted_lib, oracle, base, ov, nsteps, exact=False)
+
+
 # ---- the gates that make the tolerance-grade number a conformant one (north_star: "Orszag-Tang L2 error vs euler_cpu < 1e-12") ----
 def test_orszag_tang_gate_full_size_within_tolerance(gpu_contracted_lib, oracle):
     """data/orszag-tang.ini as shipped, 512^2 x 50 steps: relative L2 < 1e-12 per variable against the oracle"""

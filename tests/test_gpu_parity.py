@@ -57,16 +57,7 @@ def test_medium_sizes_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
     pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, nsteps)
 
 
-# The bench's launch geometry: planes of > 32768 cells, where the XCD-aware workgroup order splits each XCD's y band
-# into several sub-bands (rg_backend.h: rg_launch_planes, nsub > 1), with >= 2 chunks of the two-stream sweep and
-# the LDS-tiled kernels' full-width tile rows.  Few planes keep the oracle at seconds per step.
-BENCH_GEOMETRY = [
-    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=512;mesh.nz=16", 2),
-    # the x-y cross-section of BASELINE config 5 (512 x 1024 x 512 over 8 GPUs): 33 x 129 tiles of the MHD sweep
-    ("mhd_mri_3d", "mesh.nx=512;mesh.ny=1024;mesh.nz=16", 2),
-    ("orszag-tang3d", "mesh.nx=256;mesh.ny=256;mesh.nz=24", 2),
-    ("implode3d", "mesh.nx=512;mesh.ny=512;mesh.nz=8;hydro.riemannSolver=hllc", 2),
-]
+BENCH_GEOMETRY = pc.BENCH_GEOMETRY
 
 
 LONG_RUNS = [

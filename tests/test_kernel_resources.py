@@ -1,0 +1,70 @@
+"""What the headline kernels need from the register file and LDS -- pinned, because their speed hangs on it.
+
+The 3D MHD sweep runs two waves per SIMD with one 158 KB workgroup per CU; a register spill to scratch (measured in round 3 on
+the 12-wave variant: 280 B per lane, 24 % slower) or one more LDS byte than a CU has would silently cost tens of percent.  The
+numbers are the compiler's own kernel-resource-usage remarks of the device compile that produced the shipped libraries
+(ramsesgpu_amd/build.py keeps them next to the objects), so this test is about the .so the GPU tests load, not about a rebuild."""
+import pytest
+
+from ramsesgpu_amd import build as rb
+
+LDS_PER_CU = 160 * 1024
+
+
+def resources(out_name):
+    R = rb.kernel_resources(out_name)
+    if not R:   # library built by an older build.py: rebuild once, with the remarks
+        rb.build(verbose=False, force=True, out_name=out_name)
+        R = rb.kernel_resources(out_name)
+    assert R, "no kernel-resource-usage remarks for %s" % out_name
+    return R
+
+
+def pick(R, *needles):
+    hits = {k: v for k, v in R.items() if all(n in k for n in needles)}
+    assert hits, "no kernel matching %s" % (needles,)
+    return hits
+
+
+@pytest.fixture(scope="module", params=["librgpu.so", "librgpu_fast.so"])
+def lib_resources(request, product_lib, contracted_lib):
+    return request.param, resources(request.param)
+
+
+def test_mhd3d_sweep_resources(lib_resources):
+    name, R = lib_resources
+    exact = name == "librgpu.so"
+    for spec in ("107", "117"):   # 107: isothermal rotating box (the 512^3 MRI headline), 117: adiabatic plain box
+        (k, r), = pick(R, "mhd3d_sweep_kernel<%s>" % spec).items()
+        assert r["lds"] == 158240, (k, r)                      # T 2 x 46.5 KB + Q / B 3 x 18.4 KB + E 2 x 5 KB + 2 counters
+        assert r["lds"] <= LDS_PER_CU and r["occupancy"] == 2 and r["vgprs"] <= 256 and r["agprs"] == 0, (k, r)
+        if exact:   # one main loop per wave role: no spill at all
+            assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
+        else:       # one loop for all roles (measured faster with contracted arithmetic): at most a handful of spilled values
+            assert r["scratch"] <= 16 and r["vgpr_spill"] <= 3, (k, r)
+
+
+def test_mhd3d_update_and_2d_step_resources(lib_resources):
+    name, R = lib_resources
+    for k, r in pick(R, "K_mhd_update3d<").items():
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0 and r["occupancy"] >= 3, (k, r)
+    for k, r in pick(R, "mhd2d_step_kernel<").items():
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0 and r["occupancy"] >= 3 and 3 * r["lds"] <= LDS_PER_CU, (k, r)
+
+
+def test_hydro_sweep_resources(lib_resources):
+    name, R = lib_resources
+    for k, r in pick(R, "hydro3d_sweep_kernel<16, 16,").items():
+        generic = ", 0, 1>" in k   # SPEC_NONE: every solver and slope type in one kernel
+        assert r["vgpr_spill"] == 0 and r["scratch"] <= (64 if generic else 0), (k, r)
+        assert 2 * r["lds"] <= LDS_PER_CU and r["occupancy"] >= 2, (k, r)      # two workgroups per CU
+    for k, r in pick(R, "hydro2d_step_kernel<16, 16,").items():
+        generic = ", 0>" in k
+        assert r["vgpr_spill"] == 0 and r["scratch"] <= (40 if generic else 0), (k, r)
+        assert 3 * r["lds"] <= LDS_PER_CU and r["occupancy"] >= 3, (k, r)      # three workgroups per CU
+
+
+def test_no_kernel_exceeds_the_cu(lib_resources):
+    name, R = lib_resources
+    for k, r in R.items():
+        assert r.get("lds", 0) <= LDS_PER_CU and r.get("vgprs", 0) + r.get("agprs", 0) <= 512, (k, r)

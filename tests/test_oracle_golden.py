@@ -98,3 +98,26 @@ def test_threaded_step_equals_sequential(base, ov, nsteps, nthreads, oracle, pro
     b, db, tb = oracle.run_mt(p, U0, nsteps, nthreads)
     assert np.array_equal(da, db) and ta == tb
     assert np.array_equal(interior(a, p), interior(b, p))
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pinned_threads_change_nothing_but_the_placement(mode, oracle, product_lib):
+    """cpu_baseline_all_cores pins its threads (placement 1: all allowed CPUs in NUMA-node order, 2: the first NUMA node alone) and
+    lets every z-slab be first touched by its thread: same doubles, same time steps as the unpinned and the sequential runs;
+    the pinning is undone for the calling thread's process afterwards (threads are pinned one by one, never the process)"""
+    import os
+    base, ov, nsteps = "mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=16;MRI.amp=0.2", 4
+    p = product_lib.params_from_ini(ini(base), ov)
+    U0 = product_lib.init_condition(ini(base), ov, p)
+    a, da, ta = oracle.run(p, U0, nsteps)
+    before = os.sched_getaffinity(0)
+    ncpu = oracle.set_thread_placement(mode)
+    try:
+        assert 1 <= ncpu <= len(before)
+        secs, used = oracle.run_mt_scan(p, U0, nsteps, [4, 2], 3)
+        b, db, tb = oracle.run_mt(p, U0, nsteps, 5)
+    finally:
+        assert oracle.set_thread_placement(0) == 0
+    assert len(secs) == nsteps and used in (4, 2)
+    assert os.sched_getaffinity(0) == before
+    assert np.array_equal(da, db) and ta == tb and np.array_equal(interior(a, p), interior(b, p))
