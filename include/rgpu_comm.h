@@ -50,7 +50,8 @@ int rgpu_comm_unique_id(char id[RGPU_COMM_ID_BYTES]);
 
 /* Binds a context created with slab_rank = rank, slab_count = nranks (rgpuh_params_from_ini with slab.rank / slab.count,
  * z faces towards neighbour slabs = RGPU_BC_COPY) to a communicator of nranks processes.  Collective over all ranks.
- * The context must outlive the communicator.  nranks = 1 is allowed (periodic z: the rank is its own neighbour). */
+ * The context must outlive the communicator.  nranks = 1 is allowed: without slab interfaces nothing is exchanged; with the
+ * measurement key [run] slabSelfRing = yes (periodic z only) the rank is its own z neighbour and sends its planes to itself. */
 int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COMM_ID_BYTES], rgpu_comm** out);
 void rgpu_comm_destroy(rgpu_comm* cm);
 const char* rgpu_comm_last_error(rgpu_comm* cm);
@@ -87,6 +88,11 @@ int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out);
  * the SUM of the ranks' |mean B| (not the norm of the sum); divB, helicity and mean_rhov are the values of THIS rank alone (the
  * reference reduces them and then prints rank 0's local variables).  Collective; rank 0's result is the file's row. */
 int rgpu_comm_history_turbulence(rgpu_comm* cm, int parity, double* out14);
+
+/* Bytes this rank SENDS per halo exchange (both faces, all variables; 0: no face of this slab is a slab interface).  A launcher
+ * or test uses it to prove that planes really travel: nranks = 1 exchanges only when the context was made with the measurement
+ * key [run] slabSelfRing (periodic z faces turned into slab interfaces of a ring of one), otherwise its z ghosts are filled locally. */
+long long rgpu_comm_halo_bytes(rgpu_comm* cm);
 
 /* 0: serial schedule (exchange between the step pieces), 1: overlapped (default) */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);

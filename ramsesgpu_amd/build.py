@@ -128,13 +128,14 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code only
+    # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code + the one-thread hold kernel of the slab probe
     comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
     comm_out = os.path.join(HERE, "librgpu_comm_fast.so" if fast else "librgpu_comm.so")
     comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
     if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-I", os.path.join(CSRC, "hip"), comm_src, "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
+        # (-x hip: the transport header holds one one-thread kernel, the link-time hold of the one-GPU slab probe)
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-I", os.path.join(CSRC, "hip"), "-x", "hip", comm_src, "-x", "none", "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
                "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", comm_out]
         if verbose:
             print(" ".join(cmd))

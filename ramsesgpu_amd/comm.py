@@ -39,6 +39,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_set_device.argtypes = [C.c_int]
     lib.rgpu_comm_info.restype = C.c_int
     lib.rgpu_comm_info.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    lib.rgpu_comm_halo_bytes.restype = C.c_longlong
+    lib.rgpu_comm_halo_bytes.argtypes = [cm]
     lib.rgpu_comm_set_overlap.restype = C.c_int
     lib.rgpu_comm_set_overlap.argtypes = [cm, C.c_int]
     for name in ("rgpu_comm_exchange_z_wait",):
@@ -66,7 +68,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -80,7 +82,9 @@ def unique_id(comm_lib):
 class CommRun:
     """rank `rank` of `world` z-slabs.  comm_id: the 128 bytes of rgpu_comm_unique_id from rank 0 (any side channel)."""
 
-    def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=True):
+    def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=True, self_ring=False):
+        """self_ring (world = 1, periodic z only; measurement / test): the slab is its own z neighbour -- its periodic z faces
+        become slab interfaces ([run] slabSelfRing) and the halo planes really go through the transport, to itself"""
         self.L = library or load_library()
         # the driver library must be the one linked against self.L (librgpu_comm.so <-> librgpu.so, _fast <-> _fast):
         # a context created by one library must not be stepped by the other
@@ -92,6 +96,11 @@ class CommRun:
                 raise RgpuError("CommRun: %s does not drive %s (arithmetic %s)" % (os.path.basename(cpath), os.path.basename(self.L.path), self.L.arithmetic))
         self.rank, self.world = rank, world
         self.ini_path, self.overrides = ini_path, overrides
+        if self_ring:
+            if world != 1:
+                raise ValueError("self_ring is a ring of ONE rank")
+            overrides = (overrides + ";" if overrides else "") + "run.slabSelfRing=yes"
+            self.overrides = overrides
         self.p = self.L.params_from_ini(ini_path, overrides, slab=(rank, world))
         if not self.p.three_d:
             raise ValueError("2D problems do not shard: run replicas")
@@ -107,6 +116,10 @@ class CommRun:
     def _chk(self, rc, what):
         if rc != 0:
             raise RgpuError("%s: %s (%d)" % (what, self.CL.rgpu_comm_last_error(self.cm).decode(), rc))
+
+    def halo_bytes(self):
+        """bytes this rank sends per halo exchange (0: nothing is exchanged)"""
+        return int(self.CL.rgpu_comm_halo_bytes(self.cm))
 
     def info(self):
         """what the transport (RCCL) reports: {"ranks", "rank", "device", "pci_bus_id", "transport"}"""

@@ -295,6 +295,12 @@ int rgpu_comm_exchange_z_wait(rgpu_comm* cm) { RG_CHECK_CM(cm); return exchange_
 int rgpu_comm_make_all_boundaries(rgpu_comm* cm, int parity, double totalTime, double dt) { RG_CHECK_CM(cm); return make_all_boundaries(cm, parity & 1, totalTime, dt); }
 int rgpu_comm_compute_dt(rgpu_comm* cm, int useU, double* dt) { RG_CHECK_CM(cm); if (!dt) return RGPU_EINVAL; return compute_dt(cm, useU & 1, dt); }
 int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalTime) { RG_CHECK_CM(cm); return godunov_unsplit(cm, nStep, dt, totalTime); }
+long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
+  if (!cm || !cm->tc) return 0;
+  long long b = 0;
+  for (size_t i = 0; i < cm->ops[0].size(); ++i) if (cm->ops[0][i].send) b += (long long)(cm->ops[0][i].count * sizeof(double));
+  return b;
+}
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = overlap != 0; return RGPU_OK; }
 
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt) {

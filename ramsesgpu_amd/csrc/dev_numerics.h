@@ -511,6 +511,41 @@ RG_DEVFN double pos_max(double a0, double a1) { return fmax(a0, a1); }
 RG_DEVFN double max_of4(double a0, double a1, double a2, double a3) { return fmax(fmax(fmax(a0, a1), a2), a3); }
 RG_DEVFN double min_of4(double a0, double a1, double a2, double a3) { return fmin(fmin(fmin(a0, a1), a2), a3); }
 
+// ---- Alfven speeds of mag_riemann2d_hlld (riemann_mhd.h:727-738): which candidate wins, decided without taking roots ----
+// calfvenX = max of four |b_i| / sqrt(rho_i) and smallc, each candidate the correctly rounded quotient by the correctly rounded
+// root.  The four come in two pairs, one per state: (|b|, rho_x) and its "star" partner (|b| t, rho_x t) with t = dv / dS, both
+// built by fl(fl(. * dv) / dS).  In real arithmetic partner / plain = sqrt(t); every rounding on the way (two per star quantity,
+// two per root-and-quotient of either candidate: <= 18 of 2^-53 on the squares) moves that ratio by < 2^-48, so |dv - dS| > 2^-40 |dS| settles the order of the
+// two COMPUTED candidates (alfven_pick).  The two survivors of a group are compared through b1^2 rho2 against b2^2 rho1 (four
+// roundings against the eight of the computed candidates' squares: < 2^-49): a margin of 2^-45 settles it (alfven_duel).  Anything
+// closer -- a uniform state, an exact symmetry -- is "unsure" and the caller runs the reference's own sequence for the whole
+// wave.  Products below 2^-900 (fields below ~1e-117 at densities within 2^+-60: underflow makes the products imprecise) are not
+// compared at all: such candidates lose against smallc (>= 1e-100 is checked by the caller), whichever is picked.  The fp64
+// maximum is monotonic, so evaluating only the winner returns the bits the reference's FMAX5 chain returns.
+#ifndef RG_ALFVEN_SELECT
+#ifdef RG_ARITH_FAST
+#define RG_ALFVEN_SELECT 0   // contracted arithmetic: a root costs five instructions there, the selection would not pay
+#else
+#define RG_ALFVEN_SELECT 1
+#endif
+#endif
+struct AlfvenPair { double b, r; };
+RG_DEVFN AlfvenPair alfven_pick(double b, double rho, double bstar, double rhostar, double dv, double dS, bool& unsure) {
+  const bool star = fabs(dv) > fabs(dS);
+  unsure = unsure || !(fabs(dv - dS) > 0x1p-40 * fabs(dS));
+  AlfvenPair w;
+  w.b = star ? bstar : b;
+  w.r = star ? rhostar : rho;
+  return w;
+}
+RG_DEVFN AlfvenPair alfven_duel(const AlfvenPair& c1, const AlfvenPair& c2, bool& unsure) {
+  const double p1 = (c1.b * c1.b) * c2.r, p2 = (c2.b * c2.b) * c1.r;
+  const bool first = p1 >= p2;
+  const double hi = fmax(p1, p2), lo = fmin(p1, p2);
+  unsure = unsure || (!(lo * (1.0 + 0x1p-45) < hi) && hi > 0x1p-900);
+  return first ? c1 : c2;
+}
+
 // mag_riemann2d_hlld (riemann_mhd.h:616-821).  States are in the edge frame (u,v = the two in-plane
 // velocities, a,b = the two in-plane field components); E?? = u*b - v*a of each state.
 RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
@@ -568,16 +603,46 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rstarRR = rg_div(rstarRRx * (ST - RR.v), iST);
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
+  double calfvenL, calfvenR, calfvenB, calfvenT;
+#if RG_ALFVEN_SELECT
+  // Sixteen |b| / sqrt(rho) candidates, twelve distinct roots, four maxima consumed: pick each group's winner BEFORE any root is
+  // taken and evaluate only the winner with the reference's two operations (alfven_pick / alfven_duel above).  A lane whose
+  // ordering is not certain at fp64 round-off sends its wave down the reference's own sequence.
+  AlfvenPair wL, wR, wB, wT;
+  bool unsure = g.smallc < 1e-100;   // (candidates below ~1e-117 are assumed to lose against smallc: see alfven_duel)
+  {
+    const AlfvenPair lr = alfven_pick(LR.a, rstarLRx, AstarLR, rstarLR, ST - LR.v, iST.d, unsure);
+    const AlfvenPair ll = alfven_pick(LL.a, rstarLLx, AstarLL, rstarLL, SB - LL.v, iSB.d, unsure);
+    wL = alfven_duel(lr, ll, unsure);
+    const AlfvenPair rr = alfven_pick(RR.a, rstarRRx, AstarRR, rstarRR, ST - RR.v, iST.d, unsure);
+    const AlfvenPair rl = alfven_pick(RL.a, rstarRLx, AstarRL, rstarRL, SB - RL.v, iSB.d, unsure);
+    wR = alfven_duel(rr, rl, unsure);
+    const AlfvenPair bll = alfven_pick(LL.b, rstarLLy, BstarLL, rstarLL, SL - LL.u, iSL.d, unsure);
+    const AlfvenPair brl = alfven_pick(RL.b, rstarRLy, BstarRL, rstarRL, SR - RL.u, iSR.d, unsure);
+    wB = alfven_duel(bll, brl, unsure);
+    const AlfvenPair blr = alfven_pick(LR.b, rstarLRy, BstarLR, rstarLR, SL - LR.u, iSL.d, unsure);
+    const AlfvenPair brr = alfven_pick(RR.b, rstarRRy, BstarRR, rstarRR, SR - RR.u, iSR.d, unsure);
+    wT = alfven_duel(blr, brr, unsure);
+  }
+  if (!rgpu::rg_wave_any(unsure)) {
+    calfvenL = pos_max(rg_div(fabs(wL.b), rg_recip_sqrt_pos(wL.r)), g.smallc);
+    calfvenR = pos_max(rg_div(fabs(wR.b), rg_recip_sqrt_pos(wR.r)), g.smallc);
+    calfvenB = pos_max(rg_div(fabs(wB.b), rg_recip_sqrt_pos(wB.r)), g.smallc);
+    calfvenT = pos_max(rg_div(fabs(wT.b), rg_recip_sqrt_pos(wT.r)), g.smallc);
+  } else
+#endif
+  {
   const rg_recip_t iqLL = rg_recip_sqrt_pos(rstarLL), iqLR = rg_recip_sqrt_pos(rstarLR);
   const rg_recip_t iqRL = rg_recip_sqrt_pos(rstarRL), iqRR = rg_recip_sqrt_pos(rstarRR);
-  const double calfvenL = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.a), rg_recip_sqrt_pos(rstarLRx)), rg_div(fabs(AstarLR), iqLR)),
+  calfvenL = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.a), rg_recip_sqrt_pos(rstarLRx)), rg_div(fabs(AstarLR), iqLR)),
                                                   rg_div(fabs(LL.a), rg_recip_sqrt_pos(rstarLLx))), rg_div(fabs(AstarLL), iqLL)), g.smallc);
-  const double calfvenR = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(RR.a), rg_recip_sqrt_pos(rstarRRx)), rg_div(fabs(AstarRR), iqRR)),
+  calfvenR = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(RR.a), rg_recip_sqrt_pos(rstarRRx)), rg_div(fabs(AstarRR), iqRR)),
                                                   rg_div(fabs(RL.a), rg_recip_sqrt_pos(rstarRLx))), rg_div(fabs(AstarRL), iqRL)), g.smallc);
-  const double calfvenB = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LL.b), rg_recip_sqrt_pos(rstarLLy)), rg_div(fabs(BstarLL), iqLL)),
+  calfvenB = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LL.b), rg_recip_sqrt_pos(rstarLLy)), rg_div(fabs(BstarLL), iqLL)),
                                                   rg_div(fabs(RL.b), rg_recip_sqrt_pos(rstarRLy))), rg_div(fabs(BstarRL), iqRL)), g.smallc);
-  const double calfvenT = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.b), rg_recip_sqrt_pos(rstarLRy)), rg_div(fabs(BstarLR), iqLR)),
+  calfvenT = pos_max(pos_max(pos_max(pos_max(rg_div(fabs(LR.b), rg_recip_sqrt_pos(rstarLRy)), rg_div(fabs(BstarLR), iqLR)),
                                                   rg_div(fabs(RR.b), rg_recip_sqrt_pos(rstarRRy))), rg_div(fabs(BstarRR), iqRR)), g.smallc);
+  }
   const double SAL = fmin(ustar - calfvenL, 0.0);
   const double SAR = fmax(ustar + calfvenR, 0.0);
   const double SAB = fmin(vstar - calfvenB, 0.0);

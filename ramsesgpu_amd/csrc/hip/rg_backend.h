@@ -119,6 +119,9 @@ RG_DEVFN rg_recip_t rg_recip_sqrt_pos(double x) {
 #endif
 }
 
+// true on every lane of the wave when the predicate holds on any active lane (wave-uniform branch conditions)
+RG_DEVFN bool rg_wave_any(bool pred) { return __ballot(pred) != 0ull; }
+
 // max of non-negative doubles into one of several device slots (the CFL scan that rides in the MHD update kernel): the
 // plain read filters out almost every call once a slot holds a large value (a stale read can only cause a redundant atomic,
 // never a missed one: stale values are <= the current one)

@@ -2,7 +2,7 @@
 // One communicator per process; point-to-point halo traffic on a dedicated stream, ordered against the compute stream
 // with events; collectives on the compute stream itself.  On MI355X RCCL moves the planes over xGMI peer links.
 #pragma once
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <cstdlib>
@@ -26,13 +26,14 @@ struct Comm {
   // MEASUREMENT knob (scripts/slab_probe.py; off unless RGPU_COMM_EMULATE_GBPS is set): a one-GPU probe exchanges its halo planes
   // with itself, device-local, in ~0.03 ms; with the knob the halo stream is held for the time the same bytes would need on ONE
   // xGMI link at that rate -- RGPU_COMM_EMULATE_PEERS = 2: the two neighbours are different GPUs (N >= 3: two links in parallel,
-  // the per-peer bytes count), 1: both neighbours are the same GPU (N = 2: all bytes over one link)
-  double emulate_gbps; int emulate_peers; long long emulate_ns;
+  // the per-peer bytes count), 1: both neighbours are the same GPU (N = 2: all bytes over one link).  The hold is a one-thread
+  // kernel on the halo stream spinning on the constant-rate clock (round 4: a hipLaunchHostFunc sleep did NOT hold the stream on
+  // ROCm 7.0 -- a 51 ms "link" left the step time unchanged, gpurun_out/r4c/knob.log).
+  double emulate_gbps; int emulate_peers; long long wall_khz;
 };
-inline void emulated_link_sleep(void* ns) {   // hipLaunchHostFunc: the stream waits until this returns
-  const long long t = *static_cast<long long*>(ns);
-  timespec ts; ts.tv_sec = (time_t)(t / 1000000000ll); ts.tv_nsec = (long)(t % 1000000000ll);
-  nanosleep(&ts, 0);
+__global__ void emulated_link_hold(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 inline int fail(Comm* c, const std::string& m) { if (c) c->err = m; return -1; }
@@ -51,7 +52,13 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   c->comm = 0; c->halo = 0; c->ev_ready = 0; c->ev_done = 0; c->scratch = 0; c->rank = rank; c->nranks = nranks;
   c->emulate_gbps = std::getenv("RGPU_COMM_EMULATE_GBPS") ? std::atof(std::getenv("RGPU_COMM_EMULATE_GBPS")) : 0.0;
   c->emulate_peers = std::getenv("RGPU_COMM_EMULATE_PEERS") ? std::atoi(std::getenv("RGPU_COMM_EMULATE_PEERS")) : 2;
-  c->emulate_ns = 0;
+  c->wall_khz = 0;
+  if (c->emulate_gbps > 0) {
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+    c->wall_khz = khz > 0 ? khz : 100000;   // 100 MHz on gfx9
+  }
   *out = c;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
@@ -90,8 +97,9 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
   if (c->emulate_gbps > 0) {   // measurement knob, see Comm
     size_t sent = 0;
     for (int i = 0; i < nops; ++i) if (ops[i].send) sent += ops[i].count * sizeof(double);
-    c->emulate_ns = (long long)((double)sent / (c->emulate_peers >= 2 ? 2.0 : 1.0) / c->emulate_gbps);   // bytes / (GB/s) = ns
-    if (hipLaunchHostFunc(c->halo, emulated_link_sleep, &c->emulate_ns) != hipSuccess) return fail(c, "hipLaunchHostFunc");
+    const double ns = (double)sent / (c->emulate_peers >= 2 ? 2.0 : 1.0) / c->emulate_gbps;   // bytes / (GB/s) = ns
+    hipLaunchKernelGGL(emulated_link_hold, dim3(1), dim3(1), 0, c->halo, (long long)(ns * 1e-6 * (double)c->wall_khz));
+    if (hipGetLastError() != hipSuccess) return fail(c, "emulated_link_hold");
   }
   if (hipEventRecord(c->ev_done, c->halo) != hipSuccess) return fail(c, "event record");
   return 0;

@@ -187,6 +187,17 @@ void params_from_config(const IniConfig& cfg, int slab_rank, int slab_count, rgp
     if (slab_rank < slab_count - 1 || periodic_z) p->bc[5] = RGPU_BC_COPY;
   }
 
+  // MEASUREMENT / TEST key (not a reference key): one slab that is its own z neighbour.  The periodic z faces become slab
+  // interfaces, i.e. the local ghost fill leaves them alone and the slab driver (rgpu_comm, ring of one rank) really sends the
+  // halo planes -- to itself, device-local -- through the transport: what a rank of an N-slab run does per step, on one GPU.
+  // Only meaningful under the slab driver (a plain context would never fill its z ghosts).
+  if (slab_count == 1 && three_d && cfg.get_bool("run", "slabSelfRing", false)) {
+    if (!(p->bc[4] == RGPU_BC_PERIODIC && p->bc[5] == RGPU_BC_PERIODIC)) throw std::runtime_error("run.slabSelfRing needs periodic z faces");
+    if (p->nz < gw) throw std::runtime_error("slab thinner than the ghost width");
+    p->bc[4] = RGPU_BC_COPY;
+    p->bc[5] = RGPU_BC_COPY;
+  }
+
   rs->outputDir = cfg.get_string("output", "outputDir", "./");
   rs->outputPrefix = cfg.get_string("output", "outputPrefix", "output");
   rs->outputVtk = cfg.get_bool("output", "outputVtk", true);

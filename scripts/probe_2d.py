@@ -3,7 +3,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 from ramsesgpu_amd.solver import Library, Solver, lib_path
 L = Library(os.environ.get('RGPU_LIB') or lib_path())
-for base, ov, nst in (("jet2d_cpu", "", 200), ("kelvin_helmholtz_gpu_2d", "mesh.nx=512;mesh.ny=512", 200), ("kelvin_helmholtz_gpu_2d", "mesh.nx=4096;mesh.ny=4096", 20), ("orszag-tang", "mesh.nx=4096;mesh.ny=4096", 20)):
+for base, ov, nst in (("jet2d_cpu", "", 200), ("kelvin_helmholtz_gpu_2d", "mesh.nx=512;mesh.ny=512", 200), ("kelvin_helmholtz_gpu_2d", "mesh.nx=4096;mesh.ny=4096", 20), ("orszag-tang", "mesh.nx=512;mesh.ny=512", 500), ("orszag-tang", "mesh.nx=4096;mesh.ny=4096", 20)):
     ini = os.path.join(ROOT, "configs", base + ".ini")
     p = L.params_from_ini(ini, ov)
     U0 = L.init_condition(ini, ov, p)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-rank cost of the z-slab schedule on ONE GPU: one rank of a ring of one (periodic z: the rank is its own neighbour,
-the halo planes really travel through RCCL send / recv on the halo stream, device-local instead of over xGMI) stepping a
+"""Per-rank cost of the z-slab schedule on ONE GPU: one rank of a ring of one ([run] slabSelfRing: the rank is its own z neighbour,
+the halo planes really travel through RCCL send / recv on the halo stream, device-local instead of over xGMI; until round 4 a
+ring of one had NO slab interface and this probe exchanged nothing -- rgpu_comm_halo_bytes now proves the bytes) stepping a
 512 x 512 x (512/N) box through the C++ driver (include/rgpu_comm.h) with the overlapped and the serial schedule -- what a
 rank of bench.py --gpus N does per step.  The self-exchange itself costs ~0.03 ms; RGPU_COMM_EMULATE_GBPS=<rate> (a measurement
 knob of csrc/hip/rg_transport.h) holds the halo stream for the time the same bytes need on ONE xGMI link at that rate
@@ -25,7 +26,8 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
         os.environ["RGPU_COMM_EMULATE_GBPS"] = "%g" % rate
         os.environ["RGPU_COMM_EMULATE_PEERS"] = "1" if 512 // nz == 2 else "2"
     for overlap in ((True,) if os.environ.get('PROBE_NZ') else (True, False)):
-        run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=%d" % nz, 0, 1, cid, library=L, comm_library=CL, overlap=overlap)
+        run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=%d" % nz, 0, 1, cid, library=L, comm_library=CL, overlap=overlap, self_ring=True)
+        assert run.halo_bytes() == 2 * 3 * 518 * 518 * 8 * 8, run.halo_bytes()   # the planes really go through RCCL
         run.init_simulation()
         for _ in range(3): run.oneStepIntegration()
         run.solver.synchronize(); t0 = time.time()

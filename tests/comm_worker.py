@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 from oracle_api import Oracle  # noqa: E402
+from ramsesgpu_amd import _capi  # noqa: E402
 from ramsesgpu_amd import comm as rcomm  # noqa: E402
 from ramsesgpu_amd.solver import Library, interior  # noqa: E402
 
@@ -289,7 +290,16 @@ def main():
     ids = [rcomm.unique_id(CL) if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ini = os.path.join(ROOT, "configs", base + ".ini")
-    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0")
+    # world = 1 with periodic z: a ring of ONE rank -- the slab is its own z neighbour and its halo planes really go through the
+    # transport (run.slabSelfRing); asserted below through the bytes the driver says it sends per exchange
+    p0 = lib.params_from_ini(ini, ov)
+    ring1 = world == 1 and p0.nz_global != 1 and p0.bc[4] == _capi.BC_PERIODIC and p0.bc[5] == _capi.BC_PERIODIC
+    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0", self_ring=ring1)
+    if ring1 or world > 1:
+        gw = run.p.ghostWidth
+        faces = int(run.p.bc[4] == _capi.BC_COPY) + int(run.p.bc[5] == _capi.BC_COPY)
+        want = faces * gw * (run.p.nx + 2 * gw) * (run.p.ny + 2 * gw) * run.p.nbVar * 8
+        assert run.halo_bytes() == want and (want > 0 or not ring1), (run.halo_bytes(), want)
     run.init_simulation()
     dts = [run.oneStepIntegration() for _ in range(nsteps)]
     local = torch.from_numpy(np.ascontiguousarray(run.local_interior()))

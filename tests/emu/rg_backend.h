@@ -34,6 +34,8 @@ inline double rg_sqrt(double x) { return std::sqrt(x); }
 inline double rg_sqrt_pos(double x) { return std::sqrt(x); }
 inline rg_recip_t rg_recip_sqrt_pos(double x) { return rg_recip(std::sqrt(x)); }
 
+inline bool rg_wave_any(bool pred) { return pred; }   // one lane per "wave" on the host
+
 inline void rg_slot_max(unsigned long long* slot, double v) {
   double cur;
   std::memcpy(&cur, slot, sizeof(double));

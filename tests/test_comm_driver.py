@@ -230,7 +230,9 @@ from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import Solver, load_library
 L = load_library(); CL = rcomm.load_comm_library()
 ini = os.path.join(%r, "configs", %r + ".ini"); ov = %r
-run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True)
+RING = %r != "implode3d"   # periodic z: the slab is its own neighbour and really exchanges its planes
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True, self_ring=RING)
+assert (run.halo_bytes() > 0) == RING
 run.init_simulation()
 dts = [run.oneStepIntegration()]
 run.solver.enable_timers(True); run.solver.reset_timers()
@@ -240,7 +242,7 @@ assert tm["dt"] == 0.0 and (tm["update"] > 0 or tm["sweep"] > 0), tm
 p = L.params_from_ini(ini, ov); sv = Solver(p, L); ref = sv.start(L.init_condition(ini, ov, p), 5); sv.close()
 assert list(dts) == list(ref), (dts, ref)
 print("OK")
-''' % (ROOT, ROOT, base, ov)
+''' % (ROOT, ROOT, base, ov, base)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:]
@@ -261,7 +263,8 @@ from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import Solver, load_library, interior
 L = load_library(); CL = rcomm.load_comm_library()
 ini = os.path.join(%r, "configs", "mhd_mri_3d.ini"); ov = "mesh.nx=512;mesh.ny=1024;mesh.nz=64"
-run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True)
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True, self_ring=True)
+assert run.halo_bytes() == 2 * 3 * 518 * 1030 * 8 * 8, run.halo_bytes()
 info = run.info()
 assert info["ranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["transport"] == "rccl" and info["pci_bus_id"], info
 run.init_simulation()
@@ -310,7 +313,8 @@ arith = %r
 L = Library(lib_path(arith)); assert L.arithmetic == arith
 CL = rcomm.load_comm_library(rcomm.comm_lib_path(arith))
 ini = os.path.join(%r, "configs", "mhd_mri_3d.ini"); ov = "mesh.nx=512;mesh.ny=1024;mesh.nz=512"
-run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True)
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True, self_ring=True)
+assert run.halo_bytes() == 2 * 3 * 518 * 1030 * 8 * 8, run.halo_bytes()
 info = run.info()
 assert info["ranks"] == 1 and info["transport"] == "rccl", info
 run.init_simulation()
