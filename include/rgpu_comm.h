@@ -94,7 +94,12 @@ int rgpu_comm_history_turbulence(rgpu_comm* cm, int parity, double* out14);
  * key [run] slabSelfRing (periodic z faces turned into slab interfaces of a ring of one), otherwise its z ghosts are filled locally. */
 long long rgpu_comm_halo_bytes(rgpu_comm* cm);
 
-/* 0: serial schedule (exchange between the step pieces), 1: overlapped (default) */
+/* Step schedule.  0: serial (exchange between the step pieces).  1: overlapped -- fluxes of the whole slab, update of the boundary
+ * planes, exchange behind the update of the inner planes.  2: boundary-first (3D MHD; other solvers: same as 1) -- fluxes and
+ * update of the boundary planes first (two short launches of the z-marching sweep), exchange behind the sweep AND the update of
+ * the inner planes; costs two extra pipeline fills of the sweep, hides a link time up to the whole inner step.  -1 (default):
+ * 2 for slabs with fewer than 80 inner planes (the inner update alone is then shorter than the halo planes need on one xGMI
+ * link), else 1; RGPU_COMM_SCHEDULE=1|2 in the environment overrides the choice.  Every schedule gives the same doubles. */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
 
 /* hipSetDevice for launchers without a HIP binding of their own: call before rgpu_create / rgpu_comm_create */

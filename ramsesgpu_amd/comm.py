@@ -82,7 +82,7 @@ def unique_id(comm_lib):
 class CommRun:
     """rank `rank` of `world` z-slabs.  comm_id: the 128 bytes of rgpu_comm_unique_id from rank 0 (any side channel)."""
 
-    def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=True, self_ring=False):
+    def __init__(self, ini_path, overrides, rank, world, comm_id, library=None, comm_library=None, overlap=None, self_ring=False):
         """self_ring (world = 1, periodic z only; measurement / test): the slab is its own z neighbour -- its periodic z faces
         become slab interfaces ([run] slabSelfRing) and the halo planes really go through the transport, to itself"""
         self.L = library or load_library()
@@ -110,7 +110,9 @@ class CommRun:
         if rc != 0:
             msg = self.CL.rgpu_comm_last_error(self.cm).decode() if self.cm else "allocation"
             raise RgpuError("rgpu_comm_create: %s (%d)" % (msg, rc))
-        self._chk(self.CL.rgpu_comm_set_overlap(self.cm, 1 if overlap else 0), "set_overlap")
+        # overlap: None = the driver's choice (-1), False / True = serial / overlapped (0 / 1), 2 = boundary-first (include/rgpu_comm.h)
+        mode = -1 if overlap is None else (int(overlap) if not isinstance(overlap, bool) else (1 if overlap else 0))
+        self._chk(self.CL.rgpu_comm_set_overlap(self.cm, mode), "set_overlap")
         self.nStep, self.totalTime, self.dt = 0, 0.0, 0.0
 
     def _chk(self, rc, what):

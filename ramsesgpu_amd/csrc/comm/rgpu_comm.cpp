@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -24,7 +25,7 @@ struct rgpu_comm {
   rgpu_params p;
   rgpu_transport::Comm* tc;
   int rank, nranks;
-  bool overlap;
+  int overlap;      // 0 serial, 1 overlapped (exchange behind the inner update), 2 boundary-first (exchange behind the inner sweep + update), -1 choose per step geometry
   int primed;     // parity of the state whose ghosts are all valid, -1 = none
   int scanned;    // parity of the state whose 1/dt sits in the context's device slot, -1 = none
   std::vector<P2P> ops[2];
@@ -151,6 +152,10 @@ int random_forcing(rgpu_comm* cm, int nStep, double dt) {
   return 0;
 }
 
+// Slabs with fewer inner planes than this take the boundary-first schedule by default: 51.5 MB of halo planes per face at 512^2
+// need ~1.1 ms on one xGMI link at 45 GB/s, the inner update hides 14.5 us per plane (7.4 ms / 512 planes, 512^3 MRI).
+const int kThinSlabPlanes = 80;
+
 // exchange between the step pieces, nothing overlapped
 int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
   rgpu_ctx* c = cm->ctx;
@@ -219,13 +224,32 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // ... and the CFL scan of the new state rides in the update kernels (RGPU_CORE_SCAN) when the step allows it: no pass over
   // the output for the next compute_dt.  Otherwise, plain path: scan plane range by plane range before each fill.
   const int scan_flag = cm->fuse_scan ? RGPU_CORE_SCAN : 0;
-  RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes)");
+  // Mode 2, boundary-first (3D MHD, the one solver whose update is a kernel of its own): the fluxes of the planes the boundary
+  // updates read come from two short launches of the sweep, so that the exchange starts BEFORE the sweep of the inner planes and
+  // hides behind it and the inner update (N = 8, 512^2 x 64 slab: a window of ~4 ms instead of the ~0.85 ms of the inner update
+  // alone), for two extra pipeline fills of the z march (~4 of 67 plane iterations).  Mode -1 picks it when the inner update
+  // is shorter than the halo planes need on one link (both scale with the plane size: what decides is the slab thickness).
+  int mode = cm->overlap;
+  if (mode < 0) {
+    static const int env_mode = std::getenv("RGPU_COMM_SCHEDULE") ? std::atoi(std::getenv("RGPU_COMM_SCHEDULE")) : -1;
+    mode = env_mode >= 1 && env_mode <= 2 ? env_mode : ((cm->nranks > 1 || cm->ops[0].size()) && nz - 2 * gw < kThinSlabPlanes ? 2 : 1);
+  }
+  const bool early = mode == 2 && has_inner && cm->p.mhdEnabled && nz > 4 * gw + 2;
+  if (early) {
+    // flux planes of a FLUXES call on [a, b) are [a, b + 1): low range -> planes gw .. 2 gw, high range -> nz .. nz + gw
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[0][0], bnd[0][1], RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes, low)");
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[1][0], bnd[1][1], RGPU_CORE_FLUXES), "step_core_planes(fluxes, high)");
+  } else {
+    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes)");
+  }
   bool fused = cm->fuse_scan && rgpu_inv_dt_fused_active(c, pout) != 0;
   for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update)");
   if (scan && !fused) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
   for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
   if (int rc = exchange_start(cm, pout)) return rc;
   if (has_inner) {
+    // (boundary-first: the planes 2 gw + 1 .. nz - 1 are what the two short launches left)
+    if (early) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw + 1, nz - 1, RGPU_CORE_FLUXES), "step_core_planes(fluxes, inner)");
     RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 2 * gw, nz, RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update)");
     if (scan && !fused) RG_TRY(rgpu_inv_dt_accumulate(c, pout, 2 * gw, nz, 0), "inv_dt_accumulate");
     RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, 2 * gw, nz), "step_fill_planes");
@@ -255,7 +279,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   rgpu_comm* cm = new (std::nothrow) rgpu_comm();
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
-  cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = true; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
+  cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = -1; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
   cm->fuse_scan = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
@@ -301,7 +325,7 @@ long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
   for (size_t i = 0; i < cm->ops[0].size(); ++i) if (cm->ops[0][i].send) b += (long long)(cm->ops[0][i].count * sizeof(double));
   return b;
 }
-int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = overlap != 0; return RGPU_OK; }
+int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = (overlap < -1 || overlap > 2) ? 1 : overlap; return RGPU_OK; }
 
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt) {
   RG_CHECK_CM(cm);

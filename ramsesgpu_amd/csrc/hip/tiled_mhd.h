@@ -85,14 +85,6 @@ struct TLdsPlane {
 // work.  The two Riemann waves of a SIMD are arbitrated oldest-first: left alone the older one finishes at ~60 % of the
 // phase and the younger one runs the rest alone at single-wave issue efficiency; with the younger wave favoured for the
 // first 70 % of its work both finish together.
-#ifndef RG_PRIO_DROP_AT   // where the favoured wave gives its priority up: 0 after the edge problem, 1 after the face states, 3 at the barrier
-#define RG_PRIO_DROP_AT 0
-#endif
-// keeps the face states' arithmetic above an s_setprio (which the scheduler may otherwise move freely)
-RG_DEVFN void rg_sched_fence(Prim8& a, Prim8& b) {
-  asm volatile("" : "+v"(a.r), "+v"(a.p), "+v"(a.u), "+v"(a.v), "+v"(a.w), "+v"(a.a), "+v"(a.b), "+v"(a.c));
-  asm volatile("" : "+v"(b.r), "+v"(b.p), "+v"(b.u), "+v"(b.v), "+v"(b.w), "+v"(b.a), "+v"(b.b), "+v"(b.c));
-}
 template <int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
                           double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
@@ -104,9 +96,8 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
-      if (prio_drop && RG_PRIO_DROP_AT == 0) __builtin_amdgcn_s_setprio(0);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
-      if (prio_drop && RG_PRIO_DROP_AT == 1) { rg_sched_fence(L, R); __builtin_amdgcn_s_setprio(0); }
       double fl[8];
       mhd_face_flux<XD>(g, L, R, xPos, fl);
       store_flux<XD>(g, F, idx, fl);
@@ -119,9 +110,8 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
-      if (prio_drop && RG_PRIO_DROP_AT == 0) __builtin_amdgcn_s_setprio(0);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
-      if (prio_drop && RG_PRIO_DROP_AT == 1) { rg_sched_fence(L, R); __builtin_amdgcn_s_setprio(0); }
       double fl[8];
       mhd_face_flux<YD>(g, L, R, xPos, fl);
       store_flux<YD>(g, F, idx, fl);
@@ -133,10 +123,9 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
-      if (prio_drop && RG_PRIO_DROP_AT == 0) __builtin_amdgcn_s_setprio(0);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
       Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
-      if (prio_drop && RG_PRIO_DROP_AT == 1) { rg_sched_fence(c0, R); __builtin_amdgcn_s_setprio(0); }
       double fl[8];
       mhd_face_flux<ZD>(g, c0, R, xPos, fl);
       store_flux<ZD>(g, F, idx, fl);
@@ -355,7 +344,6 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                             \
       else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                        \
       else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                                      \
-      if (raise && RG_PRIO_DROP_AT == 3) __builtin_amdgcn_s_setprio(0);                                                  \
     }                                                                                                                    \
   }
 #ifdef RG_SWEEP_PROF
@@ -425,7 +413,6 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
         else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
         else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        if (raise && RG_PRIO_DROP_AT == 3) __builtin_amdgcn_s_setprio(0);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }

@@ -3,7 +3,7 @@
 the halo planes really travel through RCCL send / recv on the halo stream, device-local instead of over xGMI; until round 4 a
 ring of one had NO slab interface and this probe exchanged nothing -- rgpu_comm_halo_bytes now proves the bytes) stepping a
 512 x 512 x (512/N) box through the C++ driver (include/rgpu_comm.h) with the overlapped and the serial schedule -- what a
-rank of bench.py --gpus N does per step.  The self-exchange itself costs ~0.03 ms; RGPU_COMM_EMULATE_GBPS=<rate> (a measurement
+rank of bench.py --gpus N does per step.  The device-local self-exchange costs ~0.5 ms for the 103 MB; RGPU_COMM_EMULATE_GBPS=<rate> (a measurement
 knob of csrc/hip/rg_transport.h) holds the halo stream for the time the same bytes need on ONE xGMI link at that rate
 (2 x 51.5 MB per rank and step at 512^2 planes: N >= 3 -> two neighbours, two links in parallel, 51.5 MB each; N = 2 -> one
 neighbour, 103 MB over one link), so that the numbers show what the overlapped schedule really hides.  PROBE_LINK_GBPS="0 60 40"
@@ -25,7 +25,7 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
     if rate > 0:
         os.environ["RGPU_COMM_EMULATE_GBPS"] = "%g" % rate
         os.environ["RGPU_COMM_EMULATE_PEERS"] = "1" if 512 // nz == 2 else "2"
-    for overlap in ((True,) if os.environ.get('PROBE_NZ') else (True, False)):
+    for overlap in ((None,) if os.environ.get('PROBE_NZ') else (2, 1, 0)):   # schedule of include/rgpu_comm.h (None: the driver's choice)
         run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=%d" % nz, 0, 1, cid, library=L, comm_library=CL, overlap=overlap, self_ring=True)
         assert run.halo_bytes() == 2 * 3 * 518 * 518 * 8 * 8, run.halo_bytes()   # the planes really go through RCCL
         run.init_simulation()
@@ -36,6 +36,6 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
         run.solver.synchronize(); dt = (time.time() - t0) / n
         link_ms = 0.0 if rate <= 0 else 8 * 518 * 518 * 3 * 8 * (2 if 512 // nz == 2 else 1) / rate / 1e6
         print("nz=%3d (N=%d) link %3g GB/s (%.2f ms per exchange) %-8s %7.2f ms/step  -> %6.0f Mcell/s per rank, x%d = %6.0f" % (nz, 512 // nz, rate, link_ms,
-              "overlap" if overlap else "serial", dt * 1e3, 512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6), flush=True)
+              {None: "default", 2: "bnd-first", 1: "overlap", 0: "serial"}[overlap], dt * 1e3, 512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6), flush=True)
         run.close()
         cid = rcomm.unique_id(CL)

@@ -241,7 +241,7 @@ def poison():
     ids = [rcomm.unique_id(CL) if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ini = os.path.join(ROOT, "configs", base + ".ini")
-    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0")
+    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=int(os.environ.get("COMM_OVERLAP", "1")))
     run.init_simulation()
     failed_at, msg = None, ""
     for n in range(fstep + 3):
@@ -294,7 +294,7 @@ def main():
     # transport (run.slabSelfRing); asserted below through the bytes the driver says it sends per exchange
     p0 = lib.params_from_ini(ini, ov)
     ring1 = world == 1 and p0.nz_global != 1 and p0.bc[4] == _capi.BC_PERIODIC and p0.bc[5] == _capi.BC_PERIODIC
-    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=os.environ.get("COMM_OVERLAP", "1") != "0", self_ring=ring1)
+    run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=int(os.environ.get("COMM_OVERLAP", "1")), self_ring=ring1)
     if ring1 or world > 1:
         gw = run.p.ghostWidth
         faces = int(run.p.bc[4] == _capi.BC_COPY) + int(run.p.bc[5] == _capi.BC_COPY)

@@ -71,6 +71,13 @@ CASES = [
     ("mhd_mri_3d_stratified", "mesh.nx=6;mesh.ny=8;mesh.nz=27;hydro.slope_type=2.0;MRI.amp=0.3", 3, 3, 1),
     ("turbulence_hydro_ou", "mesh.nx=8;mesh.ny=8;mesh.nz=12;turbulence-Ornstein-Uhlenbeck.initialDensityPerturbationAmplitude=0.1", 3, 2, 1),   # Ornstein-Uhlenbeck forcing: same process on every rank
     ("turbulence_mhd_ou", "mesh.nx=6;mesh.ny=6;mesh.nz=18", 3, 3, 1),
+    # schedule 2, boundary-first: fluxes + update of the boundary planes, exchange, THEN the sweep of the inner planes (3D MHD)
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=40;MHD.omega0=0.02", 4, 2, 2),       # rotating + shearing box: shear remap per flux range
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=40", 4, 2, 2),
+    ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=32" + OPEN_BC, 4, 2, 2),           # end slabs with physical z faces
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=60", 3, 3, 2),
+    ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=24;MHD.omega0=0.02", 3, 1, 2),       # ring of one
+    ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=40", 3, 2, 2),                          # hydro: the sweep is the whole step, same as 1
 ]
 
 
@@ -94,7 +101,7 @@ def run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=None, timeo
 
 
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", CASES,
-                         ids=["%s-%d-x%d-%s" % (c[0], n, c[3], "overlap" if c[4] else "serial") for n, c in enumerate(CASES)])
+                         ids=["%s-%d-x%d-%s" % (c[0], n, c[3], ("serial", "overlap", "boundary-first")[c[4]]) for n, c in enumerate(CASES)])
 def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm_emu_lib, oracle, tmp_path):
     run_worker(base, ov, nsteps, world, overlap, tmp_path)
 
