@@ -389,16 +389,22 @@ def device_facts(torch, local_rank):
     return {"device": local_rank, "name": pr.name, "pci_bus_id": pci}
 
 
-def timed_steps(step, timers_src, ctl, steps, warmup):
+def timed_steps(step, timers_src, ctl, steps, warmup, batch=None):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns the max over ranks of the wall
-    time of the K steps [s].  (Per-kernel durations are a separate pass: phase_profile.)"""
+    time of the K steps [s].  (Per-kernel durations are a separate pass: phase_profile.)  batch(K): the K steps as ONE call of the
+    product's loop body (rgpu_run_steps: K turns of the reference's time loop, the same states and dt sequence; where a step is one
+    fused kernel the time step stays on the device between steps) -- single-device runs."""
     for _ in range(warmup):
         step()
     timers_src.enable_timers(False)
     ctl.sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    if batch is not None:
+        done = batch(steps)
+        assert done == steps, "rgpu_run_steps did %d of %d steps" % (done, steps)
+    else:
+        for _ in range(steps):
+            step()
     ctl.sync()
     elapsed = ctl.max(time.perf_counter() - t0)
     return elapsed
@@ -458,7 +464,7 @@ def single_gpu_record(wname, dims, arith, steps, warmup, ctl):
     del U0
     run.make_all_boundaries(0, 0.0, 0.0)
     # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
-    elapsed = timed_steps(run.oneStepIntegration, run, ctl, steps, warmup)
+    elapsed = timed_steps(run.oneStepIntegration, run, ctl, steps, warmup, batch=run.run_steps)
     prof = phase_profile(run.oneStepIntegration, run, ctl, steps)
     run.close()
     cells = float(nx) * ny * nz
@@ -598,7 +604,10 @@ def main():
                 sys.stderr.flush()
                 sys.exit(5)
             step, timers_src = srun.oneStepIntegration, srun.solver
-            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h)" % ("" if args.arith == "exact" else "_fast", info["transport"])
+            nzl, gwl = srun.p.nz, srun.p.ghostWidth
+            sched = os.environ.get("RGPU_COMM_SCHEDULE") or ("2 (boundary-first)" if (srun.p.mhdEnabled and nzl - 2 * gwl < 80 and nzl > 4 * gwl + 2) else "1 (overlap)")
+            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %.1f MB sent per rank and step" % (
+                "" if args.arith == "exact" else "_fast", info["transport"], sched, srun.halo_bytes() / 1e6)
         elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
         if args.timeline_only:
             if rank == 0:
@@ -653,6 +662,9 @@ def main():
                        "driver": driver, "rccl_ranks": rccl_ranks, "ranks": ranks,
                        "path": w["path"],
                        "arithmetic": args.arith,
+                       "time_loop": ("rgpu_run_steps(K): K turns of the reference's loop body in one call, same states and dt sequence; 2D: dt stays on the "
+                                     "device between the fused step kernels (csrc/hip/step_clock.h); 3D: the plain per-step loop" if world == 1 else
+                                     "K calls of oneStepIntegration"),
                        "parity": PARITY[args.arith]},
             "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],
         }

@@ -310,6 +310,19 @@ int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out);
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
 
+/* The body of the reference's time loop, "while (totalTime < tEnd && nStep < nStepmax) oneStepIntegration(nStep, totalTime, dt)"
+ * (MHDRunGodunov.cpp:3921-3990, HydroRunGodunov.cpp:3960), for up to nsteps steps: returns the number of steps done (< nsteps only when
+ * totalTime reached tEnd; pass HUGE_VAL for "no end") or a negative RGPU_E* code; *nStep, *t, *dt advance exactly as nsteps calls of
+ * rgpu_one_step_integration would advance them -- same states, same dt sequence, bit for bit.  What it adds: where a step is ONE fused
+ * kernel that leaves the CFL maxima and the ghost cells of its output on the device (2D hydro / MHD in a box of periodic, reflecting or
+ * outflow faces, no gravity, no rotating frame) the time step itself stays on the device (csrc/hip/step_clock.h: dt = cfl / max 1/dt, the
+ * loop condition and t += dt evaluated by a one-workgroup kernel between two steps) and a batch of steps is queued without a host round
+ * trip -- at the shipped 2D sizes that round trip costs as much as a third of the step.  Every other configuration runs the plain loop. */
+int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt);
+/* 1 when the next step of rgpu_run_steps on the state U[parity] would take its time step from the device (see above), else 0:
+ * lets a caller (and the tests) tell which loop runs. */
+int rgpu_device_time_step_ready(rgpu_ctx* c, int parity);
+
 /* Self-test of the device arithmetic the parity contract rests on: for n operand pairs computes on the device
  *   quot[i]  = rg_div(num[i], rg_recip(den[i]))   the shared-reciprocal division of csrc/hip/rg_backend.h
  *   quot2[i] = num[i] / den[i]                    the compiler's IEEE division

@@ -19,7 +19,7 @@
 // Arithmetic: the device functions of kernels_mhd2d.h (mhd_prim, mhd_trace2d_at, mhd_flux2d_at, mhd_update2d_at,
 // mhd_invdt2d_new) instantiated with LDS accessors -- same expressions, same operand order, same bits as the flat kernels.
 #pragma once
-#include "tiled_hydro.h"
+#include "step_clock.h"
 
 namespace rgpu_tiled {
 
@@ -63,8 +63,12 @@ struct F2LdsRead {
 template <int SPEC>
 __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, RotCoef rc, int nbx, const double* __restrict__ U,
                                                                    double* __restrict__ Unew, double dt, double dtdx, double dtdy,
-                                                                   unsigned long long* dt_slots, int images) {
+                                                                   unsigned long long* dt_slots, int images, const StepClock* clk) {
   spec_assume<SPEC>(g);
+  if (clk) {   // the time step lives on the device (hip/step_clock.h): a batch of steps queued without a host round trip
+    if (clk->stop) return;
+    dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy;
+  }
   __shared__ double LQ[8 * M2_ICELLS];          // primitives of the input tile; from phase 2 on: the fluxes F (13 x 128)
   __shared__ double LA[M2_ICELLS], LB[M2_ICELLS];   // face field Bx, By of the input tile
   __shared__ double LT[T2_COUNT * M2_TCELLS];   // compact traced state
@@ -198,15 +202,15 @@ template <int SPEC_PLAIN>
 // images != 0 (caller: all four faces periodic, nx, ny >= ghost width, nothing modifies the new state after this kernel): the
 // interior cells also write their periodic images, i.e. the output's ghost cells are valid on return
 inline int mhd2d_step(rg_stream_t s, const DevParams& g, const RotCoef& rc, bool spec_plain, const double* U, double* Unew, double dt,
-                      unsigned long long* dt_slots, int images) {
+                      unsigned long long* dt_slots, int images, const StepClock* clk = 0) {
   if (!mhd2d_step_covers(g)) return 1;
   const int nbx = (g.isize - 2 * g.gw + 1 + M2_OX - 1) / M2_OX;   // cells gw .. isize-gw (the CT layer included)
   const int nby = (g.jsize - 2 * g.gw + 1 + M2_OY - 1) / M2_OY;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   if (spec_plain)
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk);
   else
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

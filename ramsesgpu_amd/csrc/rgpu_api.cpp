@@ -59,6 +59,10 @@ struct rgpu_ctx {
   int ghost_ok_parity;  // parity of the state whose ghost cells the step kernel itself left valid (2D MHD, periodic box: images written
                         // by the fused kernel), -1: none -- the plain path then skips the ghost fill of that state at the next step's entry
   int scan_acc_parity;  // parity of the state whose CFL maximum is being accumulated piece by piece (RGPU_CORE_SCAN), -1: none
+  // device-side time step (hip/step_clock.h; rgpu_run_steps): records of a batch on the device / pinned host memory, and the record the
+  // step being queued reads (0: the step takes its by-value dt arguments)
+  enum { kClockBatch = 256 };
+  rgpu_tiled::StepClock* d_clk; rgpu_tiled::StepClock* h_clk; const rgpu_tiled::StepClock* clk_cur;
   std::string err;
 };
 
@@ -203,7 +207,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->G = 0;
   c->Frc = 0;
   c->ou = 0;
-  c->d_red = 0; c->h_red = 0;
+  c->d_red = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
   for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
@@ -498,7 +502,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
   const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
   unsigned long long* slots = scan2 ? c->d_red : 0;
-  if (scan2 && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  if (c->clk_cur && !(ND == 2 && scan2)) return -1;   // a device-clock step is the fused 2D kernel with the CFL term or nothing
+  if (scan2 && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
   if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
     Phase ph(c, RGPU_T_SWEEP);
     // plain faces, nothing modifying the new state after this kernel: it writes the ghost images too and the next step's fill is skipped
@@ -512,10 +517,11 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
         images |= bc << (2 * f);
       }
     }
-    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images);
+    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, c->clk_cur);
     if (rc == 0 && scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     if (rc == 0 && images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
     if (rc <= 0) return rc;
+    if (c->clk_cur) return -1;   // the flat kernels take dt by value
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
@@ -588,14 +594,15 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
       static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
       if (no_fused_dt) scan = false;
       if (rgpu_tiled::mhd2d_step_covers(g)) {
-        if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+        if (c->clk_cur && !scan) return -1;
+        if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
         Phase ph(c, RGPU_T_SWEEP);
         // periodic box on the plain path, nothing modifying the new state after this kernel: it writes the periodic images too and
         // the next step's ghost fill is skipped (step_pre)
         static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
         bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0);
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, c->clk_cur);
         if (rct < 0) return -1;
         if (rct == 0) {
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
@@ -605,6 +612,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
       }
     }
   }
+  if (c->clk_cur) return -1;   // the flat kernels take dt by value
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim<> k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   const bool gf = g.grav_on == 2;
@@ -1053,6 +1061,8 @@ void rgpu_destroy(rgpu_ctx* c) {
   rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G); rg_free(c->Frc);
   delete c->ou;
   rg_free(c->d_red); rg_host_free(c->h_red);
+  if (c->d_clk) rg_free(c->d_clk);
+  if (c->h_clk) rg_host_free(c->h_clk);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
   if (c->fork_ok) rg_event_destroy(c->ev_fork);
   for (int i = 0; i < c->n_order_events; ++i) { rg_event_destroy(c->ev_trace[i]); rg_event_destroy(c->ev_flux[i]); }
@@ -1441,6 +1451,67 @@ int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt) {
   *nStep += 1;
   *t += d;
   return RGPU_OK;
+}
+
+// A state qualifies for the device-side time step when the kernel that wrote it was a fused 2D step that left BOTH its CFL maxima
+// in the device slots and its ghost cells valid (so the next step is one launch with no ghost fill), nothing in the step depends on dt
+// through the host (no gravity: (0.5 dt) g travels in the kernel arguments; no rotating frame: its coefficients are functions of dt),
+// and the phase timers are off (they synchronise every launch anyway).
+static bool clock_ready(rgpu_ctx* c, int parity) {
+  return !c->g.three_d && !c->g.rot && !c->timers_on && c->p.gravityEnabled == 0 && !c->p.enableJet && c->p.slab_count == 1 &&
+         !(c->p.nu > 0) && !(c->p.eta > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
+         c->fused_dt_parity == parity && c->fused_dt_slots == RG_DT_SLOTS && c->ghost_ok_parity == parity && rgpu_tiled::step_clock_supported();
+}
+
+int rgpu_device_time_step_ready(rgpu_ctx* c, int parity) { return (c && c->U[0] && clock_ready(c, parity & 1)) ? 1 : 0; }
+
+int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt) {
+  RG_CHECK_CTX(c);
+  if (!nStep || !t || !dt) return fail(c, RGPU_EINVAL, "run_steps: null pointer");
+  int done = 0;
+  while (done < nsteps && *t < tEnd) {
+    const int parity = *nStep % 2;
+    if (!clock_ready(c, parity)) {   // the reference's loop body (the first step of a run always comes through here)
+      const int rc = rgpu_one_step_integration(c, nStep, t, dt);
+      if (rc) return rc;
+      ++done;
+      continue;
+    }
+    if (!c->d_clk) {
+      if (rg_malloc((void**)&c->d_clk, rgpu_ctx::kClockBatch * sizeof(rgpu_tiled::StepClock)) ||
+          rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(rgpu_tiled::StepClock))) return RG_HIPFAIL(c, "run_steps: clock records");
+    }
+    const int m = (nsteps - done < rgpu_ctx::kClockBatch) ? nsteps - done : (int)rgpu_ctx::kClockBatch;
+    const double seed = c->p.mhdEnabled ? c->p.smallc / std::fmin(c->p.dx, c->p.dy) : 0.0;   // inv_dt_fetch
+    int queued = 0, rc = 0;
+    for (; queued < m && rc == 0; ++queued) {
+      rc = rgpu_tiled::launch_step_clock(c->stream, c->d_red, c->p.cfl, seed, c->p.dx, c->p.dy, *t, tEnd, queued ? c->d_clk + queued - 1 : 0, c->d_clk + queued);
+      if (rc) break;
+      c->clk_cur = c->d_clk + queued;
+      // == rgpu_godunov_unsplit for this configuration: step_pre finds the ghost cells valid, the step is the fused kernel
+      rc = step_pre(c, *nStep + queued) || step_core(c, *nStep + queued, 0.0, 0.0);
+      c->clk_cur = 0;
+      if (rc == 0 && !clock_ready(c, (*nStep + queued + 1) % 2)) rc = -1;   // (cannot happen: same configuration, same kernel)
+    }
+    if (rc) { state_modified(c); return RG_HIPFAIL(c, "run_steps: queueing a device-clock step"); }
+    if (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(rgpu_tiled::StepClock), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "run_steps: clock read-back");
+    int ran = 0;
+    for (; ran < queued && c->h_clk[ran].stop == 0; ++ran) {   // t accumulated in the order of the reference's loop
+      *dt = c->h_clk[ran].dt;
+      *t += *dt;
+      *nStep += 1;
+    }
+    done += ran;
+    if (ran < queued) {   // the steps behind a stop were no-ops: the state of step *nStep is the last one written
+      const int stop = c->h_clk[ran].stop;
+      c->fused_dt_parity = -1;              // its CFL maxima went into the clock that stopped
+      c->scan_acc_parity = -1;
+      c->ghost_ok_parity = *nStep % 2;      // its ghost cells are the ones its kernel wrote
+      if (stop == 2) return fail(c, RGPU_EHIP, "run_steps: the time step is not a number");
+      break;
+    }
+  }
+  return done;
 }
 
 int rgpu_synchronize(rgpu_ctx* c) {

@@ -265,6 +265,16 @@ class Solver:
         self.nStep, self.totalTime, self.dt = n.value, t.value, d.value
         return self.dt
 
+    def run_steps(self, nsteps, tEnd=float("inf")):
+        """up to nsteps turns of the reference's time loop (rgpu_run_steps: where a step is one fused kernel the time step stays on
+        the device and the batch is queued without a host round trip); returns the number of steps done"""
+        n, t, d = C.c_int(self.nStep), C.c_double(self.totalTime), C.c_double(self.dt)
+        done = self.lib.rgpu_run_steps(self.ctx, int(nsteps), float(tEnd), C.byref(n), C.byref(t), C.byref(d))
+        if done < 0:
+            self._chk(done, "run_steps")
+        self.nStep, self.totalTime, self.dt = n.value, t.value, d.value
+        return done
+
     def start(self, hU, nStepmax, tEnd=float("inf")):
         """init part + time loop of start() (MHDRunGodunov.cpp:3801-3989) without outputs; returns the dt list"""
         self.upload(hU, both=False)

@@ -13,8 +13,12 @@ for base, ov, nst in (("jet2d_cpu", "", 200), ("kelvin_helmholtz_gpu_2d", "mesh.
     sv.synchronize(); t0 = time.time()
     for _ in range(nst): sv.oneStepIntegration()
     sv.synchronize(); dt = (time.time() - t0) / nst
+    sv.synchronize(); t0 = time.time()
+    assert sv.run_steps(nst) == nst       # the same steps as one call of the product's loop (device-side time step where it applies)
+    sv.synchronize(); dtb = (time.time() - t0) / nst
+    clocked = L.lib.rgpu_device_time_step_ready(sv.ctx, sv.nStep % 2)
     sv.enable_timers(True); sv.reset_timers()
     for _ in range(5): sv.oneStepIntegration()
     tm = sv.timers()
-    print("%-26s %-28s %9.1f Mcell/s %8.4f ms/step  " % (base, ov, p.nx * p.ny / dt / 1e6, dt * 1e3) + " ".join("%s=%.4f" % (k, v / 5 * 1e3) for k, v in tm.items() if v > 0), flush=True)
+    print("%-26s %-28s %9.1f Mcell/s %8.4f ms/step | run_steps%s %9.1f Mcell/s %8.4f ms/step  " % (base, ov, p.nx * p.ny / dt / 1e6, dt * 1e3, "(device dt)" if clocked else "(plain loop)", p.nx * p.ny / dtb / 1e6, dtb * 1e3) + " ".join("%s=%.4f" % (k, v / 5 * 1e3) for k, v in tm.items() if v > 0), flush=True)
     sv.close()

@@ -406,3 +406,81 @@ def test_kelvin_helmholtz_large_box_properties(gpu_lib):
     nx, ny = p.nx, p.ny
     assert np.array_equal(A[:, gw:-gw, :gw], A[:, gw:-gw, nx:nx + gw]) and np.array_equal(A[:, gw:-gw, nx + gw:], A[:, gw:-gw, gw:2 * gw])
     assert np.array_equal(A[:, :gw, :], A[:, ny:ny + gw, :]) and np.array_equal(A[:, ny + gw:, :], A[:, gw:2 * gw, :])
+
+
+RUN_STEPS_CASES = [
+    ("orszag-tang", "mesh.nx=96;mesh.ny=80", 24, True),                        # 2D MHD, periodic box: device-side time step
+    ("kelvin_helmholtz_gpu_2d", "mesh.nx=96;mesh.ny=64", 24, True),            # 2D hydro, periodic
+    ("hydro_sod2d", "mesh.nx=70;mesh.ny=50", 24, True),                        # 2D hydro, outflow faces (ghost images)
+    ("blast2d", "mesh.nx=64;mesh.ny=64;mesh.boundary_xmin=1;mesh.boundary_ymax=1;mesh.boundary_xmax=2;mesh.boundary_ymin=3;mesh.boundary_ymax=3", 24, True),
+    ("rayleigh_taylor_gpu_2d", "mesh.nx=40;mesh.ny=120", 12, False),           # gravity: (0.5 dt) g is a kernel argument -> plain loop
+    ("jet2d_cpu", "mesh.nx=40;mesh.ny=120", 12, False),                        # jet inflow: ghost fill every step -> plain loop
+    ("mhd_BrioWu", "mesh.nx=128;mesh.ny=8", 12, None),                         # 2D MHD with non-periodic faces
+    ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=24;hydro.riemannSolver=hllc", 6, False),   # 3D: plain loop
+]
+
+
+@pytest.mark.parametrize("base,ov,nsteps,clocked", RUN_STEPS_CASES, ids=[c[0] for c in RUN_STEPS_CASES])
+def test_run_steps_equals_the_reference_loop(base, ov, nsteps, clocked, gpu_lib, oracle):
+    """rgpu_run_steps(K) == K x oneStepIntegration == the oracle: every double of the state, nStep, t and the last dt -- where the
+    time step stays on the device between the fused 2D kernels (csrc/hip/step_clock.h) and where the call falls back to the plain
+    loop.  Also: in odd pieces (3 + the rest, i.e. a batch that starts in the middle of a run), and with an end time inside the batch
+    (the loop condition t < tEnd is evaluated on the device: the steps behind it are no-ops)."""
+    p = gpu_lib.params_from_ini(ini(base), ov)
+    U0 = gpu_lib.init_condition(ini(base), ov, p)
+    pc.attach_gravity(gpu_lib, base, ov, p, oracle=oracle)
+    ref, dts_ref, _ = oracle.run(p, U0, nsteps)
+    t_ref = 0.0
+    for d in dts_ref:
+        t_ref += float(d)
+
+    def fresh():
+        sv = Solver(p, gpu_lib)
+        pc.attach_gravity(gpu_lib, base, ov, p, sv=sv)
+        sv.start(U0, 0)
+        return sv
+    sv = fresh()
+    try:
+        assert sv.run_steps(nsteps) == nsteps
+        assert sv.nStep == nsteps and sv.totalTime == t_ref and sv.dt == float(dts_ref[-1]), (sv.nStep, sv.totalTime, t_ref, sv.dt, dts_ref[-1])
+        nbad = int((interior(sv.getDataHost(), p) != interior(ref, p)).sum())
+        assert nbad == 0, "%d doubles differ from the oracle" % nbad
+    finally:
+        sv.close()
+    sv = fresh()
+    try:   # pieces: the first call always starts with a plain step, the second one starts on a state a fused kernel left
+        assert sv.run_steps(3) == 3 and sv.run_steps(nsteps - 3) == nsteps - 3
+        assert sv.nStep == nsteps and sv.totalTime == t_ref and sv.dt == float(dts_ref[-1])
+        assert np.array_equal(interior(sv.getDataHost(), p), interior(ref, p))
+        # one more plain step after a batch: the context's bookkeeping (CFL slots, ghost cells) is that of the single-step path
+        more, dts_more, _ = oracle.run(p, U0, nsteps + 1)
+        sv.oneStepIntegration()
+        assert sv.dt == float(dts_more[-1]) and np.array_equal(interior(sv.getDataHost(), p), interior(more, p))
+    finally:
+        sv.close()
+    # an end time inside the batch: the reference's loop stops after the first step that carries t to or past tEnd
+    cut = nsteps // 2
+    t_cut = 0.0
+    for d in dts_ref[:cut]:
+        t_cut += float(d)
+    tEnd = t_cut - 0.25 * float(dts_ref[cut - 1])     # reached during step `cut`
+    ref_cut, dts_cut, _ = oracle.run(p, U0, cut)
+    sv = fresh()
+    try:
+        assert sv.run_steps(nsteps, tEnd) == cut, sv.nStep
+        assert sv.nStep == cut and sv.totalTime == t_cut and sv.dt == float(dts_ref[cut - 1])
+        assert np.array_equal(interior(sv.getDataHost(), p), interior(ref_cut, p))
+        assert sv.run_steps(5, tEnd) == 0                                  # t >= tEnd: nothing to do
+        sv.oneStepIntegration()                                           # and the state is usable: full CFL scan, valid ghost cells
+        assert sv.dt == float(dts_ref[cut]), (sv.dt, dts_ref[cut])
+    finally:
+        sv.close()
+    if clocked is not None and not (os.environ.get("RGPU_TILED") == "0" or os.environ.get("RGPU_NO_STEP_CLOCK") or os.environ.get("RGPU_NO_GHOST_IMAGES")):
+        # which path ran: the phase timers count launches -- a device-clock batch has no ghost fill and no stand-alone CFL scan,
+        # and the timers themselves force the plain loop, so count through the dominant-kernel statistics of an untimed run instead
+        sv = fresh()
+        try:
+            sv.run_steps(2)
+            assert bool(gpu_lib.lib.rgpu_device_time_step_ready(sv.ctx, sv.nStep % 2)) == clocked
+        finally:
+            sv.close()

@@ -2,10 +2,12 @@
 layer (tests/emu/rg_backend.h, built into tests/_build/librgpu_emu.so), against the oracle and the reference's
 golden fixtures.  This is the CPU-side proof that index ranges, the compact traced state, the gather order of the
 update and the shearing-box remaps are right; tests/test_gpu_parity.py repeats the same checks on the HIP build."""
+import numpy as np
 import pytest
 
 import parity_checks as pc
-from conftest import golden_cases
+from conftest import golden_cases, ini
+from ramsesgpu_amd.solver import Solver, interior
 
 GOLDEN = sorted(golden_cases())
 
@@ -69,3 +71,33 @@ def test_turbulence_history(base, ov, nsteps, emu_lib, oracle):
                                      ("mhd_BrioWu", "mesh.nx=12;mesh.ny=10;mesh.nz=8;BrioWu.direction=0;MHD.implementationVersion=4")])
 def test_public_ghost_fill_invalidates_fused_dt(base, ov, emu_lib, oracle):
     pc.check_public_ghost_fill_invalidates_fused_dt(emu_lib, oracle, base, ov)
+
+
+@pytest.mark.parametrize("base,ov,nsteps", [("orszag-tang", "mesh.nx=24;mesh.ny=20", 8), ("kelvin_helmholtz_gpu_2d", "mesh.nx=24;mesh.ny=16", 8),
+                                            ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8", 4)])
+def test_run_steps_plain_loop(base, ov, nsteps, emu_lib, oracle):
+    """rgpu_run_steps on the emulation backend (no fused kernels, no device-side time step: the plain loop of the reference):
+    K steps in one call, in pieces, and with an end time inside the batch == the oracle's run"""
+    p = emu_lib.params_from_ini(ini(base), ov)
+    U0 = emu_lib.init_condition(ini(base), ov, p)
+    ref, dts_ref, _ = oracle.run(p, U0, nsteps)
+    t_ref = 0.0
+    for d in dts_ref:
+        t_ref += float(d)
+    sv = Solver(p, emu_lib)
+    try:
+        sv.start(U0, 0)
+        assert emu_lib.lib.rgpu_device_time_step_ready(sv.ctx, 0) == 0
+        assert sv.run_steps(3) == 3 and sv.run_steps(nsteps - 3) == nsteps - 3
+        assert sv.nStep == nsteps and sv.totalTime == t_ref and sv.dt == float(dts_ref[-1])
+        assert np.array_equal(interior(sv.getDataHost(), p), interior(ref, p))
+        assert sv.run_steps(4, tEnd=t_ref) == 0
+    finally:
+        sv.close()
+    sv = Solver(p, emu_lib)
+    try:
+        sv.start(U0, 0)
+        tEnd = t_ref - 0.5 * float(dts_ref[-1])
+        assert sv.run_steps(nsteps + 5, tEnd) == nsteps and sv.totalTime == t_ref
+    finally:
+        sv.close()
