@@ -213,11 +213,13 @@ GPU_CASES = [
     ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 1),
     ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 0),         # serial schedule
     ("implode3d", "mesh.nx=32;mesh.ny=32;mesh.nz=32;hydro.riemannSolver=hllc", 4, 1),
+    ("mhd_mri_3d", "mesh.nx=32;mesh.ny=48;mesh.nz=40", 4, 2),            # boundary-first: three launches of the LDS-tiled sweep per step
+    ("orszag-tang3d", "mesh.nx=24;mesh.ny=24;mesh.nz=40", 3, 2),
 ]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("base,ov,nsteps,overlap", GPU_CASES, ids=["%s-%s" % (c[0], "overlap" if c[3] else "serial") for c in GPU_CASES])
+@pytest.mark.parametrize("base,ov,nsteps,overlap", GPU_CASES, ids=["%s-%s" % (c[0], ("serial", "overlap", "boundary-first")[c[3]]) for c in GPU_CASES])
 def test_rccl_driver_single_rank_on_gpu(base, ov, nsteps, overlap, gpu_lib, oracle, tmp_path):
     """the RCCL transport with nranks = 1 on the 1-GPU box (a ring of one): product libraries, no torch in the data path"""
     run_worker(base, ov, nsteps, 1, overlap, tmp_path, env_extra={"COMM_DEVICE": "cuda:0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
@@ -256,10 +258,12 @@ print("OK")
 
 
 @pytest.mark.gpu
-def test_config5_rank_geometry_through_the_rccl_driver(tmp_path):
+@pytest.mark.parametrize("schedule", [1, 2], ids=["overlap", "boundary-first"])
+def test_config5_rank_geometry_through_the_rccl_driver(schedule, tmp_path):
     """BASELINE config 5 = 512 x 1024 x 512 MRI over 8 GPUs: every rank owns a 512 x 1024 x 64 slab (+ 3 ghost planes per side).
     That per-rank box through the product's slab driver (rgpu_comm, RCCL ring of one rank: the slab is its own z neighbour,
-    2 x 102 MB per exchange on the halo stream) for 4 overlapped steps: (i) every double and every dt equal to the
+    205 MB sent per exchange on the halo stream, asserted) for 4 steps of the overlapped and of the boundary-first schedule (the
+    default at this slab thickness): (i) every double and every dt equal to the
     single-device run of the same box, (ii) div B at round-off and mass conserved to round-off (size-independent
     properties: the oracle cannot run this size in seconds), (iii) RCCL itself reports 1 rank on the device the context uses."""
     code = r'''
@@ -270,7 +274,7 @@ from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import Solver, load_library, interior
 L = load_library(); CL = rcomm.load_comm_library()
 ini = os.path.join(%r, "configs", "mhd_mri_3d.ini"); ov = "mesh.nx=512;mesh.ny=1024;mesh.nz=64"
-run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=True, self_ring=True)
+run = rcomm.CommRun(ini, ov, 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=%d, self_ring=True)
 assert run.halo_bytes() == 2 * 3 * 518 * 1030 * 8 * 8, run.halo_bytes()
 info = run.info()
 assert info["ranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["transport"] == "rccl" and info["pci_bus_id"], info
@@ -296,7 +300,7 @@ mass1 = float(gi[0].sum(dtype=np.longdouble))
 assert abs(mass1 - mass0) < 1e-12 * abs(mass0), (mass0, mass1)
 assert np.isfinite(gi).all()
 print("OK")
-''' % (ROOT, ROOT)
+''' % (ROOT, ROOT, schedule)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-3000:]
