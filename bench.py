@@ -609,6 +609,13 @@ def main():
             driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %.1f MB sent per rank and step" % (
                 "" if args.arith == "exact" else "_fast", info["transport"], sched, srun.halo_bytes() / 1e6)
         elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
+        # diagnostic of the halo exchange of the LAST timed step on this rank: its duration on the halo stream and the rate that makes
+        # of the bytes this rank sent (include/rgpu_comm.h); next to ms_per_step it tells how much of it the schedule hid
+        xchg = None
+        if info is not None and srun is not None:
+            xms = srun.last_exchange_ms()
+            if xms > 0:
+                xchg = {"exchange_ms": xms, "sent_MB": srun.halo_bytes() / 1e6, "GB_per_s_sent": srun.halo_bytes() / xms / 1e6}
         if args.timeline_only:
             if rank == 0:
                 print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
@@ -635,6 +642,8 @@ def main():
         mine = dict(device_facts(torch, local_rank), rank=rank)
         if info is not None:
             mine.update(rccl_rank=info["rank"], rccl_ranks=info["ranks"], rccl_device=info["device"], rccl_pci_bus_id=info["pci_bus_id"])
+            if xchg is not None:
+                mine.update(last_halo_exchange=xchg)
         ranks = ctl.gather(mine)
         rccl_ranks = info["ranks"] if info is not None else None
         if info is not None:   # every rank must have seen the same communicator size, and one device each

@@ -94,6 +94,11 @@ int rgpu_comm_history_turbulence(rgpu_comm* cm, int parity, double* out14);
  * key [run] slabSelfRing (periodic z faces turned into slab interfaces of a ring of one), otherwise its z ghosts are filled locally. */
 long long rgpu_comm_halo_bytes(rgpu_comm* cm);
 
+/* Duration [ms] of the last halo exchange on the halo stream -- from the moment the compute stream released the planes to the last
+ * plane received -- or a negative value if there was none; waits for that exchange.  With rgpu_comm_halo_bytes it gives the rate the
+ * links delivered; next to the step time it tells how much of the exchange the schedule hid.  A diagnostic for multi-GPU runs. */
+double rgpu_comm_last_exchange_ms(rgpu_comm* cm);
+
 /* Step schedule.  0: serial (exchange between the step pieces).  1: overlapped -- fluxes of the whole slab, update of the boundary
  * planes, exchange behind the update of the inner planes.  2: boundary-first (3D MHD; other solvers: same as 1) -- fluxes and
  * update of the boundary planes first (two short launches of the z-marching sweep), exchange behind the sweep AND the update of

@@ -39,6 +39,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_set_device.argtypes = [C.c_int]
     lib.rgpu_comm_info.restype = C.c_int
     lib.rgpu_comm_info.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+    lib.rgpu_comm_last_exchange_ms.restype = C.c_double
+    lib.rgpu_comm_last_exchange_ms.argtypes = [cm]
     lib.rgpu_comm_halo_bytes.restype = C.c_longlong
     lib.rgpu_comm_halo_bytes.argtypes = [cm]
     lib.rgpu_comm_set_overlap.restype = C.c_int
@@ -68,7 +70,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -122,6 +124,10 @@ class CommRun:
     def halo_bytes(self):
         """bytes this rank sends per halo exchange (0: nothing is exchanged)"""
         return int(self.CL.rgpu_comm_halo_bytes(self.cm))
+
+    def last_exchange_ms(self):
+        """duration of the last halo exchange on the halo stream [ms] (< 0: none)"""
+        return float(self.CL.rgpu_comm_last_exchange_ms(self.cm))
 
     def info(self):
         """what the transport (RCCL) reports: {"ranks", "rank", "device", "pci_bus_id", "transport"}"""

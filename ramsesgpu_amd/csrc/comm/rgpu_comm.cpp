@@ -319,6 +319,7 @@ int rgpu_comm_exchange_z_wait(rgpu_comm* cm) { RG_CHECK_CM(cm); return exchange_
 int rgpu_comm_make_all_boundaries(rgpu_comm* cm, int parity, double totalTime, double dt) { RG_CHECK_CM(cm); return make_all_boundaries(cm, parity & 1, totalTime, dt); }
 int rgpu_comm_compute_dt(rgpu_comm* cm, int useU, double* dt) { RG_CHECK_CM(cm); if (!dt) return RGPU_EINVAL; return compute_dt(cm, useU & 1, dt); }
 int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalTime) { RG_CHECK_CM(cm); return godunov_unsplit(cm, nStep, dt, totalTime); }
+double rgpu_comm_last_exchange_ms(rgpu_comm* cm) { return (cm && cm->tc && !cm->ops[0].empty()) ? rgpu_transport::last_exchange_ms(cm->tc) : -1.0; }
 long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
   if (!cm || !cm->tc) return 0;
   long long b = 0;

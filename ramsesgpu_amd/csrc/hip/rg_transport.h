@@ -19,7 +19,7 @@ struct P2P { double* ptr; size_t count; int peer; int send; };
 struct Comm {
   ncclComm_t comm;
   hipStream_t halo;
-  hipEvent_t ev_ready, ev_done;
+  hipEvent_t ev_ready, ev_done, ev_begin;   // ev_begin / ev_done carry time stamps: duration of the last exchange on the halo stream
   double* scratch;   // device scratch for host-value reductions
   int rank, nranks;
   std::string err;
@@ -49,7 +49,7 @@ inline int unique_id(char* id128) {
 
 inline int create(Comm** out, int rank, int nranks, const char* id128) {
   Comm* c = new Comm();
-  c->comm = 0; c->halo = 0; c->ev_ready = 0; c->ev_done = 0; c->scratch = 0; c->rank = rank; c->nranks = nranks;
+  c->comm = 0; c->halo = 0; c->ev_ready = 0; c->ev_done = 0; c->ev_begin = 0; c->scratch = 0; c->rank = rank; c->nranks = nranks;
   c->emulate_gbps = std::getenv("RGPU_COMM_EMULATE_GBPS") ? std::atof(std::getenv("RGPU_COMM_EMULATE_GBPS")) : 0.0;
   c->emulate_peers = std::getenv("RGPU_COMM_EMULATE_PEERS") ? std::atoi(std::getenv("RGPU_COMM_EMULATE_PEERS")) : 2;
   c->wall_khz = 0;
@@ -69,7 +69,7 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   // the exchange is short and on the critical path of the neighbours: highest priority
   if (hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, hi) != hipSuccess) return fail(c, "halo stream");
   if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) return fail(c, "events");
+      hipEventCreate(&c->ev_done) != hipSuccess || hipEventCreate(&c->ev_begin) != hipSuccess) return fail(c, "events");
   if (hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) return fail(c, "scratch");
   return 0;
 }
@@ -79,6 +79,7 @@ inline void destroy(Comm* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
   if (c->halo) (void)hipStreamDestroy(c->halo);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
@@ -88,6 +89,7 @@ inline void destroy(Comm* c) {
 inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nops) {
   hipStream_t cs = (hipStream_t)compute_stream;
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
+  if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
   ncclResult_t r = ncclGroupStart();
   for (int i = 0; i < nops && r == ncclSuccess; ++i)
     r = ops[i].send ? ncclSend(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo)
@@ -106,6 +108,14 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
 }
 inline int exchange_wait(Comm* c, void* compute_stream) {
   return hipStreamWaitEvent((hipStream_t)compute_stream, c->ev_done, 0) == hipSuccess ? 0 : fail(c, "stream wait");
+}
+
+// duration of the last exchange on the halo stream (from the moment the compute stream released it to the last plane received),
+// for diagnosing a multi-GPU run; blocks until that exchange is complete.  < 0: none yet
+inline double last_exchange_ms(Comm* c) {
+  float ms = -1.0f;
+  if (hipEventSynchronize(c->ev_done) != hipSuccess || hipEventElapsedTime(&ms, c->ev_begin, c->ev_done) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+  return (double)ms;
 }
 
 // in place on a device buffer, queued on `stream`

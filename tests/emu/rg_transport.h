@@ -58,6 +58,7 @@ inline int exchange_wait(Comm* c, void*) {
   c->pending.clear();
   return rc ? fail(c, "exchange callback failed") : 0;
 }
+inline double last_exchange_ms(Comm*) { return -1.0; }
 inline int allreduce_max(Comm* c, double* d, int n, void*) {
   if (c->nranks == 1) return 0;
   return callbacks().allreduce(d, n, 0) ? fail(c, "allreduce callback failed") : 0;

@@ -284,6 +284,8 @@ gw = p.ghostWidth
 A0 = run.solver.getDataHost(0)
 mass0 = float(A0[0, gw:-gw, gw:-gw, gw:-gw].sum(dtype=np.longdouble))
 dts = [run.oneStepIntegration() for _ in range(4)]
+xms = run.last_exchange_ms()
+assert 0.0 < xms < 1000.0, xms   # the exchange really ran on the halo stream (time stamps around the grouped send / recv)
 got = run.solver.getDataHost(run.nStep %% 2).copy()
 run.close()
 ps = L.params_from_ini(ini, ov); sv = Solver(ps, L); ref_dts = sv.start(L.init_condition(ini, ov, ps), 4); ref = sv.getDataHost(); sv.close()
