@@ -604,10 +604,10 @@ def main():
                 sys.stderr.flush()
                 sys.exit(5)
             step, timers_src = srun.oneStepIntegration, srun.solver
-            nzl, gwl = srun.p.nz, srun.p.ghostWidth
-            sched = os.environ.get("RGPU_COMM_SCHEDULE") or ("2 (boundary-first)" if (srun.p.mhdEnabled and nzl - 2 * gwl < 80 and nzl > 4 * gwl + 2) else "1 (overlap)")
-            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %.1f MB sent per rank and step" % (
-                "" if args.arith == "exact" else "_fast", info["transport"], sched, srun.halo_bytes() / 1e6)
+            sched = {"2": "2 (boundary-first)"}.get(os.environ.get("RGPU_COMM_SCHEDULE", ""), "1 (overlap)")
+            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
+                "" if args.arith == "exact" else "_fast", info["transport"], sched,
+                "in-place (one send / recv per variable and face)" if os.environ.get("RGPU_COMM_PACK") == "0" else "packed (one send / recv per peer)", srun.halo_bytes() / 1e6)
         elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
         # diagnostic of the halo exchange of the LAST timed step on this rank: its duration on the halo stream and the rate that makes
         # of the bytes this rank sent (include/rgpu_comm.h); next to ms_per_step it tells how much of it the schedule hid

@@ -11,8 +11,10 @@
  *   compute_dt + MPI allReduce(MIN)             HydroRunBaseMpi.cpp:509-513, 696-700     -> rgpu_comm_compute_dt
  *   godunov_unsplit / oneStepIntegration of MHDRunGodunovMpi / HydroRunGodunovMpi        -> rgpu_comm_godunov_unsplit,
  *                                                                                           rgpu_comm_one_step_integration
- * k is the slowest index, so the ghostWidth planes of one variable are one contiguous chunk: they are sent from / received
- * into the state arrays in place (no pack kernels, no host staging) with ONE grouped ncclSend / ncclRecv set per exchange on
+ * k is the slowest index, so the ghostWidth planes of one variable are one contiguous chunk.  The chunks for one peer are
+ * gathered into a device staging buffer by one small kernel, travel as ONE ncclSend / ncclRecv per peer (one grouped launch per
+ * exchange) and are scattered by a second kernel (RGPU_COMM_PACK=0: sent from / received into the state arrays in place, one
+ * operation per chunk -- which RCCL runs as eight launches), no host staging, on
  * a dedicated halo stream, ordered against the context's compute stream by events only.  The 1/dt maximum is all-reduced
  * in place in the context's device slot (ncclMax on the compute stream) and read back once per step.
  *
@@ -102,9 +104,9 @@ double rgpu_comm_last_exchange_ms(rgpu_comm* cm);
 /* Step schedule.  0: serial (exchange between the step pieces).  1: overlapped -- fluxes of the whole slab, update of the boundary
  * planes, exchange behind the update of the inner planes.  2: boundary-first (3D MHD; other solvers: same as 1) -- fluxes and
  * update of the boundary planes first (two short launches of the z-marching sweep), exchange behind the sweep AND the update of
- * the inner planes; costs two extra pipeline fills of the sweep, hides a link time up to the whole inner step.  -1 (default):
- * 2 for slabs with fewer than 80 inner planes (the inner update alone is then shorter than the halo planes need on one xGMI
- * link), else 1; RGPU_COMM_SCHEDULE=1|2 in the environment overrides the choice.  Every schedule gives the same doubles. */
+ * the inner planes; costs two extra pipeline fills of the sweep, hides a link time up to the whole inner step (for thin slabs on slow
+ * links: at 512^2 x 64 per rank it overtakes schedule 1 when a face takes longer than ~1.3 ms).  -1 (default): 1, or what
+ * RGPU_COMM_SCHEDULE=1|2 in the environment says.  Every schedule gives the same doubles. */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
 
 /* hipSetDevice for launchers without a HIP binding of their own: call before rgpu_create / rgpu_comm_create */

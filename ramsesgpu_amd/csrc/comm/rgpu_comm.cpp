@@ -152,10 +152,6 @@ int random_forcing(rgpu_comm* cm, int nStep, double dt) {
   return 0;
 }
 
-// Slabs with fewer inner planes than this take the boundary-first schedule by default: 51.5 MB of halo planes per face at 512^2
-// need ~1.1 ms on one xGMI link at 45 GB/s, the inner update hides 14.5 us per plane (7.4 ms / 512 planes, 512^3 MRI).
-const int kThinSlabPlanes = 80;
-
 // exchange between the step pieces, nothing overlapped
 int godunov_unsplit_serial(rgpu_comm* cm, int nStep, double dt, double t) {
   rgpu_ctx* c = cm->ctx;
@@ -227,12 +223,13 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // Mode 2, boundary-first (3D MHD, the one solver whose update is a kernel of its own): the fluxes of the planes the boundary
   // updates read come from two short launches of the sweep, so that the exchange starts BEFORE the sweep of the inner planes and
   // hides behind it and the inner update (N = 8, 512^2 x 64 slab: a window of ~4 ms instead of the ~0.85 ms of the inner update
-  // alone), for two extra pipeline fills of the z march (~4 of 67 plane iterations).  Mode -1 picks it when the inner update
-  // is shorter than the halo planes need on one link (both scale with the plane size: what decides is the slab thickness).
+  // alone), for two extra pipeline fills of the z march (+0.39 ms at that size).  Mode -1 = schedule 1 unless RGPU_COMM_SCHEDULE says
+  // otherwise: with the packed exchange (rg_transport.h) the one-GPU probe has schedule 1 ahead down to a 60 GB/s link even at N = 8
+  // (5.66 against 5.88 ms), level at 40 GB/s; schedule 2 is for links slower than that, to be decided by the first multi-GPU run.
   int mode = cm->overlap;
   if (mode < 0) {
     static const int env_mode = std::getenv("RGPU_COMM_SCHEDULE") ? std::atoi(std::getenv("RGPU_COMM_SCHEDULE")) : -1;
-    mode = env_mode >= 1 && env_mode <= 2 ? env_mode : ((cm->nranks > 1 || cm->ops[0].size()) && nz - 2 * gw < kThinSlabPlanes ? 2 : 1);
+    mode = env_mode >= 1 && env_mode <= 2 ? env_mode : 1;
   }
   const bool early = mode == 2 && has_inner && cm->p.mhdEnabled && nz > 4 * gw + 2;
   if (early) {

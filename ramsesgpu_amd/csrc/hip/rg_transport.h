@@ -9,6 +9,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <vector>
 
 #define RG_TRANSPORT_NAME "rccl"
 
@@ -30,7 +31,24 @@ struct Comm {
   // kernel on the halo stream spinning on the constant-rate clock (round 4: a hipLaunchHostFunc sleep did NOT hold the stream on
   // ROCm 7.0 -- a 51 ms "link" left the step time unchanged, gpurun_out/r4c/knob.log).
   double emulate_gbps; int emulate_peers; long long wall_khz;
+  // Packed exchange (RGPU_COMM_PACK, default on): the chunks that go to one peer are gathered into ONE staging buffer by one small
+  // kernel, sent / received as ONE operation per peer and direction, and scattered by a second kernel.  Round 4: RCCL turned the 32
+  // in-place send / recv operations of one grouped exchange (a chunk per variable and face) into 8 kernel launches with ~40 us
+  // between them (profiles/r04_slab_timeline.txt); two or four operations make one launch.
+  bool pack;
+  double* stage_s; double* stage_r; size_t stage_cap;   // doubles
 };
+struct PackDesc { double* ptr[32]; unsigned long long off[32]; unsigned long long count[32]; int n; };
+__global__ void pack_chunks_kernel(PackDesc d, double* __restrict__ stage, int unpack) {
+  const int seg = (int)blockIdx.y;
+  if (seg >= d.n) return;
+  double* __restrict__ p = d.ptr[seg];
+  double* __restrict__ st = stage + d.off[seg];
+  const unsigned long long n = d.count[seg];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    if (unpack) p[i] = st[i]; else st[i] = p[i];
+  }
+}
 __global__ void emulated_link_hold(long long ticks) {
   const long long t0 = (long long)wall_clock64();
   while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
@@ -53,6 +71,8 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   c->emulate_gbps = std::getenv("RGPU_COMM_EMULATE_GBPS") ? std::atof(std::getenv("RGPU_COMM_EMULATE_GBPS")) : 0.0;
   c->emulate_peers = std::getenv("RGPU_COMM_EMULATE_PEERS") ? std::atoi(std::getenv("RGPU_COMM_EMULATE_PEERS")) : 2;
   c->wall_khz = 0;
+  c->pack = !(std::getenv("RGPU_COMM_PACK") && std::atoi(std::getenv("RGPU_COMM_PACK")) == 0);
+  c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
   if (c->emulate_gbps > 0) {
     int dev = 0, khz = 0;
     (void)hipGetDevice(&dev);
@@ -77,6 +97,8 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
 inline void destroy(Comm* c) {
   if (!c) return;
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->stage_s) (void)hipFree(c->stage_s);
+  if (c->stage_r) (void)hipFree(c->stage_r);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
@@ -90,12 +112,61 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
   hipStream_t cs = (hipStream_t)compute_stream;
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
+  if (c->pack && nops <= 64) {
+    // per peer, in posting order (which is the order the peer's matching operations are posted in): one region of the send
+    // stage and one of the receive stage; the concatenation keeps that order, so ONE send matches ONE receive per peer
+    PackDesc ds, dr; ds.n = 0; dr.n = 0;
+    int peers[4]; size_t tot_s[4] = {0, 0, 0, 0}, tot_r[4] = {0, 0, 0, 0}; int npeers = 0;
+    int pidx[64];
+    for (int i = 0; i < nops; ++i) {
+      int q = 0;
+      while (q < npeers && peers[q] != ops[i].peer) ++q;
+      if (q == npeers) { if (npeers == 4) return fail(c, "packed exchange: more than four peers"); peers[npeers++] = ops[i].peer; }
+      pidx[i] = q;
+      (ops[i].send ? tot_s : tot_r)[q] += ops[i].count;
+    }
+    size_t base_s[4], base_r[4], all_s = 0, all_r = 0;
+    for (int q = 0; q < npeers; ++q) { base_s[q] = all_s; all_s += tot_s[q]; base_r[q] = all_r; all_r += tot_r[q]; }
+    const size_t need = all_s > all_r ? all_s : all_r;
+    if (need > c->stage_cap) {
+      if (hipStreamSynchronize(c->halo) != hipSuccess) return fail(c, "stage: synchronize");
+      if (c->stage_s) (void)hipFree(c->stage_s);
+      if (c->stage_r) (void)hipFree(c->stage_r);
+      c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
+      if (hipMalloc((void**)&c->stage_s, need * sizeof(double)) != hipSuccess || hipMalloc((void**)&c->stage_r, need * sizeof(double)) != hipSuccess) return fail(c, "stage buffers");
+      c->stage_cap = need;
+    }
+    size_t fill_s[4] = {0, 0, 0, 0}, fill_r[4] = {0, 0, 0, 0};
+    size_t longest = 0;
+    for (int i = 0; i < nops; ++i) {
+      PackDesc& d = ops[i].send ? ds : dr;
+      if (d.n == 32) return fail(c, "packed exchange: more than 32 chunks per direction");
+      const int q = pidx[i];
+      d.ptr[d.n] = ops[i].ptr; d.count[d.n] = ops[i].count;
+      d.off[d.n] = ops[i].send ? base_s[q] + fill_s[q] : base_r[q] + fill_r[q];
+      (ops[i].send ? fill_s : fill_r)[q] += ops[i].count;
+      if (ops[i].count > longest) longest = ops[i].count;
+      ++d.n;
+    }
+    unsigned bx = (unsigned)((longest + 255) / 256); if (bx > 256u) bx = 256u; if (bx < 1u) bx = 1u;
+    if (ds.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)ds.n), dim3(256), 0, c->halo, ds, c->stage_s, 0);
+    ncclResult_t r = ncclGroupStart();
+    for (int q = 0; q < npeers && r == ncclSuccess; ++q)
+      if (tot_s[q]) r = ncclSend(c->stage_s + base_s[q], tot_s[q], ncclDouble, peers[q], c->comm, c->halo);
+    for (int q = 0; q < npeers && r == ncclSuccess; ++q)
+      if (tot_r[q]) r = ncclRecv(c->stage_r + base_r[q], tot_r[q], ncclDouble, peers[q], c->comm, c->halo);
+    const ncclResult_t re = ncclGroupEnd();
+    if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+    if (dr.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)dr.n), dim3(256), 0, c->halo, dr, c->stage_r, 1);
+    if (hipGetLastError() != hipSuccess) return fail(c, "pack / unpack kernel");
+  } else {
   ncclResult_t r = ncclGroupStart();
   for (int i = 0; i < nops && r == ncclSuccess; ++i)
     r = ops[i].send ? ncclSend(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo)
                     : ncclRecv(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo);
   const ncclResult_t re = ncclGroupEnd();
   if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+  }
   if (c->emulate_gbps > 0) {   // measurement knob, see Comm
     size_t sent = 0;
     for (int i = 0; i < nops; ++i) if (ops[i].send) sent += ops[i].count * sizeof(double);

@@ -6,12 +6,12 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 def short(n):
-    m = re.search(r"K_\w+(<[^>]*>)?", n) or re.search(r"(mhd3d|hydro3d)_sweep_kernel", n) or re.search(r"nccl\w*|rccl\w*", n)
+    m = re.search(r"K_\w+(<[^>]*>)?", n) or re.search(r"(mhd3d|hydro3d)_sweep_kernel", n) or re.search(r"nccl\w*|rccl\w*", n) or re.search(r"emulated_link_hold|step_clock_kernel", n)
     return m.group(0) if m else n[:30]
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows]
 ks.sort()
 t_lo, t_hi = ks[0][0], max(k[1] for k in ks)
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+skip = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 0.5
 t0 = t_lo + (t_hi - t_lo) * skip            # analyse the tail (timed steps), not initialisation
 for s, e, n in ks:
     if e <= t0: continue
@@ -30,3 +30,10 @@ print("window %.1f ms" % (tot / 1e6))
 for k in sorted(hist): print("  %d kernels in flight: %5.1f %%" % (k, 100 * hist[k] / tot))
 print("top combinations:")
 for c, v in sorted(combo.items(), key=lambda x: -x[1])[:14]: print("  %5.1f %%  %s" % (100 * v / tot, " + ".join(c) if c else "(idle)"))
+
+if "--gantt" in sys.argv:   # the last launches, one per line, with start .. end relative to the first of them (about two steps of a slab run)
+    tail = ks[-56:]
+    base = tail[0][0]
+    print("the last %d launches (start .. end in ms):" % len(tail))
+    for s_, e_, n_ in tail:
+        print("  %8.3f .. %8.3f  %s" % ((s_ - base) / 1e6, (e_ - base) / 1e6, n_))
