@@ -47,7 +47,8 @@ def kernel_source_hash():
     import hashlib
     import re
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
-        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h")] + [os.path.join(CSRC, "rgpu_api.cpp")]
+        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h") and f != "rg_transport.h"] + [os.path.join(CSRC, "rgpu_api.cpp")]
+    # (rg_transport.h is the RCCL transport of librgpu_comm.so: no kernel of librgpu.so comes from it)
     h = hashlib.sha256()
     for f in files:
         text = re.sub(r"//[^\n]*", "", open(f).read())

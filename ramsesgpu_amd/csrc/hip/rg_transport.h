@@ -159,13 +159,13 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
     if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
     if (dr.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)dr.n), dim3(256), 0, c->halo, dr, c->stage_r, 1);
     if (hipGetLastError() != hipSuccess) return fail(c, "pack / unpack kernel");
-  } else {
-  ncclResult_t r = ncclGroupStart();
-  for (int i = 0; i < nops && r == ncclSuccess; ++i)
-    r = ops[i].send ? ncclSend(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo)
-                    : ncclRecv(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo);
-  const ncclResult_t re = ncclGroupEnd();
-  if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+  } else {   // in place: one operation per chunk (rounds 1-3)
+    ncclResult_t r = ncclGroupStart();
+    for (int i = 0; i < nops && r == ncclSuccess; ++i)
+      r = ops[i].send ? ncclSend(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo)
+                      : ncclRecv(ops[i].ptr, ops[i].count, ncclDouble, ops[i].peer, c->comm, c->halo);
+    const ncclResult_t re = ncclGroupEnd();
+    if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
   }
   if (c->emulate_gbps > 0) {   // measurement knob, see Comm
     size_t sent = 0;
