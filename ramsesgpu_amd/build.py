@@ -132,7 +132,8 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code + the one-thread hold kernel of the slab probe
     comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
     comm_out = os.path.join(HERE, "librgpu_comm_fast.so" if fast else "librgpu_comm.so")
-    comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(HERE, "..", "include", "rgpu_comm.h"),
+    comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(CSRC, "comm", "halo_ops.h"), os.path.join(CSRC, "comm", "pack_plan.h"),
+                 os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
     if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):
         # (-x hip: the transport header holds one one-thread kernel, the link-time hold of the one-GPU slab probe)

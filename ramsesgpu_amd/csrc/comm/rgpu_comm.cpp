@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rg_transport.h"
+#include "halo_ops.h"
 
 using rgpu_transport::P2P;
 
@@ -58,21 +59,10 @@ void build_ops(rgpu_comm* cm, int parity) {
   const rgpu_params& p = cm->p;
   const int gw = p.ghostWidth;
   const size_t plane = (size_t)(p.nx + 2 * gw) * (p.ny + 2 * gw);
-  const size_t ncell = plane * (size_t)(p.nz + 2 * gw);
-  const size_t chunk = plane * gw;
   double* U = rgpu_device_state(cm->ctx, parity);
-  const int prev = (cm->rank - 1 + cm->nranks) % cm->nranks, next = (cm->rank + 1) % cm->nranks;
-  const bool has_prev = p.bc[4] == RGPU_BC_COPY, has_next = p.bc[5] == RGPU_BC_COPY;
-  for (int v = 0; v < p.nbVar; ++v) {
-    double* Uv = U + (size_t)v * ncell;
-    if (has_prev) { const P2P o = {Uv + plane * gw, chunk, prev, 1}; ops.push_back(o); }            // low interior planes
-    if (has_next) { const P2P o = {Uv + plane * p.nz, chunk, next, 1}; ops.push_back(o); }            // high interior planes
-  }
-  for (int v = 0; v < p.nbVar; ++v) {
-    double* Uv = U + (size_t)v * ncell;
-    if (has_next) { const P2P o = {Uv + plane * (p.nz + gw), chunk, next, 0}; ops.push_back(o); }     // high ghost planes
-    if (has_prev) { const P2P o = {Uv, chunk, prev, 0}; ops.push_back(o); }                           // low ghost planes
-  }
+  std::vector<rgpu_transport::HaloOp> h;
+  rgpu_transport::halo_ops(plane, gw, p.nz, p.nbVar, cm->rank, cm->nranks, p.bc[4] == RGPU_BC_COPY, p.bc[5] == RGPU_BC_COPY, h);
+  for (size_t i = 0; i < h.size(); ++i) { const P2P o = {U + h[i].offset, h[i].count, h[i].peer, h[i].send}; ops.push_back(o); }
 }
 
 int exchange_start(rgpu_comm* cm, int parity) {

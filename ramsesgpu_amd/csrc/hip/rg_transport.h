@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "../comm/pack_plan.h"
+
 #define RG_TRANSPORT_NAME "rccl"
 
 namespace rgpu_transport {
@@ -113,41 +115,27 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
   if (c->pack && nops <= 64) {
-    // per peer, in posting order (which is the order the peer's matching operations are posted in): one region of the send
-    // stage and one of the receive stage; the concatenation keeps that order, so ONE send matches ONE receive per peer
-    PackDesc ds, dr; ds.n = 0; dr.n = 0;
-    int peers[4]; size_t tot_s[4] = {0, 0, 0, 0}, tot_r[4] = {0, 0, 0, 0}; int npeers = 0;
-    int pidx[64];
-    for (int i = 0; i < nops; ++i) {
-      int q = 0;
-      while (q < npeers && peers[q] != ops[i].peer) ++q;
-      if (q == npeers) { if (npeers == 4) return fail(c, "packed exchange: more than four peers"); peers[npeers++] = ops[i].peer; }
-      pidx[i] = q;
-      (ops[i].send ? tot_s : tot_r)[q] += ops[i].count;
-    }
-    size_t base_s[4], base_r[4], all_s = 0, all_r = 0;
-    for (int q = 0; q < npeers; ++q) { base_s[q] = all_s; all_s += tot_s[q]; base_r[q] = all_r; all_r += tot_r[q]; }
-    const size_t need = all_s > all_r ? all_s : all_r;
-    if (need > c->stage_cap) {
+    // per peer, in posting order: one region of the send stage and one of the receive stage (comm/pack_plan.h)
+    PackPlan pl;
+    if (pack_plan(ops, nops, &pl)) return fail(c, "packed exchange: too many operations / peers for one plan");
+    if (pl.stage_doubles > c->stage_cap) {
       if (hipStreamSynchronize(c->halo) != hipSuccess) return fail(c, "stage: synchronize");
       if (c->stage_s) (void)hipFree(c->stage_s);
       if (c->stage_r) (void)hipFree(c->stage_r);
       c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
-      if (hipMalloc((void**)&c->stage_s, need * sizeof(double)) != hipSuccess || hipMalloc((void**)&c->stage_r, need * sizeof(double)) != hipSuccess) return fail(c, "stage buffers");
-      c->stage_cap = need;
+      if (hipMalloc((void**)&c->stage_s, pl.stage_doubles * sizeof(double)) != hipSuccess || hipMalloc((void**)&c->stage_r, pl.stage_doubles * sizeof(double)) != hipSuccess) return fail(c, "stage buffers");
+      c->stage_cap = pl.stage_doubles;
     }
-    size_t fill_s[4] = {0, 0, 0, 0}, fill_r[4] = {0, 0, 0, 0};
-    size_t longest = 0;
+    PackDesc ds, dr; ds.n = 0; dr.n = 0;
     for (int i = 0; i < nops; ++i) {
       PackDesc& d = ops[i].send ? ds : dr;
-      if (d.n == 32) return fail(c, "packed exchange: more than 32 chunks per direction");
-      const int q = pidx[i];
-      d.ptr[d.n] = ops[i].ptr; d.count[d.n] = ops[i].count;
-      d.off[d.n] = ops[i].send ? base_s[q] + fill_s[q] : base_r[q] + fill_r[q];
-      (ops[i].send ? fill_s : fill_r)[q] += ops[i].count;
-      if (ops[i].count > longest) longest = ops[i].count;
+      d.ptr[d.n] = ops[i].ptr; d.count[d.n] = ops[i].count; d.off[d.n] = pl.off[i];
       ++d.n;
     }
+    const size_t longest = pl.longest;
+    const int npeers = pl.npeers;
+    const int* peers = pl.peer;
+    const size_t* tot_s = pl.send_total; const size_t* tot_r = pl.recv_total; const size_t* base_s = pl.send_base; const size_t* base_r = pl.recv_base;
     unsigned bx = (unsigned)((longest + 255) / 256); if (bx > 256u) bx = 256u; if (bx < 1u) bx = 1u;
     if (ds.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)ds.n), dim3(256), 0, c->halo, ds, c->stage_s, 0);
     ncclResult_t r = ncclGroupStart();
