@@ -1,10 +1,7 @@
+# the round's last GPU call of the builder: the GPU suite, the smoke check, the default bench line (what the driver runs at round end)
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4r
-export RGPU_ARITH=contracted
-( PROBE_NZ=64 PROBE_LINK_GBPS="0 60" timeout 600 python scripts/slab_probe.py 2>&1 | grep "nz=\|rror"
-  PROBE_NZ=128 PROBE_LINK_GBPS="0" timeout 600 python scripts/slab_probe.py 2>&1 | grep "nz=\|rror" ) > gpurun_out/r4r/probe.log 2>&1
-( timeout 600 python scripts/probe_sweep.py mhd_mri_3d 512 10 2>&1 | grep -v amdgpu; timeout 600 python scripts/probe_sweep.py implode3d 256 50 2>&1 | grep -v amdgpu ) > gpurun_out/r4r/sweep.log 2>&1
-bash scripts/slab_timeline.sh 1 60 > gpurun_out/r4r/tl.log 2>&1
-unset RGPU_ARITH
-( time timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_comm_driver.py -x -q -m gpu -k "not whole_box and not long_runs" 2>&1 | tail -5 ) > gpurun_out/r4r/tests.log 2>&1
-cat gpurun_out/r4r/probe.log gpurun_out/r4r/sweep.log gpurun_out/r4r/tests.log; grep -A34 "the last 56" gpurun_out/r4r/tl.log | cut -c1-100 | sed -n 14,36p
+mkdir -p gpurun_out/final
+( time timeout 2700 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 ) > gpurun_out/final/tests.log 2>&1
+( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids ) > gpurun_out/final/smoke.log 2>&1
+( time python bench.py 2>/dev/null | tail -1 ) > gpurun_out/final/bench.log 2>&1
+cat gpurun_out/final/tests.log gpurun_out/final/smoke.log; cut -c1-600 gpurun_out/final/bench.log

@@ -484,3 +484,23 @@ def test_run_steps_equals_the_reference_loop(base, ov, nsteps, clocked, gpu_lib,
             assert bool(gpu_lib.lib.rgpu_device_time_step_ready(sv.ctx, sv.nStep % 2)) == clocked
         finally:
             sv.close()
+
+
+def test_run_steps_longer_than_one_clock_batch(gpu_lib, oracle):
+    """more steps than one batch of device clock records (256): 300 steps of a small Orszag-Tang box in one rgpu_run_steps call == the
+    oracle's 300 steps (state, t, last dt), and == 300 single steps"""
+    base, ov, n = "orszag-tang", "mesh.nx=48;mesh.ny=40", 300
+    p = gpu_lib.params_from_ini(ini(base), ov)
+    U0 = gpu_lib.init_condition(ini(base), ov, p)
+    ref, dts_ref, _ = oracle.run(p, U0, n)
+    t_ref = 0.0
+    for d in dts_ref:
+        t_ref += float(d)
+    sv = Solver(p, gpu_lib)
+    try:
+        sv.start(U0, 0)
+        assert sv.run_steps(n) == n
+        assert sv.nStep == n and sv.totalTime == t_ref and sv.dt == float(dts_ref[-1])
+        assert np.array_equal(interior(sv.getDataHost(), p), interior(ref, p))
+    finally:
+        sv.close()
