@@ -151,6 +151,52 @@ def check_single_step_random(lib, oracle, base, ov, seed=3, mach=1.5, t0=2.0):
         sv.close()
 
 
+def near_uniform_state(p, seed, eps):
+    """a uniform magnetised flow + perturbations of relative size eps in every variable: with eps around 1e-12 the candidates of the
+    Alfven-speed maxima of the 2D HLLD edge solver (dev_numerics.h: alfven_pick / alfven_duel) lie within, at and beyond the margins
+    below which the solver falls back to the reference's own sequence -- lanes of one wave take different routes; eps = 0: every
+    candidate pair ties exactly"""
+    rng = np.random.RandomState(seed)
+    nv, ks, js, is_ = p.shape
+    def pert():
+        return 1.0 + eps * (2 * rng.rand(ks, js, is_) - 1)
+    rho = 1.3 * pert()
+    vel = [0.31 * pert(), -0.17 * pert(), 0.23 * pert()]
+    U = np.zeros(p.shape)
+    U[0] = rho
+    U[2], U[3] = rho * vel[0], rho * vel[1]
+    ekin = 0.5 * rho * (vel[0] ** 2 + vel[1] ** 2)
+    if nv == 8 or p.three_d:
+        U[4] = rho * vel[2]
+        ekin = ekin + 0.5 * rho * vel[2] ** 2
+    emag = 0.0
+    if nv == 8:
+        B = [0.45 * pert(), 0.36 * pert(), -0.52 * pert()]
+        for c in range(3):
+            U[5 + c] = B[c]
+        emag = 0.5 * (B[0] ** 2 + B[1] ** 2 + B[2] ** 2)
+    U[1] = 0.9 * pert() / (p.gamma0 - 1.0) + ekin + emag
+    return U
+
+
+def check_single_step_near_uniform(lib, oracle, base, ov, eps, seed=11, t0=0.0):
+    """one godunov_unsplit from near_uniform_state, every double compared (the Alfven selection must return the reference's bits
+    whichever route a lane takes)"""
+    p = lib.params_from_ini(ini(base), ov)
+    U = near_uniform_state(p, seed, eps)
+    oracle.make_all_boundaries(p, U, t0, 0.0)
+    dt = 0.4 * oracle.compute_dt(p, U)
+    sv = Solver(p, lib)
+    try:
+        sv.upload(U, both=True)
+        sv.godunov_unsplit(0, dt, t0)
+        got = sv.getDataHost(1)
+        ref = oracle.godunov_unsplit(p, U.copy(), dt, t0)
+        assert_same(interior(got, p), interior(ref, p), "%s [%s] single step from a near-uniform state, eps = %g" % (base, ov, eps))
+    finally:
+        sv.close()
+
+
 def check_run_vs_oracle(lib, oracle, base, ov, nsteps, exact=True):
     """exact=False: the contracted-arithmetic variant of the library -- relative L2 < 1e-12 on the state, dt within 1e-11"""
     p = lib.params_from_ini(ini(base), ov)

@@ -504,3 +504,14 @@ def test_run_steps_longer_than_one_clock_batch(gpu_lib, oracle):
         assert np.array_equal(interior(sv.getDataHost(), p), interior(ref, p))
     finally:
         sv.close()
+
+
+NEAR_UNIFORM = [("orszag-tang", "mesh.nx=40;mesh.ny=32"), ("orszag-tang3d", "mesh.nx=20;mesh.ny=16;mesh.nz=12"), ("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=12")]
+
+
+@pytest.mark.parametrize("eps", [0.0, 1e-15, 3e-14, 1e-12, 3e-11, 1e-8])
+@pytest.mark.parametrize("base,ov", NEAR_UNIFORM, ids=[c[0] for c in NEAR_UNIFORM])
+def test_alfven_selection_near_ties(base, ov, eps, gpu_lib, oracle):
+    """the Alfven-speed selection of the 2D HLLD edge solver at, inside and outside its margins (2^-40 on the star ratio, 2^-45 on
+    the cross products): uniform magnetised flow + perturbations of relative size eps, one step, every double equal to the oracle's"""
+    pc.check_single_step_near_uniform(gpu_lib, oracle, base, ov, eps)
