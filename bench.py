@@ -39,6 +39,10 @@ Extra objects on the JSON line:
                 beside it as value_tolerance instead.  value_arithmetic / metric_version say which build `value` is.
   other_workloads  default headline run only: short measurements of BASELINE configs[1] (implode3d 256^3) and [2]
                 (orszag-tang 512^2) with their own roofline / cpu_baseline.
+  config.fingerprint  every N: sha256 of the dt sequence of all W + K steps + the sum mod 2^64 of the bit patterns of every interior double of
+                the final state (rgpu_state_checksum per rank, added up) -- identical for every --gpus N at the same arithmetic, box, K and W,
+                because the slab driver reproduces the single-device run bit for bit: a SCALE line can be checked against the N = 1 line.
+                value_exact / value_tolerance carry their own.
   config.driver / rccl_ranks / ranks  which slab driver ran, what RCCL itself reports (ncclCommCount), device + PCI bus id per
                 rank.  --gpus N > 1 has NO fallback: it is the C++ RCCL driver or a non-zero exit.
 """
@@ -389,13 +393,26 @@ def device_facts(torch, local_rank):
     return {"device": local_rank, "name": pr.name, "pci_bus_id": pci}
 
 
-def timed_steps(step, timers_src, ctl, steps, warmup, batch=None):
+def fingerprint_record(dts, checksums):
+    """What a run computed, in a form that does not depend on the number of ranks: sha256 of the dt sequence (little-endian doubles of
+    all W + K steps) and the sum mod 2^64 of the ranks' state checksums (rgpu_state_checksum: the 64-bit patterns of every interior
+    double, an order-independent sum).  The slab driver is bit-identical to the single-device run by construction, so every N must
+    print the same record for the same arithmetic, box, W and K -- the driver's N = 1 and N = 8 lines are comparable."""
+    import hashlib
+    import struct
+    return {"dt_sha256": hashlib.sha256(b"".join(struct.pack("<d", float(d)) for d in dts)).hexdigest(),
+            "state_sum_u64": "%016x" % (sum(int(c) for c in checksums) % (1 << 64)), "steps": len(dts),
+            "of": "state after warmup + steps steps, interior cells; equal for every --gpus N at the same arithmetic, box, steps and warmup"}
+
+
+def timed_steps(step, timers_src, ctl, steps, warmup, batch=None, dts=None):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns the max over ranks of the wall
     time of the K steps [s].  (Per-kernel durations are a separate pass: phase_profile.)  batch(K): the K steps as ONE call of the
     product's loop body (rgpu_run_steps: K turns of the reference's time loop, the same states and dt sequence; where a step is one
     fused kernel the time step stays on the device between steps) -- single-device runs."""
+    log = dts if dts is not None else []      # the time step of every step, warmup included (fingerprint_record)
     for _ in range(warmup):
-        step()
+        log.append(step())
     timers_src.enable_timers(False)
     ctl.sync()
     t0 = time.perf_counter()
@@ -404,8 +421,10 @@ def timed_steps(step, timers_src, ctl, steps, warmup, batch=None):
         assert done == steps, "rgpu_run_steps did %d of %d steps" % (done, steps)
     else:
         for _ in range(steps):
-            step()
+            log.append(step())
     ctl.sync()
+    if batch is not None:
+        log.extend(timers_src.dt_log)
     elapsed = ctl.max(time.perf_counter() - t0)
     return elapsed
 
@@ -464,13 +483,16 @@ def single_gpu_record(wname, dims, arith, steps, warmup, ctl):
     del U0
     run.make_all_boundaries(0, 0.0, 0.0)
     # (the reference's h_U.copyTo(h_U2) is not needed: every step writes the whole output array)
-    elapsed = timed_steps(run.oneStepIntegration, run, ctl, steps, warmup, batch=run.run_steps)
+    dts = []
+    elapsed = timed_steps(run.oneStepIntegration, run, ctl, steps, warmup, batch=run.run_steps, dts=dts)
+    fingerprint = fingerprint_record(dts, [run.state_checksum(run.nStep % 2)])
     prof = phase_profile(run.oneStepIntegration, run, ctl, steps)
     run.close()
     cells = float(nx) * ny * nz
     roof, roof_step = roofline_of(wname, w, arith, w["bytes"] * cells, elapsed, steps, prof)
     return {"value": steps * cells / elapsed / 1e6, "unit": "Mcell-updates/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-            "roofline": roof, "roofline_step": roof_step, "library": os.path.basename(L.path), "arithmetic": arith, "parity": PARITY[arith]}
+            "roofline": roof, "roofline_step": roof_step, "library": os.path.basename(L.path), "arithmetic": arith, "parity": PARITY[arith],
+            "fingerprint": fingerprint}
 
 
 def slab_driver_run(arith, ini, ov, rank, world, ctl):
@@ -491,6 +513,17 @@ def slab_driver_run(arith, ini, ov, rank, world, ctl):
             srun.close()
         return None, None, err
     info = srun.info()
+    # planes must really travel: bytes a rank sends per exchange = (slab interfaces of this rank) x ghostWidth planes x nbVar variables
+    # (rounds 2-3 measured a ring of one that exchanged nothing -- DESIGN.md section 6 -- and nothing noticed)
+    p = srun.p
+    from ramsesgpu_amd import _capi
+    faces = int(p.bc[4] == _capi.BC_COPY) + int(p.bc[5] == _capi.BC_COPY)
+    want = faces * p.ghostWidth * (p.nx + 2 * p.ghostWidth) * (p.ny + 2 * p.ghostWidth) * p.nbVar * 8
+    bad = srun.halo_bytes() != want or (world > 1 and want == 0)
+    if ctl.min_int(0 if bad else 1) == 0:
+        err = RuntimeError("rank %d sends %d bytes per halo exchange, expected %d" % (rank, srun.halo_bytes(), want)) if bad else None
+        srun.close()
+        return None, None, err
     srun.init_simulation()
     return srun, info, None
 
@@ -608,7 +641,10 @@ def main():
             driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
                 "" if args.arith == "exact" else "_fast", info["transport"], sched,
                 "in-place (one send / recv per variable and face)" if os.environ.get("RGPU_COMM_PACK") == "0" else "packed (one send / recv per peer)", srun.halo_bytes() / 1e6)
-        elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup)
+        dts = []
+        elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup, dts=dts)
+        # what was computed, in a form every N must reproduce (fingerprint_record): every rank's checksum of its own planes
+        fingerprint = fingerprint_record(dts, ctl.gather(timers_src.state_checksum((args.warmup + args.steps) % 2)))
         # diagnostic of the halo exchange of the LAST timed step on this rank: its duration on the halo stream and the rate that makes
         # of the bytes this rank sent (include/rgpu_comm.h); next to ms_per_step it tells how much of it the schedule hid
         xchg = None
@@ -623,7 +659,8 @@ def main():
             return
         prof = phase_profile(step, timers_src, ctl, args.steps)
         roof, roof_step = roofline_of(args.workload, w, args.arith, w["bytes"] * cells_local, elapsed, args.steps, prof)
-        rec = {"value": args.steps * cells_global / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "roofline": roof, "roofline_step": roof_step}
+        rec = {"value": args.steps * cells_global / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "roofline": roof, "roofline_step": roof_step,
+               "fingerprint": fingerprint}
         if info is not None and not args.no_second and os.environ.get("RGPU_BENCH_SECOND_ARITH", "1") != "0":
             # the same slabs, same K and W, through the OTHER build of the library (a second RCCL communicator, after the first is
             # destroyed): `value` stays comparable round over round whichever build is the headline
@@ -633,8 +670,10 @@ def main():
             if srun2 is None:
                 rec["second"] = (other, {"value": None, "error": repr(err2) if err2 is not None else "another rank failed"})
             else:
-                el2 = timed_steps(srun2.oneStepIntegration, srun2.solver, ctl, args.steps, args.warmup)
-                rec["second"] = (other, {"value": args.steps * cells_global / el2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": el2 / args.steps * 1e3,
+                dts2 = []
+                el2 = timed_steps(srun2.oneStepIntegration, srun2.solver, ctl, args.steps, args.warmup, dts=dts2)
+                fp2 = fingerprint_record(dts2, ctl.gather(srun2.solver.state_checksum((args.warmup + args.steps) % 2)))
+                rec["second"] = (other, {"value": args.steps * cells_global / el2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": el2 / args.steps * 1e3, "fingerprint": fp2,
                                          "steps": args.steps, "warmup": args.warmup, "arithmetic": other, "parity": PARITY[other],
                                          "library": "librgpu_comm%s.so + %s" % ("" if other == "exact" else "_fast", os.path.basename(srun2.L.path)),
                                          "rccl_ranks": info2["ranks"]})
@@ -674,7 +713,8 @@ def main():
                        "time_loop": ("rgpu_run_steps(K): K turns of the reference's loop body in one call, same states and dt sequence; 2D: dt stays on the "
                                      "device between the fused step kernels (csrc/hip/step_clock.h); 3D: the plain per-step loop" if world == 1 else
                                      "K calls of oneStepIntegration"),
-                       "parity": PARITY[args.arith]},
+                       "parity": PARITY[args.arith],
+                       "fingerprint": rec.get("fingerprint")},
             "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],
         }
         if world > 1 and rec.get("second"):

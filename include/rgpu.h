@@ -307,6 +307,13 @@ int rgpu_history_turbulence_sums(rgpu_ctx* c, int parity, double* sums18);
  * without copying the whole array back (the reference calls copyGpuToCpu first). */
 int rgpu_read_cell(rgpu_ctx* c, int parity, int i, int j, int k, double* out);
 
+/* Reproducibility fingerprint of U[parity]: the sum, modulo 2^64, of the 64-bit patterns of every variable of every INTERIOR cell of
+ * this context (a slab: its own planes).  Integer addition is associative: the value does not depend on how the box was cut into
+ * slabs or tiles, so the sum of the slabs' checksums (mod 2^64) of an N-rank run equals the single-device run's whenever the states
+ * are equal bit for bit -- which the z-slab driver promises (rgpu_comm.h).  bench.py prints it for every N.  (The reference compares
+ * runs through its output files; this is the same check without the 8.9 GB copy, HydroRunBase.cpp:7217-7229 copyGpuToCpu.) */
+int rgpu_state_checksum(rgpu_ctx* c, int parity, unsigned long long* out);
+
 /* == oneStepIntegration(nStep, t, dt) (MHDRunGodunov.cpp:4077-4089) for a single device */
 int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
 
@@ -319,6 +326,10 @@ int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
  * loop condition and t += dt evaluated by a one-workgroup kernel between two steps) and a batch of steps is queued without a host round
  * trip -- at the shipped 2D sizes that round trip costs as much as a third of the step.  Every other configuration runs the plain loop. */
 int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt);
+/* ... the same, and dt_log[n] = the time step of the n-th step done (the "dt=" column of the reference's log, MHDRunGodunov.cpp:3958);
+ * dt_log holds nsteps doubles or is NULL.  If a launch fails after some steps of a batch were queued, *nStep, *t, *dt (and dt_log)
+ * are advanced for the steps that did run before the error is returned. */
+int rgpu_run_steps_log(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt, double* dt_log);
 /* 1 when the next step of rgpu_run_steps on the state U[parity] would take its time step from the device (see above), else 0:
  * lets a caller (and the tests) tell which loop runs. */
 int rgpu_device_time_step_ready(rgpu_ctx* c, int parity);

@@ -47,8 +47,8 @@ def kernel_source_hash():
     import hashlib
     import re
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
-        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h") and f != "rg_transport.h"] + [os.path.join(CSRC, "rgpu_api.cpp")]
-    # (rg_transport.h is the RCCL transport of librgpu_comm.so: no kernel of librgpu.so comes from it)
+        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h") and f not in ("rg_transport.h", "halo_pack.h")] + [os.path.join(CSRC, "rgpu_api.cpp")]
+    # (rg_transport.h / halo_pack.h are the RCCL transport of librgpu_comm.so: no kernel of librgpu.so comes from them)
     h = hashlib.sha256()
     for f in files:
         text = re.sub(r"//[^\n]*", "", open(f).read())
@@ -132,7 +132,7 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code + the one-thread hold kernel of the slab probe
     comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
     comm_out = os.path.join(HERE, "librgpu_comm_fast.so" if fast else "librgpu_comm.so")
-    comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(CSRC, "comm", "halo_ops.h"), os.path.join(CSRC, "comm", "pack_plan.h"),
+    comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(CSRC, "hip", "halo_pack.h"), os.path.join(CSRC, "comm", "halo_ops.h"), os.path.join(CSRC, "comm", "pack_plan.h"),
                  os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
     if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):

@@ -26,7 +26,7 @@ struct rgpu_comm {
   rgpu_params p;
   rgpu_transport::Comm* tc;
   int rank, nranks;
-  int overlap;      // 0 serial, 1 overlapped (exchange behind the inner update), 2 boundary-first (exchange behind the inner sweep + update), -1 choose per step geometry
+  int overlap;      // 0 serial, 1 overlapped (exchange behind the inner update), 2 boundary-first (exchange behind the inner sweep + update), -1: 1, or RGPU_COMM_SCHEDULE=1|2 from the environment
   int primed;     // parity of the state whose ghosts are all valid, -1 = none
   int scanned;    // parity of the state whose 1/dt sits in the context's device slot, -1 = none
   std::vector<P2P> ops[2];
@@ -278,9 +278,14 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   build_ops(cm, 1);
   // the fused CFL scan changes how many device slots the 1/dt all-reduce carries: all ranks or none (an end slab with an open
   // / stratified z face on the rotating path cannot fuse it, the inner slabs could)
-  double cannot = rgpu_inv_dt_fusable(ctx) ? 0.0 : 1.0;
-  if (nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, &cannot, 1, rgpu_stream_handle(ctx))) return tr_fail(cm, "comm_create: allreduce");
-  cm->fuse_scan = cannot < 0.5;
+  // ... and so does the packed exchange (one message per peer instead of one per chunk): its staging buffers are sized and
+  // allocated HERE, not inside the first step, and a rank that cannot have them takes every rank to the in-place exchange
+  double cannot[2] = {rgpu_inv_dt_fusable(ctx) ? 0.0 : 1.0, 0.0};
+  for (int par = 0; par < 2; ++par)
+    if (rgpu_transport::prepare_exchange(cm->tc, cm->ops[par].data(), (int)cm->ops[par].size())) cannot[1] = 1.0;
+  if (nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, cannot, 2, rgpu_stream_handle(ctx))) return tr_fail(cm, "comm_create: allreduce");
+  cm->fuse_scan = cannot[0] < 0.5;
+  if (cannot[1] > 0.5) rgpu_transport::disable_pack(cm->tc);
   return RGPU_OK;
 }
 

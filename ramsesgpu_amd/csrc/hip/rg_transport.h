@@ -11,13 +11,11 @@
 #include <string>
 #include <vector>
 
-#include "../comm/pack_plan.h"
+#include "halo_pack.h"   // P2P, the staging plan and the copy kernels of the packed exchange
 
 #define RG_TRANSPORT_NAME "rccl"
 
 namespace rgpu_transport {
-
-struct P2P { double* ptr; size_t count; int peer; int send; };
 
 struct Comm {
   ncclComm_t comm;
@@ -40,17 +38,6 @@ struct Comm {
   bool pack;
   double* stage_s; double* stage_r; size_t stage_cap;   // doubles
 };
-struct PackDesc { double* ptr[32]; unsigned long long off[32]; unsigned long long count[32]; int n; };
-__global__ void pack_chunks_kernel(PackDesc d, double* __restrict__ stage, int unpack) {
-  const int seg = (int)blockIdx.y;
-  if (seg >= d.n) return;
-  double* __restrict__ p = d.ptr[seg];
-  double* __restrict__ st = stage + d.off[seg];
-  const unsigned long long n = d.count[seg];
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-    if (unpack) p[i] = st[i]; else st[i] = p[i];
-  }
-}
 __global__ void emulated_link_hold(long long ticks) {
   const long long t0 = (long long)wall_clock64();
   while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
@@ -109,44 +96,56 @@ inline void destroy(Comm* c) {
   delete c;
 }
 
+// Called once per operation list at rgpu_comm_create: size and allocate the two stages of the packed exchange (each holds what a
+// rank sends per exchange: 2 x 103 MB at 512 x 1024 x 64 per rank).  0 = ready (or nothing to pack); 1 = the list does not fit a
+// plan or the allocation failed -- not an error: the driver then takes every rank to the in-place exchange (disable_pack), because
+// packed and in-place ranks would post different message counts.
+inline int prepare_exchange(Comm* c, const P2P* ops, int nops) {
+  if (!c->pack || nops == 0) return 0;
+  PackedExchange px;
+  if (build_packed(ops, nops, &px)) return 1;
+  if (px.pl.stage_doubles <= c->stage_cap) return 0;
+  if (c->stage_s) (void)hipFree(c->stage_s);
+  if (c->stage_r) (void)hipFree(c->stage_r);
+  c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
+  if (hipMalloc((void**)&c->stage_s, px.pl.stage_doubles * sizeof(double)) != hipSuccess || hipMalloc((void**)&c->stage_r, px.pl.stage_doubles * sizeof(double)) != hipSuccess) {
+    (void)hipGetLastError();
+    if (c->stage_s) (void)hipFree(c->stage_s);
+    c->stage_s = 0; c->stage_r = 0;
+    return 1;
+  }
+  c->stage_cap = px.pl.stage_doubles;
+  return 0;
+}
+inline void disable_pack(Comm* c) {
+  c->pack = false;
+  if (c->stage_s) (void)hipFree(c->stage_s);
+  if (c->stage_r) (void)hipFree(c->stage_r);
+  c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
+}
+inline bool packs(const Comm* c) { return c->pack; }
+
 // all ops as ONE group on the halo stream, behind what the compute stream holds now
 inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nops) {
   hipStream_t cs = (hipStream_t)compute_stream;
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
-  if (c->pack && nops <= 64) {
-    // per peer, in posting order: one region of the send stage and one of the receive stage (comm/pack_plan.h)
-    PackPlan pl;
-    if (pack_plan(ops, nops, &pl)) return fail(c, "packed exchange: too many operations / peers for one plan");
-    if (pl.stage_doubles > c->stage_cap) {
-      if (hipStreamSynchronize(c->halo) != hipSuccess) return fail(c, "stage: synchronize");
-      if (c->stage_s) (void)hipFree(c->stage_s);
-      if (c->stage_r) (void)hipFree(c->stage_r);
-      c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
-      if (hipMalloc((void**)&c->stage_s, pl.stage_doubles * sizeof(double)) != hipSuccess || hipMalloc((void**)&c->stage_r, pl.stage_doubles * sizeof(double)) != hipSuccess) return fail(c, "stage buffers");
-      c->stage_cap = pl.stage_doubles;
-    }
-    PackDesc ds, dr; ds.n = 0; dr.n = 0;
-    for (int i = 0; i < nops; ++i) {
-      PackDesc& d = ops[i].send ? ds : dr;
-      d.ptr[d.n] = ops[i].ptr; d.count[d.n] = ops[i].count; d.off[d.n] = pl.off[i];
-      ++d.n;
-    }
-    const size_t longest = pl.longest;
-    const int npeers = pl.npeers;
-    const int* peers = pl.peer;
-    const size_t* tot_s = pl.send_total; const size_t* tot_r = pl.recv_total; const size_t* base_s = pl.send_base; const size_t* base_r = pl.recv_base;
-    unsigned bx = (unsigned)((longest + 255) / 256); if (bx > 256u) bx = 256u; if (bx < 1u) bx = 1u;
-    if (ds.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)ds.n), dim3(256), 0, c->halo, ds, c->stage_s, 0);
+  PackedExchange px;
+  if (c->pack && build_packed(ops, nops, &px) == 0) {
+    // per peer, in posting order: one region of the send stage and one of the receive stage (comm/pack_plan.h).  The stages were
+    // sized and allocated by prepare_exchange at rgpu_comm_create (all ranks pack or none does): no allocation inside a step, where
+    // a failure on one rank would leave its peers in ncclRecv
+    const PackPlan& pl = px.pl;
+    if (pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
+    if (launch_pack(px, c->stage_s, c->halo)) return fail(c, "pack kernel");
     ncclResult_t r = ncclGroupStart();
-    for (int q = 0; q < npeers && r == ncclSuccess; ++q)
-      if (tot_s[q]) r = ncclSend(c->stage_s + base_s[q], tot_s[q], ncclDouble, peers[q], c->comm, c->halo);
-    for (int q = 0; q < npeers && r == ncclSuccess; ++q)
-      if (tot_r[q]) r = ncclRecv(c->stage_r + base_r[q], tot_r[q], ncclDouble, peers[q], c->comm, c->halo);
+    for (int q = 0; q < pl.npeers && r == ncclSuccess; ++q)
+      if (pl.send_total[q]) r = ncclSend(c->stage_s + pl.send_base[q], pl.send_total[q], ncclDouble, pl.peer[q], c->comm, c->halo);
+    for (int q = 0; q < pl.npeers && r == ncclSuccess; ++q)
+      if (pl.recv_total[q]) r = ncclRecv(c->stage_r + pl.recv_base[q], pl.recv_total[q], ncclDouble, pl.peer[q], c->comm, c->halo);
     const ncclResult_t re = ncclGroupEnd();
     if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
-    if (dr.n) hipLaunchKernelGGL(pack_chunks_kernel, dim3(bx, (unsigned)dr.n), dim3(256), 0, c->halo, dr, c->stage_r, 1);
-    if (hipGetLastError() != hipSuccess) return fail(c, "pack / unpack kernel");
+    if (launch_unpack(px, c->stage_r, c->halo)) return fail(c, "unpack kernel");
   } else {   // in place: one operation per chunk (rounds 1-3)
     ncclResult_t r = ncclGroupStart();
     for (int i = 0; i < nops && r == ncclSuccess; ++i)

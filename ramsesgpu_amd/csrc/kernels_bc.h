@@ -397,6 +397,27 @@ RG_DEVFN void ou_forcing_cell(const DevParams& g, double* __restrict__ U, const 
   U[idx + IP * N] = eInt + 0.5 * (mu * mu + mv * mv + mw * mw) / rho;
 }
 
+// state checksum (rgpu_state_checksum): one thread per (i, k) row of the interior adds the 64-bit patterns of all variables of its
+// ny cells, modulo 2^64 -- an order-independent sum, so slabs, tiles and launch geometry cannot change it
+RG_DEVFN void checksum_row_cell(const DevParams& g, const double* __restrict__ U, unsigned long long* __restrict__ rows, unsigned idx) {
+  const int nk = g.three_d ? g.nz : 1;
+  const int ii = (int)(idx % (unsigned)g.nx), kk = (int)(idx / (unsigned)g.nx);
+  if (kk >= nk) return;
+  const int i = ii + g.gw, k = g.three_d ? kk + g.gw : 0;
+  const size_t N = g.ncell;
+  unsigned long long acc = 0ull;
+  for (int j = g.gw; j < g.jsize - g.gw; ++j) {
+    const size_t o = (size_t)i + (size_t)g.sj * j + (size_t)g.sk * k;
+    for (int v = 0; v < g.nvar; ++v) {
+      unsigned long long b;
+      const double x = U[o + v * N];
+      __builtin_memcpy(&b, &x, sizeof(b));
+      acc += b;
+    }
+  }
+  rows[idx] = acc;
+}
+
 // column sums: thread (i,q) adds rows[q][k][i] over k
 RG_DEVFN void hist_col_cell(const DevParams& g, const double* __restrict__ rows, double* __restrict__ cols, int nq, unsigned idx) {
   const int nk = g.three_d ? g.nz : 1;

@@ -131,6 +131,10 @@ struct K_hist_cols {
   DevParams g; const double* rows; double* cols; int nq;
   RG_DEVFN void operator()(unsigned idx) const { hist_col_cell(g, rows, cols, nq, idx); }
 };
+struct K_checksum_rows {
+  DevParams g; const double* U; unsigned long long* rows;
+  RG_DEVFN void operator()(unsigned idx) const { checksum_row_cell(g, U, rows, idx); }
+};
 struct K_hist_reynolds {
   DevParams g; const double* U; const double* mean_vx; const double* mean_vy; double dTau; double* rows;
   RG_DEVFN void operator()(unsigned idx) const { hist_reynolds_cell(g, U, mean_vx, mean_vy, dTau, rows, idx); }

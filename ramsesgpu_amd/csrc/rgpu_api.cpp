@@ -491,7 +491,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     const bool scan = a <= 0 && b >= ks && cond && !acc_piece;
     const bool piece = acc_piece && cond && c->scan_acc_parity == ((out == c->U[0]) ? 0 : 1);
     if (acc_piece && !piece) c->scan_acc_parity = -1;
-    if (scan && rg_memset_async(c->d_red, 0, sizeof(unsigned long long), c->stream)) return -1;
+    if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
     const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0);
     if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }
     if (rc <= 0) return rc;
@@ -916,6 +916,11 @@ int inv_dt_scan(rgpu_ctx* c, int parity, unsigned idx0, unsigned n, bool reset) 
   c->scan_acc_parity = -1;
   Phase ph(c, RGPU_T_DT);
   const double* U = c->U[parity & 1];
+  // a fresh scan owns ALL slots: the maximum goes to slot 0, slots 1 .. RG_DT_SLOTS-1 (which a fused scan of an earlier step may
+  // have filled) are zeroed, so that whoever folds all of them -- the slab driver after its fixed-size all-reduce, whatever state
+  // each rank is in -- reads this scan and nothing older
+  if (reset && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  reset = false;
   if (c->p.mhdEnabled) {
     const int spec = c->g.three_d ? pick_spec(c->g) : 0;
     if (spec == 1) { K_mhd_invdt<kSpecMri> k = {c->g, U}; return rg_reduce_max(c->stream, n, k, c->d_red, idx0, reset); }
@@ -1264,7 +1269,10 @@ int rgpu_inv_dt_accumulate(rgpu_ctx* c, int parity, int k_lo, int k_hi, int rese
 int rgpu_inv_dt_result(rgpu_ctx* c, double* invDt) {
   RG_CHECK_CTX(c);
   if (!invDt || !c->U[0]) return fail(c, RGPU_EINVAL, "inv_dt_result: null pointer / context without state");
-  if (inv_dt_fetch(c, invDt, c->fused_dt_parity >= 0 ? c->fused_dt_slots : 1)) return RG_HIPFAIL(c, "inv_dt_result");
+  // slab contexts: always every slot -- the ranks all-reduce a fixed RG_DT_SLOTS values, and a rank after a full scan (slot 0 + zeros,
+  // inv_dt_scan) must still see a peer's fused maxima in the other slots
+  const int nslots = (c->p.slab_count > 1) ? (int)RG_DT_SLOTS : (c->fused_dt_parity >= 0 ? c->fused_dt_slots : 1);
+  if (inv_dt_fetch(c, invDt, nslots)) return RG_HIPFAIL(c, "inv_dt_result");
   return RGPU_OK;
 }
 int rgpu_inv_dt_fusable(rgpu_ctx* c) {
@@ -1367,6 +1375,23 @@ int rgpu_history_turbulence(rgpu_ctx* c, int parity, double* out) {
   return RGPU_OK;
 }
 
+int rgpu_state_checksum(rgpu_ctx* c, int parity, unsigned long long* out) {
+  RG_CHECK_CTX(c);
+  if (!out || !c->U[0]) return fail(c, RGPU_EINVAL, "state_checksum: null pointer / context without state");
+  const size_t R = (size_t)c->g.nx * (c->g.three_d ? c->g.nz : 1);
+  if (!c->F || R > c->ncell) return fail(c, RGPU_EINVAL, "state_checksum: no scratch for the row sums");
+  // row sums in the flux array, dead between steps (as the history sums)
+  unsigned long long* rows = reinterpret_cast<unsigned long long*>(c->F);
+  K_checksum_rows k = {c->g, c->U[parity & 1], rows};
+  std::vector<unsigned long long> h(R);
+  if (rg_launch<kBlock>(c->stream, (unsigned)R, k) || rg_copy_d2h(h.data(), rows, R * sizeof(unsigned long long), c->stream) || rg_stream_sync(c->stream))
+    return RG_HIPFAIL(c, "state_checksum");
+  unsigned long long sum = 0ull;
+  for (size_t n = 0; n < R; ++n) sum += h[n];
+  *out = sum;
+  return RGPU_OK;
+}
+
 double rgpu_compute_dt(rgpu_ctx* c, int useU) {
   double v = 0;
   if (!c || rgpu_compute_inv_dt(c, useU, &v) != RGPU_OK) return std::numeric_limits<double>::quiet_NaN();
@@ -1465,7 +1490,7 @@ static bool clock_ready(rgpu_ctx* c, int parity) {
 
 int rgpu_device_time_step_ready(rgpu_ctx* c, int parity) { return (c && c->U[0] && clock_ready(c, parity & 1)) ? 1 : 0; }
 
-int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt) {
+int rgpu_run_steps_log(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt, double* dt_log) {
   RG_CHECK_CTX(c);
   if (!nStep || !t || !dt) return fail(c, RGPU_EINVAL, "run_steps: null pointer");
   int done = 0;
@@ -1474,6 +1499,7 @@ int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, 
     if (!clock_ready(c, parity)) {   // the reference's loop body (the first step of a run always comes through here)
       const int rc = rgpu_one_step_integration(c, nStep, t, dt);
       if (rc) return rc;
+      if (dt_log) dt_log[done] = *dt;
       ++done;
       continue;
     }
@@ -1484,7 +1510,7 @@ int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, 
     const int m = (nsteps - done < rgpu_ctx::kClockBatch) ? nsteps - done : (int)rgpu_ctx::kClockBatch;
     const double seed = c->p.mhdEnabled ? c->p.smallc / std::fmin(c->p.dx, c->p.dy) : 0.0;   // inv_dt_fetch
     int queued = 0, rc = 0;
-    for (; queued < m && rc == 0; ++queued) {
+    for (; queued < m; ++queued) {
       rc = rgpu_tiled::launch_step_clock(c->stream, c->d_red, c->p.cfl, seed, c->p.dx, c->p.dy, *t, tEnd, queued ? c->d_clk + queued - 1 : 0, c->d_clk + queued);
       if (rc) break;
       c->clk_cur = c->d_clk + queued;
@@ -1492,16 +1518,24 @@ int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, 
       rc = step_pre(c, *nStep + queued) || step_core(c, *nStep + queued, 0.0, 0.0);
       c->clk_cur = 0;
       if (rc == 0 && !clock_ready(c, (*nStep + queued + 1) % 2)) rc = -1;   // (cannot happen: same configuration, same kernel)
+      if (rc) break;
     }
-    if (rc) { state_modified(c); return RG_HIPFAIL(c, "run_steps: queueing a device-clock step"); }
-    if (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(rgpu_tiled::StepClock), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "run_steps: clock read-back");
+    // a launch that failed after `queued` complete steps were queued: those steps still run on the device -- read their records and
+    // advance nStep / t / dt for them before reporting, so that the caller's step count and parity describe the device state
+    const std::string launch_err = rc ? std::string(rg_last_error_string()) : std::string();
+    if (queued > 0 && (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(rgpu_tiled::StepClock), c->stream) || rg_stream_sync(c->stream))) {
+      state_modified(c);
+      return RG_HIPFAIL(c, "run_steps: clock read-back");
+    }
     int ran = 0;
     for (; ran < queued && c->h_clk[ran].stop == 0; ++ran) {   // t accumulated in the order of the reference's loop
       *dt = c->h_clk[ran].dt;
       *t += *dt;
       *nStep += 1;
+      if (dt_log) dt_log[done + ran] = *dt;
     }
     done += ran;
+    if (rc) { state_modified(c); return fail(c, RGPU_EHIP, "run_steps: queueing a device-clock step: " + launch_err); }
     if (ran < queued) {   // the steps behind a stop were no-ops: the state of step *nStep is the last one written
       const int stop = c->h_clk[ran].stop;
       c->fused_dt_parity = -1;              // its CFL maxima went into the clock that stopped
@@ -1512,6 +1546,10 @@ int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, 
     }
   }
   return done;
+}
+
+int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt) {
+  return rgpu_run_steps_log(c, nsteps, tEnd, nStep, t, dt, 0);
 }
 
 int rgpu_synchronize(rgpu_ctx* c) {

@@ -233,6 +233,12 @@ class Solver:
         self._chk(self.lib.rgpu_history_mri(self.ctx, parity, out), "history_mri")
         return dict(zip(self.HISTORY_NAMES, [float(v) for v in out]))
 
+    def state_checksum(self, parity):
+        """sum mod 2^64 of the bit patterns of all interior doubles of U[parity] (rgpu_state_checksum): equal for every slab count"""
+        out = C.c_ulonglong(0)
+        self._chk(self.lib.rgpu_state_checksum(self.ctx, parity, C.byref(out)), "state_checksum")
+        return int(out.value)
+
     def history_turbulence(self, nStep=None):
         """history_turbulence (MHDRunBase.cpp:3626-3810) reduced on the device: the 18 columns after totalTime and dt"""
         parity = (self.nStep if nStep is None else nStep) % 2
@@ -269,10 +275,12 @@ class Solver:
         """up to nsteps turns of the reference's time loop (rgpu_run_steps: where a step is one fused kernel the time step stays on
         the device and the batch is queued without a host round trip); returns the number of steps done"""
         n, t, d = C.c_int(self.nStep), C.c_double(self.totalTime), C.c_double(self.dt)
-        done = self.lib.rgpu_run_steps(self.ctx, int(nsteps), float(tEnd), C.byref(n), C.byref(t), C.byref(d))
+        log = (C.c_double * max(int(nsteps), 1))()
+        done = self.lib.rgpu_run_steps_log(self.ctx, int(nsteps), float(tEnd), C.byref(n), C.byref(t), C.byref(d), log)
         if done < 0:
             self._chk(done, "run_steps")
         self.nStep, self.totalTime, self.dt = n.value, t.value, d.value
+        self.dt_log = [log[i] for i in range(done)]     # the time steps of this call, in order
         return done
 
     def start(self, hU, nStepmax, tEnd=float("inf")):

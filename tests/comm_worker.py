@@ -281,6 +281,18 @@ def main():
         keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
         CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
         assert b"test" in CL.rgpu_comm_transport_name()
+    elif device.startswith("cuda-staged"):
+        # N rank processes on ONE GPU through the PRODUCT library (real tiled HIP kernels) and the product's slab driver compiled
+        # against the TEST-ONLY device-aware transport (tests/emu_dev/rg_transport.h): the planes are packed by the product's
+        # kernels, staged through pinned memory and carried by gloo (RCCL refuses two ranks on one device)
+        from ramsesgpu_amd.solver import lib_path
+        arith = os.environ.get("COMM_ARITH", "exact")
+        lib = Library(lib_path(arith))
+        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_dev%s.so" % ("" if arith == "exact" else "_fast")))
+        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
+        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+        assert b"device-staged" in CL.rgpu_comm_transport_name() and lib.arithmetic == arith and "hip" in lib.backend
     else:
         from ramsesgpu_amd.solver import load_library
         lib = load_library()
@@ -302,6 +314,64 @@ def main():
         assert run.halo_bytes() == want and (want > 0 or not ring1), (run.halo_bytes(), want)
     run.init_simulation()
     dts = [run.oneStepIntegration() for _ in range(nsteps)]
+    staged = device.startswith("cuda-staged")
+    if staged:
+        # the wire really carried planes: one exchange per step (+ the one of the initial ghost fill), and with the packed exchange
+        # ONE message per neighbour and exchange (two when the two neighbours are distinct ranks)
+        st = (C.c_long * 3)()
+        CL.rgpu_comm_test_stats(st)
+        want_pack = os.environ.get("RGPU_COMM_PACK", "1") != "0"
+        faces = int(run.p.bc[4] == _capi.BC_COPY) + int(run.p.bc[5] == _capi.BC_COPY)
+        peers = 0 if faces == 0 else (1 if (world <= 2 or faces == 1) else 2)
+        per_exchange = peers if want_pack else faces * run.p.nbVar
+        assert st[2] == int(want_pack), list(st)
+        assert st[0] >= nsteps + 1 and st[1] == st[0] * per_exchange, (list(st), per_exchange)
+    # N-independent fingerprint (bench.py prints the same): dt sequence + the sum mod 2^64 of the slabs' state checksums
+    sums = [None] * world
+    dist.all_gather_object(sums, run.solver.state_checksum(run.nStep % 2))
+    fingerprint = sum(sums) % (1 << 64)
+    if staged and os.environ.get("COMM_CHECK", "oracle") == "single":
+        # big boxes (the oracle would take minutes): against the single-device run of the whole box through the same library
+        ok = True
+        chunk = run.local_interior()
+        if rank == 0:
+            from ramsesgpu_amd.solver import Solver
+            p = lib.params_from_ini(ini, ov)
+            one = Solver(p, lib)
+            one.upload(lib.init_condition(ini, ov, p), both=False)
+            one.make_all_boundaries(0, 0.0, 0.0)
+            dts_one = [one.oneStepIntegration() for _ in range(nsteps)]
+            fp_one = one.state_checksum(one.nStep % 2)
+            gw = p.ghostWidth
+            ref0 = one.getDataHost(one.nStep % 2)[:, gw:-gw, gw:-gw, gw:-gw]
+            one.close()
+            nzl = p.nz // world
+            nbad = int((chunk != ref0[:, :nzl]).sum())
+            ok = nbad == 0 and dts == dts_one and fp_one == fingerprint
+            msg = "rank 0: %d doubles differ, dt equal=%s, fingerprint %x / %x" % (nbad, dts == dts_one, fingerprint, fp_one)
+            box = [ref0]
+        else:
+            box = [None]
+        # the other ranks compare their own planes (the whole box does not travel through gloo three times)
+        flags = [None] * world
+        if rank == 0:
+            for r in range(1, world):
+                dist.send(torch.from_numpy(np.ascontiguousarray(box[0][:, r * nzl:(r + 1) * nzl])), dst=r)
+            mine = (ok, msg)
+        else:
+            ref = torch.empty(chunk.shape, dtype=torch.float64)
+            dist.recv(ref, src=0)
+            nbad = int((chunk != ref.numpy()).sum())
+            mine = (nbad == 0, "rank %d: %d doubles differ" % (rank, nbad))
+        dist.all_gather_object(flags, mine)
+        ok = all(f[0] for f in flags)
+        if rank == 0:
+            with open(out, "w") as f:
+                f.write("OK %016x\n" % fingerprint if ok else "MISMATCH %r\n" % (flags,))
+        dist.barrier()
+        run.close()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     local = torch.from_numpy(np.ascontiguousarray(run.local_interior()))
     parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
     dist.gather(local, parts, dst=0)
@@ -320,8 +390,10 @@ def main():
         if p.randomForcingEnabled or (p.ouForcingEnabled and device != "cpu"):   # (OU on a GPU: the device's cos())   # global normalisation sum: round-off agreement (stated tolerance 1e-12), see slab_worker.py
             rel = float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
             ok = rel < 1e-12 and np.allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
+        if ok and not (p.randomForcingEnabled or p.ouForcingEnabled):   # the fingerprint is the oracle's own
+            ok = fingerprint == int(np.ascontiguousarray(ref).view(np.uint64).sum(dtype=np.uint64))
         with open(out, "w") as f:
-            f.write("OK\n" if ok else "MISMATCH %d doubles, dt equal=%s\n" % (nbad, np.array_equal(np.array(dts), dts_ref)))
+            f.write("OK %016x\n" % fingerprint if ok else "MISMATCH %d doubles, dt equal=%s, fingerprint %x\n" % (nbad, np.array_equal(np.array(dts), dts_ref), fingerprint))
     dist.barrier()
     run.close()
     dist.destroy_process_group()

@@ -37,6 +37,10 @@ inline int create(Comm** out, int rank, int nranks, const char*) {
   return 0;
 }
 inline void destroy(Comm* c) { delete c; }
+// (the packed exchange is a device-side optimisation of the RCCL transport: nothing to stage here)
+inline int prepare_exchange(Comm*, const P2P*, int) { return 0; }
+inline void disable_pack(Comm*) {}
+inline bool packs(const Comm*) { return false; }
 // the emulation backend executes kernels at launch, so "behind what the compute stream holds" is now; the transfer itself
 // is deferred to exchange_wait so that the overlapped schedule's compute really runs between start and wait
 inline int exchange_start(Comm* c, void*, const P2P* ops, int nops) {

@@ -97,7 +97,8 @@ def run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=None, timeo
     env = dict(os.environ, OMP_NUM_THREADS="1", COMM_OVERLAP=str(overlap), **(env_extra or {}))
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-3000:]
-    assert open(out).read().strip() == "OK", open(out).read()
+    assert open(out).read().split()[0] == "OK", open(out).read()
+    return open(out).read().split()[1:]
 
 
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", CASES,
