@@ -271,6 +271,14 @@ int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalT
  * classes do with make_all_boundaries(h_UNew) (mhd_godunov_unsplit_cpu_v3.cpp:662-668). */
 int rgpu_step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime);
 int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi);
+/* The same two pieces for TWO disjoint plane ranges at once -- the two boundary ranges of a slab, [0,2gw) + [nz,ksize) and
+ * [gw,2gw) + [nz,nz+gw) -- so that what lies between the end of the flux sweep and the start of the halo exchange is a handful of
+ * launches: the 3D MHD update kernel marches both ranges in one launch; the ghost fill of both ranges is one launch whenever the
+ * x / y faces are mirror / copy / periodic or the shearing box with periodic y (one thread per ghost cell, every value a function
+ * of interior cells of its plane: X, Y -- or Y, shear remap, Y -- need no ordering).  Same doubles as the one-range calls.
+ * Either range may be empty.  (3D hydro: the sweep is the whole step, one launch per range.) */
+int rgpu_step_core_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2, int what);
+int rgpu_step_fill_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2);
 
 /* rgpu_compute_inv_dt in pieces: accumulate the max over the cells of planes [k_lo,k_hi) into the context's device
  * slot (reset != 0 starts a new maximum), asynchronously on the context stream; rgpu_inv_dt_result synchronises
@@ -340,6 +348,17 @@ int rgpu_device_time_step_ready(rgpu_ctx* c, int parity);
  *   root[i]  = rg_sqrt(num[i]),  root2[i] = sqrt(num[i])
  * (host arrays).  Inside the documented operand range all four equal the correctly rounded results bit for bit. */
 int rgpu_selftest_arith(int n, const double* num, const double* den, double* quot, double* quot2, double* root, double* root2);
+
+/* Self-test of the one place where the exact library departs from the reference's instruction sequence on data-dependent grounds:
+ * the Alfven speeds of the 2D HLLD edge solver (mag_riemann2d_hlld, riemann_mhd.h:727-738) are formed for the WINNER of each group
+ * of four |b| / sqrt(rho) candidates, picked on the operands (csrc/dev_numerics.h: alfven_pick / alfven_duel); a lane whose ordering
+ * is closer than the error bound sends its wave down the reference's sequence.  For n samples -- SoA, states36[q * n + i]: the four
+ * corner states LL, RL, LR, RR of an edge (r p u v w a b c each, q = 0..31) and their electric fields ELL, ERL, ELR, ERR (q = 32..35)
+ * -- the device evaluates the solver twice, e_select[i] through the selection and e_reference[i] through the reference's sequence,
+ * with the knobs of *p (gamma0, cIso, smallc, ...); route[i] = 1 when sample i's wave (64 consecutive samples) took the reference's
+ * sequence anyway.  e_select must equal e_reference bit for bit (tests/test_gpu_parity.py: >= 1e7 random and adversarial states).
+ * The contracted library has no selection: both outputs come from the same sequence and route is 1. */
+int rgpu_selftest_alfven(const rgpu_params* p, int n, const double* states36, double* e_select, double* e_reference, int* route);
 
 /* name of the device backend the library was built for ("hip-gfx950") */
 const char* rgpu_backend_name(void);

@@ -222,17 +222,19 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
     mode = env_mode >= 1 && env_mode <= 2 ? env_mode : 1;
   }
   const bool early = mode == 2 && has_inner && cm->p.mhdEnabled && nz > 4 * gw + 2;
+  // both boundary ranges go through the *_pair entry points: one launch of the update kernel and one of the ghost fill for the two
+  // of them -- what separates the end of the sweep from the start of the exchange is a handful of launches
+  const int b2lo = nb == 2 ? bnd[1][0] : 0, b2hi = nb == 2 ? bnd[1][1] : 0, s2lo = nb == 2 ? snd[1][0] : 0, s2hi = nb == 2 ? snd[1][1] : 0;
   if (early) {
     // flux planes of a FLUXES call on [a, b) are [a, b + 1): low range -> planes gw .. 2 gw, high range -> nz .. nz + gw
-    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[0][0], bnd[0][1], RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes, low)");
-    RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[1][0], bnd[1][1], RGPU_CORE_FLUXES), "step_core_planes(fluxes, high)");
+    RG_TRY(rgpu_step_core_planes_pair(c, nStep, dt, t, bnd[0][0], bnd[0][1], b2lo, b2hi, RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes, boundary ranges)");
   } else {
     RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, 0, ks, RGPU_CORE_FLUXES | scan_flag), "step_core_planes(fluxes)");
   }
   bool fused = cm->fuse_scan && rgpu_inv_dt_fused_active(c, pout) != 0;
-  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_core_planes_split(c, nStep, dt, t, bnd[n][0], bnd[n][1], RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update)");
+  RG_TRY(rgpu_step_core_planes_pair(c, nStep, dt, t, bnd[0][0], bnd[0][1], b2lo, b2hi, RGPU_CORE_UPDATE | scan_flag), "step_core_planes(update, boundary ranges)");
   if (scan && !fused) for (int n = 0; n < nb; ++n) RG_TRY(rgpu_inv_dt_accumulate(c, pout, bnd[n][0], bnd[n][1], n == 0), "inv_dt_accumulate");
-  for (int n = 0; n < nb; ++n) RG_TRY(rgpu_step_fill_planes(c, nStep, dt, t, snd[n][0], snd[n][1]), "step_fill_planes");
+  RG_TRY(rgpu_step_fill_planes_pair(c, nStep, dt, t, snd[0][0], snd[0][1], s2lo, s2hi), "step_fill_planes(boundary ranges)");
   if (int rc = exchange_start(cm, pout)) return rc;
   if (has_inner) {
     // (boundary-first: the planes 2 gw + 1 .. nz - 1 are what the two short launches left)

@@ -548,8 +548,11 @@ RG_DEVFN AlfvenPair alfven_duel(const AlfvenPair& c1, const AlfvenPair& c2, bool
 
 // mag_riemann2d_hlld (riemann_mhd.h:616-821).  States are in the edge frame (u,v = the two in-plane
 // velocities, a,b = the two in-plane field components); E?? = u*b - v*a of each state.
+// FORCE_REF / route: the self-test of the Alfven selection (rgpu_selftest_alfven) runs every sample twice -- the selection and, FORCE_REF,
+// the reference's own sequence -- and learns through *route (1 = the reference's sequence ran) which way the lane's wave went.
+template <bool FORCE_REF = false>
 RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL, const Prim8& LR, const Prim8& RR,
-                            double ELL, double ERL, double ELR, double ERR) {
+                            double ELL, double ERL, double ELR, double ERR, int* route = 0) {
   // 66 divisions by 24 distinct denominators: every denominator gets one shared reciprocal (rg_recip), see
   // rg_backend.h; numerators and operand order are the reference's
   const rg_recip_t iLLr = rg_recip(LL.r), iLRr = rg_recip(LR.r), iRLr = rg_recip(RL.r), iRRr = rg_recip(RR.r);
@@ -624,12 +627,16 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
     const AlfvenPair brr = alfven_pick(RR.b, rstarRRy, BstarRR, rstarRR, SR - RR.u, iSR.d, unsure);
     wT = alfven_duel(blr, brr, unsure);
   }
-  if (!rgpu::rg_wave_any(unsure)) {
+  const bool reference_sequence = FORCE_REF || rgpu::rg_wave_any(unsure);
+  if (route) *route = reference_sequence ? 1 : 0;
+  if (!reference_sequence) {
     calfvenL = pos_max(rg_div(fabs(wL.b), rg_recip_sqrt_pos(wL.r)), g.smallc);
     calfvenR = pos_max(rg_div(fabs(wR.b), rg_recip_sqrt_pos(wR.r)), g.smallc);
     calfvenB = pos_max(rg_div(fabs(wB.b), rg_recip_sqrt_pos(wB.r)), g.smallc);
     calfvenT = pos_max(rg_div(fabs(wT.b), rg_recip_sqrt_pos(wT.r)), g.smallc);
   } else
+#else
+  if (route) *route = 1;
 #endif
   {
   const rg_recip_t iqLL = rg_recip_sqrt_pos(rstarLL), iqLR = rg_recip_sqrt_pos(rstarLR);

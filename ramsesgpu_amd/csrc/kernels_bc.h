@@ -197,6 +197,103 @@ RG_DEVFN void shear_ghost_cell(const DevParams& g, const ShearGhost sg, double* 
   }
 }
 
+// ---- the in-plane ghost fill of whole z planes in ONE pass -------------------------------------------------------
+// make_all_boundaries fills x faces, then y faces over the full x extent, so that corner cells are images of images
+// (make_boundary_base.h:1040-1332; shearing box: Y, shear remap of the x borders, Y -- MHDRunGodunov.cpp:3779-3793).  Every value
+// these passes leave in a ghost cell of plane k is a function of INTERIOR cells of plane k alone:
+//   x ghost, interior row      X fill of (i, j)                                    | shearing box: the remap formula at (i, j)
+//   y ghost, interior column   Y fill: the image row src_j                         | periodic y: the wrapped row
+//   corner                     Y fill of the X-filled cell = U(src_i, src_j) s_x s_y | the remap formula at (i, wrapped row)
+// (s = -1 on the normal momentum of a reflecting face: exact), so one thread per ghost cell writes it from interior reads only:
+// one launch instead of two (plain) or three (shearing box), no ordering between threads.  The shearing-box form needs periodic
+// y faces: the remap reads the rows jr - 1 .. jr1 + 1 around its shifted rows, which the first Y pass had wrapped periodically.
+struct FillXY { int bx0, bx1, by0, by1, shear; ShearGhost sg; };   // face types at xmin, xmax, ymin, ymax (plain: 1, 2, 3)
+
+RG_DEVFN int fill_src_index(int bct, int side, int n, int gw, int ghost) {   // source index of bc_face_cell
+  if (bct == 1) return (side == 0) ? 2 * gw - 1 - ghost : 2 * n + 2 * gw - 1 - ghost;
+  if (bct == 2) return (side == 0) ? gw : n + gw - 1;
+  return (side == 0) ? n + ghost : ghost - n;
+}
+RG_DEVFN int wrap_row(int r, int gw, int ny) { return r < gw ? r + ny : (r >= ny + gw ? r - ny : r); }
+
+// value of variable v in the shearing-box x ghost column (side 0: column i, side 1: column nx + gw + i; i in 0..gw-1) at INTERIOR row j
+// of the plane starting at krow: the expressions of shear_ghost_cell, its border rows read with the periodic wrap in y
+RG_DEVFN double shear_ghost_value(const DevParams& g, const ShearGhost sg, const double* __restrict__ U, int side, int i, int j, size_t krow, int v) {
+  const int gw = g.gw, nx = g.nx, ny = g.ny;
+  const size_t N = g.ncell;
+  const double st = g.slope_type;
+  int jr, jr1;
+  double eps;
+  size_t col;
+  if (side == 0) {   // inner (xmin) ghosts <- outer interior columns (nx + i), shifted by -(jplus+1)
+    jr = j - sg.jplus - 1; jr1 = jr + 1; eps = sg.eps_min;
+    if (jr < gw) jr += ny;
+    if (jr1 < gw) jr1 += ny;
+    col = krow + (size_t)(nx + i);
+  } else {           // outer (xmax) ghosts <- inner interior columns (gw + i), shifted by +jplus
+    jr = j + sg.jplus; jr1 = jr + 1; eps = sg.eps_max;
+    if (jr > ny + gw - 1) jr -= ny;
+    if (jr1 > ny + gw - 1) jr1 -= ny;
+    col = krow + (size_t)(gw + i);
+  }
+  const double lambda = 0.5 * eps * (eps - 1.0);
+  const double* b = U + col + v * N;
+#define RG_ROW(r) b[(size_t)g.sj * wrap_row((r), gw, ny)]
+  if (v == IB) {
+    const double slope = (st == 1 || st == 2) ? RG_ROW(jr + 1) - RG_ROW(jr) : 0.0;
+    return RG_ROW(jr) + eps * slope;
+  }
+  const double s0 = shear_border_slope(st, RG_ROW(jr - 1), RG_ROW(jr), RG_ROW(jr + 1));
+  const double s1 = shear_border_slope(st, RG_ROW(jr1 - 1), RG_ROW(jr1), RG_ROW(jr1 + 1));
+  const double d = (side == 0) ? (s0 - s1) : (s1 - s0);
+  return (1.0 - eps) * RG_ROW(jr) + eps * RG_ROW(jr1) + lambda * d;
+#undef RG_ROW
+}
+
+// ghost cells of one plane: 2 gw full rows (isize cells each), then 2 gw cells of each of the ny interior rows
+// (host side: 2 gw (isize + ny) threads per plane)
+
+// t = ghost cell of the plane (see above), k = its plane
+RG_DEVFN void fill_xy_cell(const DevParams& g, const FillXY f, double* __restrict__ U, unsigned t, int k) {
+  const int gw = g.gw, nx = g.nx, ny = g.ny;
+  const unsigned full = 2u * gw * (unsigned)g.isize;
+  int i, j;
+  if (t < full) { const int r = (int)(t / (unsigned)g.isize); i = (int)(t % (unsigned)g.isize); j = r < gw ? r : ny + r; }
+  else { const unsigned q = t - full; const int a = (int)(q % (2u * gw)); j = gw + (int)(q / (2u * gw)); i = a < gw ? a : nx + a; }
+  const size_t N = g.ncell;
+  const size_t krow = (size_t)g.sk * k;
+  const bool xg = i < gw || i >= nx + gw, yg = j < gw || j >= ny + gw;
+  const int xside = i < gw ? 0 : 1, yside = j < gw ? 0 : 1;
+  const int bx = xside ? f.bx1 : f.bx0, by = yside ? f.by1 : f.by0;
+  const size_t o_out = krow + (size_t)g.sj * j + i;
+  if (f.shear) {
+    const int jw = wrap_row(j, gw, ny);   // y periodic
+    if (!xg) {   // y ghost of an interior column: the periodic image
+      const size_t o_in = krow + (size_t)g.sj * jw + i;
+      for (int v = 0; v < 8; ++v) U[o_out + v * N] = U[o_in + v * N];
+      return;
+    }
+    const int il = xside ? i - nx - gw : i;
+    for (int v = 0; v < 8; ++v) {
+      if (v == IA && xside == 1 && il == 0) {   // the first outer Bx ghost is an evolved face value, kept (MHDRunGodunov.cpp:3727-3735): its y images copy it
+        if (yg) U[o_out + v * N] = U[krow + (size_t)g.sj * jw + i + v * N];
+        continue;
+      }
+      U[o_out + v * N] = shear_ghost_value(g, f.sg, U, xside, il, jw, krow, v);
+    }
+    return;
+  }
+  const int si = xg ? fill_src_index(bx, xside, nx, gw, i) : i;
+  const int sj_ = yg ? fill_src_index(by, yside, ny, gw, j) : j;
+  const size_t o_in = krow + (size_t)g.sj * sj_ + si;
+  for (int v = 0; v < g.nvar; ++v) {
+    double x = U[o_in + v * N];
+    if (xg && bx == 1 && v == IU) x = x * -1.0;   // X pass (the order of the reference's passes; both products are exact)
+    if (yg && by == 1 && v == IV) x = x * -1.0;   // Y pass
+    U[o_out + v * N] = x;
+  }
+}
+
 // ---- CFL scan: value of one cell, 0 outside the interior (all contributions are >= 0) ----------------------
 template <int NV>
 RG_DEVFN double hydro_invdt_cell(const DevParams& g, const double* __restrict__ U, unsigned idx) {

@@ -200,7 +200,13 @@ template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_update3d {
   DevParams g; RotCoef rc; const double* Uold; double* Unew; const double* F; const double* emf; const double* remap;
   double dt, dtdx, dtdy, dtdz; unsigned long long* dt_slots; int k_lo, k_hi, seg_len;
-  RG_DEVFN void operator()(unsigned t) const { spec_assume<SPEC>(g); mhd_update3d_column<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, t, k_lo, k_hi, seg_len, dt_slots); }
+  // a second plane range in the same launch (the two boundary ranges of a slab): threads [n1, ...) march [k_lo2, k_hi2); n1 = 0xffffffff: none
+  unsigned n1; int k_lo2, k_hi2;
+  RG_DEVFN void operator()(unsigned t) const {
+    spec_assume<SPEC>(g);
+    const bool second = t >= n1;
+    mhd_update3d_column<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, second ? t - n1 : t, second ? k_lo2 : k_lo, second ? k_hi2 : k_hi, seg_len, dt_slots);
+  }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------
@@ -227,6 +233,15 @@ struct K_bc_faces_range {   // ... restricted to the face indices [first, first 
 struct K_jet {
   DevParams g; JetParams jp; double* U;
   RG_DEVFN void operator()(unsigned idx) const { jet_cell(g, jp, U, idx); }
+};
+// the in-plane ghost fill in one pass (fill_xy_cell) over the planes [lo1, lo1 + n1) and [lo2, ...): idx = plane * per_plane + ghost cell
+struct K_fill_xy {
+  DevParams g; FillXY f; double* U; unsigned per_plane; int lo1, n1, lo2;
+  RG_DEVFN void operator()(unsigned idx) const {
+    const unsigned p = idx / per_plane, t = idx - p * per_plane;
+    const int k = (int)p < n1 ? lo1 + (int)p : lo2 + ((int)p - n1);
+    fill_xy_cell(g, f, U, t, k);
+  }
 };
 struct K_shear_ghost {
   DevParams g; ShearGhost sg; double* U;

@@ -381,13 +381,64 @@ int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt
   return rg_launch_range<kBlock>(c->stream, per_plane * (unsigned)k_lo, per_plane * (unsigned)(k_hi - k_lo), k);
 }
 
+// ---- the in-plane ghost fill in one launch (kernels_bc.h: fill_xy_cell) -----------------------------------------------
+// x and y faces (and the shearing-box remap of the x borders) act within one z plane and leave, in every ghost cell, a function of
+// that plane's interior cells: one thread per ghost cell, one launch for up to two ranges of planes, instead of X, Y (plain) or
+// Y, shear, Y (shearing box) per range.  Possible when the x / y faces are plain (mirror / copy / periodic) or the shearing box
+// with periodic y; the 2D jet (re-imposed after the Y pass) is launched behind it.  RGPU_NO_FUSED_FILL=1: the separate passes.
+bool fill_xy_plan(const rgpu_ctx* c, double totalTime, double dt, FillXY* f) {
+  static const bool off = std::getenv("RGPU_NO_FUSED_FILL") != 0;
+  if (off) return false;
+  const rgpu_params& p = c->p;
+  auto plain = [](int b) { return b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC; };
+  f->bx0 = p.bc[0]; f->bx1 = p.bc[1]; f->by0 = p.bc[2]; f->by1 = p.bc[3]; f->shear = 0;
+  f->sg.jplus = 0; f->sg.eps_min = 0.0; f->sg.eps_max = 0.0;
+  if (c->g.rot && c->g.shearbox && c->g.three_d) {
+    if (p.bc[2] != RGPU_BC_PERIODIC || p.bc[3] != RGPU_BC_PERIODIC) return false;
+    double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt);   // MHDRunGodunov.cpp:3554-3557 (do_make_boundaries_shear)
+    deltay = std::fmod(deltay, (p.dy * p.ny));
+    f->sg.jplus = (int)(deltay / p.dy);
+    const double epsi = std::fmod(deltay, p.dy);
+    f->sg.eps_min = 1.0 - epsi / p.dy;
+    f->sg.eps_max = epsi / p.dy;
+    f->shear = 1;
+    return true;
+  }
+  return plain(p.bc[0]) && plain(p.bc[1]) && plain(p.bc[2]) && plain(p.bc[3]);
+}
+// ... planes [a1, b1) and [a2, b2) of U (either may be empty)
+int launch_fill_xy(rgpu_ctx* c, double* U, const FillXY& f, int a1, int b1, int a2, int b2) {
+  const int ks = c->g.ksize;
+  a1 = a1 < 0 ? 0 : a1; b1 = b1 > ks ? ks : b1; a2 = a2 < 0 ? 0 : a2; b2 = b2 > ks ? ks : b2;
+  const int n1 = b1 > a1 ? b1 - a1 : 0, n2 = b2 > a2 ? b2 - a2 : 0;
+  if (n1 + n2 == 0) return 0;
+  const unsigned per = 2u * (unsigned)c->g.gw * (unsigned)(c->g.isize + c->g.ny);   // ghost cells of one plane (fill_xy_cell)
+  K_fill_xy k = {c->g, f, U, per, a1, n1, a2};
+  if (rg_launch<kBlock>(c->stream, per * (unsigned)(n1 + n2), k)) return -1;
+  if (c->p.enableJet && !c->g.three_d) return launch_jet(c, U);   // 2D: re-imposed after the Y pass (HydroRunBase.cpp:2286-2312)
+  return 0;
+}
+// Z pass of a full fill whose X / Y passes were fused: complete ghost planes come out of complete interior planes when the z faces
+// copy planes cell by cell (mirror / copy / periodic / neighbour slab) -- not the stratified face, which treats the last row and
+// column of a plane differently
+// ... and only a single-domain context knows that about the whole box (another slab of the run may own a stratified face and would
+// send planes whose corners still wait for its last Y pass): slab contexts keep the separate passes in the whole-domain pieces;
+// their overlapped schedule fills plane ranges (step_fill_planes), which is fused whatever the z faces are
+bool z_fill_is_planewise(const rgpu_ctx* c) {
+  if (c->p.slab_count > 1) return false;
+  return !c->g.three_d || (c->p.bc[4] != RGPU_BC_Z_STRATIFIED && c->p.bc[5] != RGPU_BC_Z_STRATIFIED);
+}
+
 // ---- the step -------------------------------------------------------------------------------------------------
 int step_pre(rgpu_ctx* c, int nStep) {
   if (c->g.rot) return 0;
   if (c->ghost_ok_parity == nStep % 2) return 0;   // the kernel that wrote this state filled its ghost cells too (periodic images)
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* in = c->U[nStep % 2];
-  if (do_make_boundaries(c, in, RGPU_XDIR) || do_make_boundaries(c, in, RGPU_YDIR)) return -1;
+  FillXY f;
+  if (z_fill_is_planewise(c) && fill_xy_plan(c, 0.0, 0.0, &f)) {   // X and Y in one launch over the interior planes, then Z copies whole planes
+    if (launch_fill_xy(c, in, f, c->g.three_d ? c->g.gw : 0, c->g.three_d ? c->g.ksize - c->g.gw : 1, 0, 0)) return -1;
+  } else if (do_make_boundaries(c, in, RGPU_XDIR) || do_make_boundaries(c, in, RGPU_YDIR)) return -1;
   if (c->g.three_d && do_make_boundaries(c, in, RGPU_ZDIR)) return -1;
   return 0;
 }
@@ -396,6 +447,9 @@ int step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   if (!c->g.rot) return 0;
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* out = c->U[(nStep + 1) % 2];
+  FillXY f;
+  if (z_fill_is_planewise(c) && fill_xy_plan(c, totalTime, dt, &f))   // Y, shear, [Z], Y (or X, Y) as one pass over the interior planes; post_b adds Z
+    return launch_fill_xy(c, out, f, c->g.three_d ? c->g.gw : 0, c->g.three_d ? c->g.ksize - c->g.gw : 1, 0, 0);
   if (c->g.shearbox && c->g.three_d) {
     if (do_make_boundaries(c, out, RGPU_YDIR)) return -1;
     return do_make_boundaries_shear(c, out, totalTime, dt);
@@ -409,22 +463,29 @@ int step_post_b(rgpu_ctx* c, int nStep) {
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* out = c->U[(nStep + 1) % 2];
   if (c->g.three_d && do_make_boundaries(c, out, RGPU_ZDIR)) return -1;
-  if (c->g.shearbox && c->g.three_d) return do_make_boundaries(c, out, RGPU_YDIR);
-  return 0;
+  FillXY f;
+  if (c->g.shearbox && c->g.three_d && !(z_fill_is_planewise(c) && fill_xy_plan(c, 0.0, 0.0, &f))) return do_make_boundaries(c, out, RGPU_YDIR);
+  return 0;   // (fused post_a: the z ghost planes are copies of complete planes, the last Y pass has nothing left to do)
 }
 
-// In-plane part of the ghost fill of the step's OUTPUT state, restricted to planes [a,b): what a z-slab driver applies
+// In-plane part of the ghost fill of the step's OUTPUT state, restricted to planes [a,b) (and [a2,b2)): what a z-slab driver applies
 // to the planes it is about to send, so that the neighbour receives finished planes (x / y ghosts and corners
 // included) and never has to touch its z ghost planes again.  x and y fills (and the shear remap) act within one
 // z plane, hence plane-wise { Y, shear, Y } + copying planes equals the reference's { Y, shear, Z, Y } sequence.
-int step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b) {
+int step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int a2 = 0, int b2 = 0) {
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* out = c->U[(nStep + 1) % 2];
-  if (c->g.rot && c->g.shearbox) {
-    return do_make_boundaries(c, out, RGPU_YDIR, a, b) || do_make_boundaries_shear(c, out, totalTime, dt, a, b) ||
-           do_make_boundaries(c, out, RGPU_YDIR, a, b);
+  FillXY f;
+  if (fill_xy_plan(c, totalTime, dt, &f)) return launch_fill_xy(c, out, f, a, b, a2, b2);
+  for (int n = 0; n < 2; ++n) {
+    const int lo = n ? a2 : a, hi = n ? b2 : b;
+    if (hi <= lo) continue;
+    if (c->g.rot && c->g.shearbox) {
+      if (do_make_boundaries(c, out, RGPU_YDIR, lo, hi) || do_make_boundaries_shear(c, out, totalTime, dt, lo, hi) ||
+          do_make_boundaries(c, out, RGPU_YDIR, lo, hi)) return -1;
+    } else if (do_make_boundaries(c, out, RGPU_XDIR, lo, hi) || do_make_boundaries(c, out, RGPU_YDIR, lo, hi)) return -1;
   }
-  return do_make_boundaries(c, out, RGPU_XDIR, a, b) || do_make_boundaries(c, out, RGPU_YDIR, a, b);
+  return 0;
 }
 
 // ---- plane-range helpers -----------------------------------------------------------------------------------------
@@ -657,7 +718,9 @@ template <int S> using K_riemann_t = K_mhd_flux3d<DO_ALL, false, S>;
 // phase timers on (or RGPU_CHUNKS=1) everything is issued on the context stream in one chunk.
 // what: 0 = the whole update of planes [a,b); RGPU_CORE_FLUXES = only F, emf (+ the shear remap buffers) that update needs;
 // RGPU_CORE_UPDATE = only the update, from F, emf computed by an earlier RGPU_CORE_FLUXES call covering [a,b)
-int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what_flags = 0) {
+// (a2, b2): a second plane range handled in the same call -- split calls only (the two boundary ranges of a slab): one launch of the
+// update kernel for both
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what_flags = 0, int a2 = 0, int b2 = 0) {
   int what = what_flags;
   const DevParams& g = c->g;
   const rgpu_params& p = c->p;
@@ -741,11 +804,15 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // the update is a pure stream over F, emf and U: one thread per column and short z segment, linear workgroup order, the plane
   // k+1 entries carried in registers (mhd_update3d_column; 512^3: 8.07 -> 7.42 ms against one thread per cell)
   static const int upd_seg = std::getenv("RGPU_UPD_SEG") ? std::atoi(std::getenv("RGPU_UPD_SEG")) : 3;
-  auto update_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+  auto update_planes = [&](rg_stream_t s, PlaneRange r, PlaneRange r2 = PlaneRange{0, 0}) -> int {
+    if (r.hi <= r.lo) { r = r2; r2 = PlaneRange{0, 0}; }
     if (r.hi <= r.lo) return 0;
     const int seg_len = upd_seg > 0 ? upd_seg : 3;
-    const unsigned nt = g.sk * (unsigned)((r.hi - r.lo + seg_len - 1) / seg_len);
-#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
+    const unsigned n1 = g.sk * (unsigned)((r.hi - r.lo + seg_len - 1) / seg_len);
+    const bool two = r2.hi > r2.lo;
+    const unsigned nt = n1 + (two ? g.sk * (unsigned)((r2.hi - r2.lo + seg_len - 1) / seg_len) : 0u);
+    const unsigned split = two ? n1 : 0xffffffffu;
+#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
     if (gf) { if (g.rot) RG_UPD(true, true, SPEC_NONE) else RG_UPD(false, true, SPEC_NONE) }
     if (g.rot) { if (spec == 1) RG_UPD(true, false, kSpecMri) if (spec == 2) RG_UPD(true, false, kSpecPlain) RG_UPD(true, false, SPEC_NONE) }
     if (spec == 1) RG_UPD(false, false, kSpecMri) if (spec == 2) RG_UPD(false, false, kSpecPlain) RG_UPD(false, false, SPEC_NONE)
@@ -756,18 +823,22 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // against 55.3 ms/step at 512^3), so the two-stream chunk schedule is kept for the flat kernels only (RGPU_CHUNKS forces it)
   static const bool force_chunks = std::getenv("RGPU_CHUNKS") != 0;
   const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks);
+  const bool pair = what != 0 && b2 > a2;
   if (serial) {
     rg_stream_t s = c->stream;
     if (what != RGPU_CORE_UPDATE) {
-      if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)
-        { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(a - 2, b + 2, ks))) return -1; }
-        { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(a - 1, b + 2, ks))) return -1; }
+      for (int n = 0; n < (pair ? 2 : 1); ++n) {
+        const int lo = n ? a2 : a, hi = n ? b2 : b;
+        if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)
+          { Phase ph(c, RGPU_T_PRIM); if (prim_planes(s, clip(lo - 2, hi + 2, ks))) return -1; }
+          { Phase ph(c, RGPU_T_ELEC); if (elec_planes(s, clip(lo - 1, hi + 2, ks))) return -1; }
+        }
+        if (trace_riemann(s, lo - 1, hi + 1, clip(lo, hi + 1, ks))) return -1;
+        { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(lo, hi + 1, ks))) return -1; }
       }
-      if (trace_riemann(s, a - 1, b + 1, clip(a, b + 1, ks))) return -1;
-      { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks))) return -1; }
     }
     if (what != RGPU_CORE_FLUXES) {
-      { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks))) return -1; }
+      { Phase ph(c, RGPU_T_UPDATE); if (update_planes(s, clip(a, b, ks), pair ? clip(a2, b2, ks) : PlaneRange{0, 0})) return -1; }
       if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     }
     return 0;
@@ -811,7 +882,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
 
 // what != 0 (RGPU_CORE_FLUXES / RGPU_CORE_UPDATE) splits the 3D MHD step, the only one whose update is a kernel of its own;
 // for every other solver FLUXES is a no-op and UPDATE the whole piece, so a driver may use the split schedule blindly
-int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int what = 0) {
+int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int what = 0, int a2 = 0, int b2 = 0) {
   const bool splittable = c->g.three_d && c->p.mhdEnabled;
   const bool acc = (what & RGPU_CORE_SCAN) != 0;
   bool hydro_piece = false;
@@ -848,9 +919,17 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   }
   if (a < 0) a = 0;
   if (b > c->g.ksize) b = c->g.ksize;
+  if (a2 < 0) a2 = 0;
+  if (b2 > c->g.ksize) b2 = c->g.ksize;
+  if (b <= a) { a = a2; b = b2; a2 = b2 = 0; }
   if (b <= a) return 0;
-  if (!c->p.mhdEnabled) return hydro_core<3, 5>(c, in, out, dt, a, b, hydro_piece);
-  return mhd3d_core(c, in, out, dt, totalTime, a, b, what);
+  if (!c->p.mhdEnabled) {   // the sweep is the whole step: one launch per range
+    const int rc = hydro_core<3, 5>(c, in, out, dt, a, b, hydro_piece);
+    if (rc || b2 <= a2) return rc;
+    return hydro_core<3, 5>(c, in, out, dt, a2, b2, hydro_piece);
+  }
+  if (what == 0 && b2 > a2) return mhd3d_core(c, in, out, dt, totalTime, a, b, 0) || mhd3d_core(c, in, out, dt, totalTime, a2, b2, 0);
+  return mhd3d_core(c, in, out, dt, totalTime, a, b, what, a2, b2);
 }
 
 // Dissipative stage ([hydro] nu, [MHD] eta) on the state the step has just written: refill its ghosts (plain or
@@ -1042,6 +1121,24 @@ struct K_selftest_arith {
     quot2[i] = num[i] / den[i];
     root[i] = rg_sqrt(num[i]);
     root2[i] = sqrt(num[i]);
+  }
+};
+
+// one sample = the four corner states of an edge (LL, RL, LR, RR: r p u v w a b c each) and their four electric fields, SoA: in[q * n + i]
+struct K_selftest_alfven {
+  DevParams g; const double* in; double* e_sel; double* e_ref; int* route; unsigned n;
+  RG_DEVFN void operator()(unsigned i) const {
+    Prim8 s[4];
+    for (int q = 0; q < 4; ++q) {
+      const double* x = in + (size_t)(8 * q) * n + i;
+      s[q].r = x[0]; s[q].p = x[n]; s[q].u = x[2 * (size_t)n]; s[q].v = x[3 * (size_t)n]; s[q].w = x[4 * (size_t)n];
+      s[q].a = x[5 * (size_t)n]; s[q].b = x[6 * (size_t)n]; s[q].c = x[7 * (size_t)n];
+    }
+    const double E0 = in[(size_t)32 * n + i], E1 = in[(size_t)33 * n + i], E2 = in[(size_t)34 * n + i], E3 = in[(size_t)35 * n + i];
+    int r = 0;
+    e_sel[i] = mag_hlld_2d<false>(g, s[0], s[1], s[2], s[3], E0, E1, E2, E3, &r);
+    e_ref[i] = mag_hlld_2d<true>(g, s[0], s[1], s[2], s[3], E0, E1, E2, E3);
+    route[i] = r;
   }
 };
 
@@ -1425,6 +1522,22 @@ int rgpu_step_core_planes_split(rgpu_ctx* c, int nStep, double dt, double totalT
   if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi, what)) return RG_HIPFAIL(c, "step_core_planes_split");
   return RGPU_OK;
 }
+int rgpu_step_core_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2, int what) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if ((what & ~RGPU_CORE_SCAN) != RGPU_CORE_FLUXES && (what & ~RGPU_CORE_SCAN) != RGPU_CORE_UPDATE)
+    return fail(c, RGPU_EINVAL, "step_core_planes_pair: what must be RGPU_CORE_FLUXES or RGPU_CORE_UPDATE (| RGPU_CORE_SCAN)");
+  if (k_hi > k_lo && k_hi2 > k_lo2 && k_lo2 < k_hi && k_lo < k_hi2) return fail(c, RGPU_EINVAL, "step_core_planes_pair: the two plane ranges overlap");
+  if (step_core_planes(c, nStep, dt, totalTime, k_lo, k_hi, what, k_lo2, k_hi2)) return RG_HIPFAIL(c, "step_core_planes_pair");
+  return RGPU_OK;
+}
+int rgpu_step_fill_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (!c->g.three_d) return fail(c, RGPU_EINVAL, "step_fill_planes: plane ranges need a 3D context");
+  if (step_fill_planes(c, nStep, dt, totalTime, k_lo, k_hi, k_lo2, k_hi2)) return RG_HIPFAIL(c, "step_fill_planes_pair");
+  return RGPU_OK;
+}
 int rgpu_step_dissipative(rgpu_ctx* c, int nStep, double dt, double totalTime) {
   RG_CHECK_CTX(c);
   if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
@@ -1607,6 +1720,23 @@ int rgpu_selftest_arith(int n, const double* num, const double* den, double* quo
   rc = rc || rg_copy_d2h(quot, d + 2 * N, N * sizeof(double), s) || rg_copy_d2h(quot2, d + 3 * N, N * sizeof(double), s) ||
        rg_copy_d2h(root, d + 4 * N, N * sizeof(double), s) || rg_copy_d2h(root2, d + 5 * N, N * sizeof(double), s) || rg_stream_sync(s);
   rg_free(d);
+  return rc ? RGPU_EHIP : RGPU_OK;
+}
+
+int rgpu_selftest_alfven(const rgpu_params* p, int n, const double* states36, double* e_select, double* e_reference, int* route) {
+  if (!p || n <= 0 || !states36 || !e_select || !e_reference || !route) return RGPU_EINVAL;
+  if (rg_device_count() < 1) return RGPU_ENODEVICE;
+  DevParams g;
+  fill_dev_params(*p, &g);
+  const size_t N = (size_t)n;
+  double* d = 0; int* dr = 0;
+  if (rg_malloc((void**)&d, 38 * N * sizeof(double)) || rg_malloc((void**)&dr, N * sizeof(int))) { rg_free(d); return RGPU_ENOMEM; }
+  const rg_stream_t s = (rg_stream_t)0;
+  K_selftest_alfven k = {g, d, d + 36 * N, d + 37 * N, dr, (unsigned)n};
+  const int rc = rg_copy_h2d(d, states36, 36 * N * sizeof(double), s) || rg_launch<kBlock>(s, (unsigned)n, k) ||
+                 rg_copy_d2h(e_select, d + 36 * N, N * sizeof(double), s) || rg_copy_d2h(e_reference, d + 37 * N, N * sizeof(double), s) ||
+                 rg_copy_d2h(route, dr, N * sizeof(int), s) || rg_stream_sync(s);
+  rg_free(d); rg_free(dr);
   return rc ? RGPU_EHIP : RGPU_OK;
 }
 

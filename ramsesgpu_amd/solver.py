@@ -312,6 +312,13 @@ class Solver:
     def step_fill_planes(self, nStep, dt, t, k_lo, k_hi):
         self._chk(self.lib.rgpu_step_fill_planes(self.ctx, nStep, dt, t, k_lo, k_hi), "step_fill_planes")
 
+    def step_core_planes_pair(self, nStep, dt, t, r1, r2, what):
+        """two disjoint plane ranges in one call (rgpu_step_core_planes_pair): what as step_core_planes_split"""
+        self._chk(self.lib.rgpu_step_core_planes_pair(self.ctx, nStep, dt, t, r1[0], r1[1], r2[0], r2[1], what), "step_core_planes_pair")
+
+    def step_fill_planes_pair(self, nStep, dt, t, r1, r2):
+        self._chk(self.lib.rgpu_step_fill_planes_pair(self.ctx, nStep, dt, t, r1[0], r1[1], r2[0], r2[1]), "step_fill_planes_pair")
+
     def inv_dt_accumulate(self, parity, k_lo, k_hi, reset=False):
         self._chk(self.lib.rgpu_inv_dt_accumulate(self.ctx, parity, k_lo, k_hi, int(reset)), "inv_dt_accumulate")
 

@@ -540,3 +540,89 @@ def check_public_ghost_fill_invalidates_fused_dt(lib, oracle, base, ov):
             assert t_fused == 0.0 and t_scan > 0.0, (t_fused, t_scan)
     finally:
         sv.close()
+
+
+# ---- direct differential test of the Alfven selection in the 2D HLLD edge solver (rgpu_selftest_alfven) -------------------------
+def alfven_samples(n, seed):
+    """n edge problems (SoA [36, n]): half random rough states, half adversarial -- built to sit on the selection's margins:
+      * dv / dS = 1 +- k 2^-52 (k <= 2^14): a uniform flow (the star ratio t = dv / dS is exactly 1) whose velocities are nudged
+        by k ulp, so that candidates and their star partners tie, nearly tie, or differ by a hair more than the 2^-40 margin;
+      * equal candidates (all four states identical, or pairwise identical);
+      * |b| from 1e-120 to 1e3, density ratios 2^+-60 between the states;
+      * the kinds interleaved lane by lane, so that a wave of 64 samples holds both routes."""
+    rng = np.random.RandomState(seed)
+    S = np.empty((36, n))
+    kind = rng.randint(0, 8, n)                    # per LANE: neighbours in a wave differ
+    # base: random states
+    for q in range(4):
+        S[8 * q + 0] = np.exp(rng.uniform(-2, 2, n))            # r
+        S[8 * q + 1] = np.exp(rng.uniform(-3, 2, n))            # p
+        S[8 * q + 2:8 * q + 5] = rng.normal(0, 1.5, (3, n))     # u v w
+        S[8 * q + 5:8 * q + 8] = rng.normal(0, 1.0, (3, n))     # a b c
+    uni = kind >= 2                                # adversarial kinds start from a uniform flow: copy state 0 into the others
+    for q in range(1, 4):
+        S[8 * q:8 * q + 8, uni] = S[0:8, uni]
+    ulp = 2.0 ** -52
+    k = np.floor(np.exp2(rng.uniform(0, 14, n))) * np.where(rng.rand(n) < 0.5, -1.0, 1.0)
+    # kind 2: exactly uniform (every pair ties).  3: one velocity of one state nudged by k ulp.  4: all velocities of two states nudged
+    m = kind == 3
+    q3 = rng.randint(0, 4, n); c3 = rng.randint(2, 4, n)
+    for q in range(4):
+        for c in (2, 3):
+            sel = m & (q3 == q) & (c3 == c)
+            S[8 * q + c, sel] *= 1.0 + k[sel] * ulp
+    m = kind == 4
+    for q in (1, 2):
+        for c in (2, 3):
+            S[8 * q + c, m] *= 1.0 + k[m] * ulp * (1 if q == 1 else -1)
+    # kind 5: pairwise identical states (LL == LR, RL == RR) with a k-ulp density nudge across the pair
+    m = kind == 5
+    S[8:16, m] = S[0:8, m] * 1.0
+    S[8:9, m] *= 1.0 + k[m] * ulp
+    S[16:24, m] = S[0:8, m]
+    S[24:32, m] = S[8:16, m]
+    # kind 6: field scaled over 1e-120 .. 1e3 (all states alike, so that candidates stay comparable), velocities nudged
+    m = kind == 6
+    scale = np.exp(rng.uniform(np.log(1e-120), np.log(1e3), n))
+    for q in range(4):
+        S[8 * q + 5:8 * q + 8, m] *= scale[m]
+        S[8 * q + 2, m] *= 1.0 + (q - 1.5) * k[m] * ulp
+    # kind 7: density ratios 2^+-60 between the states (pressure follows, so that sound speeds stay finite), random fields
+    m = kind == 7
+    for q in range(1, 4):
+        e = rng.randint(-60, 61, n).astype(float)
+        S[8 * q + 0, m] = S[0, m] * np.exp2(e[m])
+        S[8 * q + 1, m] = S[1, m] * np.exp2(e[m])
+        S[8 * q + 5:8 * q + 8, m] = rng.normal(0, 1.0, (3, int(m.sum())))
+    # kind 1 (random): field scale over a wide range too
+    m = kind == 1
+    scale = np.exp(rng.uniform(np.log(1e-120), np.log(1e3), n))
+    for q in range(4):
+        S[8 * q + 5:8 * q + 8, m] *= scale[m]
+    # electric fields of the corner states, E = u b - v a (riemann_mhd.h:1115-1140)
+    for q in range(4):
+        S[32 + q] = S[8 * q + 2] * S[8 * q + 6] - S[8 * q + 3] * S[8 * q + 5]
+    return np.ascontiguousarray(S), kind
+
+
+def check_alfven_selftest(lib, n, seed, smallc, iso=False):
+    """e_select == e_reference, bit for bit; returns (waves on the selection route, waves on the reference route)"""
+    import ctypes as C
+    from conftest import ini
+    p = lib.params_from_ini(ini("mhd_mri_3d" if iso else "orszag-tang3d"), "mesh.nx=8;mesh.ny=8;mesh.nz=8")
+    p.smallc = smallc
+    S, kind = alfven_samples(n, seed)
+    e_sel, e_ref = np.empty(n), np.empty(n)
+    route = np.empty(n, dtype=np.int32)
+    f = lib.lib.rgpu_selftest_alfven
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = f(C.byref(p), n, P(S), P(e_sel), P(e_ref), route.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0, rc
+    a, b = e_sel.view(np.uint64), e_ref.view(np.uint64)
+    bad = (a != b) & ~(np.isnan(e_sel) & np.isnan(e_ref))
+    assert not bad.any(), "%d of %d edge problems differ between the selection and the reference's sequence; first: sample %d kind %d: %r vs %r" % (
+        int(bad.sum()), n, int(np.argmax(bad)), int(kind[np.argmax(bad)]), e_sel[np.argmax(bad)], e_ref[np.argmax(bad)])
+    assert np.isfinite(e_ref).mean() > 0.9, "the samples are mostly not finite: %r" % np.isfinite(e_ref).mean()
+    return int((route == 0).sum()), int((route == 1).sum()), kind, route

@@ -278,6 +278,44 @@ def test_shared_reciprocal_division_and_sqrt_are_ieee(gpu_lib):
     assert np.array_equal(root2, np.sqrt(pos)) and np.array_equal(root, np.sqrt(pos))
 
 
+@pytest.mark.parametrize("smallc,iso", [(1e-7, False), (1e-100, False), (1e-7, True), (1e-101, False)], ids=["smallc1e-7", "smallc1e-100", "isothermal", "smallc-below-the-bound"])
+def test_alfven_selection_against_the_reference_sequence(smallc, iso, gpu_lib):
+    """the 2D HLLD edge solver run twice per sample on the device -- Alfven speeds by selection (alfven_pick / alfven_duel) and by the
+    reference's own twelve roots -- on 1.2e7 random and adversarial edge states (parity_checks.alfven_samples): identical bits; both
+    routes are exercised, uniform / tied states go down the reference's sequence, and below smallc = 1e-100 every wave does"""
+    n = 1 << 22
+    sel = ref = 0
+    for seed in range(3):
+        s, r, kind, route = pc.check_alfven_selftest(gpu_lib, n, 100 + seed, smallc, iso)
+        sel += s; ref += r
+        assert (route[kind == 2] == 1).all()      # exactly uniform states tie: their waves must take the reference's sequence
+    print("alfven selftest smallc=%g: %d samples on the selection route, %d on the reference route" % (smallc, sel, ref))
+    if smallc < 1e-100:
+        assert sel == 0
+    else:
+        assert ref > 0      # (with the kinds interleaved lane by lane almost every wave holds a tied sample; the pure-selection route is
+        #                     what test_alfven_selection_rough_waves below covers)
+
+
+def test_alfven_selection_rough_waves(gpu_lib):
+    """whole waves of rough random states: the selection route itself (no tied lane in the wave), 4e6 samples, identical bits"""
+    import ctypes as C
+    n = 1 << 22
+    S, kind = pc.alfven_samples(n, 7)
+    rough = np.ascontiguousarray(S[:, kind <= 1][:, : (int((kind <= 1).sum()) // 64) * 64])
+    p = gpu_lib.params_from_ini(ini("orszag-tang3d"), "mesh.nx=8;mesh.ny=8;mesh.nz=8")
+    m = rough.shape[1]
+    e_sel, e_ref = np.empty(m), np.empty(m)
+    route = np.empty(m, dtype=np.int32)
+    f = gpu_lib.lib.rgpu_selftest_alfven
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert f(C.byref(p), m, P(rough), P(e_sel), P(e_ref), route.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    assert np.array_equal(e_sel.view(np.uint64), e_ref.view(np.uint64))
+    assert (route == 0).mean() > 0.9, (route == 0).mean()      # these waves really took the selection
+
+
 @pytest.mark.parametrize("base,ov,nsteps", pc.TURB_HISTORY_CASES, ids=["%s[%s]" % (b, o) for b, o, _ in pc.TURB_HISTORY_CASES])
 def test_turbulence_history(base, ov, nsteps, gpu_lib, oracle):
     pc.check_history_turbulence(gpu_lib, oracle, base, ov, nsteps)

@@ -112,3 +112,13 @@ def test_alfven_selection_near_ties(base, ov, eps, emu_lib, oracle):
     """the Alfven-speed selection of the 2D HLLD edge solver at, inside and outside its margins (2^-40 on the star ratio, 2^-45 on
     the cross products): uniform magnetised flow + perturbations of relative size eps, one step, every double equal to the oracle's"""
     pc.check_single_step_near_uniform(emu_lib, oracle, base, ov, eps)
+
+
+def test_alfven_selection_against_the_reference_sequence_emu(emu_lib):
+    """rgpu_selftest_alfven through the emulation build (one lane per wave: every sample takes its own route): selection == reference
+    sequence on 2e5 random and adversarial edge states, and both routes occur"""
+    sel, ref, kind, route = pc.check_alfven_selftest(emu_lib, 200000, 11, 1e-7)
+    assert sel > 0 and ref > 0
+    assert (route[kind == 2] == 1).all()
+    sel, ref, _, _ = pc.check_alfven_selftest(emu_lib, 50000, 12, 1e-101)
+    assert sel == 0
