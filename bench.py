@@ -589,6 +589,7 @@ def main():
     cells_local = cells_global / world
     dims = "%dx%d" % (nx, ny) if two_d else "%dx%dx%d" % (nx, ny, nz)
 
+    clocked_steps = None
     if world == 1:
         if args.timeline_only:
             L = Library(lib_path(args.arith))
@@ -614,6 +615,7 @@ def main():
         ov = overrides_for(w, nx, ny, nz)
         want_python = os.environ.get("RGPU_BENCH_DRIVER", "cpp") == "python"
         info = None
+        slab_batch = None
         if replicas:
             p = L.params_from_ini(ini, ov)
             srun = Solver(p, L)
@@ -637,12 +639,16 @@ def main():
                 sys.stderr.flush()
                 sys.exit(5)
             step, timers_src = srun.oneStepIntegration, srun.solver
+            slab_batch = srun.run_steps      # rgpu_comm_run_steps: the K timed steps as ONE call, the time step on the device between them
             sched = {"2": "2 (boundary-first)"}.get(os.environ.get("RGPU_COMM_SCHEDULE", ""), "1 (overlap)")
             driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
                 "" if args.arith == "exact" else "_fast", info["transport"], sched,
                 "in-place (one send / recv per variable and face)" if os.environ.get("RGPU_COMM_PACK") == "0" else "packed (one send / recv per peer)", srun.halo_bytes() / 1e6)
         dts = []
-        elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup, dts=dts)
+        if slab_batch is not None:
+            elapsed = timed_steps(step, srun, ctl, args.steps, args.warmup, batch=slab_batch, dts=dts)   # (srun: the dt log of the batch)
+        else:
+            elapsed = timed_steps(step, timers_src, ctl, args.steps, args.warmup, dts=dts)
         # what was computed, in a form every N must reproduce (fingerprint_record): every rank's checksum of its own planes
         fingerprint = fingerprint_record(dts, ctl.gather(timers_src.state_checksum((args.warmup + args.steps) % 2)))
         # diagnostic of the halo exchange of the LAST timed step on this rank: its duration on the halo stream and the rate that makes
@@ -657,6 +663,7 @@ def main():
                 print(json.dumps({"ms_per_step": elapsed / args.steps * 1e3}))
             ctl.close()
             return
+        clocked_steps = srun.clocked_steps() if slab_batch is not None else None
         prof = phase_profile(step, timers_src, ctl, args.steps)
         roof, roof_step = roofline_of(args.workload, w, args.arith, w["bytes"] * cells_local, elapsed, args.steps, prof)
         rec = {"value": args.steps * cells_global / elapsed / 1e6, "ms_per_step": elapsed / args.steps * 1e3, "roofline": roof, "roofline_step": roof_step,
@@ -671,7 +678,7 @@ def main():
                 rec["second"] = (other, {"value": None, "error": repr(err2) if err2 is not None else "another rank failed"})
             else:
                 dts2 = []
-                el2 = timed_steps(srun2.oneStepIntegration, srun2.solver, ctl, args.steps, args.warmup, dts=dts2)
+                el2 = timed_steps(srun2.oneStepIntegration, srun2, ctl, args.steps, args.warmup, batch=srun2.run_steps, dts=dts2)
                 fp2 = fingerprint_record(dts2, ctl.gather(srun2.solver.state_checksum((args.warmup + args.steps) % 2)))
                 rec["second"] = (other, {"value": args.steps * cells_global / el2 / 1e6, "unit": "Mcell-updates/s", "ms_per_step": el2 / args.steps * 1e3, "fingerprint": fp2,
                                          "steps": args.steps, "warmup": args.warmup, "arithmetic": other, "parity": PARITY[other],
@@ -710,9 +717,12 @@ def main():
                        "driver": driver, "rccl_ranks": rccl_ranks, "ranks": ranks,
                        "path": w["path"],
                        "arithmetic": args.arith,
-                       "time_loop": ("rgpu_run_steps(K): K turns of the reference's loop body in one call, same states and dt sequence; 2D: dt stays on the "
-                                     "device between the fused step kernels (csrc/hip/step_clock.h); 3D: the plain per-step loop" if world == 1 else
-                                     "K calls of oneStepIntegration"),
+                       "time_loop": ("rgpu_run_steps(K): K turns of the reference's loop body in one call, same states and dt sequence; dt, t += dt and the "
+                                     "loop condition stay on the device between the steps (csrc/step_clock_rec.h, hip/step_clock.h), the host reads the records of "
+                                     "the batch once" if world == 1 else
+                                     ("rgpu_comm_run_steps(K): the same loop body over the slabs -- per step the 1/dt slots all-reduced in place, the clock record, "
+                                      "the step pieces and the halo exchange, no host turn in between; %s of the %d timed + warm-up steps took their time step from "
+                                      "the device" % (clocked_steps, args.steps + args.warmup) if clocked_steps is not None else "K calls of oneStepIntegration")),
                        "parity": PARITY[args.arith],
                        "fingerprint": rec.get("fingerprint")},
             "roofline": rec["roofline"], "roofline_step": rec["roofline_step"],

@@ -190,6 +190,7 @@ double* rgpu_inv_dt_device_slot(rgpu_ctx* c);
  * whatever the step left in them -- a fixed count, so that ranks in different states (first step, a failed step piece) can never
  * post all-reduces of different sizes; rgpu_inv_dt_result reads the ones that are valid. */
 #define RGPU_DT_SLOTS 1024
+#define RGPU_CLOCK_BATCH 256   /* steps per batch of the device-side time step (rgpu_clock_open .. rgpu_clock_close) */
 
 /* ---- the path ------------------------------------------------------------------------------------------- */
 
@@ -332,7 +333,8 @@ int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
  * kernel that leaves the CFL maxima and the ghost cells of its output on the device (2D hydro / MHD in a box of periodic, reflecting or
  * outflow faces, no gravity, no rotating frame) the time step itself stays on the device (csrc/hip/step_clock.h: dt = cfl / max 1/dt, the
  * loop condition and t += dt evaluated by a one-workgroup kernel between two steps) and a batch of steps is queued without a host round
- * trip -- at the shipped 2D sizes that round trip costs as much as a third of the step.  Every other configuration runs the plain loop. */
+ * trip -- at the shipped 2D sizes that round trip costs as much as a third of the step.  Since round 5 the 3D steps do the same (hydro,
+ * plain / rotating / shearing-box MHD through the z-marching sweeps: rgpu_clock_capable).  Every other configuration runs the plain loop. */
 int rgpu_run_steps(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt);
 /* ... the same, and dt_log[n] = the time step of the n-th step done (the "dt=" column of the reference's log, MHDRunGodunov.cpp:3958);
  * dt_log holds nsteps doubles or is NULL.  If a launch fails after some steps of a batch were queued, *nStep, *t, *dt (and dt_log)
@@ -341,6 +343,30 @@ int rgpu_run_steps_log(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double*
 /* 1 when the next step of rgpu_run_steps on the state U[parity] would take its time step from the device (see above), else 0:
  * lets a caller (and the tests) tell which loop runs. */
 int rgpu_device_time_step_ready(rgpu_ctx* c, int parity);
+
+/* The device-side time step as pieces, for a driver that queues whole batches of steps itself (the z-slab driver: all-reduce of the
+ * 1/dt slots in place -> clock -> step pieces -> halo exchange, no host turn between steps; rgpu_run_steps is built on the same three).
+ *   rgpu_clock_capable  1 when every kernel of this context's step that depends on dt or t can read them from a device record
+ *                       (csrc/step_clock_rec.h): 2D fused steps; 3D hydro and MHD through the z-marching sweeps, incl. the rotating frame
+ *                       and the shearing box (periodic y); no gravity, dissipative stage, forcing, phase timers.
+ *   rgpu_clock_open     starts a batch at time t0; steps stop being executed once t >= tEnd (HUGE_VAL: never).
+ *   rgpu_clock_tick     queues the clock kernel of the NEXT step: folds the RGPU_DT_SLOTS device slots (which must hold the CFL maxima of
+ *                       the step's input state -- all-reduced across slabs by the caller), zeroes them for the step's own scan, forms
+ *                       dt = cfl / max(1/dt), dt/dx.., the rotating-frame coefficients, the shearing-box offsets, t += dt with the host's
+ *                       expressions (the same doubles).  Until the next tick / close every rgpu_step_* piece of this context reads that
+ *                       record on the device; its dt / totalTime arguments are ignored.  A step whose record says "stop" (t >= tEnd, or
+ *                       1/dt not finite) and every step after it are no-ops that leave state, ghost cells and slots untouched.
+ *   rgpu_clock_close    reads the records back (the one synchronisation of the batch): *ran = steps that ran, *t += their dt in order,
+ *                       *dt_last, dt_log[0..ran) (may be NULL), *stop = 0 or why the batch stopped (1: tEnd, 2: dt is NaN, 3: 1/dt not
+ *                       finite).  nStep0 = step number of the first step of the batch.  At most RGPU_CLOCK_BATCH ticks per batch. */
+int rgpu_clock_capable(rgpu_ctx* c);
+int rgpu_clock_open(rgpu_ctx* c, double t0, double tEnd);
+int rgpu_clock_tick(rgpu_ctx* c);
+int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_last, double* dt_log, int* stop);
+/* 1 when the host already KNOWS that the record of the last tick says "stop" -- never on the device backend (the record is formed
+ * asynchronously; the batch's no-op steps are simply queued), always up to date on a synchronous backend (the test-only host emulation),
+ * where a driver can end its batch at once.  The answer is the same on every slab of a run. */
+int rgpu_clock_stopped(rgpu_ctx* c);
 
 /* Self-test of the device arithmetic the parity contract rests on: for n operand pairs computes on the device
  *   quot[i]  = rg_div(num[i], rg_recip(den[i]))   the shared-reciprocal division of csrc/hip/rg_backend.h
@@ -446,6 +472,8 @@ typedef struct rgpuh_step_hooks {
   int (*agree)(void* self, int local_failed);
   /* optional: the 14 numbers after "totalTime dt" of the MPI classes' turbulence history row (rgpu_comm_history_turbulence) */
   int (*history_turbulence)(void* self, int parity, double* out14);
+  /* optional: the loop body for a run of quiet steps (rgpu_comm_run_steps; contract of rgpu_run_steps: steps done or a negative code) */
+  int (*run_steps)(void* self, int nsteps, double tEnd, int* nStep, double* totalTime, double* dt);
 } rgpuh_step_hooks;
 typedef int (*rgpuh_attach_fn)(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* hooks);
 typedef void (*rgpuh_detach_fn)(void* user);

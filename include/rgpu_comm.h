@@ -78,6 +78,19 @@ int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalT
 /* == oneStepIntegration(nStep, t, dt) of the Mpi run classes */
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt);
 
+/* The body of the reference's time loop for up to nsteps steps (rgpu.h: rgpu_run_steps_log, same contract: returns the steps done or a
+ * negative code; *nStep, *t, *dt and dt_log advance as nsteps calls of rgpu_comm_one_step_integration would advance them -- same states,
+ * same dt sequence on every rank).  What it adds: the time step stays on the device between steps (rgpu.h: rgpu_clock_*) -- per step the
+ * 1/dt slots are all-reduced in place, one small kernel forms dt / t / the shearing-box offsets / "t < tEnd" into a record, the step
+ * pieces and the halo exchange read it there -- and the host reads the records of a whole batch once (rounds 1-4: one read-back and
+ * synchronisation per step, 0.13 ms of a 5.6 ms step at 8 slabs).  Steps that cannot (the first of a run, the serial schedule, gravity,
+ * dissipative stage, forcing) are plain rgpu_comm_one_step_integration calls inside the same loop.  Collective over all ranks. */
+int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, double* t, double* dt, double* dt_log);
+
+/* how many steps of this communicator took their time step from the device record (rgpu_comm_run_steps) -- the others went through
+ * the host loop; a launcher reports it next to its timing (bench.py: config.time_loop) */
+long long rgpu_comm_clocked_steps(rgpu_comm* cm);
+
 /* MHDRunBase::history_mri / history_default over the whole box (MHDRunBase.cpp:3476-3619; the MPI classes reduce on rank 0):
  * out[8] as rgpu_history_mri -- mass, maxwell, reynolds, magnetic pressure, mean Bx, By, Bz, sum of divB.  Per-slab column
  * sums on the device (rgpu_history_columns), SUM all-reduce of the isize-long columns (the y-z means need the global sums

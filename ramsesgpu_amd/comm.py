@@ -62,6 +62,10 @@ def load_comm_library(path=None):
     lib.rgpu_comm_history_turbulence.argtypes = [cm, C.c_int, C.POINTER(C.c_double)]
     lib.rgpu_comm_one_step_integration.restype = C.c_int
     lib.rgpu_comm_one_step_integration.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rgpu_comm_clocked_steps.restype = C.c_longlong
+    lib.rgpu_comm_clocked_steps.argtypes = [cm]
+    lib.rgpu_comm_run_steps.restype = C.c_int
+    lib.rgpu_comm_run_steps.argtypes = [cm, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rgpuh_run_slabs.restype = C.c_int
     lib.rgpuh_run_slabs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
     return lib
@@ -70,7 +74,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_run_steps", "rgpu_comm_clocked_steps", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -166,6 +170,25 @@ class CommRun:
         self._chk(self.CL.rgpu_comm_one_step_integration(self.cm, C.byref(n), C.byref(t), C.byref(dt)), "oneStepIntegration")
         self.nStep, self.totalTime, self.dt = n.value, t.value, dt.value
         return self.dt
+
+    def run_steps(self, nsteps, tEnd=float("inf")):
+        """up to nsteps turns of the reference's time loop (rgpu_comm_run_steps: the time step stays on the device between steps, the
+        host reads the records of a batch once); returns the steps done, self.dt_log = their time steps"""
+        n, t, d = C.c_int(self.nStep), C.c_double(self.totalTime), C.c_double(self.dt)
+        log = (C.c_double * max(int(nsteps), 1))()
+        done = self.CL.rgpu_comm_run_steps(self.cm, int(nsteps), float(tEnd), C.byref(n), C.byref(t), C.byref(d), log)
+        if done < 0:
+            self._chk(done, "run_steps")
+        self.nStep, self.totalTime, self.dt = n.value, t.value, d.value
+        self.dt_log = [log[i] for i in range(done)]
+        return done
+
+    def enable_timers(self, on=True):
+        self.solver.enable_timers(on)
+
+    def clocked_steps(self):
+        """steps whose time step came from the device record"""
+        return int(self.CL.rgpu_comm_clocked_steps(self.cm))
 
     def local_interior(self):
         """interior cells of this slab (host copy)"""

@@ -37,6 +37,7 @@ struct rgpu_comm {
   bool fuse_scan;   // every rank's configuration lets the update pieces carry the CFL scan (agreed at create)
   int poisoned;
   int exchanges_posted, exchanges_expected;   // halo exchanges of the current step: posted so far / what the neighbours will post
+  long long clocked_steps;                    // steps whose time step came from the device record (rgpu_comm_run_steps)
   std::string err;
 };
 
@@ -269,7 +270,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
   cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = -1; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
-  cm->fuse_scan = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0;
+  cm->fuse_scan = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0; cm->clocked_steps = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
   if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");
@@ -320,6 +321,7 @@ long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
   for (size_t i = 0; i < cm->ops[0].size(); ++i) if (cm->ops[0][i].send) b += (long long)(cm->ops[0][i].count * sizeof(double));
   return b;
 }
+long long rgpu_comm_clocked_steps(rgpu_comm* cm) { return cm ? cm->clocked_steps : 0; }
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = (overlap < -1 || overlap > 2) ? 1 : overlap; return RGPU_OK; }
 
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt) {
@@ -336,6 +338,94 @@ int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double*
   *nStep += 1;
   *t += d;
   return RGPU_OK;
+}
+
+// The reference's loop body for a run of steps, the time step on the device (rgpu.h: rgpu_clock_*): per step
+//   ncclAllReduce(max) of the RGPU_DT_SLOTS 1/dt slots in place  ->  clock kernel (fold, dt, t += dt, the "t < tEnd" test, record)
+//   ->  the step pieces of the schedule (they read the record on the device)  ->  halo exchange on the side stream
+// all queued on the streams without a host turn; the host reads the records of the batch once.  A step qualifies when the CFL maxima
+// of its input sit in the slots (the update pieces of the previous step carried the scan: schedules 1 and 2, all ranks fusable) and the
+// context's configuration lets its kernels read the record (rgpu_clock_capable); every other step -- the first of a run, the
+// serial schedule -- is the plain rgpu_comm_one_step_integration.  Every rank takes the same decisions (configuration and step
+// count only), so the collectives pair up.
+int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, double* t, double* dt, double* dt_log) {
+  RG_CHECK_CM(cm);
+  if (!nStep || !t || !dt) return fail(cm, RGPU_EINVAL, "run_steps: null pointer");
+  rgpu_ctx* c = cm->ctx;
+  static const bool host_clock = std::getenv("RGPU_NO_STEP_CLOCK") != 0;
+  int done = 0;
+  while (done < nsteps && *t < tEnd) {
+    const int useU = *nStep % 2;
+    const bool batch = !host_clock && !cm->poisoned && cm->scanned == useU && cm->scan_slots > 0 && cm->fuse_scan && cm->overlap != 0 &&
+                       !dissipative(cm) && !cm->p.randomForcingEnabled && !cm->p.ouForcingEnabled && rgpu_clock_capable(c);
+    if (!batch) {
+      if (int rc = rgpu_comm_one_step_integration(cm, nStep, t, dt)) return rc;
+      if (dt_log) dt_log[done] = *dt;
+      ++done;
+      continue;
+    }
+    const int m = (nsteps - done < RGPU_CLOCK_BATCH) ? nsteps - done : RGPU_CLOCK_BATCH;
+    RG_TRY(rgpu_clock_open(c, *t, tEnd), "clock_open");
+    const int n0 = *nStep;
+    int queued = 0, rc = 0, first_fail = -1;
+    for (; queued < m; ++queued) {
+      const int n = n0 + queued;
+      if (rc != 0) {
+        // a piece failed on THIS rank at an earlier step of the batch: the other ranks keep queueing theirs, so keep pairing up with
+        // them -- +inf into the 1/dt all-reduce (their records say stop = 3 from here on) and the one halo exchange each of their
+        // no-op steps still posts
+        const std::string msg = cm->err;
+        (void)rgpu_transport::poison_slot(cm->tc, rgpu_inv_dt_device_slot(c), rgpu_stream_handle(c));
+        const bool dead = rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c)) != 0;
+        if (!dead) (void)exchange(cm, (n + 1) % 2);
+        cm->err = msg;
+        if (dead) break;
+        continue;
+      }
+      if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c))) { rc = tr_fail(cm, "allreduce(1/dt)"); first_fail = queued; break; }
+      if ((rc = rgpu_clock_tick(c)) != 0) {
+        ctx_fail(cm, rc, "clock_tick");
+        const std::string msg = cm->err;
+        if (cm->nranks > 1) (void)exchange(cm, (n + 1) % 2);      // what the neighbours' step n posts
+        cm->err = msg;
+      } else if (rgpu_clock_stopped(c)) {   // (synchronous backends: the record already says the loop has ended -- on every rank alike)
+        ++queued;
+        break;
+      } else {
+        cm->scanned = -1; cm->scan_slots = 0;
+        rc = godunov_unsplit(cm, n, 0.0, 0.0);      // the pieces read dt and t from the record; on failure it has posted the step's exchanges
+        if (rc == 0 && !(cm->scanned == (n + 1) % 2 && cm->scan_slots > 0)) rc = fail(cm, RGPU_EHIP, "run_steps: the update pieces did not carry the CFL scan");
+      }
+      if (rc) {
+        first_fail = queued;
+        cm->poisoned = rc;
+        if (cm->nranks <= 1) break;
+      }
+    }
+    int ran = 0, stop = 0;
+    const std::string msg = cm->err;
+    const int rc2 = rgpu_clock_close(c, n0, &ran, t, dt, dt_log ? dt_log + done : 0, &stop);
+    if (rc2) return ctx_fail(cm, rc2, "clock_close");
+    if (rc) {   // this rank's own failure: the steps before it ran; the run is over on every rank (poisoned)
+      cm->err = msg;
+      *nStep += first_fail < ran ? first_fail : ran;
+      cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
+      return rc;
+    }
+    *nStep += ran;
+    done += ran;
+    cm->clocked_steps += ran;
+    if (ran < queued) {
+      // steps behind a stop were no-ops: the state of step n0 + ran is the last one written, with the ghosts and the (all-reduced) CFL
+      // maxima its step left -- rgpu_clock_close has told the context; the exchanges the no-op steps posted carried unchanged planes
+      const int par = (n0 + ran) % 2;
+      cm->primed = par; cm->scanned = par; cm->scan_slots = RGPU_DT_SLOTS;
+      if (stop == 3) { cm->poisoned = RGPU_EHIP; return fail(cm, RGPU_EHIP, "1/dt is not finite after the all-reduce: another rank reported a failure (see its message), or the solution blew up"); }
+      if (stop == 2) return fail(cm, RGPU_EHIP, "run_steps: the time step is not a number");
+      break;
+    }
+  }
+  return done;
 }
 
 int rgpu_comm_history_mri(rgpu_comm* cm, int parity, double* out) {
@@ -396,6 +486,7 @@ struct SlabAttach {
 int hook_make_all_boundaries(void* self, int parity, double t, double dt) { return rgpu_comm_make_all_boundaries(static_cast<SlabAttach*>(self)->cm, parity, t, dt); }
 int hook_compute_dt(void* self, int useU, double* dt) { return rgpu_comm_compute_dt(static_cast<SlabAttach*>(self)->cm, useU, dt); }
 int hook_one_step(void* self, int* nStep, double* t, double* dt) { return rgpu_comm_one_step_integration(static_cast<SlabAttach*>(self)->cm, nStep, t, dt); }
+int hook_run_steps(void* self, int nsteps, double tEnd, int* nStep, double* t, double* dt) { return rgpu_comm_run_steps(static_cast<SlabAttach*>(self)->cm, nsteps, tEnd, nStep, t, dt, 0); }
 int hook_history_mri(void* self, int parity, double* out) { return rgpu_comm_history_mri(static_cast<SlabAttach*>(self)->cm, parity, out); }
 int hook_history_turbulence(void* self, int parity, double* out) { return rgpu_comm_history_turbulence(static_cast<SlabAttach*>(self)->cm, parity, out); }
 int hook_barrier(void* self) {
@@ -435,6 +526,7 @@ int slab_attach(void* user, rgpu_ctx* ctx, rgpuh_step_hooks* h) {
   h->make_all_boundaries = hook_make_all_boundaries;
   h->compute_dt = hook_compute_dt;
   h->one_step_integration = hook_one_step;
+  h->run_steps = hook_run_steps;
   h->barrier = hook_barrier;
   h->agree = hook_agree;
   h->history_mri = hook_history_mri;

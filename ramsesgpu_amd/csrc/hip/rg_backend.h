@@ -14,6 +14,9 @@
 // promise to the optimiser about a launch-uniform parameter (kernels specialised at launch, see launchers.h)
 #define RG_ASSUME(cond) __builtin_assume(cond)
 #define RG_BACKEND_NAME "hip-gfx950"
+// kernel launches return before the kernel has run: what a kernel leaves in device memory is not visible to the host code that queues
+// the next launch (the test-only host emulation sets 1: its "launches" are host loops)
+#define RG_SYNC_LAUNCH 0
 // store of a value that is not read again before it has left the caches (T, F, emf, the new state): nontemporal,
 // so that it does not evict the stencil neighbourhood the same XCD re-reads from its L2
 #ifdef RG_NO_STREAM_STORE

@@ -1,4 +1,4 @@
-// step_clock.h (HIP / gfx950 only) -- the time step on the device: lets a run of 2D steps be queued without a host round trip.
+// step_clock.h (HIP / gfx950 only) -- the time step on the device: lets a run of steps be queued without a host round trip.
 //
 // A 2D step of the fused kernels (hip/tiled_mhd2d.h, hip/tiled_hydro2d.h) is ONE launch of 20-50 us that leaves the CFL maxima of
 // the state it wrote in RG_DT_SLOTS device slots and, in a box of periodic / reflecting / outflow faces, that state's ghost cells.
@@ -7,22 +7,25 @@
 // step_clock_kernel does it on the device: one workgroup folds the slots (and re-zeroes them), forms dt, dt/dx, dt/dy with the
 // host's expressions (IEEE division: the same doubles), advances t, evaluates the loop condition, and leaves a StepClock record
 // that the step kernel reads instead of its by-value dt arguments.  The host reads the records of a whole batch afterwards.
+// Round 5: the record also carries what the 3D steps take from the host (dt/dz, rotating-frame coefficients, shearing-box offsets),
+// so that the 3D hydro and MHD sweeps, the update and the shearing ghost fill read it too (csrc/step_clock_rec.h), and the z-slab
+// driver queues batches of steps: all-reduce of the slots in place -> this kernel -> the step pieces, no host turn in between.
 #pragma once
 #include "tiled_hydro.h"
+#include "../step_clock_rec.h"
 
 namespace rgpu_tiled {
 
-// one record per step of a batch.  stop: 0 = the step runs; 1 = t >= tEnd before this step (it and all later steps of the batch are
-// no-ops); 2 = dt is not a number (same).
-struct StepClock { double dt, dtdx, dtdy, t_next; int stop, pad; };
-
-__global__ void __launch_bounds__(1024) step_clock_kernel(unsigned long long* __restrict__ slots, double cfl, double seed, double dx, double dy,
-                                                        double t0, double tEnd, const StepClock* prev, StepClock* out) {
+// One workgroup: folds the RG_DT_SLOTS CFL maxima (and re-zeroes them: the step kernels that follow accumulate the maxima of the
+// state they write), then thread 0 forms the record of the step (step_clock_rec.h: the host's expressions in the host's order).
+// prev: the previous record of the batch (0: the batch starts at t0).
+__global__ void __launch_bounds__(1024) step_clock_kernel(unsigned long long* __restrict__ slots, ClockConst k, double t0, double tEnd,
+                                                        const StepClock* prev, StepClock* out) {
   __shared__ double red[16];
+  __shared__ int runs;
   const int t = (int)threadIdx.x;
   static_assert(rgpu::RG_DT_SLOTS == 1024, "one slot per thread");
   double v = __longlong_as_double((long long)slots[t]);
-  slots[t] = 0ull;   // the step kernel that follows accumulates the maxima of the state it writes
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   if ((t & 63) == 0) red[t >> 6] = v;
@@ -31,25 +34,20 @@ __global__ void __launch_bounds__(1024) step_clock_kernel(unsigned long long* __
     double m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmax(m, red[w]);
-    const double tcur = prev ? prev->t_next : t0;
-    int stop = prev ? prev->stop : 0;
-    if (!stop && !(tcur < tEnd)) stop = 1;
-    // rgpu_compute_inv_dt + rgpu_compute_dt on the host: v = max(slots), MHD: v = max(v, smallc / min(dx, dy)); dt = cfl / v
-    const double inv = fmax(m, seed);
-    const double dt = cfl / inv;
-    if (!stop && !(dt == dt)) stop = 2;
-    out->stop = stop; out->pad = 0;
-    out->dt = stop ? 0.0 : dt;
-    out->dtdx = stop ? 0.0 : dt / dx;
-    out->dtdy = stop ? 0.0 : dt / dy;
-    out->t_next = stop ? tcur : tcur + dt;
+    StepClock r;
+    step_clock_form(k, m, prev ? prev->t_next : t0, tEnd, prev ? prev->stop : 0, &r);
+    *out = r;
+    runs = r.stop == 0;
   }
+  __syncthreads();
+  // a step that runs accumulates the maxima of the state it writes into zeroed slots; a stopped one (and every step behind it) is a
+  // no-op and leaves the slots as they are: after the batch they still hold the maxima of the last state written
+  if (runs) slots[t] = 0ull;
 }
 
 inline bool step_clock_supported() { return tiled_enabled() && !std::getenv("RGPU_NO_STEP_CLOCK"); }
-inline int launch_step_clock(rg_stream_t s, unsigned long long* slots, double cfl, double seed, double dx, double dy, double t0, double tEnd,
-                             const StepClock* prev, StepClock* out) {
-  hipLaunchKernelGGL(step_clock_kernel, dim3(1), dim3(1024), 0, s, slots, cfl, seed, dx, dy, t0, tEnd, prev, out);
+inline int launch_step_clock(rg_stream_t s, unsigned long long* slots, const ClockConst& k, double t0, double tEnd, const StepClock* prev, StepClock* out) {
+  hipLaunchKernelGGL(step_clock_kernel, dim3(1), dim3(1024), 0, s, slots, k, t0, tEnd, prev, out);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

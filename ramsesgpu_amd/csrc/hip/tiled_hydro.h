@@ -46,8 +46,9 @@ inline bool tiled_enabled() {
 
 // copy of whole z planes (ghost planes inside a requested plane range: the flat update kernel copies them too)
 struct K_copy_cells {
-  const double* src; double* dst; unsigned long long ncell; int nvar;
+  const double* src; double* dst; unsigned long long ncell; int nvar; const StepClock* clk;
   RG_DEVFN void operator()(unsigned idx) const {
+    if (clk && clk->stop) return;   // (a stopped step of a device-clock batch writes nothing)
     for (int v = 0; v < nvar; ++v) dst[idx + (size_t)v * ncell] = src[idx + (size_t)v * ncell];
   }
 };
@@ -126,8 +127,12 @@ inline void tile_grid_plan(TileGrid& tg, int span, int slots, int min_planes, in
 template <int TX, int TY, int SPEC, int MINW = 1>
 __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ Uin,
                                                               double* __restrict__ Uout, double dtdx, double dtdy,
-                                                              double dtdz, int za, int zb, unsigned long long* dslot) {
+                                                              double dtdz, int za, int zb, unsigned long long* dslot, const StepClock* clk) {
   spec_assume<SPEC>(g);
+  if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h)
+    if (clk->stop) return;
+    dtdx = clk->dtdx; dtdy = clk->dtdy; dtdz = clk->dtdz;
+  }
   constexpr int NV = 5;
   constexpr int NT = TX * TY;
   constexpr int RING = 2 * TX + 2 * TY;
@@ -394,7 +399,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 
 template <int TX, int TY, int SPEC, int MINW = 1>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                                double dtdz, int za, int zb, unsigned long long* dslot = 0) {
+                                double dtdz, int za, int zb, unsigned long long* dslot = 0, const StepClock* clk = 0) {
   TileGrid tg;
   tg.flags = 0;
   tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
@@ -404,7 +409,7 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   // two workgroups are resident per CU (~200 VGPRs): 64 per XCD; a segment costs two extra iterations (pipeline fill)
   tile_grid_plan(tg, span, 64, 12, 2, zseg_env);
   hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC, MINW>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
-                     dtdx, dtdy, dtdz, za, zb, dslot);
+                     dtdx, dtdy, dtdz, za, zb, dslot, clk);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -415,11 +420,11 @@ inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() &&
 // flat kernels), < 0 = launch error.
 // dslot: device slot for the CFL maximum of the new state (reset by the caller), or 0
 inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                         double dtdz, int a, int b, unsigned long long* dslot = 0) {
+                         double dtdz, int a, int b, unsigned long long* dslot = 0, const StepClock* clk = 0) {
   if (!hydro3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
   // ghost planes inside [a,b): plain copy, like the flat update kernel
-  const K_copy_cells kc = {in, out, g.ncell, 5};
+  const K_copy_cells kc = {in, out, g.ncell, 5, clk};
   if (a < g.gw && rgpu::rg_launch_range<256>(s, (unsigned)a * g.sk, (unsigned)((b < g.gw ? b : g.gw) - a) * g.sk, kc)) return -1;
   if (b > g.ksize - g.gw) {
     const int lo = a > g.ksize - g.gw ? a : g.ksize - g.gw;
@@ -433,7 +438,7 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
   if (!no_spec) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
-#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot)
+#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot, clk)
     RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
     RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
     RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
@@ -442,7 +447,7 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
     RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE1);
 #undef RG_TRY
   }
-  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot);
+  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot, clk);
 }
 
 }  // namespace rgpu_tiled

@@ -137,8 +137,13 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
 template <int SPEC>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
-                                                               double dt, double dtdx, double dtdy, double dtdz, int ra, int rb) {
+                                                               double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
+                                                               const StepClock* clk) {
   spec_assume<SPEC>(g);
+  if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
+    if (clk->stop) return;
+    dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy; dtdz = clk->dtdz;
+  }
   __shared__ __attribute__((aligned(16))) double LT[2 * MH_BUF];          // T of planes kk (read) and kk+1 (written)   (buffer = plane & 1)
   __shared__ double LQ[3 * MH_QBSLOT];       // Q / B of planes kk .. kk+2                  (slot = plane % 3)
   __shared__ double LE[2 * MH_ESLOT];        // E of planes kk+1, kk+2                      (slot = plane & 1)
@@ -459,7 +464,7 @@ struct K_copy_periodic_layer {
 // knows the boundary conditions)
 template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
-                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse) {
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk) {
   TileGrid tg;
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
@@ -474,7 +479,7 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
   tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
   hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
-                     dt, dtdx, dtdy, dtdz, ra, rb);
+                     dt, dtdx, dtdy, dtdz, ra, rb, clk);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
   if (copy_x) { const K_copy_periodic_layer k = {g, F, emf, 0, ra}; if (rgpu::rg_launch<256>(s, (unsigned)g.jsize * (unsigned)(rb - ra), k)) return -1; }
@@ -498,12 +503,12 @@ inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g
 // trace and Riemann as flat kernels), < 0 = launch error.
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
-                       double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0) {
+                       double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
 }
 
 }  // namespace rgpu_tiled

@@ -713,14 +713,19 @@ int GodunovRun::start(double* mcell_per_s, rgpuh_attach_fn attach, void* user) {
     // the turns of this loop up to the next one that logs, writes or records history do nothing but step: rgpu_run_steps runs them
     // (same states, same dt sequence; where a step is one fused kernel the time step stays on the device in between)
     int quiet = 1;
-    if (!hooked_ && !historyEnabled) {
+    if ((!hooked_ || hooks_.run_steps) && !historyEnabled) {
       quiet = rs_.nStepmax - nStep;
       if (rs_.nLog > 0 && rs_.nLog - nStep % rs_.nLog < quiet) quiet = rs_.nLog - nStep % rs_.nLog;
       if (rs_.nOutput > 0 && rs_.nOutput - nStep % rs_.nOutput < quiet) quiet = rs_.nOutput - nStep % rs_.nOutput;
     }
     if (quiet > 1) {
-      const int rc = rgpu_run_steps(ctx_, quiet, rs_.tEnd, &nStep, &totalTime_, &dt);
-      if (rc < 0) check(rc, "run_steps");
+      if (hooked_) {
+        const int rc = hooks_.run_steps(hooks_.self, quiet, rs_.tEnd, &nStep, &totalTime_, &dt);
+        if (rc < 0) hook_check(rc, "run_steps");
+      } else {
+        const int rc = rgpu_run_steps(ctx_, quiet, rs_.tEnd, &nStep, &totalTime_, &dt);
+        if (rc < 0) check(rc, "run_steps");
+      }
     } else {
       oneStepIntegration(nStep, totalTime_, dt);
     }

@@ -6,6 +6,7 @@
 #include "kernels_hydro.h"
 #include "kernels_mhd2d.h"
 #include "kernels_mhd3d.h"
+#include "step_clock_rec.h"   // StepClock: the time step as a device record (kernels with a `clk` member read it instead of their by-value arguments)
 
 namespace rgpu_dev {
 
@@ -183,17 +184,27 @@ struct K_ou_forcing {
   DevParams g; double* U; rgpu_ou::OuModes M; double dt, yMin, zMin; int kz0;
   RG_DEVFN void operator()(unsigned idx) const { ou_forcing_cell(g, U, M, dt, yMin, zMin, kz0, idx); }
 };
+// (the ghost-fill functors end in `const StepClock* clk`: inside a batch of device-clock steps a stopped step must leave the state as it
+//  is -- they take nothing else from the record.  Omitted in an aggregate initialiser it is 0.)
 struct K_bc_zstrat {
-  DevParams g; ZStrat zs; double* U; int side;
-  RG_DEVFN void operator()(unsigned ij) const { zstrat_column(g, zs, U, side, ij); }
+  DevParams g; ZStrat zs; double* U; int side; const StepClock* clk;
+  RG_DEVFN void operator()(unsigned ij) const { if (clk && clk->stop) return; zstrat_column(g, zs, U, side, ij); }
 };
 struct K_shear_save_emf {
   DevParams g; const double* emf; double* save;
   RG_DEVFN void operator()(unsigned idx) const { shear_save_emf_cell(g, emf, save, idx); }
 };
 struct K_shear_remap {
-  DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx;
-  RG_DEVFN void operator()(unsigned idx) const { shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx); }
+  DevParams g; ShearRemap sr; const double* F; double* emf; const double* save; double* remap; double dtdx; const StepClock* clk;
+  RG_DEVFN void operator()(unsigned idx) const {
+    if (clk) {   // device-side time step: offsets at t + dt/2 and dt/dx from the record
+      if (clk->stop) return;
+      const ShearRemap r = {clk->remap_jplus, clk->remap_eps_min, clk->remap_eps_max};
+      shear_remap_cell(g, r, F, emf, save, remap, clk->dtdx, idx);
+      return;
+    }
+    shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx);
+  }
 };
 // t = z segment * (isize * jsize) + column: one thread marches planes [k_lo + seg * seg_len, + seg_len) of [k_lo, k_hi)
 template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
@@ -202,23 +213,32 @@ struct K_mhd_update3d {
   double dt, dtdx, dtdy, dtdz; unsigned long long* dt_slots; int k_lo, k_hi, seg_len;
   // a second plane range in the same launch (the two boundary ranges of a slab): threads [n1, ...) march [k_lo2, k_hi2); n1 = 0xffffffff: none
   unsigned n1; int k_lo2, k_hi2;
+  const StepClock* clk;   // device-side time step (0: the by-value dt, rc above)
   RG_DEVFN void operator()(unsigned t) const {
     spec_assume<SPEC>(g);
     const bool second = t >= n1;
-    mhd_update3d_column<ROT, GF>(g, rc, Uold, Unew, F, emf, remap, dt, dtdx, dtdy, dtdz, second ? t - n1 : t, second ? k_lo2 : k_lo, second ? k_hi2 : k_hi, seg_len, dt_slots);
+    const unsigned tt = second ? t - n1 : t;
+    const int lo = second ? k_lo2 : k_lo, hi = second ? k_hi2 : k_hi;
+    // (one call site: launch-uniform selects of the scalars, not two copies of the column march)
+    const bool dev = clk != 0;
+    if (dev && clk->stop) return;
+    const RotCoef r = {dev ? clk->lambda : rc.lambda, dev ? clk->ratio : rc.ratio, dev ? clk->alpha1 : rc.alpha1, dev ? clk->alpha2 : rc.alpha2};
+    mhd_update3d_column<ROT, GF>(g, r, Uold, Unew, F, emf, remap, dev ? clk->dt : dt, dev ? clk->dtdx : dtdx, dev ? clk->dtdy : dtdy, dev ? clk->dtdz : dtdz,
+                                 tt, lo, hi, seg_len, dt_slots);
   }
 };
 
 // ---- boundaries -------------------------------------------------------------------------------------------------
 struct K_bc_face {
-  DevParams g; double* U; int dir, side, bct;
-  RG_DEVFN void operator()(unsigned idx) const { bc_face_cell(g, U, dir, side, bct, idx); }
+  DevParams g; double* U; int dir, side, bct; const StepClock* clk;
+  RG_DEVFN void operator()(unsigned idx) const { if (clk && clk->stop) return; bc_face_cell(g, U, dir, side, bct, idx); }
 };
 // both faces of one direction in one launch (they read interior cells only, so they do not depend on each other): the first
 // n indices are the low face, the next n the high face
 struct K_bc_faces {
-  DevParams g; double* U; int dir, bct_lo, bct_hi; unsigned n;
+  DevParams g; double* U; int dir, bct_lo, bct_hi; unsigned n; const StepClock* clk;
   RG_DEVFN void operator()(unsigned idx) const {
+    if (clk && clk->stop) return;
     if (idx < n) bc_face_cell(g, U, dir, 0, bct_lo, idx);
     else bc_face_cell(g, U, dir, 1, bct_hi, idx - n);
   }
@@ -226,20 +246,29 @@ struct K_bc_faces {
 struct K_bc_faces_range {   // ... restricted to the face indices [first, first + n) of each face (a range of z planes)
   K_bc_faces f; unsigned first;
   RG_DEVFN void operator()(unsigned idx) const {
+    if (f.clk && f.clk->stop) return;
     if (idx < f.n) bc_face_cell(f.g, f.U, f.dir, 0, f.bct_lo, first + idx);
     else bc_face_cell(f.g, f.U, f.dir, 1, f.bct_hi, first + (idx - f.n));
   }
 };
 struct K_jet {
-  DevParams g; JetParams jp; double* U;
-  RG_DEVFN void operator()(unsigned idx) const { jet_cell(g, jp, U, idx); }
+  DevParams g; JetParams jp; double* U; const StepClock* clk;
+  RG_DEVFN void operator()(unsigned idx) const { if (clk && clk->stop) return; jet_cell(g, jp, U, idx); }
 };
 // the in-plane ghost fill in one pass (fill_xy_cell) over the planes [lo1, lo1 + n1) and [lo2, ...): idx = plane * per_plane + ghost cell
 struct K_fill_xy {
   DevParams g; FillXY f; double* U; unsigned per_plane; int lo1, n1, lo2;
+  const StepClock* clk;   // device-side time step: the shearing-box offsets at t + dt come from the record (a stopped step fills nothing)
   RG_DEVFN void operator()(unsigned idx) const {
     const unsigned p = idx / per_plane, t = idx - p * per_plane;
     const int k = (int)p < n1 ? lo1 + (int)p : lo2 + ((int)p - n1);
+    if (clk) {
+      if (clk->stop) return;
+      FillXY fc = f;
+      fc.sg.jplus = clk->ghost_jplus; fc.sg.eps_min = clk->ghost_eps_min; fc.sg.eps_max = clk->ghost_eps_max;
+      fill_xy_cell(g, fc, U, t, k);
+      return;
+    }
     fill_xy_cell(g, f, U, t, k);
   }
 };

@@ -61,8 +61,10 @@ struct rgpu_ctx {
   int scan_acc_parity;  // parity of the state whose CFL maximum is being accumulated piece by piece (RGPU_CORE_SCAN), -1: none
   // device-side time step (hip/step_clock.h; rgpu_run_steps): records of a batch on the device / pinned host memory, and the record the
   // step being queued reads (0: the step takes its by-value dt arguments)
-  enum { kClockBatch = 256 };
-  rgpu_tiled::StepClock* d_clk; rgpu_tiled::StepClock* h_clk; const rgpu_tiled::StepClock* clk_cur;
+  enum { kClockBatch = RGPU_CLOCK_BATCH };
+  StepClock* d_clk; StepClock* h_clk; const StepClock* clk_cur;
+  int clk_n;                    // records queued in the open batch (rgpu_clock_open .. rgpu_clock_close), -1: no batch open
+  double clk_t0, clk_tEnd;
   std::string err;
 };
 
@@ -72,6 +74,25 @@ int fail(rgpu_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
   return code;
 }
+
+// ---- the time step of the step being queued ------------------------------------------------------------------------
+// By value from the caller -- or, inside a batch of device-clock steps (rgpu_clock_open .. close; csrc/step_clock_rec.h), the record
+// c->clk_cur: the kernels that depend on dt read it on the device (st.clk), the host's copies are unused.  The test-only host
+// emulation runs every "launch" at once, so there the record is already filled in and is resolved here, by value, for all kernels.
+struct StepTime { double dt, t; const StepClock* clk; bool skip; };
+inline StepTime step_time(const rgpu_ctx* c, double dt, double t) {
+  StepTime st = {dt, t, 0, false};
+  if (!c->clk_cur) return st;
+#if RG_SYNC_LAUNCH
+  st.dt = c->clk_cur->dt; st.t = c->clk_cur->t_cur; st.skip = c->clk_cur->stop != 0;
+#else
+  st.dt = 0.0; st.t = 0.0; st.clk = c->clk_cur;
+#endif
+  return st;
+}
+// the record for kernels that take nothing from it but "this step does not run"
+inline const StepClock* stop_clk(const rgpu_ctx* c) { return RG_SYNC_LAUNCH ? 0 : c->clk_cur; }
+inline bool stop_now(const rgpu_ctx* c) { return RG_SYNC_LAUNCH && c->clk_cur && c->clk_cur->stop != 0; }
 
 // ---- phase timer: events around one phase; resolved immediately (timers serialise the stream by design) ----
 struct Phase {
@@ -207,7 +228,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->G = 0;
   c->Frc = 0;
   c->ou = 0;
-  c->d_red = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0;
+  c->d_red = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0; c->clk_n = -1; c->clk_t0 = 0.0; c->clk_tEnd = 0.0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
   for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
@@ -311,12 +332,12 @@ int launch_face(rgpu_ctx* c, double* U, int dir, int side, int k_lo, int k_hi) {
         zs.r3 = std::exp(factor * (2 * (p.zMax - 0.5 * p.dz) + 5.0 * p.dz));
       }
     }
-    K_bc_zstrat k = {c->g, zs, U, side};
+    K_bc_zstrat k = {c->g, zs, U, side, stop_clk(c)};
     return rg_launch<kBlock>(c->stream, (unsigned)c->g.isize * c->g.jsize, k);
   }
   if (bct != RGPU_BC_DIRICHLET && bct != RGPU_BC_NEUMANN && bct != RGPU_BC_PERIODIC) return 0;  // shear / copy: untouched
   const DevParams& g = c->g;
-  K_bc_face k = {g, U, dir, side, bct};
+  K_bc_face k = {g, U, dir, side, bct, stop_clk(c)};
   if (dir == 2) return rg_launch<kBlock>(c->stream, (unsigned)g.isize * g.jsize * g.gw, k);
   const unsigned per_plane = (dir == 0) ? (unsigned)g.gw * g.jsize : (unsigned)g.isize * g.gw;
   return rg_launch_range<kBlock>(c->stream, per_plane * (unsigned)k_lo, per_plane * (unsigned)(k_hi - k_lo), k);
@@ -330,13 +351,14 @@ int launch_jet(rgpu_ctx* c, double* U) {
   jp.ejet = p.pjet / (p.gamma0 - 1.) + 0.5 * p.djet * p.ujet * p.ujet;   // HydroRunBase.cpp:2383
   jp.mjet = p.djet * p.ujet;
   const unsigned n = c->g.three_d ? (unsigned)p.ijet * p.ijet * c->g.gw : (unsigned)p.ijet * c->g.gw;
-  K_jet k = {c->g, jp, U};
+  K_jet k = {c->g, jp, U, stop_clk(c)};
   return rg_launch<kBlock>(c->stream, n, k);
 }
 
 int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi = -1) {
   const int dir = idim - 1;
   if (dir < 0 || dir > 2) return -1;
+  if (stop_now(c)) return 0;
   if (!c->g.three_d && dir == 2) return 0;
   if (k_hi < 0) k_hi = c->g.ksize;
   {
@@ -345,7 +367,7 @@ int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi 
     auto plain = [](int b) { return b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC; };
     if (plain(b0) && plain(b1)) {
       const DevParams& g = c->g;
-      K_bc_faces k = {g, U, dir, b0, b1, 0u};
+      K_bc_faces k = {g, U, dir, b0, b1, 0u, stop_clk(c)};
       if (dir == 2) {
         k.n = (unsigned)g.isize * g.jsize * g.gw;
         if (rg_launch<kBlock>(c->stream, 2u * k.n, k)) return -1;
@@ -353,7 +375,7 @@ int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi 
         // x and y faces are indexed with k slowest: planes [k_lo,k_hi) of a face are one contiguous index range
         const unsigned per_plane = (dir == 0) ? (unsigned)g.gw * g.jsize : (unsigned)g.isize * g.gw;
         const unsigned first = per_plane * (unsigned)k_lo, cnt = per_plane * (unsigned)(k_hi - k_lo);
-        K_bc_faces kr = {g, U, dir, b0, b1, cnt};
+        K_bc_faces kr = {g, U, dir, b0, b1, cnt, stop_clk(c)};
         K_bc_faces_range kk = {kr, first};
         if (rg_launch<kBlock>(c->stream, 2u * cnt, kk)) return -1;
       }
@@ -367,6 +389,8 @@ int do_make_boundaries(rgpu_ctx* c, double* U, int idim, int k_lo = 0, int k_hi 
 
 int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt, int k_lo = 0, int k_hi = -1) {
   const rgpu_params& p = c->p;
+  if (c->clk_cur && !RG_SYNC_LAUNCH) return -1;   // (the separate shear pass takes its offsets by value: device-clock steps use the fused fill)
+  if (stop_now(c)) return 0;
   // MHDRunGodunov.cpp:3554-3557
   double deltay = 1.5 * p.Omega0 * (p.dx * p.nx) * (totalTime + dt);
   deltay = std::fmod(deltay, (p.dy * p.ny));
@@ -413,7 +437,8 @@ int launch_fill_xy(rgpu_ctx* c, double* U, const FillXY& f, int a1, int b1, int 
   const int n1 = b1 > a1 ? b1 - a1 : 0, n2 = b2 > a2 ? b2 - a2 : 0;
   if (n1 + n2 == 0) return 0;
   const unsigned per = 2u * (unsigned)c->g.gw * (unsigned)(c->g.isize + c->g.ny);   // ghost cells of one plane (fill_xy_cell)
-  K_fill_xy k = {c->g, f, U, per, a1, n1, a2};
+  if (stop_now(c)) return 0;
+  K_fill_xy k = {c->g, f, U, per, a1, n1, a2, (f.shear && !RG_SYNC_LAUNCH) ? c->clk_cur : stop_clk(c)};
   if (rg_launch<kBlock>(c->stream, per * (unsigned)(n1 + n2), k)) return -1;
   if (c->p.enableJet && !c->g.three_d) return launch_jet(c, U);   // 2D: re-imposed after the Y pass (HydroRunBase.cpp:2286-2312)
   return 0;
@@ -443,8 +468,11 @@ int step_pre(rgpu_ctx* c, int nStep) {
   return 0;
 }
 
-int step_post_a(rgpu_ctx* c, int nStep, double dt, double totalTime) {
+int step_post_a(rgpu_ctx* c, int nStep, double dt_arg, double t_arg) {
   if (!c->g.rot) return 0;
+  const StepTime st = step_time(c, dt_arg, t_arg);
+  if (st.skip) return 0;
+  const double dt = st.dt, totalTime = st.t;
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* out = c->U[(nStep + 1) % 2];
   FillXY f;
@@ -472,7 +500,10 @@ int step_post_b(rgpu_ctx* c, int nStep) {
 // to the planes it is about to send, so that the neighbour receives finished planes (x / y ghosts and corners
 // included) and never has to touch its z ghost planes again.  x and y fills (and the shear remap) act within one
 // z plane, hence plane-wise { Y, shear, Y } + copying planes equals the reference's { Y, shear, Z, Y } sequence.
-int step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a, int b, int a2 = 0, int b2 = 0) {
+int step_fill_planes(rgpu_ctx* c, int nStep, double dt_arg, double t_arg, int a, int b, int a2 = 0, int b2 = 0) {
+  const StepTime st = step_time(c, dt_arg, t_arg);
+  if (st.skip) return 0;
+  const double dt = st.dt, totalTime = st.t;
   Phase ph(c, RGPU_T_BOUNDARIES);
   double* out = c->U[(nStep + 1) % 2];
   FillXY f;
@@ -540,8 +571,11 @@ int hydro_flux_trace_spec(rgpu_ctx* c, double dtdx, double dtdy, double dtdz, in
 }
 
 template <int ND, int NV>
-int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int b, bool acc_piece = false) {
+int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a, int b, bool acc_piece = false) {
   const DevParams& g = c->g;
+  const StepTime st = step_time(c, dt_arg, 0.0);
+  if (st.skip) return 0;
+  const double dt = st.dt;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy, dtdz = dt / g.dz;
   const int ks = g.ksize;
   if (ND == 3) {   // LDS-tiled z-marching sweep: the whole step in one kernel (hip/tiled_hydro.h)
@@ -552,10 +586,11 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
     const bool scan = a <= 0 && b >= ks && cond && !acc_piece;
     const bool piece = acc_piece && cond && c->scan_acc_parity == ((out == c->U[0]) ? 0 : 1);
     if (acc_piece && !piece) c->scan_acc_parity = -1;
-    if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
-    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0);
+    if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (a clock kernel zeroed them)
+    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0, st.clk);
     if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }
     if (rc <= 0) return rc;
+    if (st.clk) return -1;   // the flat kernels take dt by value
     if (acc_piece) c->scan_acc_parity = -1;   // flat kernels took over: no accumulated scan for this step
   }
   // the CFL scan of the new state rides in the kernel that writes it when the whole domain is updated in this call and nothing
@@ -563,7 +598,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
   const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
   unsigned long long* slots = scan2 ? c->d_red : 0;
-  if (c->clk_cur && !(ND == 2 && scan2)) return -1;   // a device-clock step is the fused 2D kernel with the CFL term or nothing
+  if (st.clk && !(ND == 2 && scan2)) return -1;   // a device-clock step is a fused kernel with the CFL term or nothing
   if (scan2 && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
   if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
     Phase ph(c, RGPU_T_SWEEP);
@@ -578,11 +613,11 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt, int a, int
         images |= bc << (2 * f);
       }
     }
-    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, c->clk_cur);
+    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, st.clk);
     if (rc == 0 && scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     if (rc == 0 && images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
     if (rc <= 0) return rc;
-    if (c->clk_cur) return -1;   // the flat kernels take dt by value
+    if (st.clk) return -1;   // the flat kernels take dt by value
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
@@ -638,8 +673,11 @@ inline int pick_spec(const DevParams& g) {
   return off ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
 }
 
-int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
+int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
   const DevParams& g = c->g;
+  const StepTime st = step_time(c, dt_arg, 0.0);
+  if (st.skip) return 0;
+  const double dt = st.dt;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   const RotCoef rc = rot_coef(c, dt);
   {
@@ -655,7 +693,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
       static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
       if (no_fused_dt) scan = false;
       if (rgpu_tiled::mhd2d_step_covers(g)) {
-        if (c->clk_cur && !scan) return -1;
+        if (st.clk && !scan) return -1;
         if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
         Phase ph(c, RGPU_T_SWEEP);
         // periodic box on the plain path, nothing modifying the new state after this kernel: it writes the periodic images too and
@@ -663,7 +701,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
         static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
         bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, c->clk_cur);
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, st.clk);
         if (rct < 0) return -1;
         if (rct == 0) {
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
@@ -673,7 +711,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
       }
     }
   }
-  if (c->clk_cur) return -1;   // the flat kernels take dt by value
+  if (st.clk) return -1;   // the flat kernels take dt by value
   { Phase ph(c, RGPU_T_PRIM); K_mhd_prim<> k = {g, in, c->Q, dt}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   { Phase ph(c, RGPU_T_TRACE); K_mhd_trace2d k = {g, in, c->Q, c->T, dtdx, dtdy}; if (rg_launch<kBlock>(c->stream, c->n32, k)) return -1; }
   const bool gf = g.grav_on == 2;
@@ -692,7 +730,7 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt) {
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
   if (no_fused_dt) scan = false;
   unsigned long long* slots = scan ? c->d_red : 0;
-  if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   {
     Phase ph(c, RGPU_T_UPDATE);
     K_mhd_update2d<false> k = {g, rc, in, out, c->F, dt, dtdx, dtdy, slots};
@@ -720,7 +758,10 @@ template <int S> using K_riemann_t = K_mhd_flux3d<DO_ALL, false, S>;
 // RGPU_CORE_UPDATE = only the update, from F, emf computed by an earlier RGPU_CORE_FLUXES call covering [a,b)
 // (a2, b2): a second plane range handled in the same call -- split calls only (the two boundary ranges of a slab): one launch of the
 // update kernel for both
-int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double totalTime, int a, int b, int what_flags = 0, int a2 = 0, int b2 = 0) {
+int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double t_arg, int a, int b, int what_flags = 0, int a2 = 0, int b2 = 0) {
+  const StepTime st = step_time(c, dt_arg, t_arg);
+  if (st.skip) return 0;
+  const double dt = st.dt, totalTime = st.t;
   int what = what_flags;
   const DevParams& g = c->g;
   const rgpu_params& p = c->p;
@@ -763,10 +804,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
       if (p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC) reuse |= 2;
       if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     }
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse);
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
+  if (st.clk && !use_sweep) return -1;   // the flat prim / elec / trace / Riemann kernels take dt by value
   auto trace_riemann = [&](rg_stream_t s, int t_lo, int t_hi, PlaneRange rf) -> int {
     if (use_sweep) { Phase ph(c, RGPU_T_SWEEP); return sweep_planes(s, rf); }
     { Phase ph(c, RGPU_T_TRACE); if (trace_planes(s, clip(t_lo, t_hi, ks))) return -1; }
@@ -774,7 +816,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     return 0;
   };
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
-  K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx};
+  K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx, st.clk};
   auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
     if (!shear || r.hi <= r.lo) return 0;
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
@@ -796,11 +838,11 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   if (scan && g.rot && (p.bc[4] == RGPU_BC_COPY || p.bc[5] == RGPU_BC_COPY)) scan = false;   // whole-slab call of a slab: the driver scans
   if (acc && what == RGPU_CORE_FLUXES) {
     c->scan_acc_parity = cond ? out_parity : -1;
-    if (cond && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+    if (cond && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (a clock kernel zeroed them)
   }
   const bool scan_piece = acc && what == RGPU_CORE_UPDATE && cond && c->scan_acc_parity == out_parity;
   unsigned long long* slots = (scan || scan_piece) ? c->d_red : 0;
-  if (scan && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+  if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   // the update is a pure stream over F, emf and U: one thread per column and short z segment, linear workgroup order, the plane
   // k+1 entries carried in registers (mhd_update3d_column; 512^3: 8.07 -> 7.42 ms against one thread per cell)
   static const int upd_seg = std::getenv("RGPU_UPD_SEG") ? std::atoi(std::getenv("RGPU_UPD_SEG")) : 3;
@@ -812,7 +854,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
     const bool two = r2.hi > r2.lo;
     const unsigned nt = n1 + (two ? g.sk * (unsigned)((r2.hi - r2.lo + seg_len - 1) / seg_len) : 0u);
     const unsigned split = two ? n1 : 0xffffffffu;
-#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
+#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi, st.clk}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
     if (gf) { if (g.rot) RG_UPD(true, true, SPEC_NONE) else RG_UPD(false, true, SPEC_NONE) }
     if (g.rot) { if (spec == 1) RG_UPD(true, false, kSpecMri) if (spec == 2) RG_UPD(true, false, kSpecPlain) RG_UPD(true, false, SPEC_NONE) }
     if (spec == 1) RG_UPD(false, false, kSpecMri) if (spec == 2) RG_UPD(false, false, kSpecPlain) RG_UPD(false, false, SPEC_NONE)
@@ -822,7 +864,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt, double tot
   // the fused sweep marches along z inside one launch: cutting the range into chunks only adds prologues (measured 60.4
   // against 55.3 ms/step at 512^3), so the two-stream chunk schedule is kept for the flat kernels only (RGPU_CHUNKS forces it)
   static const bool force_chunks = std::getenv("RGPU_CHUNKS") != 0;
-  const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks);
+  const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks) || c->clk_cur;
   const bool pair = what != 0 && b2 > a2;
   if (serial) {
     rg_stream_t s = c->stream;
@@ -892,7 +934,7 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
       c->scan_acc_parity = -1;
       if (acc && c->g.three_d && !c->p.mhdEnabled && !no_fused_dt && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
           rgpu_tiled::hydro3d_sweep_covers(c->g) && c->p.gravityEnabled != 2) {
-        if (rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
+        if (!c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (a clock kernel zeroed them)
         c->scan_acc_parity = (nStep + 1) % 2;
       }
       return 0;
@@ -1591,17 +1633,99 @@ int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt) {
   return RGPU_OK;
 }
 
-// A state qualifies for the device-side time step when the kernel that wrote it was a fused 2D step that left BOTH its CFL maxima
-// in the device slots and its ghost cells valid (so the next step is one launch with no ghost fill), nothing in the step depends on dt
-// through the host (no gravity: (0.5 dt) g travels in the kernel arguments; no rotating frame: its coefficients are functions of dt),
-// and the phase timers are off (they synchronise every launch anyway).
+// ---- the device-side time step (csrc/step_clock_rec.h, hip/step_clock.h) ---------------------------------------------------
+// Configuration: every kernel of the step that depends on dt or t reads the record, and nothing in the step needs the host between
+// two steps.  2D: the fused step kernels (which also leave the ghost cells of their output: clock_ready).  3D: the z-marching
+// sweeps, the MHD update, the shear remap and the fused ghost fill.  Not with gravity ((0.5 dt) g travels in DevParams), the
+// dissipative stage, the forcings, the 2D rotating frame, the 2D jet, or the phase timers (they synchronise every launch anyway).
+static bool clock_config_ok(rgpu_ctx* c) {
+  const rgpu_params& p = c->p;
+  if (c->timers_on || p.gravityEnabled != 0 || p.nu > 0 || (p.mhdEnabled && p.eta > 0) || p.randomForcingEnabled || p.ouForcingEnabled) return false;
+  if (!rgpu_tiled::step_clock_supported()) return false;
+  if (!c->g.three_d) return !c->g.rot && !p.enableJet;
+  if (RG_SYNC_LAUNCH) return true;   // (host emulation: the record is resolved by value for every kernel)
+  if (!p.mhdEnabled) return rgpu_tiled::hydro3d_sweep_covers(c->g);
+  if (!rgpu_tiled::mhd3d_sweep_covers(c->g)) return false;
+  FillXY f;
+  return !(c->g.rot && c->g.shearbox) || fill_xy_plan(c, 0.0, 0.0, &f);   // the shearing ghost fill reads the record in its fused form only
+}
+// ... and the state U[parity]: its CFL maxima sit in the device slots; 2D: its ghost cells are the ones its kernel wrote
 static bool clock_ready(rgpu_ctx* c, int parity) {
-  return !c->g.three_d && !c->g.rot && !c->timers_on && c->p.gravityEnabled == 0 && !c->p.enableJet && c->p.slab_count == 1 &&
-         !(c->p.nu > 0) && !(c->p.eta > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
-         c->fused_dt_parity == parity && c->fused_dt_slots == RG_DT_SLOTS && c->ghost_ok_parity == parity && rgpu_tiled::step_clock_supported();
+  if (c->p.slab_count != 1 || !clock_config_ok(c) || c->fused_dt_parity != parity) return false;
+  if (!c->g.three_d) return c->fused_dt_slots == RG_DT_SLOTS && c->ghost_ok_parity == parity;
+  return true;
+}
+static ClockConst clock_const(const rgpu_ctx* c) {
+  const rgpu_params& p = c->p;
+  ClockConst k;
+  k.cfl = p.cfl;
+  k.seed = 0.0;                                                                  // inv_dt_fetch: the floors of 1/dt
+  if (p.mhdEnabled) k.seed = std::fmax(k.seed, p.smallc / std::fmin(p.dx, p.dy));
+  if (p.enableJet) k.seed = std::fmax(k.seed, (p.ujet + p.cjet) / p.dx);
+  k.dx = p.dx; k.dy = p.dy; k.dz = p.dz;
+  k.Omega0 = p.Omega0; k.xlen = p.dx * p.nx; k.ylen = p.dy * p.ny;
+  k.rot = c->g.rot; k.shear = (c->g.rot && c->g.shearbox && c->g.three_d) ? 1 : 0;
+  return k;
 }
 
 int rgpu_device_time_step_ready(rgpu_ctx* c, int parity) { return (c && c->U[0] && clock_ready(c, parity & 1)) ? 1 : 0; }
+int rgpu_clock_capable(rgpu_ctx* c) { return (c && c->U[0] && clock_config_ok(c)) ? 1 : 0; }
+
+int rgpu_clock_open(rgpu_ctx* c, double t0, double tEnd) {
+  RG_CHECK_CTX(c);
+  if (!c->U[0]) return fail(c, RGPU_EINVAL, "context was not created");
+  if (c->clk_n >= 0) return fail(c, RGPU_EINVAL, "clock_open: a batch is already open");
+  if (!clock_config_ok(c)) return fail(c, RGPU_EUNSUPPORTED, "clock_open: this configuration takes its time step from the host");
+  if (!c->d_clk) {
+    if (rg_malloc((void**)&c->d_clk, rgpu_ctx::kClockBatch * sizeof(StepClock)) ||
+        rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(StepClock))) return RG_HIPFAIL(c, "clock_open: records");
+  }
+  c->clk_n = 0; c->clk_t0 = t0; c->clk_tEnd = tEnd; c->clk_cur = 0;
+  return RGPU_OK;
+}
+
+int rgpu_clock_tick(rgpu_ctx* c) {
+  RG_CHECK_CTX(c);
+  if (c->clk_n < 0) return fail(c, RGPU_EINVAL, "clock_tick: no batch open");
+  if (c->clk_n >= rgpu_ctx::kClockBatch) return fail(c, RGPU_EINVAL, "clock_tick: the batch is full");
+  const int n = c->clk_n;
+  if (rgpu_tiled::launch_step_clock(c->stream, c->d_red, clock_const(c), c->clk_t0, c->clk_tEnd, n ? c->d_clk + n - 1 : 0, c->d_clk + n)) return RG_HIPFAIL(c, "clock_tick");
+  c->clk_cur = c->d_clk + n;
+  c->clk_n = n + 1;
+  return RGPU_OK;
+}
+
+int rgpu_clock_stopped(rgpu_ctx* c) { return (c && stop_now(c)) ? 1 : 0; }
+
+int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_last, double* dt_log, int* stop) {
+  RG_CHECK_CTX(c);
+  if (c->clk_n < 0) return fail(c, RGPU_EINVAL, "clock_close: no batch open");
+  const int queued = c->clk_n;
+  c->clk_n = -1; c->clk_cur = 0;
+  if (ran) *ran = 0;
+  if (stop) *stop = 0;
+  if (queued > 0 && (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(StepClock), c->stream) || rg_stream_sync(c->stream))) {
+    state_modified(c);
+    return RG_HIPFAIL(c, "clock_close: read-back of the records");
+  }
+  int r = 0;
+  for (; r < queued && c->h_clk[r].stop == 0; ++r) {   // t accumulated in the order of the reference's loop
+    if (dt_last) *dt_last = c->h_clk[r].dt;
+    if (t) *t += c->h_clk[r].dt;
+    if (dt_log) dt_log[r] = c->h_clk[r].dt;
+  }
+  if (ran) *ran = r;
+  if (r < queued) {
+    // the steps behind a stop were no-ops (every kernel of a batch honours the flag, the stopping clock kernel left the slots alone):
+    // the state of step nStep0 + r is the last one written, its CFL maxima are still in the slots, its ghost cells as its kernels left them
+    if (stop) *stop = c->h_clk[r].stop;
+    const int par = (nStep0 + r) % 2;
+    c->scan_acc_parity = -1;
+    c->fused_dt_parity = par;
+    c->ghost_ok_parity = c->g.three_d ? -1 : par;
+  }
+  return RGPU_OK;
+}
 
 int rgpu_run_steps_log(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double* t, double* dt, double* dt_log) {
   RG_CHECK_CTX(c);
@@ -1616,45 +1740,30 @@ int rgpu_run_steps_log(rgpu_ctx* c, int nsteps, double tEnd, int* nStep, double*
       ++done;
       continue;
     }
-    if (!c->d_clk) {
-      if (rg_malloc((void**)&c->d_clk, rgpu_ctx::kClockBatch * sizeof(rgpu_tiled::StepClock)) ||
-          rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(rgpu_tiled::StepClock))) return RG_HIPFAIL(c, "run_steps: clock records");
-    }
     const int m = (nsteps - done < rgpu_ctx::kClockBatch) ? nsteps - done : (int)rgpu_ctx::kClockBatch;
-    const double seed = c->p.mhdEnabled ? c->p.smallc / std::fmin(c->p.dx, c->p.dy) : 0.0;   // inv_dt_fetch
+    if (const int rc = rgpu_clock_open(c, *t, tEnd)) return rc;
     int queued = 0, rc = 0;
+    const int n0 = *nStep;
     for (; queued < m; ++queued) {
-      rc = rgpu_tiled::launch_step_clock(c->stream, c->d_red, c->p.cfl, seed, c->p.dx, c->p.dy, *t, tEnd, queued ? c->d_clk + queued - 1 : 0, c->d_clk + queued);
-      if (rc) break;
-      c->clk_cur = c->d_clk + queued;
-      // == rgpu_godunov_unsplit for this configuration: step_pre finds the ghost cells valid, the step is the fused kernel
-      rc = step_pre(c, *nStep + queued) || step_core(c, *nStep + queued, 0.0, 0.0);
-      c->clk_cur = 0;
-      if (rc == 0 && !clock_ready(c, (*nStep + queued + 1) % 2)) rc = -1;   // (cannot happen: same configuration, same kernel)
-      if (rc) break;
+      if ((rc = rgpu_clock_tick(c)) != 0) break;
+      if (stop_now(c)) { ++queued; break; }   // (host emulation: the record is already there and says the loop has ended)
+      // == rgpu_godunov_unsplit for this configuration, every dt / t dependence read from the record on the device
+      const int n = n0 + queued;
+      rc = (step_pre(c, n) || step_core(c, n, 0.0, 0.0) || step_post_a(c, n, 0.0, 0.0) || step_post_b(c, n)) ? RGPU_EHIP : 0;
+      if (rc == 0 && c->fused_dt_parity != (n + 1) % 2) rc = RGPU_EHIP;   // (cannot happen: same configuration, same kernels)
+      if (rc) { c->clk_n = queued; break; }   // the record of the step that failed to queue is not read back
     }
     // a launch that failed after `queued` complete steps were queued: those steps still run on the device -- read their records and
     // advance nStep / t / dt for them before reporting, so that the caller's step count and parity describe the device state
-    const std::string launch_err = rc ? std::string(rg_last_error_string()) : std::string();
-    if (queued > 0 && (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(rgpu_tiled::StepClock), c->stream) || rg_stream_sync(c->stream))) {
-      state_modified(c);
-      return RG_HIPFAIL(c, "run_steps: clock read-back");
-    }
-    int ran = 0;
-    for (; ran < queued && c->h_clk[ran].stop == 0; ++ran) {   // t accumulated in the order of the reference's loop
-      *dt = c->h_clk[ran].dt;
-      *t += *dt;
-      *nStep += 1;
-      if (dt_log) dt_log[done + ran] = *dt;
-    }
+    const std::string launch_err = rc ? c->err + " " + rg_last_error_string() : std::string();
+    int ran = 0, stop = 0;
+    const int rc2 = rgpu_clock_close(c, n0, &ran, t, dt, dt_log ? dt_log + done : 0, &stop);
+    if (rc2) return rc2;
+    *nStep += ran;
     done += ran;
     if (rc) { state_modified(c); return fail(c, RGPU_EHIP, "run_steps: queueing a device-clock step: " + launch_err); }
-    if (ran < queued) {   // the steps behind a stop were no-ops: the state of step *nStep is the last one written
-      const int stop = c->h_clk[ran].stop;
-      c->fused_dt_parity = -1;              // its CFL maxima went into the clock that stopped
-      c->scan_acc_parity = -1;
-      c->ghost_ok_parity = *nStep % 2;      // its ghost cells are the ones its kernel wrote
-      if (stop == 2) return fail(c, RGPU_EHIP, "run_steps: the time step is not a number");
+    if (ran < queued) {
+      if (stop >= 2) return fail(c, RGPU_EHIP, stop == 2 ? "run_steps: the time step is not a number" : "run_steps: 1/dt is not finite");
       break;
     }
   }

@@ -32,7 +32,10 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
         for _ in range(3): run.oneStepIntegration()
         run.solver.synchronize(); t0 = time.time()
         n = 10
-        for _ in range(n): run.oneStepIntegration()
+        if os.environ.get("PROBE_HOST_LOOP"):      # rounds 1-4: one host turn per step
+            for _ in range(n): run.oneStepIntegration()
+        else:                                      # round 5: rgpu_comm_run_steps, the time step on the device between the steps
+            assert run.run_steps(n) == n and run.clocked_steps() == n, run.clocked_steps()
         run.solver.synchronize(); dt = (time.time() - t0) / n
         link_ms = 0.0 if rate <= 0 else 8 * 518 * 518 * 3 * 8 * (2 if 512 // nz == 2 else 1) / rate / 1e6
         print("nz=%3d (N=%d) link %3g GB/s (%.2f ms per exchange) %-8s %7.2f ms/step  -> %6.0f Mcell/s per rank, x%d = %6.0f" % (nz, 512 // nz, rate, link_ms,

@@ -17,7 +17,8 @@ ini = os.path.join("$R", "configs", "mhd_mri_3d.ini")
 run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=64", 0, 1, rcomm.unique_id(CL), library=L, comm_library=CL, overlap=$SCHED, self_ring=True)
 assert run.halo_bytes() > 0
 run.init_simulation()
-for _ in range(12): run.oneStepIntegration()
+for _ in range(2): run.oneStepIntegration()
+assert run.run_steps(10) == 10
 run.solver.synchronize(); run.close()
 PY
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr$SCHED -o b -- python /tmp/slab_tl.py > /dev/null 2> $OUT/err$SCHED.txt

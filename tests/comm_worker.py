@@ -313,7 +313,29 @@ def main():
         want = faces * gw * (run.p.nx + 2 * gw) * (run.p.ny + 2 * gw) * run.p.nbVar * 8
         assert run.halo_bytes() == want and (want > 0 or not ring1), (run.halo_bytes(), want)
     run.init_simulation()
-    dts = [run.oneStepIntegration() for _ in range(nsteps)]
+    # COMM_RUN_STEPS=k: the steps through rgpu_comm_run_steps in two calls (k, then the rest) instead of one oneStepIntegration per step:
+    # where the configuration allows it the time step stays on the device between steps and the host reads a batch of records once
+    pieces = int(os.environ.get("COMM_RUN_STEPS", "0"))
+    if pieces:
+        dts = []
+        for k in (min(pieces, nsteps), nsteps - min(pieces, nsteps)):
+            if k:
+                assert run.run_steps(k) == k, (k, run.nStep)
+                dts += run.dt_log
+        assert run.nStep == nsteps and len(dts) == nsteps and run.dt == dts[-1]
+        # which loop ran: everything but the first step from the device record, unless the configuration keeps the host loop
+        host_loop = (os.environ.get("COMM_OVERLAP", "1") == "0" or run.p.nu > 0 or (run.p.mhdEnabled and run.p.eta > 0) or run.p.randomForcingEnabled
+                     or run.p.ouForcingEnabled or run.p.gravityEnabled != 0 or os.environ.get("RGPU_NO_STEP_CLOCK")
+                     or (device == "cpu" and not run.p.mhdEnabled))   # (emulation: the 3D hydro pieces cannot carry the CFL scan without the tiled sweep)
+        want_clocked = 0 if host_loop else nsteps - 1
+        if os.environ.get("COMM_EXPECT_CLOCK", "1") == "1":
+            assert run.clocked_steps() == want_clocked, (run.clocked_steps(), want_clocked)
+        t_sum = 0.0
+        for d in dts:
+            t_sum += d
+        assert run.totalTime == t_sum
+    else:
+        dts = [run.oneStepIntegration() for _ in range(nsteps)]
     staged = device.startswith("cuda-staged")
     if staged:
         # the wire really carried planes: one exchange per step (+ the one of the initial ghost fill), and with the packed exchange
@@ -390,10 +412,45 @@ def main():
         if p.randomForcingEnabled or (p.ouForcingEnabled and device != "cpu"):   # (OU on a GPU: the device's cos())   # global normalisation sum: round-off agreement (stated tolerance 1e-12), see slab_worker.py
             rel = float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
             ok = rel < 1e-12 and np.allclose(np.array(dts), dts_ref, rtol=1e-12, atol=0)
+        box = [dts_ref.tolist() if pieces else None]
         if ok and not (p.randomForcingEnabled or p.ouForcingEnabled):   # the fingerprint is the oracle's own
             ok = fingerprint == int(np.ascontiguousarray(ref).view(np.uint64).sum(dtype=np.uint64))
         with open(out, "w") as f:
             f.write("OK %016x\n" % fingerprint if ok else "MISMATCH %d doubles, dt equal=%s, fingerprint %x\n" % (nbad, np.array_equal(np.array(dts), dts_ref), fingerprint))
+    if pieces and nsteps >= 2:
+        # an end time inside a batch: the loop condition "t < tEnd" is evaluated on the device, the steps queued behind it are no-ops on
+        # every rank; afterwards the state, its ghost planes and its CFL maxima are those of the last step that ran
+        box = box if rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0)
+        dts_ref_l = box[0]
+        cut = max(1, nsteps // 2)
+        t_cut = 0.0
+        for d in dts_ref_l[:cut]:
+            t_cut += d
+        tEnd = t_cut - 0.25 * dts_ref_l[cut - 1]
+        run.close()
+        ids = [rcomm.unique_id(CL) if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=int(os.environ.get("COMM_OVERLAP", "1")), self_ring=ring1)
+        run.init_simulation()
+        done = run.run_steps(nsteps + 3, tEnd)
+        good = done == cut and run.nStep == cut and run.totalTime == t_cut and run.dt == dts_ref_l[cut - 1]
+        local = torch.from_numpy(np.ascontiguousarray(run.local_interior()))
+        parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+        dist.gather(local, parts, dst=0)
+        good = good and run.run_steps(5, tEnd) == 0
+        dt_next = run.oneStepIntegration()                      # the state is usable: same next dt as the uninterrupted run
+        good = good and (cut >= len(dts_ref_l) or dt_next == dts_ref_l[cut])
+        flags = [None] * world
+        dist.all_gather_object(flags, (good, done, run.totalTime))
+        if rank == 0:
+            ref_cut, _, _ = oracle.run(p, U0, cut)
+            nbad2 = int((torch.cat(parts, dim=1).numpy() != interior(ref_cut, p)).sum())
+            ok2 = all(f[0] for f in flags) and nbad2 == 0
+            if not ok2:
+                with open(out, "w") as f:
+                    f.write("MISMATCH end time inside the batch: %d doubles differ, per rank (ok, steps, t) = %r, expected %d steps, t = %r\n" % (nbad2, flags, cut, t_cut))
+            ok = ok and ok2
     dist.barrier()
     run.close()
     dist.destroy_process_group()

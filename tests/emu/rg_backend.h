@@ -14,6 +14,7 @@
 
 #define RG_DEVFN inline
 #define RG_BACKEND_NAME "host-emulation(test-only)"
+#define RG_SYNC_LAUNCH 1   // a "launch" is a host loop: its results are there when it returns (the step driver may read a StepClock record on the host)
 #define RG_STREAM_STORE(ptr, val) (*(ptr) = (val))
 #define RG_ASSUME(cond) ((void)0)
 

@@ -104,6 +104,17 @@ def test_exact_ranks_in_place_exchange(dev_comm_exact, gpu_lib, oracle, tmp_path
     run_worker("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=40;" + MRI, 3, 2, 1, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", RGPU_COMM_PACK="0"), timeout=600)
 
 
+RUN_STEPS = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[7], SMALL[9], SMALL[10], SMALL[13], SMALL[14], SMALL[15], SMALL[16]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ov,nsteps,world,overlap", RUN_STEPS, ids=["%s-%d-x%d-%s" % (c[0], n, c[3], SCHED[c[4]]) for n, c in enumerate(RUN_STEPS)])
+def test_exact_ranks_run_steps_with_the_time_step_on_the_device(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path):
+    """rgpu_comm_run_steps on the real kernels with a real neighbour: the 1/dt slots all-reduced in place, the clock kernel, the sweeps /
+    update / shear remap / fused ghost fill reading the record; one plain step then a batch of 5, and an end time inside a batch"""
+    run_worker(base, ov, 6, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), timeout=600)
+
+
 CONTRACTED = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[9], SMALL[14]]
 
 

@@ -107,6 +107,18 @@ def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm
     run_worker(base, ov, nsteps, world, overlap, tmp_path)
 
 
+RUN_STEPS = [CASES[n] for n in (0, 2, 4, 6, 7, 9, 10, 11, 12, 14, 18, 19, 20, 21, 22, 23)]
+
+
+@pytest.mark.parametrize("base,ov,nsteps,world,overlap", RUN_STEPS,
+                         ids=["%s-%d-x%d-%s" % (c[0], n, c[3], ("serial", "overlap", "boundary-first")[c[4]]) for n, c in enumerate(RUN_STEPS)])
+def test_cpp_driver_run_steps_matches_single_domain(base, ov, nsteps, world, overlap, comm_emu_lib, oracle, tmp_path):
+    """the same runs through rgpu_comm_run_steps (one plain step, then the rest as one batch: per step the 1/dt slots all-reduced in
+    place, the clock record formed from them, the step pieces reading it -- csrc/step_clock_rec.h; the emulation backend forms the same
+    records) and with an end time inside the batch: state, dt sequence, step count and t equal the single-domain oracle's"""
+    run_worker(base, ov, nsteps + 1, world, overlap, tmp_path, env_extra={"COMM_RUN_STEPS": "1"})
+
+
 @pytest.mark.parametrize("base,ov,world,fail_rank,fail_step,overlap", [
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 2, 1, 0, 1),     # step 0: the failing rank has only ever all-reduced after a FULL scan
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 2, 0, 2, 1),     # steady state of the overlapped schedule (fused scan)

@@ -454,7 +454,15 @@ RUN_STEPS_CASES = [
     ("rayleigh_taylor_gpu_2d", "mesh.nx=40;mesh.ny=120", 12, False),           # gravity: (0.5 dt) g is a kernel argument -> plain loop
     ("jet2d_cpu", "mesh.nx=40;mesh.ny=120", 12, False),                        # jet inflow: ghost fill every step -> plain loop
     ("mhd_BrioWu", "mesh.nx=128;mesh.ny=8", 12, None),                         # 2D MHD with non-periodic faces
-    ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=24;hydro.riemannSolver=hllc", 6, False),   # 3D: plain loop
+    # 3D (round 5): the z-marching sweeps, the MHD update, the shear remap and the fused ghost fill read the record too
+    ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=24;hydro.riemannSolver=hllc", 8, True),    # 3D hydro, reflecting walls: one sweep + ghost fill per step
+    ("implode3d", "mesh.nx=20;mesh.ny=24;mesh.nz=28", 8, True),                              # ... approx solver
+    ("orszag-tang3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16", 8, True),                          # plain 3D MHD, periodic
+    ("mhd_mri_3d", "mesh.nx=24;mesh.ny=32;mesh.nz=16;MHD.omega0=0.02", 8, True),             # rotating frame + shearing box: offsets at t + dt/2 and t + dt from the record
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=32;mesh.nz=16", 8, True),                             # ... as shipped (Omega0 = 0.001)
+    ("mhd_BrioWu", "mesh.nx=32;mesh.ny=12;mesh.nz=12;BrioWu.direction=0;MHD.implementationVersion=4", 8, True),   # 3D MHD, outflow faces: the CFL scan sees unfilled ghosts
+    ("rayleigh_taylor_gpu_3d_mhd", "mesh.nx=8;mesh.ny=8;mesh.nz=32", 6, False),              # gravity: plain loop
+    ("orszag-tang3d", "mesh.nx=12;mesh.ny=12;mesh.nz=16;hydro.nu=0.005;MHD.eta=0.01", 6, False),   # dissipative stage: plain loop
 ]
 
 

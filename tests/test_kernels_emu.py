@@ -74,9 +74,13 @@ def test_public_ghost_fill_invalidates_fused_dt(base, ov, emu_lib, oracle):
 
 
 @pytest.mark.parametrize("base,ov,nsteps", [("orszag-tang", "mesh.nx=24;mesh.ny=20", 8), ("kelvin_helmholtz_gpu_2d", "mesh.nx=24;mesh.ny=16", 8),
-                                            ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8", 4)])
+                                            ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8", 4),
+                                            ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=8", 6),
+                                            ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=8;MHD.omega0=0.02", 6),
+                                            ("mhd_BrioWu", "mesh.nx=12;mesh.ny=10;mesh.nz=8;BrioWu.direction=0;MHD.implementationVersion=4", 6)])
 def test_run_steps_plain_loop(base, ov, nsteps, emu_lib, oracle):
-    """rgpu_run_steps on the emulation backend (no fused kernels, no device-side time step: the plain loop of the reference):
+    """rgpu_run_steps on the emulation backend: 2D -- no fused kernels, the plain loop of the reference; 3D -- the batch logic of the
+    device-side time step with the record formed by the same expressions (csrc/step_clock_rec.h) and resolved by value.
     K steps in one call, in pieces, and with an end time inside the batch == the oracle's run"""
     p = emu_lib.params_from_ini(ini(base), ov)
     U0 = emu_lib.init_condition(ini(base), ov, p)
@@ -99,6 +103,12 @@ def test_run_steps_plain_loop(base, ov, nsteps, emu_lib, oracle):
         sv.start(U0, 0)
         tEnd = t_ref - 0.5 * float(dts_ref[-1])
         assert sv.run_steps(nsteps + 5, tEnd) == nsteps and sv.totalTime == t_ref
+        assert np.array_equal(interior(sv.getDataHost(), p), interior(ref, p))      # the no-op steps behind the end time left the state alone
+        more, dts_more, _ = oracle.run(p, U0, nsteps + 1)
+        sv.oneStepIntegration()                                                      # ... and its CFL maxima and ghost cells
+        assert sv.dt == float(dts_more[-1]) and np.array_equal(interior(sv.getDataHost(), p), interior(more, p))
+        if p.three_d:
+            assert emu_lib.lib.rgpu_clock_capable(sv.ctx) == 1
     finally:
         sv.close()
 
