@@ -45,6 +45,35 @@ __global__ void __launch_bounds__(1024) step_clock_kernel(unsigned long long* __
   if (runs) slots[t] = 0ull;
 }
 
+// the fold of csrc/step_clock_rec.h (ClockFold) for a workgroup of NT threads; red: NT / 64 doubles of LDS of its own.  Contains one
+// workgroup barrier.  Returns the record of this step (the same on every thread of every workgroup).
+template <int NT>
+__device__ __forceinline__ StepClock clock_fold(const ClockFold& f, double* red) {
+  static_assert(NT % 64 == 0 && rgpu::RG_DT_SLOTS % NT == 0, "whole waves, whole trips over the slots");
+  const int t = (int)threadIdx.x;
+  double v = 0.0;
+#pragma unroll
+  for (int s = 0; s < rgpu::RG_DT_SLOTS / NT; ++s) v = fmax(v, __longlong_as_double((long long)f.in[s * NT + t]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  double m = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) m = fmax(m, red[w]);
+  StepClock r;
+  step_clock_form(f.k, m, f.prev ? f.prev->t_next : f.t0, f.tEnd, f.prev ? f.prev->stop : 0, &r);
+  if (blockIdx.x == 0) {
+    if (t == 0) *f.out = r;
+    if (!r.stop) {   // (a stopped step leaves every slot array as it is)
+#pragma unroll
+      for (int s = 0; s < rgpu::RG_DT_SLOTS / NT; ++s) f.zero[s * NT + t] = 0ull;
+    }
+  }
+  return r;
+}
+
+inline bool step_clock_fold_enabled() { static const bool on = !std::getenv("RGPU_NO_CLOCK_FOLD"); return on; }
 inline bool step_clock_supported() { return tiled_enabled() && !std::getenv("RGPU_NO_STEP_CLOCK"); }
 inline int launch_step_clock(rg_stream_t s, unsigned long long* slots, const ClockConst& k, double t0, double tEnd, const StepClock* prev, StepClock* out) {
   hipLaunchKernelGGL(step_clock_kernel, dim3(1), dim3(1024), 0, s, slots, k, t0, tEnd, prev, out);

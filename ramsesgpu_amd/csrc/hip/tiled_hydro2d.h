@@ -53,9 +53,14 @@ RG_DEVFN ImgDim images_of(int x, int n, int gw, int bc_lo, int bc_hi) {
 // the ghost cells' own threads do not store: one writer per location, and that fill is not launched (ghost_ok_parity).
 template <int TX, int TY, int SPEC>
 __global__ void __launch_bounds__(TX * TY) hydro2d_step_kernel(DevParams g, int nbx, const double* __restrict__ Uin, double* __restrict__ Uout,
-                                                               double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk) {
+                                                               double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk, ClockFold fold) {
   spec_assume<SPEC>(g);
-  if (clk) {   // the time step lives on the device (hip/step_clock.h)
+  if (fold.out) {   // the clock of this step is part of the kernel (step_clock.h: clock_fold)
+    __shared__ double Lred[TX * TY / 64];
+    const StepClock r = clock_fold<TX * TY>(fold, Lred);
+    if (r.stop) return;
+    dtdx = r.dtdx; dtdy = r.dtdy;
+  } else if (clk) {   // the time step lives on the device (hip/step_clock.h)
     if (clk->stop) return;
     dtdx = clk->dtdx; dtdy = clk->dtdy;
   }
@@ -227,10 +232,10 @@ __global__ void __launch_bounds__(TX * TY) hydro2d_step_kernel(DevParams g, int 
 }
 
 template <int TX, int TY, int SPEC>
-inline int launch_hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk) {
+inline int launch_hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk, const ClockFold& fold) {
   const int nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
   const int nby = (g.jsize - 1 + (TY - 2) - 1) / (TY - 2);
-  hipLaunchKernelGGL((hydro2d_step_kernel<TX, TY, SPEC>), dim3((unsigned)(nbx * nby)), dim3(TX * TY), 0, s, g, nbx, in, out, dtdx, dtdy, dt_slots, images, clk);
+  hipLaunchKernelGGL((hydro2d_step_kernel<TX, TY, SPEC>), dim3((unsigned)(nbx * nby)), dim3(TX * TY), 0, s, g, nbx, in, out, dtdx, dtdy, dt_slots, images, clk, fold);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -239,11 +244,14 @@ inline bool hydro2d_step_covers(const DevParams& g) { return tiled_enabled() && 
 
 // The whole 2D hydro step U -> Unew.  dt_slots: RG_DT_SLOTS device slots for the CFL maximum of the new state (reset by the caller),
 // or 0; images: see the kernel.  Returns 0 = done, 1 = not covered (the caller runs the flat kernels), < 0 = launch error.
-inline int hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk = 0) {
+inline int hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy, unsigned long long* dt_slots, int images, const StepClock* clk = 0,
+                        const ClockFold* fold_in = 0) {
   if (!hydro2d_step_covers(g)) return 1;
+  ClockFold fold;
+  if (fold_in) fold = *fold_in; else { fold.prev = 0; fold.out = 0; fold.in = 0; fold.zero = 0; fold.t0 = 0.0; fold.tEnd = 0.0; }
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
   constexpr int TX = 16, TY = 16;
-#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro2d_step<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images, clk);
+#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro2d_step<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images, clk, fold);
   if (!no_spec) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
     RG_TRY(SPEC_HYDRO_HLLC | SL2) RG_TRY(SPEC_HYDRO_HLLC | SL1)
@@ -252,7 +260,7 @@ inline int hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, dou
     RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE2) RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE1)   // with uniform gravity
   }
 #undef RG_TRY
-  return launch_hydro2d_step<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dt_slots, images, clk);
+  return launch_hydro2d_step<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dt_slots, images, clk, fold);
 }
 
 }  // namespace rgpu_tiled

@@ -446,9 +446,24 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 // layer j = gw (i = gw) sees, so their fluxes and EMFs are the same doubles.  When that layer would need a tile row (column) of
 // its own -- ny (nx) a multiple of the tile edge -- the sweep leaves it out and this kernel copies it: 15 + 3 components per
 // cell of one layer instead of 1/65 (1/33) of the sweep.  axis 1: y layer (all i), axis 0: x layer (all j).
+// shear_save != 0 (the shearing box; axis 1 launches only): the same launch also saves the two emfY border columns of planes
+// [k0, k0 + nk) for the flux / emf remap (shear_save_emf_cell, MHDRunGodunov.cpp:3203-3300) -- threads [n_copy, ...): one per (j, k).
+// The row j = jsize - gw they read is the layer being copied by the other threads: they take its source row instead.
 struct K_copy_periodic_layer {
   DevParams g; double* F; double* emf; int axis, k0;
+  double* shear_save; unsigned n_copy; int copy_on;
   RG_DEVFN void operator()(unsigned t) const {
+    if (t >= n_copy) {
+      const unsigned q = t - n_copy;
+      const unsigned j = q % (unsigned)g.jsize, k = (unsigned)k0 + q / (unsigned)g.jsize;
+      const unsigned js = (copy_on && (int)j == g.jsize - g.gw) ? (unsigned)g.gw : j;
+      const size_t N = g.ncell, P = (size_t)g.jsize * g.ksize;
+      const size_t row = (size_t)g.sj * js + (size_t)g.sk * k;
+      const unsigned idx2 = j + (unsigned)g.jsize * k;
+      shear_save[idx2] = emf[row + g.gw + (size_t)EMF_Y * N];
+      shear_save[idx2 + P] = emf[row + g.nx + g.gw + (size_t)EMF_Y * N];
+      return;
+    }
     const unsigned n = (axis == 1) ? (unsigned)g.isize : (unsigned)g.jsize;
     const unsigned a = t % n, k = (unsigned)k0 + t / n;
     const size_t N = g.ncell;
@@ -464,7 +479,7 @@ struct K_copy_periodic_layer {
 // knows the boundary conditions)
 template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
-                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk) {
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save) {
   TileGrid tg;
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
@@ -482,8 +497,12 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
                      dt, dtdx, dtdy, dtdz, ra, rb, clk);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
-  if (copy_x) { const K_copy_periodic_layer k = {g, F, emf, 0, ra}; if (rgpu::rg_launch<256>(s, (unsigned)g.jsize * (unsigned)(rb - ra), k)) return -1; }
-  if (copy_y) { const K_copy_periodic_layer k = {g, F, emf, 1, ra}; if (rgpu::rg_launch<256>(s, (unsigned)g.isize * (unsigned)(rb - ra), k)) return -1; }
+  if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)(rb - ra); const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
+  if (copy_y || shear_save) {   // one launch: the y layer (all i) and, shearing box, the emfY border columns for the remap
+    const unsigned nc = copy_y ? (unsigned)g.isize * (unsigned)(rb - ra) : 0u, ns = shear_save ? (unsigned)g.jsize * (unsigned)(rb - ra) : 0u;
+    const K_copy_periodic_layer k = {g, F, emf, 1, ra, shear_save, nc, copy_y ? 1 : 0};
+    if (rgpu::rg_launch<256>(s, nc + ns, k)) return -1;
+  }
   return 0;
 }
 
@@ -503,12 +522,13 @@ inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g
 // trace and Riemann as flat kernels), < 0 = launch error.
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
-                       double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0) {
+                       double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0,
+                       double* shear_save = 0) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
 }
 
 }  // namespace rgpu_tiled

@@ -65,6 +65,10 @@ struct rgpu_ctx {
   StepClock* d_clk; StepClock* h_clk; const StepClock* clk_cur;
   int clk_n;                    // records queued in the open batch (rgpu_clock_open .. rgpu_clock_close), -1: no batch open
   double clk_t0, clk_tEnd;
+  // fused 2D steps: the clock is folded into the step kernel itself (step_clock_rec.h: ClockFold) over three rotating slot arrays;
+  // d_red always points at the array that holds the maxima of the current state
+  unsigned long long* d_red_base;   // 3 x RG_DT_SLOTS
+  bool fold_mode; int fold_phase0; ClockFold fold; unsigned long long* fold_acc;
   std::string err;
 };
 
@@ -228,7 +232,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->G = 0;
   c->Frc = 0;
   c->ou = 0;
-  c->d_red = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0; c->clk_n = -1; c->clk_t0 = 0.0; c->clk_tEnd = 0.0;
+  c->d_red = 0; c->d_red_base = 0; c->fold_mode = false; c->fold_phase0 = 0; c->fold_acc = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0; c->clk_n = -1; c->clk_t0 = 0.0; c->clk_tEnd = 0.0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
   for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
@@ -281,9 +285,10 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
       return fail(c, RGPU_ENOMEM, "device allocation of the shear buffers failed");
   }
   static_assert((int)RG_DT_SLOTS == RGPU_DT_SLOTS, "include/rgpu.h promises RGPU_DT_SLOTS device slots");
-  if (rg_malloc((void**)&c->d_red, RG_DT_SLOTS * sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, RG_DT_SLOTS * sizeof(unsigned long long)) ||
-      rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream))
+  if (rg_malloc((void**)&c->d_red_base, 3 * RG_DT_SLOTS * sizeof(unsigned long long)) || rg_host_alloc((void**)&c->h_red, RG_DT_SLOTS * sizeof(unsigned long long)) ||
+      rg_memset_async(c->d_red_base, 0, 3 * RG_DT_SLOTS * sizeof(unsigned long long), c->stream))
     return fail(c, RGPU_ENOMEM, "allocation of the reduction slots failed");
+  c->d_red = c->d_red_base;
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
   // sub-band size (cells) of the XCD-aware workgroup order, 0 = linear order (rg_backend.h: rg_launch_planes)
@@ -597,7 +602,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
   // modifies the state afterwards (2D: the fused step or the flat update kernel; 3D with a per-cell gravity field: the flat one)
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
   const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
-  unsigned long long* slots = scan2 ? c->d_red : 0;
+  const bool folding = c->clk_cur && c->fold_mode;   // 2D batch: the clock is part of this step's kernel (ClockFold)
+  unsigned long long* slots = scan2 ? (folding ? c->fold_acc : c->d_red) : 0;
   if (st.clk && !(ND == 2 && scan2)) return -1;   // a device-clock step is a fused kernel with the CFL term or nothing
   if (scan2 && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
   if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
@@ -613,7 +619,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
         images |= bc << (2 * f);
       }
     }
-    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, st.clk);
+    const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, folding ? 0 : st.clk, folding ? &c->fold : 0);
+    if (rc == 0 && folding) c->d_red = c->fold_acc;   // the maxima of the state just written
     if (rc == 0 && scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     if (rc == 0 && images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
     if (rc <= 0) return rc;
@@ -701,9 +708,12 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
         static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
         bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, st.clk);
+        const bool folding = c->clk_cur && c->fold_mode;   // 2D batch: the clock is part of this step's kernel (ClockFold)
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? (folding ? c->fold_acc : c->d_red) : 0, images ? 1 : 0,
+                                                           folding ? 0 : st.clk, folding ? &c->fold : 0);
         if (rct < 0) return -1;
         if (rct == 0) {
+          if (folding) c->d_red = c->fold_acc;   // the maxima of the state just written
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
           if (images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
           return 0;
@@ -804,7 +814,8 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
       if (p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC) reuse |= 2;
       if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     }
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk);
+    // shearing box: the launch that copies the periodic y layer also saves the emfY border columns of these planes for the remap
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
@@ -819,6 +830,12 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx, st.clk};
   auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
     if (!shear || r.hi <= r.lo) return 0;
+    if (use_sweep) {   // the sweep's closing launch saved the emfY columns of its planes: the remap of exactly those
+      if (r.lo < g.gw) r.lo = g.gw;
+      if (r.hi > ks - g.gw + 1) r.hi = ks - g.gw + 1;
+      if (r.hi <= r.lo) return 0;
+      return rg_launch_range<kBlock>(s, (unsigned)r.lo * g.jsize, (unsigned)(r.hi - r.lo) * g.jsize, k_sremap);
+    }
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
     return rg_launch_range<kBlock>(s, j0, jn, k_ssave) || rg_launch_range<kBlock>(s, j0, jn, k_sremap);
   };
@@ -1204,7 +1221,7 @@ void rgpu_destroy(rgpu_ctx* c) {
   if (c->own_state) { rg_free(c->U[0]); rg_free(c->U[1]); }
   rg_free(c->Q); rg_free(c->E); rg_free(c->T); rg_free(c->F); rg_free(c->emf); rg_free(c->shear_save); rg_free(c->shear_remap); rg_free(c->G); rg_free(c->Frc);
   delete c->ou;
-  rg_free(c->d_red); rg_host_free(c->h_red);
+  rg_free(c->d_red_base); rg_host_free(c->h_red);
   if (c->d_clk) rg_free(c->d_clk);
   if (c->h_clk) rg_host_free(c->h_clk);
   if (c->ev_ok) { rg_event_destroy(c->ev0); rg_event_destroy(c->ev1); }
@@ -1681,6 +1698,12 @@ int rgpu_clock_open(rgpu_ctx* c, double t0, double tEnd) {
         rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(StepClock))) return RG_HIPFAIL(c, "clock_open: records");
   }
   c->clk_n = 0; c->clk_t0 = t0; c->clk_tEnd = tEnd; c->clk_cur = 0;
+  c->fold_mode = !RG_SYNC_LAUNCH && !c->g.three_d && rgpu_tiled::step_clock_fold_enabled();
+  if (c->fold_mode) {   // the two slot arrays the first steps accumulate into / zero: clean (the host loop uses one array at a time)
+    c->fold_phase0 = (int)((c->d_red - c->d_red_base) / RG_DT_SLOTS);
+    for (int q = 1; q <= 2; ++q)
+      if (rg_memset_async(c->d_red_base + ((c->fold_phase0 + q) % 3) * RG_DT_SLOTS, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) { c->clk_n = -1; return RG_HIPFAIL(c, "clock_open"); }
+  }
   return RGPU_OK;
 }
 
@@ -1689,6 +1712,15 @@ int rgpu_clock_tick(rgpu_ctx* c) {
   if (c->clk_n < 0) return fail(c, RGPU_EINVAL, "clock_tick: no batch open");
   if (c->clk_n >= rgpu_ctx::kClockBatch) return fail(c, RGPU_EINVAL, "clock_tick: the batch is full");
   const int n = c->clk_n;
+  if (c->fold_mode) {   // no launch: the step kernel that follows folds, forms and writes the record itself
+    const int ph = (int)((c->d_red - c->d_red_base) / RG_DT_SLOTS);
+    c->fold.prev = n ? c->d_clk + n - 1 : 0; c->fold.out = c->d_clk + n;
+    c->fold.in = c->d_red; c->fold_acc = c->d_red_base + ((ph + 1) % 3) * RG_DT_SLOTS; c->fold.zero = c->d_red_base + ((ph + 2) % 3) * RG_DT_SLOTS;
+    c->fold.k = clock_const(c); c->fold.t0 = c->clk_t0; c->fold.tEnd = c->clk_tEnd;
+    c->clk_cur = c->d_clk + n;
+    c->clk_n = n + 1;
+    return RGPU_OK;
+  }
   if (rgpu_tiled::launch_step_clock(c->stream, c->d_red, clock_const(c), c->clk_t0, c->clk_tEnd, n ? c->d_clk + n - 1 : 0, c->d_clk + n)) return RG_HIPFAIL(c, "clock_tick");
   c->clk_cur = c->d_clk + n;
   c->clk_n = n + 1;
@@ -1702,6 +1734,8 @@ int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_la
   if (c->clk_n < 0) return fail(c, RGPU_EINVAL, "clock_close: no batch open");
   const int queued = c->clk_n;
   c->clk_n = -1; c->clk_cur = 0;
+  const bool folded = c->fold_mode;
+  c->fold_mode = false;
   if (ran) *ran = 0;
   if (stop) *stop = 0;
   if (queued > 0 && (rg_copy_d2h(c->h_clk, c->d_clk, (size_t)queued * sizeof(StepClock), c->stream) || rg_stream_sync(c->stream))) {
@@ -1715,6 +1749,7 @@ int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_la
     if (dt_log) dt_log[r] = c->h_clk[r].dt;
   }
   if (ran) *ran = r;
+  if (folded) c->d_red = c->d_red_base + ((c->fold_phase0 + r) % 3) * RG_DT_SLOTS;   // the array the last step that ran accumulated into
   if (r < queued) {
     // the steps behind a stop were no-ops (every kernel of a batch honours the flag, the stopping clock kernel left the slots alone):
     // the state of step nStep0 + r is the last one written, its CFL maxima are still in the slots, its ghost cells as its kernels left them

@@ -36,6 +36,21 @@ struct ClockConst {
   int rot, shear;
 };
 
+// The clock of a step INSIDE the step kernel (the fused 2D steps, 20-50 us each, where a clock kernel of its own is 10 % of the step):
+// every workgroup folds the CFL maxima of the input state itself -- `in`, RG_DT_SLOTS values, L2-resident -- and forms the same
+// record (the maximum is exact, so all workgroups get the same doubles); workgroup 0 writes it to `out` (for the host, and for the
+// next step's t) and zeroes `zero`, the slot array the NEXT step accumulates into.  Three slot arrays rotate: step n reads S[n % 3],
+// accumulates the maxima of the state it writes into S[(n + 1) % 3] (zeroed by step n - 1) and zeroes S[(n + 2) % 3] (read by step
+// n - 1, which is complete).  out == 0: no fold (the kernel takes its by-value arguments, or a record through `clk`).
+struct ClockFold {
+  const StepClock* prev;            // record of the previous step of the batch (0: the batch starts at t0)
+  StepClock* out;
+  const unsigned long long* in;
+  unsigned long long* zero;
+  ClockConst k;
+  double t0, tEnd;
+};
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
