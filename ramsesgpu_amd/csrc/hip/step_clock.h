@@ -73,6 +73,14 @@ __device__ __forceinline__ StepClock clock_fold(const ClockFold& f, double* red)
   return r;
 }
 
+// a double that every lane of the wave holds alike, moved to scalar registers (the record formed by clock_fold is computed on the
+// vector unit; the kernels keep dt, dt/dx .. for their whole life, and their vector register file is what limits them)
+__device__ __forceinline__ double rg_uniform(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 inline bool step_clock_fold_enabled() { static const bool on = !std::getenv("RGPU_NO_CLOCK_FOLD"); return on; }
 inline bool step_clock_supported() { return tiled_enabled() && !std::getenv("RGPU_NO_STEP_CLOCK"); }
 inline int launch_step_clock(rg_stream_t s, unsigned long long* slots, const ClockConst& k, double t0, double tEnd, const StepClock* prev, StepClock* out) {

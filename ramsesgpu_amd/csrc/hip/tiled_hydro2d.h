@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(TX * TY) hydro2d_step_kernel(DevParams g, int 
     __shared__ double Lred[TX * TY / 64];
     const StepClock r = clock_fold<TX * TY>(fold, Lred);
     if (r.stop) return;
-    dtdx = r.dtdx; dtdy = r.dtdy;
+    dtdx = rg_uniform(r.dtdx); dtdy = rg_uniform(r.dtdy);
   } else if (clk) {   // the time step lives on the device (hip/step_clock.h)
     if (clk->stop) return;
     dtdx = clk->dtdx; dtdy = clk->dtdy;

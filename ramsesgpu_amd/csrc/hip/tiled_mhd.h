@@ -24,6 +24,7 @@
 // expressions, same operand order, same bits.
 #pragma once
 #include "tiled_hydro.h"
+#include "step_clock.h"   // clock_fold: the clock of a rotating-path step is part of its (first) sweep launch
 
 namespace rgpu_tiled {
 
@@ -39,6 +40,26 @@ constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E
 constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
 constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
 constexpr int MH_THREADS = 512;
+// Loop-invariant per-thread decodes that the compiler hoists out of the z march into VGPRs -- which traced cell is mine (LDS addresses
+// of three passes), the x position of my Riemann cell, which of the 512 edge values is mine -- can instead be recomputed every plane
+// from an opaque copy of the lane index (a dozen integer instructions per plane against ~3000).  With the one-loop form of the
+// contracted build the register file is full: with the first two recomputed the kernel has no spill left (round 4: 2 VGPRs / 12 B
+// of scratch, reloaded five times per plane; with the clock fold of round 5: 6 / 28 B); the exact build (one loop per wave role, 249
+// VGPRs, no spill) does not need them.
+#ifndef RG_E_DECODE_PER_PLANE
+#define RG_E_DECODE_PER_PLANE 0
+#endif
+#ifdef RG_ARITH_FAST
+#define RG_DECODE_DEFAULT 1
+#else
+#define RG_DECODE_DEFAULT 0
+#endif
+#ifndef RG_XPOS_PER_PLANE
+#define RG_XPOS_PER_PLANE RG_DECODE_DEFAULT
+#endif
+#ifndef RG_TRACE_DECODE_PER_PLANE
+#define RG_TRACE_DECODE_PER_PLANE RG_DECODE_DEFAULT
+#endif
 #ifndef RG_SWEEP_SPLIT_LOOPS   // main loop of the sweep once per wave role (1) or once for all waves (0): see mhd3d_sweep_kernel
 #ifdef RG_ARITH_FAST
 #define RG_SWEEP_SPLIT_LOOPS 0
@@ -138,9 +159,14 @@ template <int SPEC>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
-                                                               const StepClock* clk) {
+                                                               const StepClock* clk, ClockFold fold) {
   spec_assume<SPEC>(g);
-  if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
+  if (fold.out) {   // rotating path, first sweep launch of a step: the clock of the step is part of this kernel (step_clock.h: clock_fold)
+    __shared__ double Lred[MH_THREADS / 64];
+    const StepClock r = clock_fold<MH_THREADS>(fold, Lred);
+    if (r.stop) return;
+    dt = rg_uniform(r.dt); dtdx = rg_uniform(r.dtdx); dtdy = rg_uniform(r.dtdy); dtdz = rg_uniform(r.dtdz);
+  } else if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
     if (clk->stop) return;
     dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy; dtdz = clk->dtdz;
   }
@@ -318,13 +344,19 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #define RG_TRACE_ON tracing
 #define RG_RIEMANN_ON (fl_ok && kk >= sa - 1)
 #endif
+#if RG_TRACE_DECODE_PER_PLANE
+#define RG_TRACE_LANE(v) int v = lane; asm volatile("" : "+v"(v));
+#else
+#define RG_TRACE_LANE(v) const int v = lane;
+#endif
 #define RG_PRODUCER_PLANE(kk, nit) {                                                                                     \
     const bool more = kk + 3 <= sb;                                                                                      \
     const bool tracing = kk + 1 < sb;                                                                                    \
     if (more) prim_load(kk + 3);                                                                                         \
     if (RG_TRACE_ON) {                                                                                                   \
-      if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }        \
-      else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);                                                                \
+      RG_TRACE_LANE(tl)                                                                                                  \
+      if (pid == 0) { trace_cell(kk + 1, tl, E_NWAVES * nit); trace_cell(kk + 1, 128 + tl, E_NWAVES * nit); }            \
+      else trace_cell(kk + 1, 64 + tl, E_NWAVES * nit);                                                                  \
     }                                                                                                                    \
     if (more) {                                                                                                          \
       prim_compute();                                                                                                    \
@@ -334,8 +366,18 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   }
   // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
   //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-#define RG_E_STEP(kk) if (ethread >= 0) { const bool tracing_e = kk + 1 < sb;                                            \
-    if (tracing_e) elec_plane(kk + 2, ethread, E_NTHREADS);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */   \
+#if RG_XPOS_PER_PLANE   /* x position of the thread's cell: two VGPRs for the whole march, or four integer / fp instructions per plane */
+#define RG_XPOS(v) int xl_ = lane; asm volatile("" : "+v"(xl_)); const double v = g.xMin + g.dx / 2 + (i0 + (xl_ & (MH_OX - 1)) - gw) * g.dx;
+#else
+#define RG_XPOS(v) const double v = xPos;
+#endif
+#if RG_E_DECODE_PER_PLANE
+#define RG_E_FIRST(v) int v = ethread; asm volatile("" : "+v"(v));
+#else
+#define RG_E_FIRST(v) const int v = ethread;
+#endif
+#define RG_E_STEP(kk) if (ethread >= 0) { const bool tracing_e = kk + 1 < sb; RG_E_FIRST(e_first)                        \
+    if (tracing_e) elec_plane(kk + 2, e_first, E_NTHREADS);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */   \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                               \
     if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
@@ -346,9 +388,10 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       const bool solve = kk >= sa;                                                                                       \
       const bool raise = prio_mode && solve && wave >= 4;                                                                \
       if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
-      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                             \
-      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                        \
-      else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);                                      \
+      RG_XPOS(xp)                                                                                                        \
+      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                               \
+      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                          \
+      else riemann_dir<ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                                        \
     }                                                                                                                    \
   }
 #ifdef RG_SWEEP_PROF
@@ -391,8 +434,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #else
       if (tracing) {
 #endif
-        if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }
-        else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);
+        RG_TRACE_LANE(tl)
+        if (pid == 0) { trace_cell(kk + 1, tl, E_NWAVES * nit); trace_cell(kk + 1, 128 + tl, E_NWAVES * nit); }
+        else trace_cell(kk + 1, 64 + tl, E_NWAVES * nit);
       }
       if (more) {
         prim_compute();
@@ -415,9 +459,10 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         if (raise) __builtin_amdgcn_s_setprio(1);
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
-        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<ZD>(g, Tk, cm, xPos, F, emf, idx, c0, c1, solve, raise);
+        RG_XPOS(xp)
+        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        else riemann_dir<ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }
@@ -479,8 +524,10 @@ struct K_copy_periodic_layer {
 // knows the boundary conditions)
 template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
-                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save) {
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save, const ClockFold* fold_in) {
   TileGrid tg;
+  ClockFold fold;
+  if (fold_in) fold = *fold_in; else { fold.prev = 0; fold.out = 0; fold.in = 0; fold.zero = 0; fold.t0 = 0.0; fold.tEnd = 0.0; }
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
   tg.nbx = (g.isize - 2 * g.gw + 1 + MH_SX - 1) / MH_SX;   // cells gw .. isize-gw
@@ -494,7 +541,7 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
   tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
   hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
-                     dt, dtdx, dtdy, dtdz, ra, rb, clk);
+                     dt, dtdx, dtdy, dtdz, ra, rb, clk, fold);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
   if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)(rb - ra); const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
@@ -523,12 +570,12 @@ inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
                        double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0,
-                       double* shear_save = 0) {
+                       double* shear_save = 0, const ClockFold* fold = 0) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
 }
 
 }  // namespace rgpu_tiled

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, 
     __shared__ double Lred[M2_THREADS / 64];
     const StepClock r = clock_fold<M2_THREADS>(fold, Lred);
     if (r.stop) return;
-    dt = r.dt; dtdx = r.dtdx; dtdy = r.dtdy;
+    dt = rg_uniform(r.dt); dtdx = rg_uniform(r.dtdx); dtdy = rg_uniform(r.dtdy);
   } else if (clk) {   // the time step lives on the device (hip/step_clock.h): a batch of steps queued without a host round trip
     if (clk->stop) return;
     dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy;

@@ -68,7 +68,7 @@ struct rgpu_ctx {
   // fused 2D steps: the clock is folded into the step kernel itself (step_clock_rec.h: ClockFold) over three rotating slot arrays;
   // d_red always points at the array that holds the maxima of the current state
   unsigned long long* d_red_base;   // 3 x RG_DT_SLOTS
-  bool fold_mode; int fold_phase0; ClockFold fold; unsigned long long* fold_acc;
+  bool fold_mode, fold_pending; int fold_phase0; ClockFold fold;
   std::string err;
 };
 
@@ -232,7 +232,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   c->G = 0;
   c->Frc = 0;
   c->ou = 0;
-  c->d_red = 0; c->d_red_base = 0; c->fold_mode = false; c->fold_phase0 = 0; c->fold_acc = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0; c->clk_n = -1; c->clk_t0 = 0.0; c->clk_tEnd = 0.0;
+  c->d_red = 0; c->d_red_base = 0; c->fold_mode = false; c->fold_pending = false; c->fold_phase0 = 0; c->h_red = 0; c->d_clk = 0; c->h_clk = 0; c->clk_cur = 0; c->clk_n = -1; c->clk_t0 = 0.0; c->clk_tEnd = 0.0;
   c->scratch_bytes = 0;
   c->timers_on = false; c->ev_ok = false;
   for (int i = 0; i < RGPU_T_COUNT; ++i) { c->t_acc[i] = 0; c->t_calls[i] = 0; }
@@ -602,8 +602,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
   // modifies the state afterwards (2D: the fused step or the flat update kernel; 3D with a per-cell gravity field: the flat one)
   static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
   const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
-  const bool folding = c->clk_cur && c->fold_mode;   // 2D batch: the clock is part of this step's kernel (ClockFold)
-  unsigned long long* slots = scan2 ? (folding ? c->fold_acc : c->d_red) : 0;
+  const bool folding = c->clk_cur && c->fold_mode && c->fold_pending;   // 2D batch: the clock is part of this step's kernel (ClockFold)
+  unsigned long long* slots = scan2 ? c->d_red : 0;
   if (st.clk && !(ND == 2 && scan2)) return -1;   // a device-clock step is a fused kernel with the CFL term or nothing
   if (scan2 && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
   if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
@@ -620,7 +620,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
       }
     }
     const int rc = rgpu_tiled::hydro2d_step(c->stream, g, in, out, dtdx, dtdy, slots, images, folding ? 0 : st.clk, folding ? &c->fold : 0);
-    if (rc == 0 && folding) c->d_red = c->fold_acc;   // the maxima of the state just written
+    if (rc == 0 && folding) c->fold_pending = false;
     if (rc == 0 && scan2) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
     if (rc == 0 && images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
     if (rc <= 0) return rc;
@@ -708,12 +708,12 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
         static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
         bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
-        const bool folding = c->clk_cur && c->fold_mode;   // 2D batch: the clock is part of this step's kernel (ClockFold)
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? (folding ? c->fold_acc : c->d_red) : 0, images ? 1 : 0,
+        const bool folding = c->clk_cur && c->fold_mode && c->fold_pending;   // 2D batch: the clock is part of this step's kernel (ClockFold)
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0,
                                                            folding ? 0 : st.clk, folding ? &c->fold : 0);
         if (rct < 0) return -1;
         if (rct == 0) {
-          if (folding) c->d_red = c->fold_acc;   // the maxima of the state just written
+          if (folding) c->fold_pending = false;
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
           if (images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
           return 0;
@@ -815,7 +815,12 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
       if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     }
     // shearing box: the launch that copies the periodic y layer also saves the emfY border columns of these planes for the remap
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0);
+    // inside a batch whose clock is folded into the kernels (rotating path: the sweep is the first kernel of the step): the first sweep
+    // launch of the step folds and writes the record, every later kernel of the step reads it
+    const bool folding = st.clk && c->fold_mode && c->fold_pending;
+    if (folding) c->fold_pending = false;
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, folding ? 0 : st.clk, shear ? c->shear_save : 0,
+                                                         folding ? &c->fold : 0);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
@@ -1698,7 +1703,11 @@ int rgpu_clock_open(rgpu_ctx* c, double t0, double tEnd) {
         rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(StepClock))) return RG_HIPFAIL(c, "clock_open: records");
   }
   c->clk_n = 0; c->clk_t0 = t0; c->clk_tEnd = tEnd; c->clk_cur = 0;
-  c->fold_mode = !RG_SYNC_LAUNCH && !c->g.three_d && rgpu_tiled::step_clock_fold_enabled();
+  // the clock is folded into the FIRST kernel of a step where that kernel is one of the cooperative ones: the fused 2D steps, and the
+  // 3D MHD sweep on the rotating path (ghost fill at the END of the step; the plain path starts with the ghost fill of its input)
+  c->fold_mode = !RG_SYNC_LAUNCH && rgpu_tiled::step_clock_fold_enabled() &&
+                 (!c->g.three_d || (c->p.mhdEnabled && c->g.rot && rgpu_tiled::mhd3d_sweep_covers(c->g)));
+  c->fold_pending = false;
   if (c->fold_mode) {   // the two slot arrays the first steps accumulate into / zero: clean (the host loop uses one array at a time)
     c->fold_phase0 = (int)((c->d_red - c->d_red_base) / RG_DT_SLOTS);
     for (int q = 1; q <= 2; ++q)
@@ -1715,7 +1724,10 @@ int rgpu_clock_tick(rgpu_ctx* c) {
   if (c->fold_mode) {   // no launch: the step kernel that follows folds, forms and writes the record itself
     const int ph = (int)((c->d_red - c->d_red_base) / RG_DT_SLOTS);
     c->fold.prev = n ? c->d_clk + n - 1 : 0; c->fold.out = c->d_clk + n;
-    c->fold.in = c->d_red; c->fold_acc = c->d_red_base + ((ph + 1) % 3) * RG_DT_SLOTS; c->fold.zero = c->d_red_base + ((ph + 2) % 3) * RG_DT_SLOTS;
+    // the step reads the maxima of its input from the current array and accumulates those of its output into the next one -- which
+    // d_red names from here on (the step's update kernels, the slab driver's all-reduce before the next tick)
+    c->fold.in = c->d_red; c->d_red = c->d_red_base + ((ph + 1) % 3) * RG_DT_SLOTS; c->fold.zero = c->d_red_base + ((ph + 2) % 3) * RG_DT_SLOTS;
+    c->fold_pending = true;
     c->fold.k = clock_const(c); c->fold.t0 = c->clk_t0; c->fold.tEnd = c->clk_tEnd;
     c->clk_cur = c->d_clk + n;
     c->clk_n = n + 1;
