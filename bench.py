@@ -336,10 +336,21 @@ class Control:
             import torch.distributed as dist
             self.dist = dist
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            self.backend = os.environ.get("RGPU_BENCH_BACKEND", "nccl")
+            # Control plane = gloo by default (round 5): it carries 128 bytes, a few python objects and the barriers around the timed region,
+            # all on the host; the ONE RCCL communicator of the process is then the slab driver's own (a second one -- torch's NCCL process
+            # group -- would share the device's CUs and queues with it for no benefit, and that pairing has never run anywhere).
+            # RGPU_BENCH_BACKEND=nccl selects torch's RCCL group instead; if gloo cannot be set up it is the fallback.
+            self.backend = os.environ.get("RGPU_BENCH_BACKEND", "gloo")
+            if self.backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node (the contract's launch line): the loopback interface
+                try:
+                    dist.init_process_group("gloo")
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("bench.py: gloo control plane failed (%r), using torch's nccl group\n" % (e,))
+                    self.backend = "nccl"
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:
+            elif self.backend != "gloo":
                 dist.init_process_group(self.backend)
 
     def _dev(self):
@@ -503,7 +514,18 @@ def slab_driver_run(arith, ini, ov, rank, world, ctl):
     err, srun, info = None, None, None
     try:
         L = Library(lib_path(arith))
-        CL = rcomm.load_comm_library(rcomm.comm_lib_path(arith))
+        if os.environ.get("RGPU_BENCH_DRIVER") == "staged-test":
+            # TEST HOOK (tests/test_bench_contract.py): the product's C++ driver compiled against the test-only device-staged transport
+            # (tests/emu_dev/rg_transport.h: RCCL's wire replaced by pinned host buffers + gloo), so that the N > 1 line -- schedule,
+            # batched time loop, fingerprint -- can be produced by several ranks on ONE GPU and compared with the N = 1 line
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import comm_worker as cw
+            CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_dev%s.so" % ("" if arith == "exact" else "_fast")))
+            keep = [cw.EXCHANGE_FN(cw._exchange), cw.ALLREDUCE_FN(cw._allreduce)]
+            CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+            CL._keep_callbacks = keep
+        else:
+            CL = rcomm.load_comm_library(rcomm.comm_lib_path(arith))
         cid = ctl.bcast(rcomm.unique_id(CL) if rank == 0 else None)
         srun = rcomm.CommRun(ini, ov, rank, world, cid, library=L, comm_library=CL)
     except Exception as e:  # noqa: BLE001 -- reported by the caller, on every rank
@@ -641,7 +663,8 @@ def main():
             step, timers_src = srun.oneStepIntegration, srun.solver
             slab_batch = srun.run_steps      # rgpu_comm_run_steps: the K timed steps as ONE call, the time step on the device between them
             sched = {"2": "2 (boundary-first)"}.get(os.environ.get("RGPU_COMM_SCHEDULE", ""), "1 (overlap)")
-            driver = "C++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
+            driver = "%sC++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
+                "TEST TRANSPORT (RGPU_BENCH_DRIVER=staged-test) -- " if os.environ.get("RGPU_BENCH_DRIVER") == "staged-test" else "",
                 "" if args.arith == "exact" else "_fast", info["transport"], sched,
                 "in-place (one send / recv per variable and face)" if os.environ.get("RGPU_COMM_PACK") == "0" else "packed (one send / recv per peer)", srun.halo_bytes() / 1e6)
         dts = []
@@ -695,7 +718,7 @@ def main():
         if info is not None:   # every rank must have seen the same communicator size, and one device each
             sizes = sorted(set(r.get("rccl_ranks") for r in ranks))
             buses = [r.get("rccl_pci_bus_id") for r in ranks]
-            if sizes != [world] or len(set(buses)) != world:
+            if sizes != [world] or (len(set(buses)) != world and os.environ.get("RGPU_BENCH_DRIVER") != "staged-test"):
                 if rank == 0:
                     sys.stderr.write("bench.py: RCCL saw communicator sizes %s for WORLD_SIZE=%d, devices %s\n" % (sizes, world, buses))
                 ctl.close()

@@ -24,7 +24,6 @@
 // expressions, same operand order, same bits.
 #pragma once
 #include "tiled_hydro.h"
-#include "step_clock.h"   // clock_fold: the clock of a rotating-path step is part of its (first) sweep launch
 
 namespace rgpu_tiled {
 
@@ -159,14 +158,9 @@ template <int SPEC>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
-                                                               const StepClock* clk, ClockFold fold) {
+                                                               const StepClock* clk) {
   spec_assume<SPEC>(g);
-  if (fold.out) {   // rotating path, first sweep launch of a step: the clock of the step is part of this kernel (step_clock.h: clock_fold)
-    __shared__ double Lred[MH_THREADS / 64];
-    const StepClock r = clock_fold<MH_THREADS>(fold, Lred);
-    if (r.stop) return;
-    dt = rg_uniform(r.dt); dtdx = rg_uniform(r.dtdx); dtdy = rg_uniform(r.dtdy); dtdz = rg_uniform(r.dtdz);
-  } else if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
+  if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
     if (clk->stop) return;
     dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy; dtdz = clk->dtdz;
   }
@@ -524,10 +518,8 @@ struct K_copy_periodic_layer {
 // knows the boundary conditions)
 template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
-                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save, const ClockFold* fold_in) {
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save) {
   TileGrid tg;
-  ClockFold fold;
-  if (fold_in) fold = *fold_in; else { fold.prev = 0; fold.out = 0; fold.in = 0; fold.zero = 0; fold.t0 = 0.0; fold.tEnd = 0.0; }
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
   tg.nbx = (g.isize - 2 * g.gw + 1 + MH_SX - 1) / MH_SX;   // cells gw .. isize-gw
@@ -541,7 +533,7 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
   tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
   hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
-                     dt, dtdx, dtdy, dtdz, ra, rb, clk, fold);
+                     dt, dtdx, dtdy, dtdz, ra, rb, clk);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
   if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)(rb - ra); const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
@@ -570,12 +562,12 @@ inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
                        double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0,
-                       double* shear_save = 0, const ClockFold* fold = 0) {
+                       double* shear_save = 0) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, fold);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
 }
 
 }  // namespace rgpu_tiled

@@ -63,14 +63,9 @@ struct F2LdsRead {
 template <int SPEC>
 __global__ void __launch_bounds__(M2_THREADS, 2) mhd2d_step_kernel(DevParams g, RotCoef rc, int nbx, const double* __restrict__ U,
                                                                    double* __restrict__ Unew, double dt, double dtdx, double dtdy,
-                                                                   unsigned long long* dt_slots, int images, const StepClock* clk, ClockFold fold) {
+                                                                   unsigned long long* dt_slots, int images, const StepClock* clk) {
   spec_assume<SPEC>(g);
-  if (fold.out) {   // the clock of this step is part of the kernel: fold the maxima of the input state, form dt, t, "t < tEnd" (step_clock.h)
-    __shared__ double Lred[M2_THREADS / 64];
-    const StepClock r = clock_fold<M2_THREADS>(fold, Lred);
-    if (r.stop) return;
-    dt = rg_uniform(r.dt); dtdx = rg_uniform(r.dtdx); dtdy = rg_uniform(r.dtdy);
-  } else if (clk) {   // the time step lives on the device (hip/step_clock.h): a batch of steps queued without a host round trip
+  if (clk) {   // the time step lives on the device (hip/step_clock.h): a batch of steps queued without a host round trip
     if (clk->stop) return;
     dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy;
   }
@@ -207,17 +202,15 @@ template <int SPEC_PLAIN>
 // images != 0 (caller: all four faces periodic, nx, ny >= ghost width, nothing modifies the new state after this kernel): the
 // interior cells also write their periodic images, i.e. the output's ghost cells are valid on return
 inline int mhd2d_step(rg_stream_t s, const DevParams& g, const RotCoef& rc, bool spec_plain, const double* U, double* Unew, double dt,
-                      unsigned long long* dt_slots, int images, const StepClock* clk = 0, const ClockFold* fold_in = 0) {
+                      unsigned long long* dt_slots, int images, const StepClock* clk = 0) {
   if (!mhd2d_step_covers(g)) return 1;
-  ClockFold fold;
-  if (fold_in) fold = *fold_in; else { fold.prev = 0; fold.out = 0; fold.in = 0; fold.zero = 0; fold.t0 = 0.0; fold.tEnd = 0.0; }
   const int nbx = (g.isize - 2 * g.gw + 1 + M2_OX - 1) / M2_OX;   // cells gw .. isize-gw (the CT layer included)
   const int nby = (g.jsize - 2 * g.gw + 1 + M2_OY - 1) / M2_OY;
   const double dtdx = dt / g.dx, dtdy = dt / g.dy;
   if (spec_plain)
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk, fold);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_PLAIN>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk);
   else
-    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk, fold);
+    hipLaunchKernelGGL((mhd2d_step_kernel<SPEC_NONE>), dim3((unsigned)(nbx * nby)), dim3(M2_THREADS), 0, s, g, rc, nbx, U, Unew, dt, dtdx, dtdy, dt_slots, images, clk);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -708,12 +708,9 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
         static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
         bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
-        const bool folding = c->clk_cur && c->fold_mode && c->fold_pending;   // 2D batch: the clock is part of this step's kernel (ClockFold)
-        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0,
-                                                           folding ? 0 : st.clk, folding ? &c->fold : 0);
+        const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, st.clk);
         if (rct < 0) return -1;
         if (rct == 0) {
-          if (folding) c->fold_pending = false;
           if (scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = RG_DT_SLOTS; }
           if (images) c->ghost_ok_parity = (out == c->U[0]) ? 0 : 1;
           return 0;
@@ -815,12 +812,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
       if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     }
     // shearing box: the launch that copies the periodic y layer also saves the emfY border columns of these planes for the remap
-    // inside a batch whose clock is folded into the kernels (rotating path: the sweep is the first kernel of the step): the first sweep
-    // launch of the step folds and writes the record, every later kernel of the step reads it
-    const bool folding = st.clk && c->fold_mode && c->fold_pending;
-    if (folding) c->fold_pending = false;
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, folding ? 0 : st.clk, shear ? c->shear_save : 0,
-                                                         folding ? &c->fold : 0);
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
@@ -1703,10 +1695,15 @@ int rgpu_clock_open(rgpu_ctx* c, double t0, double tEnd) {
         rg_host_alloc((void**)&c->h_clk, rgpu_ctx::kClockBatch * sizeof(StepClock))) return RG_HIPFAIL(c, "clock_open: records");
   }
   c->clk_n = 0; c->clk_t0 = t0; c->clk_tEnd = tEnd; c->clk_cur = 0;
-  // the clock is folded into the FIRST kernel of a step where that kernel is one of the cooperative ones: the fused 2D steps, and the
-  // 3D MHD sweep on the rotating path (ghost fill at the END of the step; the plain path starts with the ghost fill of its input)
-  c->fold_mode = !RG_SYNC_LAUNCH && rgpu_tiled::step_clock_fold_enabled() &&
-                 (!c->g.three_d || (c->p.mhdEnabled && c->g.rot && rgpu_tiled::mhd3d_sweep_covers(c->g)));
+  // The clock folded into the step kernel itself (ClockFold): the fused 2D HYDRO step on grids of at most two rounds of resident
+  // workgroups.  Measured (profiles/r05_2d_clock_fold.txt): Kelvin-Helmholtz 512^2 (1369 workgroups) 0.0210 -> 0.0197 ms per step; but
+  // every workgroup pays the fold (1024 slot reads, a barrier, the record) -- Orszag-Tang 512^2 (2145 workgroups of the MHD kernel)
+  // 0.0439 -> 0.0458, 4096^2 +15 % -- and in the 3D MHD sweep (tried on the rotating path) the extra kernel argument alone moved the
+  // register allocation of the z march: 25.1 -> 25.6 ms at 512^3.  Everything else keeps the one-workgroup clock kernel.
+  {
+    const int nwg = ((c->g.isize - 1 + 13) / 14) * ((c->g.jsize - 1 + 13) / 14);   // 16 x 16 thread tiles, 14 x 14 owned cells (tiled_hydro2d.h)
+    c->fold_mode = !RG_SYNC_LAUNCH && rgpu_tiled::step_clock_fold_enabled() && !c->g.three_d && !c->p.mhdEnabled && nwg <= 2 * 768;
+  }
   c->fold_pending = false;
   if (c->fold_mode) {   // the two slot arrays the first steps accumulate into / zero: clean (the host loop uses one array at a time)
     c->fold_phase0 = (int)((c->d_red - c->d_red_base) / RG_DT_SLOTS);

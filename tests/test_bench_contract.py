@@ -81,6 +81,26 @@ def test_bench_two_ranks_through_the_launch_line(gpu_lib):
     assert "TEST HARNESS" in d["config"]["driver"] and d["config"]["rccl_ranks"] is None and len(d["config"]["ranks"]) == 2
 
 
+def test_bench_fingerprint_of_two_ranks_equals_the_single_device_line(gpu_lib, gpu_contracted_lib):
+    """the N > 1 bench line through the product's C++ slab driver (schedule, rgpu_comm_run_steps, fingerprint) -- with the test-only
+    device-staged transport in place of RCCL's wire, two ranks on the one GPU -- carries the SAME config.fingerprint (dt-sequence hash +
+    state checksum) as the N = 1 line of the same box, steps and warmup, for both arithmetics: what makes the driver's SCALE lines checkable"""
+    from test_comm_device import build_dev_comm
+    build_dev_comm("exact"); build_dev_comm("contracted")
+    two = launch_two_ranks(dict(RGPU_BENCH_ONE_DEVICE="1", RGPU_BENCH_DRIVER="staged-test"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = last_json(two.stdout)
+    assert "TEST TRANSPORT" in d2["config"]["driver"] and d2["n_gpus"] == 2 and "took their time step from the device" in d2["config"]["time_loop"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--nx", "32", "--ny", "48", "--nz", "32",
+                          "--no-cpu-baseline", "--no-other-workloads"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = last_json(one.stdout)
+    for key in ("dt_sha256", "state_sum_u64", "steps"):
+        assert d2["config"]["fingerprint"][key] == d1["config"]["fingerprint"][key], (key, d2["config"]["fingerprint"], d1["config"]["fingerprint"])
+        assert d2["value_exact"]["fingerprint"][key] == d1["value_exact"]["fingerprint"][key], (key, d2["value_exact"]["fingerprint"], d1["value_exact"]["fingerprint"])
+    assert d1["config"]["fingerprint"]["state_sum_u64"] != d1["value_exact"]["fingerprint"]["state_sum_u64"]      # (two arithmetics, two states)
+
+
 def test_bench_default_driver_fails_cleanly_with_two_ranks_on_one_device(gpu_lib):
     """default driver = the C++ RCCL one, no fallback: two ranks on the box's one GPU make ncclCommInitRank fail; every rank
     reports it and exits non-zero, no JSON line is printed (what a misconfigured 8-GPU launch would look like)"""
