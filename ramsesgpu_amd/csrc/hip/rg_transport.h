@@ -31,6 +31,10 @@ struct Comm {
   // kernel on the halo stream spinning on the constant-rate clock (round 4: a hipLaunchHostFunc sleep did NOT hold the stream on
   // ROCm 7.0 -- a 51 ms "link" left the step time unchanged, gpurun_out/r4c/knob.log).
   double emulate_gbps; int emulate_peers; long long wall_khz;
+  // RGPU_COMM_EMULATE_MODE=parallel: the hold runs NEXT TO the device-local RCCL copy (on a stream of its own, joined before the
+  // unpack) instead of behind it -- on real links the copy IS the transfer, so the exchange takes max(local copy, link time), not
+  // their sum; "serial" (default, rounds 4-5 tables) double-counts the ~0.2 ms local copy
+  int emulate_parallel; hipStream_t hold_stream; hipEvent_t ev_hold0, ev_hold1;
   // Packed exchange (RGPU_COMM_PACK, default on): the chunks that go to one peer are gathered into ONE staging buffer by one small
   // kernel, sent / received as ONE operation per peer and direction, and scattered by a second kernel.  Round 4: RCCL turned the 32
   // in-place send / recv operations of one grouped exchange (a chunk per variable and face) into 8 kernel launches with ~40 us
@@ -60,6 +64,8 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   c->emulate_gbps = std::getenv("RGPU_COMM_EMULATE_GBPS") ? std::atof(std::getenv("RGPU_COMM_EMULATE_GBPS")) : 0.0;
   c->emulate_peers = std::getenv("RGPU_COMM_EMULATE_PEERS") ? std::atoi(std::getenv("RGPU_COMM_EMULATE_PEERS")) : 2;
   c->wall_khz = 0;
+  c->emulate_parallel = (std::getenv("RGPU_COMM_EMULATE_MODE") && std::strcmp(std::getenv("RGPU_COMM_EMULATE_MODE"), "parallel") == 0) ? 1 : 0;
+  c->hold_stream = 0; c->ev_hold0 = 0; c->ev_hold1 = 0;
   c->pack = !(std::getenv("RGPU_COMM_PACK") && std::atoi(std::getenv("RGPU_COMM_PACK")) == 0);
   c->stage_s = 0; c->stage_r = 0; c->stage_cap = 0;
   if (c->emulate_gbps > 0) {
@@ -80,6 +86,9 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&c->ev_done) != hipSuccess || hipEventCreate(&c->ev_begin) != hipSuccess) return fail(c, "events");
   if (hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) return fail(c, "scratch");
+  if (c->emulate_gbps > 0 && c->emulate_parallel &&
+      (hipStreamCreateWithPriority(&c->hold_stream, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&c->ev_hold0, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&c->ev_hold1, hipEventDisableTiming) != hipSuccess)) return fail(c, "hold stream");
   return 0;
 }
 
@@ -91,6 +100,9 @@ inline void destroy(Comm* c) {
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->ev_begin) (void)hipEventDestroy(c->ev_begin);
+  if (c->ev_hold0) (void)hipEventDestroy(c->ev_hold0);
+  if (c->ev_hold1) (void)hipEventDestroy(c->ev_hold1);
+  if (c->hold_stream) (void)hipStreamDestroy(c->hold_stream);
   if (c->halo) (void)hipStreamDestroy(c->halo);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
@@ -130,6 +142,15 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
   hipStream_t cs = (hipStream_t)compute_stream;
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
+  long long hold_ticks = 0;
+  if (c->emulate_gbps > 0) {   // measurement knob, see Comm
+    size_t sent = 0;
+    for (int i = 0; i < nops; ++i) if (ops[i].send) sent += ops[i].count * sizeof(double);
+    const double ns = (double)sent / (c->emulate_peers >= 2 ? 2.0 : 1.0) / c->emulate_gbps;   // bytes / (GB/s) = ns
+    hold_ticks = (long long)(ns * 1e-6 * (double)c->wall_khz);
+  }
+  const bool hold_beside = hold_ticks > 0 && c->emulate_parallel && c->hold_stream;
+  bool held = false;
   PackedExchange px;
   if (c->pack && build_packed(ops, nops, &px) == 0) {
     // per peer, in posting order: one region of the send stage and one of the receive stage (comm/pack_plan.h).  The stages were
@@ -138,6 +159,12 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
     const PackPlan& pl = px.pl;
     if (pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
     if (launch_pack(px, c->stage_s, c->halo)) return fail(c, "pack kernel");
+    if (hold_beside) {   // the emulated link time starts with the transfer
+      if (hipEventRecord(c->ev_hold0, c->halo) != hipSuccess || hipStreamWaitEvent(c->hold_stream, c->ev_hold0, 0) != hipSuccess) return fail(c, "hold fork");
+      hipLaunchKernelGGL(emulated_link_hold, dim3(1), dim3(1), 0, c->hold_stream, hold_ticks);
+      if (hipGetLastError() != hipSuccess || hipEventRecord(c->ev_hold1, c->hold_stream) != hipSuccess) return fail(c, "emulated_link_hold");
+      held = true;
+    }
     ncclResult_t r = ncclGroupStart();
     for (int q = 0; q < pl.npeers && r == ncclSuccess; ++q)
       if (pl.send_total[q]) r = ncclSend(c->stage_s + pl.send_base[q], pl.send_total[q], ncclDouble, pl.peer[q], c->comm, c->halo);
@@ -145,6 +172,7 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
       if (pl.recv_total[q]) r = ncclRecv(c->stage_r + pl.recv_base[q], pl.recv_total[q], ncclDouble, pl.peer[q], c->comm, c->halo);
     const ncclResult_t re = ncclGroupEnd();
     if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
+    if (hold_beside && hipStreamWaitEvent(c->halo, c->ev_hold1, 0) != hipSuccess) return fail(c, "hold join");
     if (launch_unpack(px, c->stage_r, c->halo)) return fail(c, "unpack kernel");
   } else {   // in place: one operation per chunk (rounds 1-3)
     ncclResult_t r = ncclGroupStart();
@@ -154,11 +182,8 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
     const ncclResult_t re = ncclGroupEnd();
     if (r != ncclSuccess || re != ncclSuccess) return fail(c, std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(r != ncclSuccess ? r : re));
   }
-  if (c->emulate_gbps > 0) {   // measurement knob, see Comm
-    size_t sent = 0;
-    for (int i = 0; i < nops; ++i) if (ops[i].send) sent += ops[i].count * sizeof(double);
-    const double ns = (double)sent / (c->emulate_peers >= 2 ? 2.0 : 1.0) / c->emulate_gbps;   // bytes / (GB/s) = ns
-    hipLaunchKernelGGL(emulated_link_hold, dim3(1), dim3(1), 0, c->halo, (long long)(ns * 1e-6 * (double)c->wall_khz));
+  if (hold_ticks > 0 && !held) {   // serial form: behind the device-local transfer (also the in-place exchange)
+    hipLaunchKernelGGL(emulated_link_hold, dim3(1), dim3(1), 0, c->halo, hold_ticks);
     if (hipGetLastError() != hipSuccess) return fail(c, "emulated_link_hold");
   }
   if (hipEventRecord(c->ev_done, c->halo) != hipSuccess) return fail(c, "event record");

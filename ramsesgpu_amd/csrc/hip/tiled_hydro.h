@@ -73,6 +73,10 @@ struct TileGrid {
   int ipx, full, tail;     // items per XCD; whole items per XCD; sub-segments per item of the last round (>= 1)
   int per_xcd;             // workgroups per XCD = full + (ipx - full) * tail
   int flags;               // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
+  // a second plane range of the SAME length in the same launch (the two boundary ranges of a slab): the kernel's [za, zb) is then
+  // the concatenation, 2 L planes long; planes at or beyond zsplit = za + L belong to the second range and lie zgap planes further
+  // up.  nseg is even, so no segment straddles the seam.  One range: zsplit = INT_MAX, zgap = 0.
+  int zsplit, zgap;
 };
 struct TileItem { int bx, by, sa, sb; bool valid; };
 // planes [sa, sb) of [za, zb) and the tile of block b
@@ -92,11 +96,26 @@ RG_DEVFN TileItem tile_item(const TileGrid& tg, int b, int za, int zb) {
   it.sa = a0 + (int)(((long long)(b0 - a0) * sub) / nsub);
   it.sb = a0 + (int)(((long long)(b0 - a0) * (sub + 1)) / nsub);
   if (it.sb <= it.sa) it.valid = false;
+  if (it.sa >= tg.zsplit) { it.sa += tg.zgap; it.sb += tg.zgap; }   // second range of a two-range launch
   return it;
 }
 // host: base segment count and tail split minimising the modelled duration (iterations of the z march; a segment costs
 // `fill` extra iterations), for `slots` resident workgroups per XCD
-inline void tile_grid_plan(TileGrid& tg, int span, int slots, int min_planes, int fill, int zseg_env) {
+// pair: the launch covers two ranges of `span` planes each (TileGrid::zsplit): twice the base segments of the one-range plan
+inline void tile_grid_plan(TileGrid& tg, int span, int slots, int min_planes, int fill, int zseg_env, bool pair = false) {
+  tg.zsplit = 0x7fffffff; tg.zgap = 0;
+  if (pair) {
+    TileGrid one = tg;
+    one.nby *= 2;   // as many items as two launches: the last-round split is planned for all of them
+    tile_grid_plan(one, span, slots, min_planes, fill, zseg_env, false);
+    tg.nseg = 2 * one.nseg;
+    const int items = tg.nbx * tg.nby * tg.nseg;
+    tg.ipx = (items + 7) / 8;
+    tg.full = (tg.ipx / slots) * slots;
+    tg.tail = (tg.ipx - tg.full) > 0 ? one.tail : 1;
+    tg.per_xcd = tg.full + (tg.ipx - tg.full) * tg.tail;
+    return;
+  }
   const int tiles = tg.nbx * tg.nby;
   int best_n = 1, best_tail = 1;
   double best = 1e300;
@@ -399,7 +418,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 
 template <int TX, int TY, int SPEC, int MINW = 1>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                                double dtdz, int za, int zb, unsigned long long* dslot = 0, const StepClock* clk = 0) {
+                                double dtdz, int za, int zb, unsigned long long* dslot = 0, const StepClock* clk = 0, int za2 = 0) {
   TileGrid tg;
   tg.flags = 0;
   tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
@@ -407,9 +426,11 @@ inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double*
   const int span = zb - za;
   static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
   // two workgroups are resident per CU (~200 VGPRs): 64 per XCD; a segment costs two extra iterations (pipeline fill)
-  tile_grid_plan(tg, span, 64, 12, 2, zseg_env);
+  const bool pair = za2 > 0;   // a second range [za2, za2 + span) in the same launch
+  tile_grid_plan(tg, span, 64, 12, 2, zseg_env, pair);
+  if (pair) { tg.zsplit = za + span; tg.zgap = za2 - (za + span); }
   hipLaunchKernelGGL((hydro3d_sweep_kernel<TX, TY, SPEC, MINW>), dim3(8u * (unsigned)tg.per_xcd), dim3(TX * TY), 0, s, g, tg, in, out,
-                     dtdx, dtdy, dtdz, za, zb, dslot, clk);
+                     dtdx, dtdy, dtdz, za, pair ? zb + span : zb, dslot, clk);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

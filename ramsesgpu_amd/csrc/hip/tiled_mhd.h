@@ -42,16 +42,17 @@ constexpr int MH_THREADS = 512;
 // Loop-invariant per-thread decodes that the compiler hoists out of the z march into VGPRs -- which traced cell is mine (LDS addresses
 // of three passes), the x position of my Riemann cell, which of the 512 edge values is mine -- can instead be recomputed every plane
 // from an opaque copy of the lane index (a dozen integer instructions per plane against ~3000).  With the one-loop form of the
-// contracted build the register file is full: with the first two recomputed the kernel has no spill left (round 4: 2 VGPRs / 12 B
-// of scratch, reloaded five times per plane; with the clock fold of round 5: 6 / 28 B); the exact build (one loop per wave role, 249
-// VGPRs, no spill) does not need them.
-#ifndef RG_E_DECODE_PER_PLANE
-#define RG_E_DECODE_PER_PLANE 0
-#endif
+// contracted build the register file is full: with them recomputed the kernel has no spill left (round 4: 2 VGPRs / 12 B of scratch,
+// reloaded five times per plane) at the same speed -- profiles/r05_sweep_variants.txt, 512^3 sweep: 25.00 / 25.17 ms with the
+// spills, 25.04 / 25.07 with all three decodes per plane, 25.5 with the first two only -- the kernel is issue-bound, not spill-bound.
+// The exact build (one loop per wave role, 249 VGPRs, no spill) does not need them.
 #ifdef RG_ARITH_FAST
 #define RG_DECODE_DEFAULT 1
 #else
 #define RG_DECODE_DEFAULT 0
+#endif
+#ifndef RG_E_DECODE_PER_PLANE
+#define RG_E_DECODE_PER_PLANE RG_DECODE_DEFAULT
 #endif
 #ifndef RG_XPOS_PER_PLANE
 #define RG_XPOS_PER_PLANE RG_DECODE_DEFAULT
@@ -488,13 +489,16 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 // shear_save != 0 (the shearing box; axis 1 launches only): the same launch also saves the two emfY border columns of planes
 // [k0, k0 + nk) for the flux / emf remap (shear_save_emf_cell, MHDRunGodunov.cpp:3203-3300) -- threads [n_copy, ...): one per (j, k).
 // The row j = jsize - gw they read is the layer being copied by the other threads: they take its source row instead.
+// Two plane ranges in one launch (the boundary ranges of a slab): planes k0 .. k0 + nk1 - 1, then k0b .. (nk1 < 0: one range).
 struct K_copy_periodic_layer {
   DevParams g; double* F; double* emf; int axis, k0;
   double* shear_save; unsigned n_copy; int copy_on;
+  int nk1, k0b;
+  RG_DEVFN unsigned plane(unsigned kk) const { return (nk1 >= 0 && (int)kk >= nk1) ? (unsigned)k0b + (kk - (unsigned)nk1) : (unsigned)k0 + kk; }
   RG_DEVFN void operator()(unsigned t) const {
     if (t >= n_copy) {
       const unsigned q = t - n_copy;
-      const unsigned j = q % (unsigned)g.jsize, k = (unsigned)k0 + q / (unsigned)g.jsize;
+      const unsigned j = q % (unsigned)g.jsize, k = plane(q / (unsigned)g.jsize);
       const unsigned js = (copy_on && (int)j == g.jsize - g.gw) ? (unsigned)g.gw : j;
       const size_t N = g.ncell, P = (size_t)g.jsize * g.ksize;
       const size_t row = (size_t)g.sj * js + (size_t)g.sk * k;
@@ -504,7 +508,7 @@ struct K_copy_periodic_layer {
       return;
     }
     const unsigned n = (axis == 1) ? (unsigned)g.isize : (unsigned)g.jsize;
-    const unsigned a = t % n, k = (unsigned)k0 + t / n;
+    const unsigned a = t % n, k = plane(t / n);
     const size_t N = g.ncell;
     size_t src, dst;
     if (axis == 1) { src = a + (size_t)g.sj * g.gw + (size_t)g.sk * k; dst = a + (size_t)g.sj * (g.jsize - g.gw) + (size_t)g.sk * k; }
@@ -518,7 +522,7 @@ struct K_copy_periodic_layer {
 // knows the boundary conditions)
 template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
-                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save) {
+                              double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save, int ra2) {
   TileGrid tg;
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
@@ -531,15 +535,21 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
   // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3: one base
   // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
-  tile_grid_plan(tg, span, 32, 8, 2, zseg_env);
+  // ra2 > 0: a second range [ra2, ra2 + span) of the same length in the same launch (TileGrid::zsplit) -- the boundary ranges of a
+  // slab in the boundary-first schedule: one launch, one last round of workgroups, instead of two
+  const bool pair = ra2 > 0;
+  const int nplanes = pair ? 2 * span : span;
+  tile_grid_plan(tg, span, 32, 8, 2, zseg_env, pair);
+  if (pair) { tg.zsplit = ra + span; tg.zgap = ra2 - (ra + span); }
   hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
-                     dt, dtdx, dtdy, dtdz, ra, rb, clk);
+                     dt, dtdx, dtdy, dtdz, ra, ra + nplanes, clk);
   if (hipGetLastError() != hipSuccess) return -1;
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
-  if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)(rb - ra); const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
+  const int nk1 = pair ? span : -1;
+  if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)nplanes; const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1, nk1, ra2}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
   if (copy_y || shear_save) {   // one launch: the y layer (all i) and, shearing box, the emfY border columns for the remap
-    const unsigned nc = copy_y ? (unsigned)g.isize * (unsigned)(rb - ra) : 0u, ns = shear_save ? (unsigned)g.jsize * (unsigned)(rb - ra) : 0u;
-    const K_copy_periodic_layer k = {g, F, emf, 1, ra, shear_save, nc, copy_y ? 1 : 0};
+    const unsigned nc = copy_y ? (unsigned)g.isize * (unsigned)nplanes : 0u, ns = shear_save ? (unsigned)g.jsize * (unsigned)nplanes : 0u;
+    const K_copy_periodic_layer k = {g, F, emf, 1, ra, shear_save, nc, copy_y ? 1 : 0, nk1, ra2};
     if (rgpu::rg_launch<256>(s, nc + ns, k)) return -1;
   }
   return 0;
@@ -562,12 +572,12 @@ inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rg_stream_t s, const DevParams& g, int spec, const double* U, double* F,
                        double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse = 0, const StepClock* clk = 0,
-                       double* shear_save = 0) {
+                       double* shear_save = 0, int ra2 = 0) {
   if (!mhd3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
   if (rb <= ra) return 0;
-  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
-  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
-  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save);
+  if (spec == 1) return launch_mhd3d_sweep<SPEC_MRI>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, ra2);
+  if (spec == 2) return launch_mhd3d_sweep<SPEC_PLAIN>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, ra2);
+  return launch_mhd3d_sweep<SPEC_NONE>(s, g, U, F, emf, dt, dtdx, dtdy, dtdz, ra, rb, reuse, clk, shear_save, ra2);
 }
 
 }  // namespace rgpu_tiled

@@ -206,6 +206,12 @@ struct K_shear_remap {
     shear_remap_cell(g, sr, F, emf, save, remap, dtdx, idx);
   }
 };
+// a functor over two disjoint index ranges in one launch: t < n1 -> k(first1 + t), else k(first2 + t - n1)
+template <class K>
+struct K_two_ranges {
+  K k; unsigned first1, n1, first2;
+  RG_DEVFN void operator()(unsigned t) const { k(t < n1 ? first1 + t : first2 + (t - n1)); }
+};
 // t = z segment * (isize * jsize) + column: one thread marches planes [k_lo + seg * seg_len, + seg_len) of [k_lo, k_hi)
 template <bool ROT, bool GF = false, int SPEC = SPEC_NONE>
 struct K_mhd_update3d {

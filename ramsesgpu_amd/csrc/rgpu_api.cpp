@@ -801,8 +801,17 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
     return launch_spec<K_riemann_t, kBlockHeavy>(spec, s, g, r, T, c->F, c->emf);
   };
   // LDS-tiled fused trace + Riemann sweep over the Riemann planes r (hip/tiled_mhd.h); 1 = not covered
-  auto sweep_planes = [&](rg_stream_t s, PlaneRange r) -> int {
+  // r2: a second range in the same launch (split calls on the two boundary ranges of a slab) -- taken when both ranges clip to the
+  // same number of planes; returns 2 when it was not (the caller launches range by range)
+  auto sweep_planes = [&](rg_stream_t s, PlaneRange r, PlaneRange r2 = PlaneRange{0, 0}) -> int {
     const int lo = r.lo < g.gw ? g.gw : r.lo, hi = r.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r.hi;
+    int lo2 = 0;
+    if (r2.hi > r2.lo) {
+      lo2 = r2.lo < g.gw ? g.gw : r2.lo;
+      const int hi2 = r2.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r2.hi;
+      static const bool no_pair = std::getenv("RGPU_NO_SWEEP_PAIR") != 0;
+      if (no_pair || hi <= lo || hi2 - lo2 != hi - lo || lo2 < hi) return 2;
+    }
     // periodic faces whose fluxes / EMFs are bit-identical copies of the opposite layer (see K_copy_periodic_layer): y when both
     // y faces are periodic; x when both x faces are periodic and the frame does not rotate (the rotating-frame terms carry xPos)
     static const bool no_reuse = std::getenv("RGPU_NO_PERIODIC_REUSE") != 0;
@@ -812,7 +821,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
       if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     }
     // shearing box: the launch that copies the periodic y layer also saves the emfY border columns of these planes for the remap
-    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0);
+    return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0, lo2);
   };
   // trace of planes [t_lo, t_hi) + Riemann problems of planes rf: fused when the backend covers the configuration
   const bool use_sweep = !gf && rgpu_tiled::mhd3d_sweep_covers(g);
@@ -825,12 +834,19 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   };
   K_shear_save_emf k_ssave = {g, c->emf, c->shear_save};
   K_shear_remap k_sremap = {g, sr, c->F, c->emf, c->shear_save, c->shear_remap, dtdx, st.clk};
-  auto shear_planes = [&](rg_stream_t s, PlaneRange r) -> int {  // the two 2D (j,k) kernels restricted to planes r
+  auto shear_planes = [&](rg_stream_t s, PlaneRange r, PlaneRange r2 = PlaneRange{0, 0}) -> int {  // the two 2D (j,k) kernels restricted to planes r (and r2)
     if (!shear || r.hi <= r.lo) return 0;
     if (use_sweep) {   // the sweep's closing launch saved the emfY columns of its planes: the remap of exactly those
       if (r.lo < g.gw) r.lo = g.gw;
       if (r.hi > ks - g.gw + 1) r.hi = ks - g.gw + 1;
       if (r.hi <= r.lo) return 0;
+      if (r2.hi > r2.lo) {   // both boundary ranges in one launch (after a two-range sweep)
+        if (r2.lo < g.gw) r2.lo = g.gw;
+        if (r2.hi > ks - g.gw + 1) r2.hi = ks - g.gw + 1;
+        const unsigned n1 = (unsigned)(r.hi - r.lo) * g.jsize, n2 = (unsigned)(r2.hi - r2.lo) * g.jsize;
+        K_two_ranges<K_shear_remap> k2 = {k_sremap, (unsigned)r.lo * g.jsize, n1, (unsigned)r2.lo * g.jsize};
+        return rg_launch<kBlock>(s, n1 + n2, k2);
+      }
       return rg_launch_range<kBlock>(s, (unsigned)r.lo * g.jsize, (unsigned)(r.hi - r.lo) * g.jsize, k_sremap);
     }
     const unsigned j0 = (unsigned)r.lo * g.jsize, jn = (unsigned)(r.hi - r.lo) * g.jsize;
@@ -882,7 +898,15 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   const bool pair = what != 0 && b2 > a2;
   if (serial) {
     rg_stream_t s = c->stream;
-    if (what != RGPU_CORE_UPDATE) {
+    bool fluxes_done = false;
+    if (what != RGPU_CORE_UPDATE && pair && use_sweep) {   // both boundary ranges: one launch of the sweep, one of the remap
+      Phase ph(c, RGPU_T_SWEEP);
+      const int rcs = sweep_planes(s, clip(a, b + 1, ks), clip(a2, b2 + 1, ks));
+      if (rcs < 0 || rcs == 1) return -1;
+      fluxes_done = rcs == 0;
+    }
+    if (fluxes_done) { Phase ph(c, RGPU_T_SHEAR); if (shear_planes(s, clip(a, b + 1, ks), clip(a2, b2 + 1, ks))) return -1; }
+    if (what != RGPU_CORE_UPDATE && !fluxes_done) {
       for (int n = 0; n < (pair ? 2 : 1); ++n) {
         const int lo = n ? a2 : a, hi = n ? b2 : b;
         if (!use_sweep) {   // the sweep computes primitives and electric field itself (in LDS)

@@ -38,7 +38,8 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
             assert run.run_steps(n) == n and run.clocked_steps() == n, run.clocked_steps()
         run.solver.synchronize(); dt = (time.time() - t0) / n
         link_ms = 0.0 if rate <= 0 else 8 * 518 * 518 * 3 * 8 * (2 if 512 // nz == 2 else 1) / rate / 1e6
+        mode = "%s" % ("link time beside the local copy" if os.environ.get("RGPU_COMM_EMULATE_MODE") == "parallel" else "link time behind the local copy") if rate > 0 else ""
         print("nz=%3d (N=%d) link %3g GB/s (%.2f ms per exchange) %-8s %7.2f ms/step  -> %6.0f Mcell/s per rank, x%d = %6.0f" % (nz, 512 // nz, rate, link_ms,
-              {None: "default", 2: "bnd-first", 1: "overlap", 0: "serial"}[overlap], dt * 1e3, 512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6), flush=True)
+              {None: "default", 2: "bnd-first", 1: "overlap", 0: "serial"}[overlap], dt * 1e3, 512 * 512 * nz / dt / 1e6, 512 // nz, 512 * 512 * 512 / dt / 1e6) + ("  [%s]" % mode if mode else ""), flush=True)
         run.close()
         cid = rcomm.unique_id(CL)

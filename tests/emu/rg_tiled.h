@@ -28,7 +28,7 @@ inline int hydro2d_step(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const dou
 inline bool step_clock_fold_enabled() { return false; }
 template <int SPEC_MRI, int SPEC_PLAIN>
 inline int mhd3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, int, const double*, double*, double*,
-                       double, double, double, double, int, int, int = 0, const StepClock* = 0, double* = 0) { return 1; }
+                       double, double, double, double, int, int, int = 0, const StepClock* = 0, double* = 0, int = 0) { return 1; }
 template <int SPEC_PLAIN>
 inline int mhd2d_step(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const rgpu_dev::RotCoef&, bool, const double*, double*, double,
                       unsigned long long*, int, const StepClock* = 0) { return 1; }
