@@ -81,10 +81,18 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
   if (r != ncclSuccess) return fail(c, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  // the exchange is short and on the critical path of the neighbours: highest priority
-  if (hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, hi) != hipSuccess) return fail(c, "halo stream");
+  // NORMAL priority (round 5).  Rounds 2-4 created the halo stream with the highest priority ("the exchange is short and on the
+  // critical path of the neighbours"): on this runtime a priority stream takes one of the process's few hardware queues for itself and
+  // the compute stream's kernels -- every one of them, the sweep included -- ran 5-9 % slower for as long as the communicator existed
+  // (N = 8 slab, no link hold: 4.97 -> 4.55 ms per step with normal priority, 4.61 with GPU_MAX_HW_QUEUES=8 and high priority;
+  // profiles/r05_halo_stream_priority.txt).  RGPU_HALO_PRIO=high|low for experiments.
+  int prio = 0;
+  if (const char* e = std::getenv("RGPU_HALO_PRIO")) prio = std::strcmp(e, "high") == 0 ? hi : std::strcmp(e, "low") == 0 ? lo : 0;
+  if (hipStreamCreateWithPriority(&c->halo, hipStreamNonBlocking, prio) != hipSuccess) return fail(c, "halo stream");
+  // ev_begin / ev_done carry time stamps (rgpu_comm_last_exchange_ms) unless RGPU_COMM_NO_TIMING=1 (ordering only)
+  const unsigned tflag = (std::getenv("RGPU_COMM_NO_TIMING") && std::atoi(std::getenv("RGPU_COMM_NO_TIMING"))) ? hipEventDisableTiming : hipEventDefault;
   if (hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreate(&c->ev_done) != hipSuccess || hipEventCreate(&c->ev_begin) != hipSuccess) return fail(c, "events");
+      hipEventCreateWithFlags(&c->ev_done, tflag) != hipSuccess || hipEventCreateWithFlags(&c->ev_begin, tflag) != hipSuccess) return fail(c, "events");
   if (hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) return fail(c, "scratch");
   if (c->emulate_gbps > 0 && c->emulate_parallel &&
       (hipStreamCreateWithPriority(&c->hold_stream, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&c->ev_hold0, hipEventDisableTiming) != hipSuccess ||

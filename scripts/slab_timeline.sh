@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 cat > /tmp/slab_tl.py <<PY
 import os, sys
 sys.path.insert(0, "$R")
-os.environ["RGPU_COMM_EMULATE_GBPS"] = "$RATE"; os.environ["RGPU_COMM_EMULATE_PEERS"] = "2"
+if float("$RATE") > 0: os.environ["RGPU_COMM_EMULATE_GBPS"] = "$RATE"; os.environ["RGPU_COMM_EMULATE_PEERS"] = "2"
 from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import load_library
 L = load_library(); CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))
@@ -18,10 +18,13 @@ run = rcomm.CommRun(ini, "mesh.nx=512;mesh.ny=512;mesh.nz=64", 0, 1, rcomm.uniqu
 assert run.halo_bytes() > 0
 run.init_simulation()
 for _ in range(2): run.oneStepIntegration()
-assert run.run_steps(10) == 10
+if os.environ.get("PROBE_HOST_LOOP"):
+    for _ in range(10): run.oneStepIntegration()
+else:
+    assert run.run_steps(10) == 10
 run.solver.synchronize(); run.close()
 PY
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr$SCHED -o b -- python /tmp/slab_tl.py > /dev/null 2> $OUT/err$SCHED.txt
-( echo "== schedule $SCHED, emulated link $RATE GB/s ($(python -c "print('%.2f' % (51.5 / $RATE))") ms per face), $RGPU_ARITH arithmetic"
+( echo "== schedule $SCHED, emulated link $RATE GB/s, $RGPU_ARITH arithmetic, host loop: ${PROBE_HOST_LOOP:-no}"
   python $R/scripts/timeline.py $(find $OUT/tr$SCHED -name "*kernel_trace.csv" | head -1) 0.5 --gantt ) | tee $OUT/timeline_s${SCHED}.txt
 rm -rf $OUT/tr$SCHED

@@ -13,6 +13,7 @@ dst = os.path.join(ROOT, "profiles")
 PHASE = [("mhd3d_sweep_kernel", "sweep"), ("hydro3d_sweep_kernel", "sweep"), ("mhd2d_step_kernel", "sweep"), ("K_mhd_invdt", "dt"), ("K_hydro_invdt", "dt"),
          ("K_mhd_prim", "prim"), ("K_mhd_elec", "elec"), ("K_mhd_trace3d", "trace"), ("K_mhd_flux3d", "flux"),
          ("K_mhd_update3d", "update"), ("K_shear_save_emf", "shear"), ("K_shear_remap", "shear"), ("K_shear_ghost", "boundaries"),
+         ("K_fill_xy", "boundaries"), ("K_copy_periodic_layer", "sweep_copy"), ("step_clock_kernel", "clock"),
          ("K_bc_face", "boundaries"), ("K_copy_cells", "boundaries"), ("K_hydro_prim", "prim"), ("K_hydro_trace", "trace"),
          ("K_hydro_flux", "flux"), ("K_hydro_update", "update")]
 CELLS = {"mri": 512.0 ** 3, "implode3d": 256.0 ** 3, "orszag-tang": 512.0 ** 2}
