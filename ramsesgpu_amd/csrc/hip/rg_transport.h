@@ -95,7 +95,7 @@ inline int create(Comm** out, int rank, int nranks, const char* id128) {
       hipEventCreateWithFlags(&c->ev_done, tflag) != hipSuccess || hipEventCreateWithFlags(&c->ev_begin, tflag) != hipSuccess) return fail(c, "events");
   if (hipMalloc((void**)&c->scratch, 64 * sizeof(double)) != hipSuccess) return fail(c, "scratch");
   if (c->emulate_gbps > 0 && c->emulate_parallel &&
-      (hipStreamCreateWithPriority(&c->hold_stream, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreateWithFlags(&c->ev_hold0, hipEventDisableTiming) != hipSuccess ||
+      (hipStreamCreateWithPriority(&c->hold_stream, hipStreamNonBlocking, 0) != hipSuccess || hipEventCreateWithFlags(&c->ev_hold0, hipEventDisableTiming) != hipSuccess ||
        hipEventCreateWithFlags(&c->ev_hold1, hipEventDisableTiming) != hipSuccess)) return fail(c, "hold stream");
   return 0;
 }

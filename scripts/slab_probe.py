@@ -38,7 +38,7 @@ for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] i
             k = int(os.environ.get("PROBE_BATCH", n))   # steps per rgpu_comm_run_steps call
             for _ in range(n // k):
                 assert run.run_steps(k) == k
-            assert run.clocked_steps() == (n // k) * k, run.clocked_steps()
+            assert run.clocked_steps() == (0 if overlap == 0 else (n // k) * k), run.clocked_steps()   # (the serial schedule keeps the host loop)
         run.solver.synchronize(); dt = (time.time() - t0) / n
         link_ms = 0.0 if rate <= 0 else 8 * 518 * 518 * 3 * 8 * (2 if 512 // nz == 2 else 1) / rate / 1e6
         mode = "%s" % ("link time beside the local copy" if os.environ.get("RGPU_COMM_EMULATE_MODE") == "parallel" else "link time behind the local copy") if rate > 0 else ""
