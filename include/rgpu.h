@@ -330,8 +330,9 @@ int rgpu_one_step_integration(rgpu_ctx* c, int* nStep, double* t, double* dt);
  * (MHDRunGodunov.cpp:3921-3990, HydroRunGodunov.cpp:3960), for up to nsteps steps: returns the number of steps done (< nsteps only when
  * totalTime reached tEnd; pass HUGE_VAL for "no end") or a negative RGPU_E* code; *nStep, *t, *dt advance exactly as nsteps calls of
  * rgpu_one_step_integration would advance them -- same states, same dt sequence, bit for bit.  What it adds: where a step is ONE fused
- * kernel that leaves the CFL maxima and the ghost cells of its output on the device (2D hydro / MHD in a box of periodic, reflecting or
- * outflow faces, no gravity, no rotating frame) the time step itself stays on the device (csrc/hip/step_clock.h: dt = cfl / max 1/dt, the
+ * kernel that leaves the CFL maxima and the ghost cells of its output on the device (2D hydro in a box of periodic, reflecting or
+ * outflow faces; 2D MHD in an all-periodic box -- with a Neumann face its kernel writes no ghost images and the plain loop runs; no
+ * gravity, no rotating frame) the time step itself stays on the device (csrc/hip/step_clock.h: dt = cfl / max 1/dt, the
  * loop condition and t += dt evaluated by a one-workgroup kernel between two steps) and a batch of steps is queued without a host round
  * trip -- at the shipped 2D sizes that round trip costs as much as a third of the step.  Since round 5 the 3D steps do the same (hydro,
  * plain / rotating / shearing-box MHD through the z-marching sweeps: rgpu_clock_capable).  Every other configuration runs the plain loop. */
