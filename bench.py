@@ -769,7 +769,7 @@ def main():
         if world == 1 and args.workload == "mri" and not custom_size and not args.no_other_workloads:
             # BASELINE.json configs[1] and configs[2], short, so that their numbers are the driver's too (not builder-only claims)
             others = {}
-            for name, st, wu, budget in (("implode3d", 50, 5, 8.0), ("orszag-tang", 50, 5, 6.0)):
+            for name, st, wu, budget in (("implode3d", 100, 5, 8.0), ("orszag-tang", 400, 10, 6.0)):   # (2D steps take ~0.05 ms: enough of them that the one synchronisation of the batch does not show)
                 try:
                     ow = WORKLOADS[name]
                     o = single_gpu_record(name, ow["size"], args.arith, st, wu, ctl)
