@@ -277,7 +277,7 @@ int rgpu_step_fill_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, i
  * launches: the 3D MHD update kernel marches both ranges in one launch; the ghost fill of both ranges is one launch whenever the
  * x / y faces are mirror / copy / periodic or the shearing box with periodic y (one thread per ghost cell, every value a function
  * of interior cells of its plane: X, Y -- or Y, shear remap, Y -- need no ordering).  Same doubles as the one-range calls.
- * Either range may be empty.  (3D hydro: the sweep is the whole step, one launch per range.) */
+ * Either range may be empty.  (3D hydro: the sweep is the whole step -- both ranges in one launch of it.) */
 int rgpu_step_core_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2, int what);
 int rgpu_step_fill_planes_pair(rgpu_ctx* c, int nStep, double dt, double totalTime, int k_lo, int k_hi, int k_lo2, int k_hi2);
 

@@ -441,34 +441,48 @@ inline bool hydro3d_sweep_covers(const DevParams& g) { return tiled_enabled() &&
 // flat kernels), < 0 = launch error.
 // dslot: device slot for the CFL maximum of the new state (reset by the caller), or 0
 inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
-                         double dtdz, int a, int b, unsigned long long* dslot = 0, const StepClock* clk = 0) {
+                         double dtdz, int a, int b, unsigned long long* dslot = 0, const StepClock* clk = 0, int a2 = 0, int b2 = 0) {
   if (!hydro3d_sweep_covers(g) || g.grav_on == 2) return 1;   // per-cell gravity field: flat kernels
-  const int za = a < g.gw ? g.gw : a, zb = b > g.ksize - g.gw ? g.ksize - g.gw : b;
-  // ghost planes inside [a,b): plain copy, like the flat update kernel
+  // ghost planes inside a range: plain copy, like the flat update kernel
   const K_copy_cells kc = {in, out, g.ncell, 5, clk};
-  if (a < g.gw && rgpu::rg_launch_range<256>(s, (unsigned)a * g.sk, (unsigned)((b < g.gw ? b : g.gw) - a) * g.sk, kc)) return -1;
-  if (b > g.ksize - g.gw) {
-    const int lo = a > g.ksize - g.gw ? a : g.ksize - g.gw;
-    if (rgpu::rg_launch_range<256>(s, (unsigned)lo * g.sk, (unsigned)(b - lo) * g.sk, kc)) return -1;
+  int za[2], zb[2];
+  for (int n = 0; n < 2; ++n) {
+    const int lo_ = n ? a2 : a, hi_ = n ? b2 : b;
+    za[n] = zb[n] = 0;
+    if (hi_ <= lo_) continue;
+    za[n] = lo_ < g.gw ? g.gw : lo_; zb[n] = hi_ > g.ksize - g.gw ? g.ksize - g.gw : hi_;
+    if (lo_ < g.gw && rgpu::rg_launch_range<256>(s, (unsigned)lo_ * g.sk, (unsigned)((hi_ < g.gw ? hi_ : g.gw) - lo_) * g.sk, kc)) return -1;
+    if (hi_ > g.ksize - g.gw) {
+      const int lo = lo_ > g.ksize - g.gw ? lo_ : g.ksize - g.gw;
+      if (rgpu::rg_launch_range<256>(s, (unsigned)lo * g.sk, (unsigned)(hi_ - lo) * g.sk, kc)) return -1;
+    }
   }
-  if (zb <= za) return 0;
   // thread tile: 16 x 16 measured best at 256^3 (sweep 1.18 ms; 32 x 8: 1.24, 32 x 16: 1.19-1.26, 64 x 8: 1.43, 64 x 4: 1.75;
   // a 168-VGPR build for three workgroups per CU: 1.46) -- the squarest tile recomputes the least halo (196 of 256 threads
   // update a cell)
   constexpr int TX = 16, TY = 16;
   static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
-  if (!no_spec) {
-    const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
-#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot, clk)
-    RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
-    RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
-    RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
-    // with uniform gravity (g.grav_on == 1)
-    RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE1);
-    RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE1);
+  // planes [lo, hi) and, second > 0, a second range of the same length starting there, in one launch (TileGrid::zsplit)
+  auto launch = [&](int lo, int hi, int second) -> int {
+    if (!no_spec) {
+      const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
+#define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro3d_sweep<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dtdz, lo, hi, dslot, clk, second)
+      RG_TRY(SPEC_HYDRO_HLLC | SL2); RG_TRY(SPEC_HYDRO_HLLC | SL1);
+      RG_TRY(SPEC_HYDRO_APPROX | SL2); RG_TRY(SPEC_HYDRO_APPROX | SL1);
+      RG_TRY(SPEC_HYDRO_HLL | SL2); RG_TRY(SPEC_HYDRO_HLL | SL1);
+      // with uniform gravity (g.grav_on == 1)
+      RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_HLLC | SPEC_SLOPE1);
+      RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE2); RG_TRY(SPEC_HYDRO_APPROX | SPEC_SLOPE1);
 #undef RG_TRY
-  }
-  return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, za, zb, dslot, clk);
+    }
+    return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, lo, hi, dslot, clk, second);
+  };
+  static const bool no_pair = std::getenv("RGPU_NO_SWEEP_PAIR") != 0;
+  const bool one = zb[0] > za[0], two = zb[1] > za[1];
+  if (one && two && !no_pair && zb[1] - za[1] == zb[0] - za[0] && za[1] >= zb[0]) return launch(za[0], zb[0], za[1]);   // the two boundary ranges of a slab
+  if (one) { const int rc = launch(za[0], zb[0], 0); if (rc) return rc; }
+  if (two) return launch(za[1], zb[1], 0);
+  return 0;
 }
 
 }  // namespace rgpu_tiled

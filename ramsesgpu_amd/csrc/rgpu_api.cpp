@@ -576,7 +576,8 @@ int hydro_flux_trace_spec(rgpu_ctx* c, double dtdx, double dtdy, double dtdz, in
 }
 
 template <int ND, int NV>
-int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a, int b, bool acc_piece = false) {
+// (a2, b2): 3D, tiled sweep only -- a second plane range in the same launch (the two boundary ranges of a slab)
+int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a, int b, bool acc_piece = false, int a2 = 0, int b2 = 0) {
   const DevParams& g = c->g;
   const StepTime st = step_time(c, dt_arg, 0.0);
   if (st.skip) return 0;
@@ -592,7 +593,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
     const bool piece = acc_piece && cond && c->scan_acc_parity == ((out == c->U[0]) ? 0 : 1);
     if (acc_piece && !piece) c->scan_acc_parity = -1;
     if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (a clock kernel zeroed them)
-    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0, st.clk);
+    const int rc = rgpu_tiled::hydro3d_sweep(c->stream, g, in, out, dtdx, dtdy, dtdz, a, b, (scan || piece) ? c->d_red : 0, st.clk, a2, b2);
     if (rc == 0 && scan) { c->fused_dt_parity = (out == c->U[0]) ? 0 : 1; c->fused_dt_slots = 1; }
     if (rc <= 0) return rc;
     if (st.clk) return -1;   // the flat kernels take dt by value
@@ -1003,7 +1004,8 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   if (b2 > c->g.ksize) b2 = c->g.ksize;
   if (b <= a) { a = a2; b = b2; a2 = b2 = 0; }
   if (b <= a) return 0;
-  if (!c->p.mhdEnabled) {   // the sweep is the whole step: one launch per range
+  if (!c->p.mhdEnabled) {   // the sweep is the whole step: both ranges in one launch of the tiled sweep, else range by range
+    if (b2 > a2 && rgpu_tiled::hydro3d_sweep_covers(c->g) && c->g.grav_on != 2) return hydro_core<3, 5>(c, in, out, dt, a, b, hydro_piece, a2, b2);
     const int rc = hydro_core<3, 5>(c, in, out, dt, a, b, hydro_piece);
     if (rc || b2 <= a2) return rc;
     return hydro_core<3, 5>(c, in, out, dt, a2, b2, hydro_piece);

@@ -20,7 +20,7 @@ inline int launch_step_clock(rgpu::rg_stream_t, unsigned long long* slots, const
   if (out->stop == 0) for (int s = 0; s < (int)rgpu::RG_DT_SLOTS; ++s) slots[s] = 0ull;   // (a stopped step keeps the maxima of the last state written)
   return 0;
 }
-inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int, unsigned long long* = 0, const StepClock* = 0) { return 1; }
+inline int hydro3d_sweep(rgpu::rg_stream_t, const rgpu_dev::DevParams&, const double*, double*, double, double, double, int, int, unsigned long long* = 0, const StepClock* = 0, int = 0, int = 0) { return 1; }
 inline bool mhd3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool hydro3d_sweep_covers(const rgpu_dev::DevParams&) { return false; }
 inline bool mhd2d_step_covers(const rgpu_dev::DevParams&) { return false; }

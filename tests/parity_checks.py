@@ -626,3 +626,39 @@ def check_alfven_selftest(lib, n, seed, smallc, iso=False):
         int(bad.sum()), n, int(np.argmax(bad)), int(kind[np.argmax(bad)]), e_sel[np.argmax(bad)], e_ref[np.argmax(bad)])
     assert np.isfinite(e_ref).mean() > 0.9, "the samples are mostly not finite: %r" % np.isfinite(e_ref).mean()
     return int((route == 0).sum()), int((route == 1).sum()), kind, route
+
+
+def check_fused_fill(lib, oracle, base, ov, seed=5, t0=3.7, dt=0.9):
+    """rgpu_step_fill_planes_pair (one launch for x and y faces / the shearing-box remap, corners included, two plane ranges) against the
+    oracle's separate passes -- X then Y, or the whole shearing-box sequence Y, shear, Z, Y -- on a random state: every ghost cell of the
+    planes asked for equal, every other plane untouched"""
+    p = lib.params_from_ini(ini(base), ov)
+    U = random_state(p, seed)
+    gw, ks = p.ghostWidth, p.nz + 2 * p.ghostWidth
+    ref = U.copy()
+    shear = bool(p.shearingBoxEnabled)
+    if shear:
+        oracle.make_all_boundaries(p, ref, t0, dt)
+    else:
+        oracle.make_boundaries(p, ref, 1)
+        oracle.make_boundaries(p, ref, 2)
+    r1, r2 = (gw, 2 * gw), (p.nz, p.nz + gw)            # the planes a slab sends
+    if r2[0] < r1[1]:
+        r1, r2 = (gw, p.nz + gw), (0, 0)
+    sv = Solver(p, lib)
+    try:
+        sv.upload(U, both=True)
+        sv.step_fill_planes_pair(1, dt, t0, r1, r2)      # step 1 writes U[0]
+        got = sv.getDataHost(0)
+        planes = list(range(*r1)) + list(range(*r2))
+        for k in range(ks):
+            if k in planes:
+                assert np.array_equal(got[:, k], ref[:, k]), "%s: plane %d differs from the separate passes in %d doubles" % (base, k, int((got[:, k] != ref[:, k]).sum()))
+            else:
+                assert np.array_equal(got[:, k], U[:, k]), "%s: plane %d outside the ranges was touched" % (base, k)
+        sv.upload(U, both=True)                          # one range, all interior planes
+        sv.step_fill_planes_pair(1, dt, t0, (gw, ks - gw), (0, 0))
+        got = sv.getDataHost(0)
+        assert np.array_equal(got[:, gw:ks - gw], ref[:, gw:ks - gw])
+    finally:
+        sv.close()

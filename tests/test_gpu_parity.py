@@ -561,3 +561,14 @@ def test_alfven_selection_near_ties(base, ov, eps, gpu_lib, oracle):
     """the Alfven-speed selection of the 2D HLLD edge solver at, inside and outside its margins (2^-40 on the star ratio, 2^-45 on
     the cross products): uniform magnetised flow + perturbations of relative size eps, one step, every double equal to the oracle's"""
     pc.check_single_step_near_uniform(gpu_lib, oracle, base, ov, eps)
+
+
+@pytest.mark.parametrize("base,ov", [("implode3d", "mesh.nx=20;mesh.ny=17;mesh.nz=12"),
+                                     ("implode3d", "mesh.nx=19;mesh.ny=33;mesh.nz=12;mesh.boundary_xmin=2;mesh.boundary_xmax=3;mesh.boundary_ymin=3;mesh.boundary_ymax=1"),
+                                     ("orszag-tang3d", "mesh.nx=24;mesh.ny=20;mesh.nz=12;mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_ymin=1;mesh.boundary_ymax=2"),
+                                     ("mhd_mri_3d", "mesh.nx=24;mesh.ny=36;mesh.nz=12;MHD.omega0=0.05"),
+                                     ("mhd_mri_3d", "mesh.nx=70;mesh.ny=130;mesh.nz=12;MHD.omega0=0.3")],
+                         ids=["implode", "mixed-faces", "ot3d-open", "mri", "mri-large-shift"])
+def test_one_launch_ghost_fill_equals_the_separate_passes(base, ov, gpu_lib, oracle):
+    """K_fill_xy (x and y faces / shearing-box remap, corners included, two plane ranges in one launch) == the oracle's separate passes"""
+    pc.check_fused_fill(gpu_lib, oracle, base, ov)

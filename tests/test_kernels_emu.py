@@ -132,3 +132,16 @@ def test_alfven_selection_against_the_reference_sequence_emu(emu_lib):
     assert (route[kind == 2] == 1).all()
     sel, ref, _, _ = pc.check_alfven_selftest(emu_lib, 50000, 12, 1e-101)
     assert sel == 0
+
+
+FUSED_FILL = [("implode3d", "mesh.nx=10;mesh.ny=8;mesh.nz=12"),                                                        # reflecting walls: corners = images of images, both signs
+              ("implode3d", "mesh.nx=9;mesh.ny=7;mesh.nz=12;mesh.boundary_xmin=2;mesh.boundary_xmax=3;mesh.boundary_ymin=3;mesh.boundary_ymax=1"),   # mixed (x: not a pair of equals)
+              ("orszag-tang3d", "mesh.nx=8;mesh.ny=10;mesh.nz=12"),                                                     # periodic MHD
+              ("orszag-tang3d", "mesh.nx=8;mesh.ny=10;mesh.nz=12;mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_ymin=1;mesh.boundary_ymax=2"),   # Dirichlet leaves B alone
+              ("mhd_mri_3d", "mesh.nx=8;mesh.ny=12;mesh.nz=12;MHD.omega0=0.05"),                                        # shearing box: remap at (i, wrapped row), kept Bx face
+              ("mhd_mri_3d", "mesh.nx=6;mesh.ny=6;mesh.nz=12;MHD.omega0=0.3")]                                          # ... shift of several cells, ny = 2 gw
+
+
+@pytest.mark.parametrize("base,ov", FUSED_FILL, ids=["%s-%d" % (c[0], n) for n, c in enumerate(FUSED_FILL)])
+def test_one_launch_ghost_fill_equals_the_separate_passes(base, ov, emu_lib, oracle):
+    pc.check_fused_fill(emu_lib, oracle, base, ov)
