@@ -115,6 +115,21 @@ def test_exact_ranks_run_steps_with_the_time_step_on_the_device(base, ov, nsteps
     run_worker(base, ov, 6, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), timeout=600)
 
 
+# the rank counts of the scaling run (SCALE: N = 2, 4, 8): every rank a process of its own on the one GPU
+MANY = [("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=64;" + MRI, 4, 4, 1),
+        ("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=128;" + MRI, 4, 8, 1),          # 8 slabs of 16 planes: the shape of BASELINE config 5
+        ("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=128;" + MRI, 4, 8, 2),
+        ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=64;hydro.riemannSolver=hllc", 4, 8, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ov,nsteps,world,overlap", MANY, ids=["%s-x%d-%s" % (c[0], c[3], SCHED[c[4]]) for c in MANY])
+def test_exact_four_and_eight_ranks_on_one_gpu(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path):
+    """4 and 8 rank processes (the rank counts of the scaling run) through the batched loop: == the single-domain oracle, dt sequence,
+    fingerprint and an end time inside a batch included"""
+    run_worker(base, ov, 6, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), timeout=900)
+
+
 CONTRACTED = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[9], SMALL[14]]
 
 

@@ -107,7 +107,9 @@ def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm
     run_worker(base, ov, nsteps, world, overlap, tmp_path)
 
 
-RUN_STEPS = [CASES[n] for n in (0, 2, 4, 6, 7, 9, 10, 11, 12, 14, 18, 19, 20, 21, 22, 23)]
+RUN_STEPS = [CASES[n] for n in (0, 2, 4, 6, 7, 9, 10, 11, 12, 14, 18, 19, 20, 21, 22, 23)] + [
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=32;MHD.omega0=0.02", 3, 4, 1),      # four slabs
+    ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=64;MHD.omega0=0.02", 3, 4, 2)]
 
 
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", RUN_STEPS,
