@@ -202,7 +202,12 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   bool has_inner;
   if (nz <= 2 * gw) { nb = 1; bnd[0][0] = 0; bnd[0][1] = ks; snd[0][0] = gw; snd[0][1] = nz + gw; has_inner = false; }
   else {
-    nb = 2; bnd[0][0] = 0; bnd[0][1] = 2 * gw; bnd[1][0] = nz; bnd[1][1] = ks;
+    // ghost planes behind a slab interface are not updated: the planes received in this step overwrite them whole (x / y ghosts
+    // included), so their update -- old values + the CT of plane ksize - gw, what the reference leaves there until its next ghost
+    // fill -- is 6 of the 70 planes of an N = 8 slab for nothing.  Physical z faces keep theirs (the reference's array contents).
+    static const bool all_planes = std::getenv("RGPU_COMM_UPDATE_GHOST_PLANES") != 0;
+    const bool lo_if = !all_planes && cm->p.bc[4] == RGPU_BC_COPY, hi_if = !all_planes && cm->p.bc[5] == RGPU_BC_COPY;
+    nb = 2; bnd[0][0] = lo_if ? gw : 0; bnd[0][1] = 2 * gw; bnd[1][0] = nz; bnd[1][1] = hi_if ? nz + gw : ks;
     snd[0][0] = gw; snd[0][1] = 2 * gw; snd[1][0] = nz; snd[1][1] = nz + gw; has_inner = true;
   }
   const bool scan = !rot;   // rotating path: the reference's compute_dt sees the refilled ghosts -> full scan next step
