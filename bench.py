@@ -57,6 +57,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before anything can initialise the HSA runtime: the host driver of this pool only supports dmabuf IPC (RCCL's peer buffers)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK = 8.0e12                 # B/s, MI355X HBM3E (guide: MI355X_MICROARCH.md)
 

@@ -63,6 +63,8 @@ int main(int argc, char** argv) {
   double mcell = 0.0;
   int n;
   if (slabs > 0) {
+    // RCCL's peer buffers between the rank processes: this pool's host driver supports dmabuf IPC only (set before the first HIP call)
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", slabs), local = env_int("LOCAL_RANK", rank);
     if (world != slabs || rank < 0 || rank >= world) {
       std::fprintf(stderr, "euler_hip: --slabs %d but RANK=%d WORLD_SIZE=%d\n", slabs, rank, world);
