@@ -27,17 +27,29 @@
 
 namespace rgpu_tiled {
 
-constexpr int MH_OX = 16, MH_OY = 8;              // cells whose Riemann problems a workgroup solves per plane
-constexpr int MH_PX = MH_OX + 1, MH_PY = MH_OY + 1;
-constexpr int MH_CELLS = MH_PX * MH_PY;           // 153 traced cells per plane (tile + low-side halo)
-constexpr int MH_BUF = T_COUNT * MH_CELLS;        // doubles per plane buffer of T
-constexpr int MH_QX = MH_OX + 3, MH_QY = MH_OY + 3;
-constexpr int MH_QCELLS = MH_QX * MH_QY;          // 209 input cells per plane (traced cells +- 1), origin (i0-2, j0-2)
-constexpr int MH_NQB = 11;                        // per input cell: 8 primitives + 3 face-field components
-constexpr int MH_QBSLOT = MH_NQB * MH_QCELLS;     // doubles per plane slot of Q / B
-constexpr int MH_ESLOT = 3 * MH_QCELLS;           // doubles per plane slot of E (same cell geometry as Q)
-constexpr int MH_EX = MH_OX + 2, MH_EY = MH_OY + 2;
-constexpr int MH_ECELLS = MH_EX * MH_EY;          // 180 cells whose edge fields the trace reads, origin (i0-1, j0-1)
+// Tile geometry: OX x OY cells whose Riemann problems a workgroup solves per plane, and what follows from it.
+//   MhMain   16 x 8: 128 cells = two waves per direction -- the tiles of the sweep
+//   MhLastX  2 x 32, at the LAST x face column i = isize - gw alone (round 5).  513 face columns in tiles of 16 are 33 tile columns, the
+//            last with one valid column: 64 of the 2112 tile marches of the 512^3 box, 3.1 % of the sweep for 0.2 % of its faces (a
+//            periodic layer is copied instead, K_copy_periodic_layer; the shearing-box x faces have no image to copy).  The same kernel
+//            with this geometry marches that column in 16 tiles of 32 rows (column 1 of the tile lies outside the face range; 64 cells =
+//            one wave per direction, the waves of the second half idle): a quarter of the marches, and short ones (launch_mhd3d_sweep).
+template <int OX_, int OY_, bool LASTX_>
+struct MhTile {
+  static constexpr int OX = OX_, OY = OY_;              // cells whose Riemann problems a workgroup solves per plane
+  static constexpr bool LASTX = LASTX_;                 // the tile column sits at i0 = isize - gw
+  static constexpr int PX = OX + 1, PY = OY + 1;
+  static constexpr int CELLS = PX * PY;                 // traced cells per plane (tile + low-side halo): 153
+  static constexpr int BUF = T_COUNT * CELLS;           // doubles per plane buffer of T
+  static constexpr int QX = OX + 3, QY = OY + 3;
+  static constexpr int QCELLS = QX * QY;                // input cells per plane (traced cells +- 1), origin (i0-2, j0-2): 209
+  static constexpr int NQB = 11;                        // per input cell: 8 primitives + 3 face-field components
+  static constexpr int QBSLOT = NQB * QCELLS;           // doubles per plane slot of Q / B
+  static constexpr int ESLOT = 3 * QCELLS;              // doubles per plane slot of E (same cell geometry as Q)
+  static constexpr int SX = OX, SY = OY;                // tile pitch = tile size: every Riemann problem is solved by exactly one tile
+};
+typedef MhTile<16, 8, false> MhMain;
+typedef MhTile<2, 32, true> MhLastX;
 constexpr int MH_THREADS = 512;
 // Loop-invariant per-thread decodes that the compiler hoists out of the z march into VGPRs -- which traced cell is mine (LDS addresses
 // of three passes), the x position of my Riemann cell, which of the 512 edge values is mine -- can instead be recomputed every plane
@@ -67,12 +79,13 @@ constexpr int MH_THREADS = 512;
 #define RG_SWEEP_SPLIT_LOOPS 1
 #endif
 #endif
-constexpr int MH_SX = MH_OX, MH_SY = MH_OY;       // tile pitch = tile size: every Riemann problem is solved by exactly one tile
 
+template <class G>
 struct TLdsWrite {
   double* cell;
-  RG_DEVFN void put(int slot, double v) const { cell[slot * MH_CELLS] = v; }
+  RG_DEVFN void put(int slot, double v) const { cell[slot * G::CELLS] = v; }
 };
+template <class G>
 struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B, planes kk, kk+1 of E
   const double* qb[3]; const double* eb[2];
   const int* flag; int want;   // E of plane kk+1 is complete once *flag >= want (written by the Riemann waves)
@@ -82,19 +95,20 @@ struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
-  RG_DEVFN double q(int v, int dz, unsigned m) const { return qb[dz + 1][v * MH_QCELLS + m]; }
-  RG_DEVFN double bf(int comp, int dz, unsigned m) const { return qb[dz + 1][(8 + comp) * MH_QCELLS + m]; }
-  RG_DEVFN double e(int comp, int dz, unsigned m) const { return eb[dz][comp * MH_QCELLS + m]; }
-  RG_DEVFN unsigned sj() const { return (unsigned)MH_QX; }
+  RG_DEVFN double q(int v, int dz, unsigned m) const { return qb[dz + 1][v * G::QCELLS + m]; }
+  RG_DEVFN double bf(int comp, int dz, unsigned m) const { return qb[dz + 1][(8 + comp) * G::QCELLS + m]; }
+  RG_DEVFN double e(int comp, int dz, unsigned m) const { return eb[dz][comp * G::QCELLS + m]; }
+  RG_DEVFN unsigned sj() const { return (unsigned)G::QX; }
 };
 
 // T accessor of ONE plane buffer: the +z neighbour of a cell is not in it.  stride(ZD) = 0 makes the one component of a
 // state that reads the plane above (the face field on the + side) read this plane instead; the caller replaces that
 // component when the plane above has been traced (see "carried states" below).
+template <class G>
 struct TLdsPlane {
   const double* base;
-  RG_DEVFN double get(int slot, unsigned m) const { return base[slot * MH_CELLS + m]; }
-  RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)MH_PX : 0u; }
+  RG_DEVFN double get(int slot, unsigned m) const { return base[slot * G::CELLS + m]; }
+  RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)G::PX : 0u; }
 };
 
 // Riemann problems of one direction d at cell m of plane kk: the edge EMF along d and the flux through the low d face.
@@ -106,11 +120,11 @@ struct TLdsPlane {
 // work.  The two Riemann waves of a SIMD are arbitrated oldest-first: left alone the older one finishes at ~60 % of the
 // phase and the younger one runs the rest alone at single-wave issue efficiency; with the younger wave favoured for the
 // first 70 % of its work both finish together.
-template <int DIR>
-RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, double xPos, double* __restrict__ F,
+template <class G, int DIR>
+RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m, double xPos, double* __restrict__ F,
                           double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
   const size_t N = g.ncell;
-  const unsigned sx = 1u, sj = (unsigned)MH_PX;
+  const unsigned sx = 1u, sj = (unsigned)G::PX;
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
     if (solve) {
       c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);        // b2 = CL(m2) + s1 * dCLy(m2), s1 = +1, m2 = the cell above
@@ -155,12 +169,14 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane& Tk, unsigned m, d
   }
 }
 
-template <int SPEC>
+template <int SPEC, class G>
 __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
                                                                const StepClock* clk) {
   spec_assume<SPEC>(g);
+  constexpr int MH_OX = G::OX, MH_OY = G::OY, MH_PX = G::PX, MH_PY = G::PY, MH_CELLS = G::CELLS, MH_BUF = G::BUF, MH_QX = G::QX, MH_QCELLS = G::QCELLS,
+                MH_NQB = G::NQB, MH_QBSLOT = G::QBSLOT, MH_ESLOT = G::ESLOT, MH_SX = G::SX, MH_SY = G::SY;
   if (clk) {   // the time step lives on the device (csrc/step_clock_rec.h): a batch of steps queued without a host round trip
     if (clk->stop) return;
     dt = clk->dt; dtdx = clk->dtdx; dtdy = clk->dtdy; dtdz = clk->dtdz;
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int bx = item.bx, by = item.by, sa = item.sa, sb = item.sb;
 
   const int gw = g.gw;
-  const int i0 = gw + bx * MH_SX, j0 = gw + by * MH_SY;   // first cell of the tile
+  const int i0 = G::LASTX ? g.isize - gw : gw + bx * MH_SX, j0 = gw + by * MH_SY;   // first cell of the tile
   const int t = (int)threadIdx.x;
   const size_t N = g.ncell;
   const unsigned sk = g.sk;
@@ -251,11 +267,12 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   // Ex at (c, c+y), Ey at (c, c+x), Ez at (c, c+x, c+y): 17 x 10 + 18 x 9 + 18 x 10 = 512 values -- one per thread. ----
   // value e of the 512: computed by thread `first` + n * `stride`
   auto elec_plane = [&](int k, int first, int stride) {
-    const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT}, {0, 0}, 0, 0};
+    const TraceInLds<G> in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT}, {0, 0}, 0, 0};
     double* ed = LE + (k & 1) * MH_ESLOT;
     constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY;
-    static_assert(NEX + NEY + (MH_PX + 1) * (MH_PY + 1) == MH_THREADS, "512 edge values per plane");
-    for (int e = first; e < MH_THREADS; e += stride) {
+    constexpr int NE = NEX + NEY + (MH_PX + 1) * (MH_PY + 1);
+    static_assert(NE <= MH_THREADS, "at most one edge value per thread and plane (16 x 8 tile: exactly 512)");
+    for (int e = first; e < NE; e += stride) {
       int comp, ex, ey;
       if (e < NEX) { comp = 0; ey = e / MH_PX; ex = e - ey * MH_PX; }
       else if (e < NEX + NEY) { comp = 1; const int c = e - NEX; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
@@ -292,8 +309,8 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
     if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
       const IJK c = {ti, tj, k};
-      const TLdsWrite tw = {LT + (k & 1) * MH_BUF + cell};
-      const TraceInLds in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
+      const TLdsWrite<G> tw = {LT + (k & 1) * MH_BUF + cell};
+      const TraceInLds<G> in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
                              {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
       mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
     }
@@ -307,7 +324,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int cl = half * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
-  const bool fl_ok = !producer && ci <= g.isize - gw && cj <= g.jsize - gw;
+  const bool fl_ok = !producer && cl < MH_OX * MH_OY && ci <= g.isize - gw && cj <= g.jsize - gw;
   const unsigned cidx2 = fl_ok ? (unsigned)ci + (unsigned)cj * g.sj : 0u;
   const unsigned cm = (unsigned)((oy + 1) * MH_PX + ox + 1);
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
@@ -378,15 +395,15 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
     RG_E_STEP(kk)                                                                                                        \
     if (RG_RIEMANN_ON) {                                                                                                 \
-      const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
+      const TLdsPlane<G> Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
       const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
       const bool solve = kk >= sa;                                                                                       \
       const bool raise = prio_mode && solve && wave >= 4;                                                                \
       if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
       RG_XPOS(xp)                                                                                                        \
-      if (dir == 0) riemann_dir<XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                               \
-      else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                          \
-      else riemann_dir<ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                                        \
+      if (dir == 0) riemann_dir<G, XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                               \
+      else if (dir == 1) riemann_dir<G, YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                          \
+      else riemann_dir<G, ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                                        \
     }                                                                                                                    \
   }
 #ifdef RG_SWEEP_PROF
@@ -447,7 +464,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #else
       if (fl_ok && kk >= sa - 1) {
 #endif
-        const TLdsPlane Tk = {LT + (kk & 1) * MH_BUF};
+        const TLdsPlane<G> Tk = {LT + (kk & 1) * MH_BUF};
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;
         const bool raise = prio_mode && solve && wave >= 4;
@@ -455,9 +472,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
         RG_XPOS(xp)
-        if (dir == 0) riemann_dir<XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        if (dir == 0) riemann_dir<G, XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        else if (dir == 1) riemann_dir<G, YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        else riemann_dir<G, ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }
@@ -526,24 +543,42 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   TileGrid tg;
   static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
   tg.flags = flags_env;
-  tg.nbx = (g.isize - 2 * g.gw + 1 + MH_SX - 1) / MH_SX;   // cells gw .. isize-gw
-  tg.nby = (g.jsize - 2 * g.gw + 1 + MH_SY - 1) / MH_SY;
-  const bool copy_x = (reuse & 1) && g.nx % MH_OX == 0 && g.nx >= MH_OX, copy_y = (reuse & 2) && g.ny % MH_OY == 0 && g.ny >= MH_OY;
+  constexpr int OX = MhMain::OX, OY = MhMain::OY;
+  tg.nbx = (g.isize - 2 * g.gw + 1 + OX - 1) / OX;   // cells gw .. isize-gw
+  tg.nby = (g.jsize - 2 * g.gw + 1 + OY - 1) / OY;
+  const bool copy_x = (reuse & 1) && g.nx % OX == 0 && g.nx >= OX, copy_y = (reuse & 2) && g.ny % OY == 0 && g.ny >= OY;
   if (copy_x) tg.nbx -= 1;
   if (copy_y) tg.nby -= 1;
+  // nx a multiple of the tile width and no periodic image to copy (the shearing box): the face column i = isize - gw would be a tile
+  // column of its own with one valid column in 16 -- it goes to a second launch with the 2 x 32 geometry instead (MhLastX)
+  static const bool no_lastx = std::getenv("RGPU_NO_LASTX_TILES") != 0;
+  const bool lastx = !no_lastx && !copy_x && g.nx % OX == 0 && tg.nbx >= 2;
+  if (lastx) tg.nbx -= 1;
   const int span = rb - ra;
   static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
-  // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3: one base
-  // segment per tile (2112 items, 264 per XCD = 8 rounds + 8 items cut into 4 sub-segments each)
+  // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3 shearing box: 2048 tiles
+  // of one base segment = 8 rounds of workgroups exactly, then 16 tiles of the last face column in 16 segments = one short round (round
+  // 4: 2112 tiles, 8 rounds + 8 items per XCD cut into 4 sub-segments each)
   // ra2 > 0: a second range [ra2, ra2 + span) of the same length in the same launch (TileGrid::zsplit) -- the boundary ranges of a
   // slab in the boundary-first schedule: one launch, one last round of workgroups, instead of two
   const bool pair = ra2 > 0;
   const int nplanes = pair ? 2 * span : span;
   tile_grid_plan(tg, span, 32, 8, 2, zseg_env, pair);
   if (pair) { tg.zsplit = ra + span; tg.zgap = ra2 - (ra + span); }
-  hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
+  hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC, MhMain>), dim3(8u * (unsigned)tg.per_xcd), dim3(MH_THREADS), 0, s, g, tg, U, F, emf,
                      dt, dtdx, dtdy, dtdz, ra, ra + nplanes, clk);
   if (hipGetLastError() != hipSuccess) return -1;
+  if (lastx) {
+    TileGrid tl;
+    tl.flags = flags_env;
+    tl.nbx = 1;
+    tl.nby = (g.jsize - 2 * g.gw + (copy_y ? 0 : 1) + MhLastX::OY - 1) / MhLastX::OY;   // (rows past the face range are masked in the kernel)
+    tile_grid_plan(tl, span, 32, 8, 2, zseg_env, pair);
+    if (pair) { tl.zsplit = ra + span; tl.zgap = ra2 - (ra + span); }
+    hipLaunchKernelGGL((mhd3d_sweep_kernel<SPEC, MhLastX>), dim3(8u * (unsigned)tl.per_xcd), dim3(MH_THREADS), 0, s, g, tl, U, F, emf,
+                       dt, dtdx, dtdy, dtdz, ra, ra + nplanes, clk);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
   // x layer first (rows gw .. jsize-gw-1 hold sweep results), then the y layer over all i: the corner comes out right
   const int nk1 = pair ? span : -1;
   if (copy_x) { const unsigned n = (unsigned)g.jsize * (unsigned)nplanes; const K_copy_periodic_layer k = {g, F, emf, 0, ra, 0, n, 1, nk1, ra2}; if (rgpu::rg_launch<256>(s, n, k)) return -1; }
