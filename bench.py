@@ -469,7 +469,9 @@ def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
                             "128-B read requests at 64 B; 0.49-0.77 of known byte counts on this code's 8 B per lane streams), and with FETCH_SIZE doubled as "
                             "MI355X_MICROARCH.md prescribes for wide streaming reads = an upper bound",
             "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": dom_ms, "launches_per_step": dom_launches / nprof, "launches_timed": dom_launches,
-            "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md" if w["bytes"] == 128.0 else
+            "note": ("fp64-VALU-bound kernel (div / sqrt heavy HLLD + 2D HLLD solvers): see DESIGN.md; avg_launch_ms is the sweep PHASE of a step -- "
+                     "mhd3d_sweep_kernel<SPEC, MhTile<16, 8>> (3D MHD: + its short second launch with the 2 x 32 geometry for the last x face column, "
+                     "~0.2 ms at 512^3, + the periodic-layer copy, 0.03 ms)" if w["bytes"] == 128.0 else
                      "LDS-tiled z-marching sweep, one kernel per step: see DESIGN.md"),
             "valu_ceiling": valu_ceiling(pkey, dom_name, dom_ms / max(dom_launches / nprof, 1.0))}
     if _PMC.get("note"):

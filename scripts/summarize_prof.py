@@ -10,7 +10,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02a"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 
-PHASE = [("mhd3d_sweep_kernel", "sweep"), ("hydro3d_sweep_kernel", "sweep"), ("mhd2d_step_kernel", "sweep"), ("K_mhd_invdt", "dt"), ("K_hydro_invdt", "dt"),
+PHASE = [("MhTile<2, 32", "sweep_lastx"),   # the short launch of the sweep kernel for the last x face column (hip/tiled_mhd.h: MhLastX)
+         ("mhd3d_sweep_kernel", "sweep"), ("hydro3d_sweep_kernel", "sweep"), ("mhd2d_step_kernel", "sweep"), ("K_mhd_invdt", "dt"), ("K_hydro_invdt", "dt"),
          ("K_mhd_prim", "prim"), ("K_mhd_elec", "elec"), ("K_mhd_trace3d", "trace"), ("K_mhd_flux3d", "flux"),
          ("K_mhd_update3d", "update"), ("K_shear_save_emf", "shear"), ("K_shear_remap", "shear"), ("K_shear_ghost", "boundaries"),
          ("K_fill_xy", "boundaries"), ("K_copy_periodic_layer", "sweep_copy"), ("step_clock_kernel", "clock"),
@@ -54,7 +55,7 @@ for w in ("mri", "implode3d", "orszag-tang", "mri_contracted", "implode3d_contra
     traffic[w] = {}
     with open(os.path.join(dst, "%s_pmc_per_kernel_%s.csv" % (tag, w)), "w") as out:
         out.write("phase(kernel),launches_sampled," + ",".join(counters) + ",VALU_inst_per_cell,HBM_bytes_per_cell\n")
-        for ph in ["dt", "prim", "elec", "trace", "flux", "sweep", "update"]:
+        for ph in ["dt", "prim", "elec", "trace", "flux", "sweep", "sweep_lastx", "update"]:
             if ph not in acc:
                 continue
             vals, n = [], 0
