@@ -72,6 +72,16 @@ constexpr int MH_THREADS = 512;
 #ifndef RG_TRACE_DECODE_PER_PLANE
 #define RG_TRACE_DECODE_PER_PLANE RG_DECODE_DEFAULT
 #endif
+// Prologue of a workgroup (primitives of planes sa-2 .. sa): the loads of the three planes in flight at once (1) or plane after plane (0).
+// Same-box A/B, 512^3 / a 64-plane slab (profiles/r05_sweep_prologue.txt): exact build 30.2-30.6 against 30.85-30.98 ms / 3.82 against 3.85-3.91;
+// contracted build 24.85-25.38 against 24.91-25.03 / 3.26-3.32 against 3.21-3.29 -- it keeps the serial form.
+#ifndef RG_PROLOGUE_LOADS_IN_FLIGHT
+#ifdef RG_ARITH_FAST
+#define RG_PROLOGUE_LOADS_IN_FLIGHT 0
+#else
+#define RG_PROLOGUE_LOADS_IN_FLIGHT 1
+#endif
+#endif
 #ifndef RG_SWEEP_SPLIT_LOOPS   // main loop of the sweep once per wave role (1) or once for all waves (0): see mhd3d_sweep_kernel
 #ifdef RG_ARITH_FAST
 #define RG_SWEEP_SPLIT_LOOPS 0
@@ -334,6 +344,41 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #endif
   // prologue: primitives of planes sa-2, sa-1, sa; electric field of plane sa-1
   if (t == 0) { Lsync = 0; Lesync = 0; }
+#if RG_PROLOGUE_LOADS_IN_FLIGHT
+  {
+    // the loads of all three planes in flight at once (the start-up of a workgroup is 5 % of a 64-plane slab's march): the second and third
+    // plane wait in registers of their own, dead before the main loop starts
+    double pq[2][2][11];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (pok[r]) {
+          const double* u = U + pidx2[r] + (size_t)(sa - 1 + q) * sk;
+#pragma unroll
+          for (int v = 0; v < 8; ++v) pq[q][r][v] = u[(size_t)v * N];
+          pq[q][r][8] = u[(size_t)IA * N + 1];
+          pq[q][r][9] = u[(size_t)IB * N + g.sj];
+          pq[q][r][10] = u[(size_t)IC * N + sk];
+        }
+    prim_load(sa - 2);
+    prim_compute();
+    prim_store(sa - 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (pok[r]) {
+#pragma unroll
+          for (int v = 0; v < 11; ++v) pu[r][v] = pq[q][r][v];
+        }
+      prim_compute();
+      prim_store(sa - 1 + q);
+    }
+    __syncthreads();
+    elec_plane(sa - 1, t, MH_THREADS);
+  }
+#else
   for (int k = sa - 2; k <= sa; ++k) {
     prim_load(k);
     prim_compute();
@@ -341,6 +386,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     __syncthreads();
     if (k == sa - 1) elec_plane(k, t, MH_THREADS);
   }
+#endif
   __syncthreads();
   // iteration kk.  Riemann waves: electric field of plane kk+2 (from Q / B of planes kk+1, kk+2, complete since the last
   // barrier) into the slot E(kk) vacated, announce it, then the Riemann problems of plane kk.  Producers: loads of U(kk+3),
