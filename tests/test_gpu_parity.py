@@ -41,6 +41,10 @@ MEDIUM = [
     ("mhd_BrioWu", "mesh.nx=96;mesh.ny=128", 20),
     ("mhd_mri_3d", "mesh.nx=32;mesh.ny=64;mesh.nz=32", 10),
     ("orszag-tang3d", "mesh.nx=32;mesh.ny=32;mesh.nz=32", 5),
+    # the last x face column in its own 2 x 32 tiles (hip/tiled_mhd.h: MhLastX): nx a multiple of 16 without a periodic image in x --
+    # shearing box with a partly filled second tile of rows; open box whose y layer is not copied either (33 face rows: a tile with one row)
+    ("mhd_mri_3d", "mesh.nx=48;mesh.ny=40;mesh.nz=12", 6),
+    ("orszag-tang3d", "mesh.nx=32;mesh.ny=32;mesh.nz=10;mesh.boundary_xmin=2;mesh.boundary_xmax=2;mesh.boundary_ymin=2;mesh.boundary_ymax=2", 5),
     ("implode3d", "mesh.nx=48;mesh.ny=48;mesh.nz=48;hydro.riemannSolver=hllc", 10),
     ("implode3d", "mesh.nx=128;mesh.ny=128;mesh.nz=128;hydro.riemannSolver=hllc", 2),
     ("jet2d_cpu", "mesh.nx=100;mesh.ny=400", 30),
