@@ -148,6 +148,15 @@ inline bool packs(const Comm* c) { return c->pack; }
 // all ops as ONE group on the halo stream, behind what the compute stream holds now
 inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nops) {
   hipStream_t cs = (hipStream_t)compute_stream;
+  // The pack kernel runs on the COMPUTE stream, ahead of the kernels the exchange overlaps with: alone it takes 0.03 ms for the 103 MB of a
+  // 512^2 slab; on the halo stream, next to the inner update, it took 0.12 ms and the transfer started that much later -- N = 8 slab probe
+  // with the link time beside the copy 4.44 against 4.52 ms per step, level without a link (profiles/r05_slab_pack_stream.txt).
+  // RGPU_COMM_PACK_STREAM=halo: on the halo stream (rounds 4-5).  The stage is free: the compute stream has waited for the previous exchange.
+  static const bool pack_on_compute = !(std::getenv("RGPU_COMM_PACK_STREAM") && std::string(std::getenv("RGPU_COMM_PACK_STREAM")) == "halo");
+  PackedExchange px;
+  const bool packed = c->pack && build_packed(ops, nops, &px) == 0;
+  if (packed && px.pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
+  if (packed && pack_on_compute && launch_pack(px, c->stage_s, cs)) return fail(c, "pack kernel");
   if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (hipEventRecord(c->ev_begin, c->halo) != hipSuccess) return fail(c, "event record");
   long long hold_ticks = 0;
@@ -159,14 +168,12 @@ inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nop
   }
   const bool hold_beside = hold_ticks > 0 && c->emulate_parallel && c->hold_stream;
   bool held = false;
-  PackedExchange px;
-  if (c->pack && build_packed(ops, nops, &px) == 0) {
+  if (packed) {
     // per peer, in posting order: one region of the send stage and one of the receive stage (comm/pack_plan.h).  The stages were
     // sized and allocated by prepare_exchange at rgpu_comm_create (all ranks pack or none does): no allocation inside a step, where
     // a failure on one rank would leave its peers in ncclRecv
     const PackPlan& pl = px.pl;
-    if (pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
-    if (launch_pack(px, c->stage_s, c->halo)) return fail(c, "pack kernel");
+    if (!pack_on_compute && launch_pack(px, c->stage_s, c->halo)) return fail(c, "pack kernel");
     if (hold_beside) {   // the emulated link time starts with the transfer
       if (hipEventRecord(c->ev_hold0, c->halo) != hipSuccess || hipStreamWaitEvent(c->hold_stream, c->ev_hold0, 0) != hipSuccess) return fail(c, "hold fork");
       hipLaunchKernelGGL(emulated_link_hold, dim3(1), dim3(1), 0, c->hold_stream, hold_ticks);

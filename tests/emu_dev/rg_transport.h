@@ -119,15 +119,16 @@ inline bool packs(const Comm* c) { return c->pack; }
 inline int exchange_start(Comm* c, void* compute_stream, const P2P* ops, int nops) {
   hipStream_t cs = (hipStream_t)compute_stream;
   if (c->pending) return fail(c, "exchange_start: the previous exchange was not waited for");
-  if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (total_doubles(ops, nops, 1) > c->h_cap || total_doubles(ops, nops, 0) > c->h_cap) return fail(c, "exchange_start: host images were not prepared for this operation list");
   c->dev_ops.assign(ops, ops + nops);
   c->host_ops.clear();
   c->pending_packed = c->pack && build_packed(ops, nops, &c->px) == 0;
+  // as in the product's transport: the pack kernel on the compute stream, ahead of the kernels the exchange overlaps with
+  if (c->pending_packed && c->px.pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
+  if (c->pending_packed && launch_pack(c->px, c->stage_s, cs)) return fail(c, "pack kernel");
+  if (hipEventRecord(c->ev_ready, cs) != hipSuccess || hipStreamWaitEvent(c->halo, c->ev_ready, 0) != hipSuccess) return fail(c, "event record / wait");
   if (c->pending_packed) {
     const PackPlan& pl = c->px.pl;
-    if (pl.stage_doubles > c->stage_cap) return fail(c, "packed exchange: the operation list outgrew the stages sized at create");
-    if (launch_pack(c->px, c->stage_s, c->halo)) return fail(c, "pack kernel");
     size_t all_s = 0;
     for (int q = 0; q < pl.npeers; ++q) all_s += pl.send_total[q];
     if (all_s && hipMemcpyAsync(c->h_s, c->stage_s, all_s * sizeof(double), hipMemcpyDeviceToHost, c->halo) != hipSuccess) return fail(c, "D2H of the send stage");
