@@ -77,6 +77,20 @@ RG_DEVFN double tvd_slope(double st, double qm, double q0, double qp) {
   return dsgn * fmin(dlim, fabs(dcen));
 }
 
+// HALF of that slope, as the 3D MHD trace consumes it (trace_mhd.h:1902-1936: "0.5 * dq"), formed without a compare or a select:
+//   0.5 * dsgn * min(min(|st dl|, |st dr|) [dl dr > 0], |0.5 dc|)  =  max(min(a, b, c), 0) + min(max(a, b, c), 0)
+// with a = (st / 2) dl, b = (st / 2) dr, c = dc / 4.  Scaling by 1/2 commutes with every rounding, the minimum and the product's sign,
+// and dl, dr > 0 imply dc > 0 (qp > q0 > qm), so where all three have one sign the sum is that sign's smallest magnitude -- the
+// reference's value bit for bit -- and +-0 elsewhere: 11 fp64 instructions instead of 16 with two compares and three selects.
+// Differences to tvd_slope: the sign of a zero result, and |st dl * st dr| < 2^-1074 (the reference's product underflows to 0 and
+// its test fails: it returns 0, this returns the sub-1e-150 minimum).
+RG_DEVFN double tvd_half_slope(double st, double qm, double q0, double qp) {
+  const double hs = 0.5 * st;
+  const double a = hs * (q0 - qm), b = hs * (qp - q0), c = 0.25 * (qp - qm);
+  const double lo = fmin(fmin(a, b), c), hi = fmax(fmax(a, b), c);
+  return fmax(lo, 0.0) + fmin(hi, 0.0);
+}
+
 // slope_unsplit_3d, slope_type == 1 (slope.h:351-384)
 RG_DEVFN double minmod_slope(double qm, double q0, double qp) {
   const double dlft = q0 - qm;
@@ -322,7 +336,7 @@ RG_DEVFN double fast_speed_sq(const DevParams& g, const Prim8& q, double bn, con
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
   const double c2 = rg_div(g.gamma0 * q.p, inv_r);
   const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
-  return d2 + rg_sqrt(d2 * d2 - rg_div(c2 * bn * bn, inv_r));
+  return d2 + rgpu::rg_sqrt_radicand(d2 * d2 - rg_div(c2 * bn * bn, inv_r));
 }
 RG_DEVFN double fast_speed(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
   return rg_sqrt_pos(fast_speed_sq(g, q, bn, inv_r));   // d2 > 0: p > 0

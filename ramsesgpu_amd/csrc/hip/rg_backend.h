@@ -105,6 +105,18 @@ RG_DEVFN double rg_sqrt_pos(double x) {
 #endif
 }
 
+// root of d2^2 - c2 bn^2 / rho inside the fast magnetosonic speed: non-negative in real arithmetic, exactly 0 for a purely normal
+// field at b^2 = rho c2.  Exact arithmetic: the reference's sqrt (0 -> 0, a negative round-off residue -> NaN like the reference).
+// Contracted arithmetic: the radicand clamped to 2^-1000 from below (one v_max_f64 instead of a class test and two selects; the root
+// of the clamp, 1e-151, is added to d2 > 0)
+RG_DEVFN double rg_sqrt_radicand(double x) {
+#ifdef RG_ARITH_FAST
+  return rg_sqrt_pos(fmax(x, 0x1p-1000));
+#else
+  return rg_sqrt(x);
+#endif
+}
+
 // reciprocal of sqrt(x), x positive and finite, for "n / sqrt(x)" (the Alfven speeds of the 2D HLLD solver divide by twelve
 // such roots per edge).  Exact arithmetic: the correctly rounded root, then its shared reciprocal -- the reference's two
 // operations.  Contracted arithmetic: one refined rsq.

@@ -40,7 +40,13 @@ struct MhTile {
   static constexpr bool LASTX = LASTX_;                 // the tile column sits at i0 = isize - gw
   static constexpr int PX = OX + 1, PY = OY + 1;
   static constexpr int CELLS = PX * PY;                 // traced cells per plane (tile + low-side halo): 153
-  static constexpr int BUF = T_COUNT * CELLS;           // doubles per plane buffer of T
+  // LDS layout (round 6): CELL-MAJOR records.  DS instructions take unsigned immediate offsets only (16 bits; 8 bits x 8 bytes each for
+  // the two halves of a ds_read2_b64), so with the variable-major layout of rounds 2-5 every access below or far above "the" cell of a
+  // thread cost a v_add_u32 for its address: 15 % of the sweep's VALU instructions were 32-bit integer work.  With records, everything a
+  // thread reads lies within 2040 bytes above one of a few per-thread row bases (rg_opaque), and neighbouring slots pair up into
+  // ds_read2_b64 / ds_write2_b64 without any address arithmetic.  TREC is odd x 8 bytes: lanes of consecutive cells hit distinct banks.
+  static constexpr int TREC = T_COUNT + 1;              // doubles per traced-cell record of T (38 used)
+  static constexpr int BUF = TREC * CELLS;              // doubles per plane buffer of T
   static constexpr int QX = OX + 3, QY = OY + 3;
   static constexpr int QCELLS = QX * QY;                // input cells per plane (traced cells +- 1), origin (i0-2, j0-2): 209
   static constexpr int NQB = 11;                        // per input cell: 8 primitives + 3 face-field components
@@ -90,14 +96,24 @@ constexpr int MH_THREADS = 512;
 #endif
 #endif
 
+// a copy of an integer that the optimiser cannot fold constants into or derive from another value: the LDS addresses formed from
+// it are "this register + a non-negative immediate"
+RG_DEVFN unsigned rg_opaque(unsigned x) { asm("" : "+v"(x)); return x; }
+
 template <class G>
-struct TLdsWrite {
+struct TLdsWrite {   // bound to the record of one traced cell
   double* cell;
-  RG_DEVFN void put(int slot, double v) const { cell[slot * G::CELLS] = v; }
+  RG_DEVFN void put(int slot, double v) const { cell[slot] = v; }
 };
+// Trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B (records of NQB doubles per input cell), planes kk, kk+1 of E (records
+// of 3).  The cell index m the numerics pass is RELATIVE to the thread's 3 x 3 input neighbourhood: m = row * QX + col, centre =
+// QX + 1 (what mhd_trace3d_at / mhd_elec_comp receive), m - 1, m + sj() ... its neighbours -- compile-time constants after inlining.
+// qA[dz + 1] / qB[dz + 1]: byte offsets in LQ of the records of the neighbourhood's cells (row 0, col 0) / (row 2, col 0) of plane
+// dz; eA[dz]: of the E record of cell (row 1, col 0).
 template <class G>
-struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q / B, planes kk, kk+1 of E
-  const double* qb[3]; const double* eb[2];
+struct TraceInLds {
+  const char* lq; const char* le;
+  unsigned qA[3], qB[3], eA[2];
   const int* flag; int want;   // E of plane kk+1 is complete once *flag >= want (written by the Riemann waves)
   RG_DEVFN void e_ready() const {
     if (flag) {
@@ -105,19 +121,31 @@ struct TraceInLds {   // trace inputs staged in LDS: planes kk-1, kk, kk+1 of Q 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   }
-  RG_DEVFN double q(int v, int dz, unsigned m) const { return qb[dz + 1][v * G::QCELLS + m]; }
-  RG_DEVFN double bf(int comp, int dz, unsigned m) const { return qb[dz + 1][(8 + comp) * G::QCELLS + m]; }
-  RG_DEVFN double e(int comp, int dz, unsigned m) const { return eb[dz][comp * G::QCELLS + m]; }
+  RG_DEVFN double q(int v, int dz, unsigned m) const {
+    const unsigned row = m / (unsigned)G::QX, col = m - row * (unsigned)G::QX;
+    const unsigned rec = (row >= 2u) ? qB[dz + 1] + (row - 2u) * (unsigned)(G::QX * G::NQB * 8) : qA[dz + 1] + row * (unsigned)(G::QX * G::NQB * 8);
+    return *reinterpret_cast<const double*>(lq + rec + (col * (unsigned)G::NQB + (unsigned)v) * 8u);
+  }
+  RG_DEVFN double bf(int comp, int dz, unsigned m) const { return q(8 + comp, dz, m); }
+  RG_DEVFN double e(int comp, int dz, unsigned m) const {   // m >= QX: rows 1 and 2 of the neighbourhood
+    return *reinterpret_cast<const double*>(le + eA[dz] + ((m - (unsigned)G::QX) * 3u + (unsigned)comp) * 8u);
+  }
   RG_DEVFN unsigned sj() const { return (unsigned)G::QX; }
 };
 
 // T accessor of ONE plane buffer: the +z neighbour of a cell is not in it.  stride(ZD) = 0 makes the one component of a
 // state that reads the plane above (the face field on the + side) read this plane instead; the caller replaces that
 // component when the plane above has been traced (see "carried states" below).
+// The cell index m is RELATIVE to the 2 x 2 traced cells a Riemann thread reads: m = row * PX + col, the thread's own cell = PX + 1
+// (what riemann_dir passes), m - 1, m - PX, m - PX - 1 its low-side neighbours.  row0 / row1: byte offsets in this plane's buffer of
+// the records of (row 0, col 0) and (row 1, col 0).
 template <class G>
 struct TLdsPlane {
-  const double* base;
-  RG_DEVFN double get(int slot, unsigned m) const { return base[slot * G::CELLS + m]; }
+  const char* lt; unsigned row0, row1;
+  RG_DEVFN double get(int slot, unsigned m) const {
+    const unsigned row = m / (unsigned)G::PX, col = m - row * (unsigned)G::PX;
+    return *reinterpret_cast<const double*>(lt + (row ? row1 + (row - 1u) * (unsigned)(G::PX * G::TREC * 8) : row0) + (col * (unsigned)G::TREC + (unsigned)slot) * 8u);
+  }
   RG_DEVFN unsigned stride(int D) const { return (D == XD) ? 1u : (D == YD) ? (unsigned)G::PX : 0u; }
 };
 
@@ -179,8 +207,13 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
   }
 }
 
+#ifdef RG_SWEEP_VGPRS
+#define RG_SWEEP_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RG_SWEEP_VGPRS)))
+#else
+#define RG_SWEEP_VGPR_ATTR
+#endif
 template <int SPEC, class G>
-__global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
+__global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
                                                                const StepClock* clk) {
@@ -269,7 +302,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     for (int r = 0; r < 2; ++r)
       if (pok[r]) {
 #pragma unroll
-        for (int v = 0; v < MH_NQB; ++v) qd[v * MH_QCELLS + pw + 128 * r] = pu[r][v];
+        for (int v = 0; v < MH_NQB; ++v) qd[(pw + 128 * r) * MH_NQB + v] = pu[r][v];
       }
   };
 
@@ -277,7 +310,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   // Ex at (c, c+y), Ey at (c, c+x), Ez at (c, c+x, c+y): 17 x 10 + 18 x 9 + 18 x 10 = 512 values -- one per thread. ----
   // value e of the 512: computed by thread `first` + n * `stride`
   auto elec_plane = [&](int k, int first, int stride) {
-    const TraceInLds<G> in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT}, {0, 0}, 0, 0};
+    const unsigned qlo = (unsigned)(((k - 1) % 3) * MH_QBSLOT), qhi = (unsigned)((k % 3) * MH_QBSLOT);
     double* ed = LE + (k & 1) * MH_ESLOT;
     constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY;
     constexpr int NE = NEX + NEY + (MH_PX + 1) * (MH_PY + 1);
@@ -290,12 +323,18 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       const int ei = i0 - 1 + ex, ej = j0 - 1 + ey;
       if (ei < g.isize - 1 && ej < g.jsize - 1) {   // range of mhd_elec_cell (low bounds hold by construction)
         const unsigned qm = (unsigned)((ey + 1) * MH_QX + ex + 1);
+        const unsigned q00 = (unsigned)(ey * MH_QX + ex) * (unsigned)MH_NQB;   // the cell diagonally below: (row 0, col 0) of the 2 x 2 cells read
+        TraceInLds<G> in;
+        in.lq = reinterpret_cast<const char*>(LQ); in.le = 0; in.flag = 0; in.want = 0;
+        in.qA[0] = rg_opaque((qlo + q00) * 8u); in.qA[1] = rg_opaque((qhi + q00) * 8u); in.qA[2] = 0;
+        in.qB[0] = in.qB[1] = in.qB[2] = 0; in.eA[0] = in.eA[1] = 0;
         const double xPos = g.xMin + g.dx / 2 + (ei - gw) * g.dx;
+        constexpr unsigned MC = (unsigned)(MH_QX + 1);   // the cell itself, relative to that neighbourhood
         double v;
-        if (comp == 0) v = mhd_elec_comp<0>(g, in, xPos, qm);
-        else if (comp == 1) v = mhd_elec_comp<1>(g, in, xPos, qm);
-        else v = mhd_elec_comp<2>(g, in, xPos, qm);
-        ed[comp * MH_QCELLS + qm] = v;
+        if (comp == 0) v = mhd_elec_comp<0>(g, in, xPos, MC);
+        else if (comp == 1) v = mhd_elec_comp<1>(g, in, xPos, MC);
+        else v = mhd_elec_comp<2>(g, in, xPos, MC);
+        ed[qm * 3u + (unsigned)comp] = v;
       }
     }
   };
@@ -319,10 +358,20 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
     const int ti = i0 - 1 + tx, tj = j0 - 1 + ty;
     if (cell < MH_CELLS && ti <= g.isize - gw && tj <= g.jsize - gw) {   // low bounds hold by construction
       const IJK c = {ti, tj, k};
-      const TLdsWrite<G> tw = {LT + (k & 1) * MH_BUF + cell};
-      const TraceInLds<G> in = {{LQ + ((k - 1) % 3) * MH_QBSLOT, LQ + (k % 3) * MH_QBSLOT, LQ + ((k + 1) % 3) * MH_QBSLOT},
-                             {LE + (k & 1) * MH_ESLOT, LE + ((k + 1) & 1) * MH_ESLOT}, &Lesync, e_want};
-      mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)((ty + 1) * MH_QX + tx + 1));
+      const TLdsWrite<G> tw = {LT + (k & 1) * MH_BUF + cell * G::TREC};
+      // input cell (tx, ty) of the 19 x 11 input tile = (row 0, col 0) of this traced cell's 3 x 3 neighbourhood
+      const unsigned q00 = (unsigned)(ty * MH_QX + tx) * (unsigned)MH_NQB, e10 = (unsigned)((ty + 1) * MH_QX + tx) * 3u;
+      TraceInLds<G> in;
+      in.lq = reinterpret_cast<const char*>(LQ); in.le = reinterpret_cast<const char*>(LE); in.flag = &Lesync; in.want = e_want;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned rec = (unsigned)(((k - 1 + p) % 3) * MH_QBSLOT) + q00;
+        in.qA[p] = rg_opaque(rec * 8u);
+        in.qB[p] = rg_opaque((rec + (unsigned)(2 * MH_QX * MH_NQB)) * 8u);
+      }
+      in.eA[0] = rg_opaque(((unsigned)((k & 1) * MH_ESLOT) + e10) * 8u);
+      in.eA[1] = rg_opaque(((unsigned)(((k + 1) & 1) * MH_ESLOT) + e10) * 8u);
+      mhd_trace3d_at(g, in, tw, dtdx, dtdy, dtdz, c, (unsigned)(MH_QX + 1));
     }
   };
 
@@ -336,7 +385,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int ci = i0 + ox, cj = j0 + oy;
   const bool fl_ok = !producer && cl < MH_OX * MH_OY && ci <= g.isize - gw && cj <= g.jsize - gw;
   const unsigned cidx2 = fl_ok ? (unsigned)ci + (unsigned)cj * g.sj : 0u;
-  const unsigned cm = (unsigned)((oy + 1) * MH_PX + ox + 1);
+  const unsigned cm00 = (unsigned)(oy * MH_PX + ox) * (unsigned)(G::TREC * 8);   // byte offset of the T record of the cell diagonally below
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
 
 #ifdef RG_SWEEP_PROF
@@ -441,15 +490,16 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
     RG_E_STEP(kk)                                                                                                        \
     if (RG_RIEMANN_ON) {                                                                                                 \
-      const TLdsPlane<G> Tk = {LT + (kk & 1) * MH_BUF};                                                                     \
+      const unsigned tk0 = (unsigned)((kk & 1) * MH_BUF * 8) + cm00;                                                     \
+      const TLdsPlane<G> Tk = {reinterpret_cast<const char*>(LT), rg_opaque(tk0), rg_opaque(tk0 + (unsigned)(MH_PX * G::TREC * 8))};  \
       const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
       const bool solve = kk >= sa;                                                                                       \
       const bool raise = prio_mode && solve && wave >= 4;                                                                \
       if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
       RG_XPOS(xp)                                                                                                        \
-      if (dir == 0) riemann_dir<G, XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                               \
-      else if (dir == 1) riemann_dir<G, YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                          \
-      else riemann_dir<G, ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);                                        \
+      if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                               \
+      else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                          \
+      else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                                        \
     }                                                                                                                    \
   }
 #ifdef RG_SWEEP_PROF
@@ -510,7 +560,8 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
 #else
       if (fl_ok && kk >= sa - 1) {
 #endif
-        const TLdsPlane<G> Tk = {LT + (kk & 1) * MH_BUF};
+        const unsigned tk0 = (unsigned)((kk & 1) * MH_BUF * 8) + cm00;
+        const TLdsPlane<G> Tk = {reinterpret_cast<const char*>(LT), rg_opaque(tk0), rg_opaque(tk0 + (unsigned)(MH_PX * G::TREC * 8))};
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;
         const bool raise = prio_mode && solve && wave >= 4;
@@ -518,9 +569,9 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
         Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
         RG_XPOS(xp)
-        if (dir == 0) riemann_dir<G, XD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<G, YD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<G, ZD>(g, Tk, cm, xp, F, emf, idx, c0, c1, solve, raise);
+        if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
+        else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
+        else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
         keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
         keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
       }

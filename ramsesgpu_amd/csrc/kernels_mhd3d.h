@@ -153,12 +153,12 @@ RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const TIN& in, const TW& tw
   const double AR = in.bf(0, 0, m + 1), BR = in.bf(1, 0, m + sj), CR = in.bf(2, +1, m);
   // transverse slopes of the low-face field (slope_unsplit_mhd_3d: slope type capped at 2)
   const double mst = g.mag_slope_type;
-  const double dALy = 0.5 * tvd_slope(mst, in.bf(0, 0, m - sj), AL, in.bf(0, 0, m + sj));
-  const double dALz = 0.5 * tvd_slope(mst, in.bf(0, -1, m), AL, in.bf(0, +1, m));
-  const double dBLx = 0.5 * tvd_slope(mst, in.bf(1, 0, m - 1), BL, in.bf(1, 0, m + 1));
-  const double dBLz = 0.5 * tvd_slope(mst, in.bf(1, -1, m), BL, in.bf(1, +1, m));
-  const double dCLx = 0.5 * tvd_slope(mst, in.bf(2, 0, m - 1), CL, in.bf(2, 0, m + 1));
-  const double dCLy = 0.5 * tvd_slope(mst, in.bf(2, 0, m - sj), CL, in.bf(2, 0, m + sj));
+  const double dALy = tvd_half_slope(mst, in.bf(0, 0, m - sj), AL, in.bf(0, 0, m + sj));
+  const double dALz = tvd_half_slope(mst, in.bf(0, -1, m), AL, in.bf(0, +1, m));
+  const double dBLx = tvd_half_slope(mst, in.bf(1, 0, m - 1), BL, in.bf(1, 0, m + 1));
+  const double dBLz = tvd_half_slope(mst, in.bf(1, -1, m), BL, in.bf(1, +1, m));
+  const double dCLx = tvd_half_slope(mst, in.bf(2, 0, m - 1), CL, in.bf(2, 0, m + 1));
+  const double dCLy = tvd_half_slope(mst, in.bf(2, 0, m - sj), CL, in.bf(2, 0, m + sj));
 
   // electric field at the edges bounding the three low faces
   const double ELL = E9[0], ELR = E9[1], ERL = E9[2];
@@ -166,12 +166,10 @@ RG_DEVFN void mhd_trace3d_finish(const DevParams& g, const TIN& in, const TW& tw
   const double GLL = E9[6], GLR = E9[7], GRL = E9[8];
 
   double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = q[IW], A = q[IA], B = q[IB], C = q[IC];
-  const double drx = dx_[ID] * 0.5, dpx = dx_[IP] * 0.5, dux = dx_[IU] * 0.5, dvx = dx_[IV] * 0.5, dwx = dx_[IW] * 0.5,
-               dCx = dx_[IC] * 0.5, dBx = dx_[IB] * 0.5;
-  const double dry = dy_[ID] * 0.5, dpy = dy_[IP] * 0.5, duy = dy_[IU] * 0.5, dvy = dy_[IV] * 0.5, dwy = dy_[IW] * 0.5,
-               dCy = dy_[IC] * 0.5, dAy = dy_[IA] * 0.5;
-  const double drz = dz_[ID] * 0.5, dpz = dz_[IP] * 0.5, duz = dz_[IU] * 0.5, dvz = dz_[IV] * 0.5, dwz = dz_[IW] * 0.5,
-               dAz = dz_[IA] * 0.5, dBz = dz_[IB] * 0.5;
+  // (dx_, dy_, dz_ arrive as HALF slopes: the reference's "0.5 * dq" is taken where the slope is formed)
+  const double drx = dx_[ID], dpx = dx_[IP], dux = dx_[IU], dvx = dx_[IV], dwx = dx_[IW], dCx = dx_[IC], dBx = dx_[IB];
+  const double dry = dy_[ID], dpy = dy_[IP], duy = dy_[IU], dvy = dy_[IV], dwy = dy_[IW], dCy = dy_[IC], dAy = dy_[IA];
+  const double drz = dz_[ID], dpz = dz_[IP], duz = dz_[IU], dvz = dz_[IV], dwz = dz_[IW], dAz = dz_[IA], dBz = dz_[IB];
   const double dAx = 0.5 * (AR - AL), dBy = 0.5 * (BR - BL), dCz = 0.5 * (CR - CL);
   const double gamma = g.gamma0;
 
@@ -248,13 +246,13 @@ RG_DEVFN void mhd_trace3d_at(const DevParams& g, const TIN& in, const TW& tw, do
       const double dfx = 0.5 * (in.q(v, 0, m + 1) - in.q(v, 0, m - 1)), dfy = 0.5 * (in.q(v, 0, m + sj) - in.q(v, 0, m - sj));
       const double dfz = 0.5 * (in.q(v, +1, m) - in.q(v, -1, m));
       const double dlim = positivity_limiter(lo, hi, q[v], fabs(dfx) + fabs(dfy) + fabs(dfz));
-      dx_[v] = dlim * dfx;
-      dy_[v] = dlim * dfy;
-      dz_[v] = dlim * dfz;
+      dx_[v] = dlim * dfx * 0.5;
+      dy_[v] = dlim * dfy * 0.5;
+      dz_[v] = dlim * dfz * 0.5;
     } else {
-      dx_[v] = tvd_slope(st, in.q(v, 0, m - 1), q[v], in.q(v, 0, m + 1));
-      dy_[v] = tvd_slope(st, in.q(v, 0, m - sj), q[v], in.q(v, 0, m + sj));
-      dz_[v] = tvd_slope(st, in.q(v, -1, m), q[v], in.q(v, +1, m));
+      dx_[v] = tvd_half_slope(st, in.q(v, 0, m - 1), q[v], in.q(v, 0, m + 1));
+      dy_[v] = tvd_half_slope(st, in.q(v, 0, m - sj), q[v], in.q(v, 0, m + sj));
+      dz_[v] = tvd_half_slope(st, in.q(v, -1, m), q[v], in.q(v, +1, m));
     }
   }
   in.e_ready();

@@ -222,6 +222,9 @@ struct K_mhd_update3d {
   const StepClock* clk;   // device-side time step (0: the by-value dt, rc above)
   RG_DEVFN void operator()(unsigned t) const {
     spec_assume<SPEC>(g);
+#ifdef RG_UPD_SETPRIO
+    __builtin_amdgcn_s_setprio(RG_UPD_SETPRIO);
+#endif
     const bool second = t >= n1;
     const unsigned tt = second ? t - n1 : t;
     const int lo = second ? k_lo2 : k_lo, hi = second ? k_hi2 : k_hi;

@@ -876,6 +876,9 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   // the update is a pure stream over F, emf and U: one thread per column and short z segment, linear workgroup order, the plane
   // k+1 entries carried in registers (mhd_update3d_column; 512^3: 8.07 -> 7.42 ms against one thread per cell)
+#ifndef RG_UPD_MINW
+#define RG_UPD_MINW 1
+#endif
   static const int upd_seg = std::getenv("RGPU_UPD_SEG") ? std::atoi(std::getenv("RGPU_UPD_SEG")) : 3;
   auto update_planes = [&](rg_stream_t s, PlaneRange r, PlaneRange r2 = PlaneRange{0, 0}) -> int {
     if (r.hi <= r.lo) { r = r2; r2 = PlaneRange{0, 0}; }
@@ -885,7 +888,7 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
     const bool two = r2.hi > r2.lo;
     const unsigned nt = n1 + (two ? g.sk * (unsigned)((r2.hi - r2.lo + seg_len - 1) / seg_len) : 0u);
     const unsigned split = two ? n1 : 0xffffffffu;
-#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi, st.clk}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
+#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi, st.clk}; return rg_launch_range<kBlock, RG_UPD_MINW>(s, 0u, nt, k); }
     if (gf) { if (g.rot) RG_UPD(true, true, SPEC_NONE) else RG_UPD(false, true, SPEC_NONE) }
     if (g.rot) { if (spec == 1) RG_UPD(true, false, kSpecMri) if (spec == 2) RG_UPD(true, false, kSpecPlain) RG_UPD(true, false, SPEC_NONE) }
     if (spec == 1) RG_UPD(false, false, kSpecMri) if (spec == 2) RG_UPD(false, false, kSpecPlain) RG_UPD(false, false, SPEC_NONE)

@@ -1,9 +1,35 @@
 #!/usr/bin/env python3
-"""Static instruction mix of one kernel in a hipcc -S listing: per basic block and in total.
-   python scripts/isa_mix.py file.s <substring of the kernel's mangled name> [--blocks]"""
+"""Instruction mix of one kernel in a hipcc -S listing.
+
+  static:   python scripts/isa_mix.py file.s <substring of the kernel's mangled name> [--blocks]
+            per instruction class, in total and (--blocks) per basic block
+
+  dynamic:  python scripts/isa_mix.py --sweep fast|exact [--measured SQ_INSTS_VALU] [--iters N]
+            compiles csrc/rgpu_api.cpp with the flags of ramsesgpu_amd/build.py + -gline-tables-only into a listing and weights the
+            basic blocks of the main loop(s) of mhd3d_sweep_kernel<107, MhTile<16, 8>> by how many waves of the 512-thread
+            workgroup execute them per z plane:
+              * every instruction carries the source line it was inlined from (.loc); a line belongs to a device function, a
+                function to a wave ROLE (riemann / trace / prim / elec / sync; arithmetic helpers are shared);
+              * a basic block belongs to the role most of its role-specific instructions come from (the roles are separated by
+                wave-uniform branches, so blocks are role-pure; blocks without role-specific lines are loop control);
+              * trip counts per plane and workgroup: the compiler emits one copy of the Riemann code per direction, each run by the
+                two waves (cell halves) of that direction -> x 2; one copy of the trace per pass (producer 0: two passes, producer
+                1: one) -> x 1; primitives: both producers -> x 2; electric field: 512 values = 8 wave trips through its loop ->
+                x 8; the producer pair's rendezvous x 2; loop control x 8.  Blocks outside the z loop (prologue) are not counted;
+              * the 2D HLLD solver evaluates only the regions of the Riemann fan some lane of the wave needs (dev_numerics.h,
+                "Region selection by sign bits"): in the shearing box every speed is below the fast speed, all lanes take the
+                inner region and the four outer-region blocks are skipped (s_cbranch_execz) -> x 0.
+            --measured: SQ_INSTS_VALU of one launch (rocprofv3 --pmc, scripts/pmc_ab.sh); --iters: workgroup x plane iterations of
+            that launch (default: the 512^3 shearing box, 2048 tiles x 515 iterations) -> the reconciliation line.
+"""
+import os
 import re
+import subprocess
 import sys
-from collections import Counter, OrderedDict
+from collections import Counter, OrderedDict, defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VALU_CLASSES = ("fma64", "mul64", "add64", "trans64", "minmax64", "vcmp", "cndmask", "lane", "accvgpr", "vmov", "vint", "vother")
 
 
 def classify(op):
@@ -29,59 +55,213 @@ def classify(op):
     return "other"
 
 
-def main():
-    path, key = sys.argv[1], sys.argv[2]
-    show_blocks = "--blocks" in sys.argv
-    lines = open(path).read().splitlines()
+def kernel_lines(lines, key):
+    """the lines of the first function whose mangled name contains `key`"""
     start = None
     for i, l in enumerate(lines):
-        if l.startswith("_Z") and key in l and l.rstrip().endswith(("", )) and ":" in l and not l.startswith("\t"):
-            if re.match(r"^_Z\S+:", l):
-                start = i
-                break
+        if l.startswith("_Z") and key in l and re.match(r"^_Z\S+:", l):
+            start = i
+            break
     if start is None:
-        sys.exit("kernel not found")
+        sys.exit("kernel not found: " + key)
+    end = start
+    for j in range(start + 1, len(lines)):
+        if lines[j].startswith(".Lfunc_end"):
+            end = j
+            break
+    return start, end
+
+
+def parse_blocks(lines, start, end):
+    """OrderedDict label -> {"ops": [(class, (file, line))], "in_loop": bool}"""
     blocks = OrderedDict()
     cur = "entry"
-    blocks[cur] = Counter()
-    meta = {}
-    for l in lines[start + 1:]:
-        if l.startswith(".Lfunc_end"):
-            break
-        m = re.match(r"^(\.LBB\S+):", l)
+    blocks[cur] = {"ops": [], "in_loop": False}
+    loc = (0, 0)
+    for l in lines[start + 1:end]:
+        m = re.match(r"^(\.LBB\S+):(.*)", l)
         if m:
             cur = m.group(1)
-            blocks[cur] = Counter()
+            blocks[cur] = {"ops": [], "in_loop": "in Loop:" in m.group(2) or "Loop Header" in m.group(2)}
             continue
         t = l.strip()
+        m = re.match(r"^\.loc\s+(\d+)\s+(\d+)", t)
+        if m:
+            loc = (int(m.group(1)), int(m.group(2)))
+            continue
+        if t.startswith("; %bb") or t.startswith(";   in Loop") or "Loop Header" in t:
+            if "in Loop" in t or "Loop Header" in t:
+                blocks[cur]["in_loop"] = True
+            continue
         if not t or t.startswith((";", ".", "//")):
             continue
-        op = t.split()[0]
-        blocks[cur][classify(op)] += 1
+        blocks[cur]["ops"].append((classify(t.split()[0]), loc))
+    return blocks
+
+
+def static_report(path, key, show_blocks):
+    lines = open(path).read().splitlines()
+    start, end = kernel_lines(lines, key)
+    blocks = parse_blocks(lines, start, end)
+    meta = {}
     for l in lines[start:]:
         m = re.match(r"^; (NumVgprs|NumAgprs|TotalNumVgprs|ScratchSize|SGPRBlocks|NumSgprs|Occupancy|LDSByteSize|codeLenInByte): (\S+)", l)
         if m and m.group(1) not in meta:
             meta[m.group(1)] = m.group(2)
-        if l.startswith(".Lfunc_end") and meta.get("Occupancy"):
-            pass
         if len(meta) >= 8:
             break
-    # spill counts from the .amdhsa / metadata block
-    txt = "\n".join(lines)
     tot = Counter()
-    for c in blocks.values():
-        tot.update(c)
-    valu = sum(v for k, v in tot.items() if k in ("fma64", "mul64", "add64", "trans64", "minmax64", "vcmp", "cndmask", "lane", "accvgpr", "vmov", "vint", "vother"))
+    for b in blocks.values():
+        tot.update(c for c, _ in b["ops"])
+    valu = sum(v for k, v in tot.items() if k in VALU_CLASSES)
     print("kernel", key, meta)
     print("total static instructions", sum(tot.values()), " VALU", valu)
     for k, v in tot.most_common():
         print("  %-10s %6d" % (k, v))
     if show_blocks:
         print("blocks with >= 40 instructions:")
-        for b, c in blocks.items():
+        for name, b in blocks.items():
+            c = Counter(x for x, _ in b["ops"])
             n = sum(c.values())
             if n >= 40:
-                print("  %-14s %5d  %s" % (b, n, dict(c.most_common(8))))
+                print("  %-14s %5d  %s" % (name, n, dict(c.most_common(8))))
+
+
+# ---- dynamic mix of the MHD sweep -------------------------------------------------------------------------------------------
+ROLE_OF = {}
+for fn in ("riemann_dir edge_state3d face_state3d floor3d edge_emf mag_hlld_2d mhd_hlld mhd_face_flux store_flux fast_speed_sq fast_speed mhd_riemann "
+           "max_of4 min_of4 pos_max sel_max sel_min alfven_pick alfven_duel rg_recip_sqrt_pos rg_sqrt_radicand get stride mhd_hll mhd_llf mag_hlla_2d mag_hllf_2d mag_llf_2d mag_hll_average").split():
+    ROLE_OF[fn] = "riemann"
+for fn in "mhd_trace3d_at mhd_trace3d_finish tvd_half_slope tvd_slope positivity_limiter trace_cell put e_ready".split():
+    ROLE_OF[fn] = "trace"
+for fn in "mhd_prim prim_load prim_compute prim_store".split():
+    ROLE_OF[fn] = "prim"
+for fn in "mhd_elec_comp elec_plane".split():
+    ROLE_OF[fn] = "elec"
+ROLE_OF["pair_sync"] = "sync"
+TRIPS = {"riemann": 2, "trace": 1, "prim": 2, "elec": 8, "sync": 2, "control": 8, "riemann_outer": 0}
+
+
+def outer_region_lines():
+    """line range of the four outer-region branches of mag_hlld_2d in csrc/dev_numerics.h"""
+    src = open(os.path.join(ROOT, "ramsesgpu_amd", "csrc", "dev_numerics.h")).read().splitlines()
+    lo = hi = 0
+    for n, l in enumerate(src, 1):
+        if lo == 0 and l.strip().startswith("if (SB_pos) {"):
+            lo = n
+        if lo and l.strip() == "return E;":
+            hi = n
+            break
+    return lo, hi
+
+
+def function_map(path):
+    """line number -> name of the function / lambda whose definition precedes it"""
+    out, cur = {}, None
+    try:
+        src = open(path).read().splitlines()
+    except OSError:
+        return out
+    for n, l in enumerate(src, 1):
+        m = re.match(r"^\s*(?:template\s*<[^>]*>\s*)?(?:RG_DEVFN|inline|static|__global__|__device__)\b[^;=]*?\b(\w+)\s*\([^;]*$", l)
+        if m and not l.strip().startswith(("return", "if", "for", "while")):
+            cur = m.group(1)
+        m2 = re.match(r"^\s*auto\s+(\w+)\s*=\s*\[&\]", l)
+        if m2:
+            cur = m2.group(1)
+        out[n] = cur
+    return out
+
+
+def dynamic_report(arith, measured, iters):
+    sys.path.insert(0, ROOT)
+    from ramsesgpu_amd import build as rb
+    out = "/tmp/isa_mix_%s.s" % arith
+    src = os.path.join(rb.CSRC, "rgpu_api.cpp")
+    cmd = [rb.HIPCC, "--offload-arch=" + rb.ARCH] + rb.COMMON + (rb.FAST_FLAGS if arith == "fast" else []) + \
+        ["-gline-tables-only", "-x", "hip", "--offload-device-only", "-S", src, "-o", out]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    lines = open(out).read().splitlines()
+    files = {}
+    for l in lines:
+        m = re.match(r'^\s*\.file\s+(\d+)\s+"([^"]*)"\s+"([^"]*)"', l)
+        if m:
+            d, f = m.group(2), m.group(3)
+            files[int(m.group(1))] = f if os.path.isabs(f) else os.path.join(d if os.path.isabs(d) else os.path.join(ROOT, d), f)
+    fmaps = {}
+    key = "mhd3d_sweep_kernelILi107ENS_6MhTileILi16ELi8ELb0"
+    start, end = kernel_lines(lines, key)
+    blocks = parse_blocks(lines, start, end)
+
+    def role_of_loc(loc):
+        fid, ln = loc
+        path = files.get(fid)
+        if not path:
+            return None
+        if path not in fmaps:
+            fmaps[path] = function_map(path)
+        return ROLE_OF.get(fmaps[path].get(ln))
+
+    olo, ohi = outer_region_lines()
+    dn = os.path.join(ROOT, "ramsesgpu_amd", "csrc", "dev_numerics.h")
+    per_role = defaultdict(Counter)      # role -> class -> wave instructions per plane and workgroup
+    static_role = defaultdict(Counter)
+    copies = Counter()
+    for name, b in blocks.items():
+        if not b["in_loop"] or not b["ops"]:
+            continue
+        votes = Counter(r for r in (role_of_loc(loc) for _, loc in b["ops"]) if r)
+        role = votes.most_common(1)[0][0] if votes else "control"
+        if role == "riemann":   # an outer-region block of the 2D HLLD solver?
+            inside = sum(1 for _, (fid, ln) in b["ops"] if os.path.realpath(files.get(fid, "")) == os.path.realpath(dn) and olo <= ln < ohi)
+            if 2 * inside > len(b["ops"]):
+                role = "riemann_outer"
+        c = Counter(x for x, _ in b["ops"])
+        if sum(c.values()) >= 200:
+            copies[role] += 1
+        for k, v in c.items():
+            static_role[role][k] += v
+            per_role[role][k] += v * TRIPS[role]
+    print("# dynamic instruction mix of mhd3d_sweep_kernel<107, MhTile<16, 8>>, %s arithmetic" % ("contracted" if arith == "fast" else "exact"))
+    print("# wave instructions per z plane and 512-thread workgroup = static count of the role's blocks in the z loop x trips (see the header of scripts/isa_mix.py)")
+    print("# large (>= 200 instructions) copies found per role:", dict(copies), " expected: riemann 6 (EMF + flux per direction), trace 3")
+    classes = list(VALU_CLASSES) + ["lds", "vmem", "salu", "waitcnt", "branch", "barrier"]
+    print("%-9s %5s %8s | " % ("role", "trips", "VALU") + " ".join("%8s" % c for c in classes))
+    tot = Counter()
+    for role in ("riemann", "riemann_outer", "trace", "prim", "elec", "sync", "control"):
+        c = per_role[role] if TRIPS[role] else static_role[role]
+        valu = sum(c[k] for k in VALU_CLASSES)
+        if TRIPS[role]:
+            tot.update(c)
+        print("%-9s %5d %8d | " % (role if TRIPS[role] else "(outer)", TRIPS[role], valu) + " ".join("%8d" % c[k] for k in classes))
+    valu = sum(tot[k] for k in VALU_CLASSES)
+    print("%-9s %5s %8d | " % ("all", "", valu) + " ".join("%8d" % tot[k] for k in classes))
+    f64 = sum(tot[k] for k in ("fma64", "mul64", "add64", "trans64", "minmax64"))
+    print("fp64 arithmetic %.1f %% of the VALU instructions (fma %.1f, mul %.1f, add %.1f, min/max %.1f, rcp/rsq %.1f); 32-bit integer %.1f %%, "
+          "compares + selects %.1f %%, moves / lane ops / other %.1f %%" %
+          (100.0 * f64 / valu, 100.0 * tot["fma64"] / valu, 100.0 * tot["mul64"] / valu, 100.0 * tot["add64"] / valu, 100.0 * tot["minmax64"] / valu,
+           100.0 * tot["trans64"] / valu, 100.0 * tot["vint"] / valu, 100.0 * (tot["vcmp"] + tot["cndmask"]) / valu,
+           100.0 * (tot["vmov"] + tot["lane"] + tot["vother"] + tot["accvgpr"]) / valu))
+    print("per cell (128 cells per plane and workgroup): %.0f VALU thread-instructions" % (valu * 64.0 / 128.0))
+    # per-SIMD view: waves w and w + 4 share a SIMD
+    r, t, p, e, s, ctl = (sum(static_role[x][k] for k in VALU_CLASSES) for x in ("riemann", "trace", "prim", "elec", "sync", "control"))
+    print("per SIMD and plane (VALU): Riemann SIMD = 2 x (%.0f + control %.0f) + its share of the electric field (3 of 8 trips x %.0f) = %.0f;  "
+          "producer SIMD = 3 x %.0f + 2 x (%.0f + %.0f + control %.0f) = %.0f" %
+          (r / 3.0, ctl, e, 2 * (r / 3.0 + ctl) + 3 * e, t / 3.0, p, s, ctl, t + 2 * (p + s + ctl)))
+    if measured:
+        pred = valu * iters
+        print("reconciliation: predicted %.4g wave instructions per launch (%d workgroup x plane iterations), SQ_INSTS_VALU measured %.4g: %+.1f %%" %
+              (pred, iters, measured, 100.0 * (pred / measured - 1.0)))
+
+
+def main():
+    if "--sweep" in sys.argv:
+        arith = sys.argv[sys.argv.index("--sweep") + 1]
+        measured = float(sys.argv[sys.argv.index("--measured") + 1]) if "--measured" in sys.argv else 0.0
+        iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 2048 * 515
+        dynamic_report(arith, measured, iters)
+        return
+    static_report(sys.argv[1], sys.argv[2], "--blocks" in sys.argv)
 
 
 if __name__ == "__main__":

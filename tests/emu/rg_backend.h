@@ -33,6 +33,7 @@ inline rg_recip_t rg_recip(double d) { rg_recip_t R; R.d = d; return R; }
 inline double rg_div(double n, const rg_recip_t& R) { return n / R.d; }
 inline double rg_sqrt(double x) { return std::sqrt(x); }
 inline double rg_sqrt_pos(double x) { return std::sqrt(x); }
+inline double rg_sqrt_radicand(double x) { return std::sqrt(x); }
 inline rg_recip_t rg_recip_sqrt_pos(double x) { return rg_recip(std::sqrt(x)); }
 
 inline bool rg_wave_any(bool pred) { return pred; }   // one lane per "wave" on the host
