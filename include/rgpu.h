@@ -368,6 +368,10 @@ int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_la
  * asynchronously; the batch's no-op steps are simply queued), always up to date on a synchronous backend (the test-only host emulation),
  * where a driver can end its batch at once.  The answer is the same on every slab of a run. */
 int rgpu_clock_stopped(rgpu_ctx* c);
+/* The same answer on ANY backend, at the price of a synchronisation: waits for the record of the last tick and returns its stop flag
+ * (0 = the step runs, 1 / 2 / 3 as in rgpu_clock_close; < 0: error).  The slab driver checks the first step of every batch this way:
+ * a rank that failed in an unbatched step has told the others through ONE poisoned all-reduce and left the loop. */
+int rgpu_clock_check(rgpu_ctx* c);
 
 /* Self-test of the device arithmetic the parity contract rests on: for n operand pairs computes on the device
  *   quot[i]  = rg_div(num[i], rg_recip(den[i]))   the shared-reciprocal division of csrc/hip/rg_backend.h
@@ -386,6 +390,28 @@ int rgpu_selftest_arith(int n, const double* num, const double* den, double* quo
  * sequence anyway.  e_select must equal e_reference bit for bit (tests/test_gpu_parity.py: >= 1e7 random and adversarial states).
  * The contracted library has no selection: both outputs come from the same sequence and route is 1. */
 int rgpu_selftest_alfven(const rgpu_params* p, int n, const double* states36, double* e_select, double* e_reference, int* route);
+
+/* ---- Environment and options ------------------------------------------------------------------------------------------------
+ * Environment variables the libraries read (all optional; everything else is an argument of an entry point):
+ *   RGPU_TILED=0              librgpu.so: the flat per-cell kernels everywhere instead of the LDS-tiled cooperative ones (a second,
+ *                             independently tested implementation of every step; 3-10x slower)
+ *   RGPU_COMM_SCHEDULE=1|2    librgpu_comm.so: default step schedule of the slab driver (rgpu_comm_set_overlap, rgpu_comm.h)
+ *   RGPU_COMM_PACK=0          ... one send / recv per variable and face instead of the packed exchange
+ *   RGPU_HALO_PRIO=high|low   ... priority of the halo stream (default: normal)
+ *   RGPU_COMM_ONE_STREAM=1    ... halo traffic on the compute stream (no overlap): fallback should two streams on one RCCL
+ *                             communicator misbehave on a given node
+ *   RGPU_HDF5_LIB=<path>      host layer: the libhdf5 to load (default: the system's)
+ *   RGPU_RESTART_FORMAT=...   host layer: what rgpuh_* writes for restarts (run_driver.h)
+ * Diagnostic options (process-wide; tests run a configuration both ways through them -- a user needs none):
+ *   "spec" (1)          kernels specialised for the solver configuration; 0: the generic instantiations
+ *   "ghost_images" (1)  the fused 2D steps write the ghost images of their output; 0: the next step fills the ghost cells
+ *   "step_clock" (1)    the time step stays on the device between the steps of rgpu_run_steps; 0: one host turn per step
+ *   "xcd_sub" (-1)      sub-band size (cells) of the XCD-aware workgroup order of the flat kernels, read by rgpu_create; 0: linear
+ *   "zseg" (0)          planes per z segment of the tiled sweeps; 0: planned per launch
+ *   "chunks" (-1)       chunks of the two-stream schedule of the flat 3D MHD kernels, read by rgpu_create; 1: one stream
+ * rgpu_set_option returns the previous value (-1: unknown name; the options above are never negative except "as created"). */
+int rgpu_set_option(const char* name, int value);
+int rgpu_get_option(const char* name);
 
 /* name of the device backend the library was built for ("hip-gfx950") */
 const char* rgpu_backend_name(void);

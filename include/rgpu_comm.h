@@ -131,6 +131,10 @@ int rgpu_comm_set_device(int device);
  * with these (bench.py prints them per rank, euler_hip --slabs logs them).  Any pointer may be NULL. */
 int rgpu_comm_info(rgpu_comm* cm, int* transport_ranks, int* transport_rank, int* device, char* pci_bus_id, int pci_len);
 
+/* version of the RCCL library the communicator runs on (ncclGetVersion: 10000 major + 100 minor + patch); 0 if unknown.  Logged by
+ * bench.py and euler_hip --slabs with the binding above: the first thing to look at when a multi-GPU run misbehaves. */
+int rgpu_comm_rccl_version(rgpu_comm* cm);
+
 /* name of the transport the library was built with ("rccl") */
 const char* rgpu_comm_transport_name(void);
 

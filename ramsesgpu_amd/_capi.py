@@ -195,6 +195,12 @@ def declare_device_api(lib):
     lib.rgpu_backend_name.argtypes = []
     lib.rgpu_arithmetic.restype = C.c_char_p
     lib.rgpu_arithmetic.argtypes = []
+    lib.rgpu_set_option.restype = C.c_int
+    lib.rgpu_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.rgpu_get_option.restype = C.c_int
+    lib.rgpu_get_option.argtypes = [C.c_char_p]
+    lib.rgpu_clock_check.restype = C.c_int
+    lib.rgpu_clock_check.argtypes = [ctx]
     return lib
 
 
@@ -204,7 +210,7 @@ DECLARED_SYMBOLS = [
     "rgpu_upload", "rgpu_download", "rgpu_device_state", "rgpu_get_params", "rgpu_stream_handle", "rgpu_inv_dt_device_slot", "rgpu_make_boundaries", "rgpu_make_boundaries_shear",
     "rgpu_make_all_boundaries", "rgpu_history_columns", "rgpu_history_reynolds", "rgpu_history_mri", "rgpu_history_turbulence", "rgpu_history_turbulence_sums", "rgpu_state_checksum", "rgpu_read_cell", "rgpu_compute_inv_dt", "rgpu_invalidate_dt", "rgpu_compute_dt", "rgpu_godunov_unsplit", "rgpu_step_pre",
     "rgpu_step_core", "rgpu_step_dissipative", "rgpu_step_core_planes", "rgpu_step_core_planes_split", "rgpu_inv_dt_fused_commit", "rgpu_inv_dt_fused_active", "rgpu_inv_dt_fusable", "rgpu_step_fill_planes", "rgpu_step_core_planes_pair", "rgpu_step_fill_planes_pair", "rgpu_inv_dt_accumulate", "rgpu_inv_dt_result",
-    "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_run_steps", "rgpu_run_steps_log", "rgpu_device_time_step_ready", "rgpu_clock_capable", "rgpu_clock_open", "rgpu_clock_tick", "rgpu_clock_close", "rgpu_clock_stopped", "rgpu_synchronize",
+    "rgpu_step_post_a", "rgpu_step_post_b", "rgpu_one_step_integration", "rgpu_run_steps", "rgpu_run_steps_log", "rgpu_device_time_step_ready", "rgpu_clock_capable", "rgpu_clock_open", "rgpu_clock_tick", "rgpu_clock_close", "rgpu_clock_stopped", "rgpu_clock_check", "rgpu_set_option", "rgpu_get_option", "rgpu_synchronize",
     "rgpu_enable_timers", "rgpu_get_timers", "rgpu_reset_timers", "rgpu_timer_name", "rgpu_dominant_kernel",
     "rgpu_backend_name", "rgpu_arithmetic", "rgpu_selftest_arith", "rgpu_selftest_alfven", "rgpu_step_ou_forcing", "rgpu_ou_forcing_state", "rgpu_ou_forcing_get_state", "rgpu_ou_forcing_set_state", "rgpuh_params_from_ini", "rgpuh_run_settings", "rgpuh_init_condition", "rgpuh_init_gravity", "rgpu_set_gravity_field", "rgpuh_init_forcing", "rgpu_set_forcing_field", "rgpu_forcing_sums", "rgpu_add_forcing", "rgpuh_run", "rgpuh_run_hooked",
 ]

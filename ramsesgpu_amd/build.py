@@ -129,14 +129,14 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h); host code + the one-thread hold kernel of the slab probe
+    # z-slab driver: librgpu_comm.so = csrc/comm/rgpu_comm.cpp + the RCCL transport (csrc/hip/rg_transport.h)
     comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
     comm_out = os.path.join(HERE, "librgpu_comm_fast.so" if fast else "librgpu_comm.so")
     comm_deps = [comm_src, os.path.join(CSRC, "hip", "rg_transport.h"), os.path.join(CSRC, "hip", "halo_pack.h"), os.path.join(CSRC, "comm", "halo_ops.h"), os.path.join(CSRC, "comm", "pack_plan.h"),
                  os.path.join(HERE, "..", "include", "rgpu_comm.h"),
                  os.path.join(HERE, "..", "include", "rgpu.h"), out]
     if (out_name == "librgpu.so" or fast) and (force or _newer(comm_out, comm_deps)):
-        # (-x hip: the transport header holds one one-thread kernel, the link-time hold of the one-GPU slab probe)
+        # (-x hip: halo_pack.h holds the pack / unpack kernels of the packed exchange)
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-I", os.path.join(CSRC, "hip"), "-x", "hip", comm_src, "-x", "none", "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
                "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", comm_out]
         if verbose:
@@ -151,6 +151,22 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
     return out
 
 
+def build_measure(verbose=True, fast=True):
+    """MEASUREMENT build of the slab driver, NOT the product: librgpu_comm_measure.so = csrc/comm/rgpu_comm.cpp with -DRG_MEASURE and
+    scripts/measure/link_hold.h (the emulated xGMI link time of the one-GPU slab probe, scripts/slab_probe.py), linked against the
+    product library librgpu_fast.so / librgpu.so"""
+    build(verbose=verbose, out_name="librgpu_fast.so" if fast else "librgpu.so")
+    out = os.path.join(HERE, "librgpu_comm_measure.so")
+    comm_src = os.path.join(CSRC, "comm", "rgpu_comm.cpp")
+    cmd = [HIPCC, "--offload-arch=" + ARCH, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-DRG_MEASURE", "-I", os.path.join(HERE, "..", "scripts", "measure"),
+           "-I", os.path.join(CSRC, "hip"), "-x", "hip", comm_src, "-x", "none", "-L", HERE, "-lrgpu_fast" if fast else "-lrgpu",
+           "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(verbose=True, force=False):
     """the product library and its contracted-arithmetic variant"""
     out = build(verbose=verbose, force=force)
@@ -159,4 +175,7 @@ def build_all(verbose=True, force=False):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--measure" in sys.argv:
+        build_measure()
+    else:
+        build_all(force="--force" in sys.argv)

@@ -37,6 +37,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_transport_name.restype = C.c_char_p
     lib.rgpu_comm_set_device.restype = C.c_int
     lib.rgpu_comm_set_device.argtypes = [C.c_int]
+    lib.rgpu_comm_rccl_version.restype = C.c_int
+    lib.rgpu_comm_rccl_version.argtypes = [cm]
     lib.rgpu_comm_info.restype = C.c_int
     lib.rgpu_comm_info.argtypes = [cm, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]
     lib.rgpu_comm_last_exchange_ms.restype = C.c_double
@@ -74,7 +76,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_run_steps", "rgpu_comm_clocked_steps", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_run_steps", "rgpu_comm_clocked_steps", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_rccl_version", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -139,7 +141,7 @@ class CommRun:
         pci = C.create_string_buffer(64)
         self._chk(self.CL.rgpu_comm_info(self.cm, C.byref(n), C.byref(r), C.byref(d), pci, 64), "comm_info")
         return {"ranks": n.value, "rank": r.value, "device": d.value, "pci_bus_id": pci.value.decode(),
-                "transport": self.CL.rgpu_comm_transport_name().decode()}
+                "transport": self.CL.rgpu_comm_transport_name().decode(), "rccl_version": int(self.CL.rgpu_comm_rccl_version(self.cm))}
 
     def init_simulation(self):
         """each rank builds its own slab of the initial condition (no scatter from rank 0)"""

@@ -35,6 +35,8 @@ struct rgpu_comm {
   // that no neighbour waits for planes that never come) and poisons the next 1/dt all-reduce with +inf: every rank then
   // returns an error from the same rgpu_comm_compute_dt instead of one rank leaving the others in a collective.
   bool fuse_scan;   // every rank's configuration lets the update pieces carry the CFL scan (agreed at create)
+  bool clock_ok;    // every rank can keep the time step on the device between steps (agreed at create: a rank that batches while another
+                    // takes the host loop would post collectives the other never matches)
   int poisoned;
   int exchanges_posted, exchanges_expected;   // halo exchanges of the current step: posted so far / what the neighbours will post
   long long clocked_steps;                    // steps whose time step came from the device record (rgpu_comm_run_steps)
@@ -205,8 +207,7 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
     // ghost planes behind a slab interface are not updated: the planes received in this step overwrite them whole (x / y ghosts
     // included), so their update -- old values + the CT of plane ksize - gw, what the reference leaves there until its next ghost
     // fill -- is 6 of the 70 planes of an N = 8 slab for nothing.  Physical z faces keep theirs (the reference's array contents).
-    static const bool all_planes = std::getenv("RGPU_COMM_UPDATE_GHOST_PLANES") != 0;
-    const bool lo_if = !all_planes && cm->p.bc[4] == RGPU_BC_COPY, hi_if = !all_planes && cm->p.bc[5] == RGPU_BC_COPY;
+    const bool lo_if = cm->p.bc[4] == RGPU_BC_COPY, hi_if = cm->p.bc[5] == RGPU_BC_COPY;
     nb = 2; bnd[0][0] = lo_if ? gw : 0; bnd[0][1] = 2 * gw; bnd[1][0] = nz; bnd[1][1] = hi_if ? nz + gw : ks;
     snd[0][0] = gw; snd[0][1] = 2 * gw; snd[1][0] = nz; snd[1][1] = nz + gw; has_inner = true;
   }
@@ -224,7 +225,8 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // (5.66 against 5.88 ms), level at 40 GB/s; schedule 2 is for links slower than that, to be decided by the first multi-GPU run.
   int mode = cm->overlap;
   if (mode < 0) {
-    static const int env_mode = std::getenv("RGPU_COMM_SCHEDULE") ? std::atoi(std::getenv("RGPU_COMM_SCHEDULE")) : -1;
+    static const char* e_mode = std::getenv("RGPU_COMM_SCHEDULE");   // 1 / 2 (include/rgpu_comm.h)
+    static const int env_mode = e_mode ? std::atoi(e_mode) : -1;
     mode = env_mode >= 1 && env_mode <= 2 ? env_mode : 1;
   }
   const bool early = mode == 2 && has_inner && cm->p.mhdEnabled && nz > 4 * gw + 2;
@@ -275,7 +277,7 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   if (!cm) return RGPU_ENOMEM;
   *out = cm;   // returned on failure too, for rgpu_comm_last_error
   cm->ctx = ctx; cm->tc = 0; cm->rank = rank; cm->nranks = nranks; cm->overlap = -1; cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;
-  cm->fuse_scan = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0; cm->clocked_steps = 0;
+  cm->fuse_scan = false; cm->clock_ok = false; cm->poisoned = 0; cm->exchanges_posted = 0; cm->exchanges_expected = 0; cm->clocked_steps = 0;
   if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(cm, RGPU_EINVAL, "comm_create: bad arguments");
   if (rgpu_get_params(ctx, &cm->p)) return fail(cm, RGPU_EINVAL, "comm_create: no parameters in the context");
   if (cm->p.nz_global == 1) return fail(cm, RGPU_EUNSUPPORTED, "2D problems do not shard: run replicas");
@@ -288,12 +290,14 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
   // / stratified z face on the rotating path cannot fuse it, the inner slabs could)
   // ... and so does the packed exchange (one message per peer instead of one per chunk): its staging buffers are sized and
   // allocated HERE, not inside the first step, and a rank that cannot have them takes every rank to the in-place exchange
-  double cannot[2] = {rgpu_inv_dt_fusable(ctx) ? 0.0 : 1.0, 0.0};
+  // ... and so does the device-side time step (a batch posts its collectives without a host turn: every rank batches, or none)
+  double cannot[3] = {rgpu_inv_dt_fusable(ctx) ? 0.0 : 1.0, 0.0, (rgpu_clock_capable(ctx) && rgpu_get_option("step_clock") != 0) ? 0.0 : 1.0};
   for (int par = 0; par < 2; ++par)
     if (rgpu_transport::prepare_exchange(cm->tc, cm->ops[par].data(), (int)cm->ops[par].size())) cannot[1] = 1.0;
-  if (nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, cannot, 2, rgpu_stream_handle(ctx))) return tr_fail(cm, "comm_create: allreduce");
+  if (nranks > 1 && rgpu_transport::allreduce_sum_host(cm->tc, cannot, 3, rgpu_stream_handle(ctx))) return tr_fail(cm, "comm_create: allreduce");
   cm->fuse_scan = cannot[0] < 0.5;
   if (cannot[1] > 0.5) rgpu_transport::disable_pack(cm->tc);
+  cm->clock_ok = cannot[2] < 0.5;
   return RGPU_OK;
 }
 
@@ -319,6 +323,7 @@ int rgpu_comm_exchange_z_wait(rgpu_comm* cm) { RG_CHECK_CM(cm); return exchange_
 int rgpu_comm_make_all_boundaries(rgpu_comm* cm, int parity, double totalTime, double dt) { RG_CHECK_CM(cm); return make_all_boundaries(cm, parity & 1, totalTime, dt); }
 int rgpu_comm_compute_dt(rgpu_comm* cm, int useU, double* dt) { RG_CHECK_CM(cm); if (!dt) return RGPU_EINVAL; return compute_dt(cm, useU & 1, dt); }
 int rgpu_comm_godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double totalTime) { RG_CHECK_CM(cm); return godunov_unsplit(cm, nStep, dt, totalTime); }
+int rgpu_comm_rccl_version(rgpu_comm* cm) { return (cm && cm->tc) ? rgpu_transport::version(cm->tc) : 0; }
 double rgpu_comm_last_exchange_ms(rgpu_comm* cm) { return (cm && cm->tc && !cm->ops[0].empty()) ? rgpu_transport::last_exchange_ms(cm->tc) : -1.0; }
 long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
   if (!cm || !cm->tc) return 0;
@@ -357,11 +362,12 @@ int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, doub
   RG_CHECK_CM(cm);
   if (!nStep || !t || !dt) return fail(cm, RGPU_EINVAL, "run_steps: null pointer");
   rgpu_ctx* c = cm->ctx;
-  static const bool host_clock = std::getenv("RGPU_NO_STEP_CLOCK") != 0;
   int done = 0;
   while (done < nsteps && *t < tEnd) {
     const int useU = *nStep % 2;
-    const bool batch = !host_clock && !cm->poisoned && cm->scanned == useU && cm->scan_slots > 0 && cm->fuse_scan && cm->overlap != 0 &&
+    // (clock_ok: agreed between the ranks at create; a context whose phase timers were switched on since then -- rgpu_clock_capable --
+    // must have had them switched on on every rank, as bench.py and the run driver do)
+    const bool batch = cm->clock_ok && !cm->poisoned && cm->scanned == useU && cm->scan_slots > 0 && cm->fuse_scan && cm->overlap != 0 &&
                        !dissipative(cm) && !cm->p.randomForcingEnabled && !cm->p.ouForcingEnabled && rgpu_clock_capable(c);
     if (!batch) {
       if (int rc = rgpu_comm_one_step_integration(cm, nStep, t, dt)) return rc;
@@ -393,7 +399,11 @@ int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, doub
         const std::string msg = cm->err;
         if (cm->nranks > 1) (void)exchange(cm, (n + 1) % 2);      // what the neighbours' step n posts
         cm->err = msg;
-      } else if (rgpu_clock_stopped(c)) {   // (synchronous backends: the record already says the loop has ended -- on every rank alike)
+      } else if (rgpu_clock_stopped(c) || (queued == 0 && cm->nranks > 1 && rgpu_clock_check(c) != 0)) {
+        // the record says the loop has ended -- on every rank alike (the 1/dt it was formed from is all-reduced).  Synchronous
+        // backends know at once; on the device the FIRST step of every batch is checked on the host (one synchronisation per
+        // RGPU_CLOCK_BATCH steps): a rank whose previous, unbatched step failed has posted one poisoned all-reduce and left -- without
+        // this check its peers would queue a whole batch of no-op steps whose exchanges and all-reduces nobody matches, and hang
         ++queued;
         break;
       } else {

@@ -13,6 +13,8 @@ namespace rgpu_dev {
 
 using rgpu::rg_recip_t;
 using rgpu::rg_recip;
+using rgpu::rg_recip2;
+using rgpu::rg_recip4;
 using rgpu::rg_div;
 using rgpu::rg_sqrt;
 using rgpu::rg_sqrt_pos;
@@ -332,9 +334,16 @@ RG_DEVFN Prim8 mhd_prim(const DevParams& g, const double* u, double bnx, double 
 // rounded, so the MAXIMUM of several fast speeds is the root of the maximum radicand, bit for bit: where the reference only
 // consumes max(cf_1 .. cf_n) -- the wave-speed bounds of riemann_hlld / riemann_hll, mag_riemann2d_hlld / _hllf -- one root
 // is taken instead of n (a NaN radicand is dropped by fmax exactly like the NaN root would be).
+// ISO_P: the caller has set q.p = q.r cIso^2 if the gas is isothermal (the HLLD solvers do).  Contracted arithmetic then takes the
+// sound speed squared as the constant it is, gamma0 cIso^2, instead of gamma0 (rho cIso cIso) / rho.
+template <bool ISO_P = false>
 RG_DEVFN double fast_speed_sq(const DevParams& g, const Prim8& q, double bn, const rg_recip_t& inv_r) {
   const double b2 = q.a * q.a + q.b * q.b + q.c * q.c;
+#ifdef RG_ARITH_FAST
+  const double c2 = (ISO_P && g.cIso > 0) ? g.gamma0 * (g.cIso * g.cIso) : rg_div(g.gamma0 * q.p, inv_r);
+#else
   const double c2 = rg_div(g.gamma0 * q.p, inv_r);
+#endif
   const double d2 = 0.5 * (rg_div(b2, inv_r) + c2);
   return d2 + rgpu::rg_sqrt_radicand(d2 * d2 - rg_div(c2 * bn * bn, inv_r));
 }
@@ -380,6 +389,15 @@ RG_DEVFN void mhd_physical_flux(const DevParams& g, const Prim8& q, double* cv, 
 // path reuses for the shear correction of the y flux.
 // ---------------------------------------------------------------------------------------------------------
 
+// isothermal pressure rho cIso cIso (riemann_mhd.h:157-160, 1071-1076): the reference's two products; contracted arithmetic: one, by cIso^2
+RG_DEVFN double iso_pressure(const DevParams& g, double r) {
+#ifdef RG_ARITH_FAST
+  return r * (g.cIso * g.cIso);
+#else
+  return r * g.cIso * g.cIso;
+#endif
+}
+
 // riemann_hlld (riemann_mhd.h:140-342), Miyoshi & Kusano 2005
 RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double entho = 1.0 / (g.gamma0 - 1.0);
@@ -388,8 +406,8 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   L.a = a;
   R.a = a;
   if (g.cIso > 0) {
-    L.p = L.r * g.cIso * g.cIso;
-    R.p = R.r * g.cIso * g.cIso;
+    L.p = iso_pressure(g, L.r);
+    R.p = iso_pressure(g, R.r);
   }
   const double rl = L.r, pl = L.p, ul = L.u, vl = L.v, wl = L.w, bl = L.b, cl = L.c;
   const double ecinl = 0.5 * (ul * ul + vl * vl + wl * wl) * rl;
@@ -403,7 +421,9 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double etotr = pr * entho + ecinr + emagr;
   const double ptotr = pr + emagr;
   const double vdotbr = ur * a + vr * br + wr * cr;
-  const double cfast = rg_sqrt_pos(fmax(fast_speed_sq(g, L, L.a, rg_recip(L.r)), fast_speed_sq(g, R, R.a, rg_recip(R.r))));   // = max(cfastl, cfastr)
+  rg_recip_t inv_rl, inv_rr;
+  rg_recip2(L.r, R.r, inv_rl, inv_rr);
+  const double cfast = rg_sqrt_pos(fmax(fast_speed_sq<true>(g, L, L.a, inv_rl), fast_speed_sq<true>(g, R, R.a, inv_rr)));   // = max(cfastl, cfastr)
   const double sl = fmin(ul, ur) - cfast;
   const double sr = fmax(ul, ur) + cfast;
   const double rcl = rl * (ul - sl), rcr = rr * (sr - ur);
@@ -412,8 +432,9 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double ptotstar = rg_div(rcr * ptotl + rcl * ptotr + rcl * rcr * (ul - ur), inv_rc);
   const double a2 = a * a;
   const rg_recip_t inv_a2 = rg_recip(a2);
-  // left star state
-  const rg_recip_t inv_sl = rg_recip(sl - ustar);
+  // left star state  (sl < ustar < sr: neither difference vanishes)
+  rg_recip_t inv_sl, inv_sr;
+  rg_recip2(sl - ustar, sr - ustar, inv_sl, inv_sr);
   const double rstarl = rg_div(rl * (sl - ul), inv_sl);
   const double estarl = rl * (sl - ul) * (sl - ustar) - a2;
   const double el = rl * (sl - ul) * (sl - ul) - a2;
@@ -426,9 +447,7 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double vdotbstarl = ustar * a + vstarl * bstarl + wstarl * cstarl;
   const double etotstarl = rg_div((sl - ul) * etotl - ptotl * ul + ptotstar * ustar + a * (vdotbl - vdotbstarl), inv_sl);
   const double sqrrstarl = rg_sqrt_pos(rstarl);
-  const double sal = ustar - rg_div(fabs(a), rg_recip(sqrrstarl));
   // right star state
-  const rg_recip_t inv_sr = rg_recip(sr - ustar);
   const double rstarr = rg_div(rr * (sr - ur), inv_sr);
   const double estarr = rr * (sr - ur) * (sr - ustar) - a2;
   const double er = rr * (sr - ur) * (sr - ur) - a2;
@@ -441,7 +460,10 @@ RG_DEVFN void mhd_hlld(const DevParams& g, Prim8& L, Prim8& R, double* flux) {
   const double vdotbstarr = ustar * a + vstarr * bstarr + wstarr * cstarr;
   const double etotstarr = rg_div((sr - ur) * etotr - ptotr * ur + ptotstar * ustar + a * (vdotbr - vdotbstarr), inv_sr);
   const double sqrrstarr = rg_sqrt_pos(rstarr);
-  const double sar = ustar + rg_div(fabs(a), rg_recip(sqrrstarr));
+  rg_recip_t inv_ql, inv_qr;
+  rg_recip2(sqrrstarl, sqrrstarr, inv_ql, inv_qr);
+  const double sal = ustar - rg_div(fabs(a), inv_ql);
+  const double sar = ustar + rg_div(fabs(a), inv_qr);
   // double star state
   const rg_recip_t inv_sq = rg_recip(sqrrstarl + sqrrstarr);
   const double vstarstar = rg_div(sqrrstarl * vstarl + sqrrstarr * vstarr + sgnm * (bstarr - bstarl), inv_sq);
@@ -569,12 +591,14 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
                             double ELL, double ERL, double ELR, double ERR, int* route = 0) {
   // 66 divisions by 24 distinct denominators: every denominator gets one shared reciprocal (rg_recip), see
   // rg_backend.h; numerators and operand order are the reference's
-  const rg_recip_t iLLr = rg_recip(LL.r), iLRr = rg_recip(LR.r), iRLr = rg_recip(RL.r), iRRr = rg_recip(RR.r);
+  rg_recip_t iLLr, iLRr, iRLr, iRRr;
+  rg_recip4(LL.r, LR.r, RL.r, RR.r, iLLr, iLRr, iRLr, iRRr);
   // the eight fast speeds are only consumed through their maxima per direction: two roots instead of eight (fast_speed_sq)
-  const double cxmax = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.a, iLLr), fast_speed_sq(g, LR, LR.a, iLRr),
-                                           fast_speed_sq(g, RL, RL.a, iRLr), fast_speed_sq(g, RR, RR.a, iRRr)));
-  const double cymax = rg_sqrt_pos(max_of4(fast_speed_sq(g, LL, LL.b, iLLr), fast_speed_sq(g, LR, LR.b, iLRr),
-                                           fast_speed_sq(g, RL, RL.b, iRLr), fast_speed_sq(g, RR, RR.b, iRRr)));
+  // (edge_emf has set the isothermal pressures: fast_speed_sq<true>)
+  const double cxmax = rg_sqrt_pos(max_of4(fast_speed_sq<true>(g, LL, LL.a, iLLr), fast_speed_sq<true>(g, LR, LR.a, iLRr),
+                                           fast_speed_sq<true>(g, RL, RL.a, iRLr), fast_speed_sq<true>(g, RR, RR.a, iRRr)));
+  const double cymax = rg_sqrt_pos(max_of4(fast_speed_sq<true>(g, LL, LL.b, iLLr), fast_speed_sq<true>(g, LR, LR.b, iLRr),
+                                           fast_speed_sq<true>(g, RL, RL.b, iRLr), fast_speed_sq<true>(g, RR, RR.b, iRRr)));
   const double SL = min_of4(LL.u, LR.u, RL.u, RR.u) - cxmax;
   const double SR = max_of4(LL.u, LR.u, RL.u, RR.u) + cxmax;
   const double SB = min_of4(LL.v, LR.v, RL.v, RR.v) - cymax;
@@ -587,14 +611,25 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rcLRx = LR.r * (LR.u - SL), rcRRx = RR.r * (SR - RR.u);
   const double rcLLy = LL.r * (LL.v - SB), rcLRy = LR.r * (ST - LR.v);
   const double rcRLy = RL.r * (RL.v - SB), rcRRy = RR.r * (ST - RR.v);
-  const double ustar = rg_div(rcLLx * LL.u + rcLRx * LR.u + rcRLx * RL.u + rcRRx * RR.u + (PtotLL - PtotRL + PtotLR - PtotRR),
-                              rg_recip(rcLLx + rcLRx + rcRLx + rcRRx));
-  const double vstar = rg_div(rcLLy * LL.v + rcLRy * LR.v + rcRLy * RL.v + rcRRy * RR.v + (PtotLL - PtotLR + PtotRL - PtotRR),
-                              rg_recip(rcLLy + rcLRy + rcRLy + rcRRy));
-  const rg_recip_t iSL = rg_recip(SL - ustar), iSR = rg_recip(SR - ustar);
-  const rg_recip_t iSB = rg_recip(SB - vstar), iST = rg_recip(ST - vstar);
+  rg_recip_t irx, iry;   // (sums of positive rho (u - S) terms)
+  rg_recip2(rcLLx + rcLRx + rcRLx + rcRRx, rcLLy + rcLRy + rcRLy + rcRRy, irx, iry);
+  const double ustar = rg_div(rcLLx * LL.u + rcLRx * LR.u + rcRLx * RL.u + rcRRx * RR.u + (PtotLL - PtotRL + PtotLR - PtotRR), irx);
+  const double vstar = rg_div(rcLLy * LL.v + rcLRy * LR.v + rcRLy * RL.v + rcRRy * RR.v + (PtotLL - PtotLR + PtotRL - PtotRR), iry);
+  rg_recip_t iSL, iSR, iSB, iST;   // (SL < ustar < SR, SB < vstar < ST)
+  rg_recip4(SL - ustar, SR - ustar, SB - vstar, ST - vstar, iSL, iSR, iSB, iST);
   // per-state star quantities.  rstar = r*(S-u)/(S-ustar) is needed twice in the reference (alone and inside
   // the product with the y ratio); the identical sub-expression gives the identical value.
+#ifdef RG_ARITH_FAST
+  // contracted arithmetic: the ratios (S - u) / (S - ustar), (S - v) / (S - vstar) of a state once, then one product per quantity
+  const double tLLx = (SL - LL.u) * iSL.r, tLLy = (SB - LL.v) * iSB.r;
+  const double rstarLLx = LL.r * tLLx, BstarLL = LL.b * tLLx, rstarLLy = LL.r * tLLy, AstarLL = LL.a * tLLy, rstarLL = rstarLLx * tLLy;
+  const double tLRx = (SL - LR.u) * iSL.r, tLRy = (ST - LR.v) * iST.r;
+  const double rstarLRx = LR.r * tLRx, BstarLR = LR.b * tLRx, rstarLRy = LR.r * tLRy, AstarLR = LR.a * tLRy, rstarLR = rstarLRx * tLRy;
+  const double tRLx = (SR - RL.u) * iSR.r, tRLy = (SB - RL.v) * iSB.r;
+  const double rstarRLx = RL.r * tRLx, BstarRL = RL.b * tRLx, rstarRLy = RL.r * tRLy, AstarRL = RL.a * tRLy, rstarRL = rstarRLx * tRLy;
+  const double tRRx = (SR - RR.u) * iSR.r, tRRy = (ST - RR.v) * iST.r;
+  const double rstarRRx = RR.r * tRRx, BstarRR = RR.b * tRRx, rstarRRy = RR.r * tRRy, AstarRR = RR.a * tRRy, rstarRR = rstarRRx * tRRy;
+#else
   const double rstarLLx = rg_div(LL.r * (SL - LL.u), iSL);
   const double BstarLL = rg_div(LL.b * (SL - LL.u), iSL);
   const double rstarLLy = rg_div(LL.r * (SB - LL.v), iSB);
@@ -618,6 +653,8 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double rstarRRy = rg_div(RR.r * (ST - RR.v), iST);
   const double AstarRR = rg_div(RR.a * (ST - RR.v), iST);
   const double rstarRR = rg_div(rstarRRx * (ST - RR.v), iST);
+
+#endif
 
   // FMAX5 chains (riemann_mhd.h:401-411, 727-738): "a1 > ret ? a1 : ret" selections in argument order
   double calfvenL, calfvenR, calfvenB, calfvenT;
@@ -668,7 +705,8 @@ RG_DEVFN double mag_hlld_2d(const DevParams& g, const Prim8& LL, const Prim8& RL
   const double SAR = fmax(ustar + calfvenR, 0.0);
   const double SAB = fmin(vstar - calfvenB, 0.0);
   const double SAT = fmax(vstar + calfvenT, 0.0);
-  const rg_recip_t iSA = rg_recip(SAR - SAL), iSAy = rg_recip(SAT - SAB);
+  rg_recip_t iSA, iSAy;   // (the Alfven speeds are at least smallc: both differences are positive)
+  rg_recip2(SAR - SAL, SAT - SAB, iSA, iSAy);
 
   // Region selection by sign bits.  The reference evaluates all five candidate values and adds each multiplied by its
   // 0 / 1 integer mask (riemann_mhd.h:759-787).  A term with mask 0 adds (0 * finite value) = +-0, which leaves the sum
@@ -789,10 +827,10 @@ RG_DEVFN double edge_emf(const DevParams& g, const Prim8& sRT, const Prim8& sRB,
                          double xPos) {
   Prim8 LL = sRT, RL = sLT, LR = sRB, RR = sLB;
   if (g.cIso > 0) {
-    LL.p = LL.r * g.cIso * g.cIso;
-    RL.p = RL.r * g.cIso * g.cIso;
-    LR.p = LR.r * g.cIso * g.cIso;
-    RR.p = RR.r * g.cIso * g.cIso;
+    LL.p = iso_pressure(g, LL.r);
+    RL.p = iso_pressure(g, RL.r);
+    LR.p = iso_pressure(g, LR.r);
+    RR.p = iso_pressure(g, RR.r);
   }
   // enforce continuity of the two in-plane field components across the faces meeting at the edge
   const double aT = 0.5 * (sRT.a + sLT.a), aB = 0.5 * (sRB.a + sLB.a);

@@ -81,8 +81,8 @@ __device__ __forceinline__ double rg_uniform(double x) {
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
 }
 
-inline bool step_clock_fold_enabled() { static const bool on = !std::getenv("RGPU_NO_CLOCK_FOLD"); return on; }
-inline bool step_clock_supported() { return tiled_enabled() && !std::getenv("RGPU_NO_STEP_CLOCK"); }
+inline bool step_clock_fold_enabled() { return true; }
+inline bool step_clock_supported() { return tiled_enabled() && rgpu::options().step_clock != 0; }
 inline int launch_step_clock(rg_stream_t s, unsigned long long* slots, const ClockConst& k, double t0, double tEnd, const StepClock* prev, StepClock* out) {
   hipLaunchKernelGGL(step_clock_kernel, dim3(1), dim3(1024), 0, s, slots, k, t0, tEnd, prev, out);
   return hipGetLastError() == hipSuccess ? 0 : -1;

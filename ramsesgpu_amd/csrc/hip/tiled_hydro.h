@@ -26,21 +26,17 @@
 #include <cstdlib>
 
 #include "launchers.h"
+#include "rg_options.h"
 
 namespace rgpu_tiled {
 
 using namespace rgpu_dev;
 using rgpu::rg_stream_t;
 
-#ifdef RG_SWEEP_PROF   // experiment builds only (scripts/probe_sweep.py --prof): per-wave cycle accounting of the phases
-__device__ unsigned long long rg_prof[8 * 4];
-#define RG_PROF_T(x) const long long x = (long long)__builtin_readcyclecounter()
-#else
-#define RG_PROF_T(x)
-#endif
 
 inline bool tiled_enabled() {
-  static const bool on = !(std::getenv("RGPU_TILED") && std::atoi(std::getenv("RGPU_TILED")) == 0);
+  static const char* v = std::getenv("RGPU_TILED");   // RGPU_TILED=0: the flat per-cell kernels everywhere (include/rgpu.h, "Environment")
+  static const bool on = !(v && std::atoi(v) == 0);
   return on;
 }
 
@@ -72,7 +68,6 @@ struct TileGrid {
   int nbx, nby, nseg;      // tiles and base z segments per tile
   int ipx, full, tail;     // items per XCD; whole items per XCD; sub-segments per item of the last round (>= 1)
   int per_xcd;             // workgroups per XCD = full + (ipx - full) * tail
-  int flags;               // experiment switches of the MHD sweep (RGPU_SWEEP_FLAGS), 0 = defaults
   // a second plane range of the SAME length in the same launch (the two boundary ranges of a slab): the kernel's [za, zb) is then
   // the concatenation, 2 L planes long; planes at or beyond zsplit = za + L belong to the second range and lie zgap planes further
   // up.  nseg is even, so no segment straddles the seam.  One range: zsplit = INT_MAX, zgap = 0.
@@ -233,10 +228,6 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     __syncthreads();
   }
 
-#ifdef RG_SWEEP_PROF
-  long long pacc[4] = {0, 0, 0, 0};
-  const long long tStart = (long long)__builtin_readcyclecounter();
-#endif
   for (int kk = sa - 1; kk <= sb; ++kk) {
     // ---- A: issue the loads of plane kk+2 (consumed at the bottom of the iteration) and of the ring of plane kk+1
     // (consumed in E).  The primitives of plane kk are in LDS since the last barrier. ----
@@ -251,7 +242,6 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     }
 
     // ---- B: slopes and trace of cell (i,j,kk)  (hydro_trace_cell) ----
-    RG_PROF_T(tA);
     double q[NV], h[3][NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -299,9 +289,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #pragma unroll
       for (int n = 0; n < NV; ++n) { L.qm[0][n][tj][ti] = qmx[n]; L.qm[1][n][tj][ti] = qmy[n]; }
     }
-    RG_PROF_T(tB);
     __syncthreads();
-    RG_PROF_T(tC);
 
     // ---- C: Riemann problems at the three low faces of cell (i,j,kk)  (hydro_flux_cell) ----
     double fx[NV], fy[NV], fz[NV];
@@ -360,14 +348,7 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
 #pragma unroll
       for (int v = 0; v < NV; ++v) L.q[v][tj + 1][ti + 1] = qC[v];
     }
-    RG_PROF_T(tD);
     __syncthreads();
-#ifdef RG_SWEEP_PROF
-    {
-      const long long tE = (long long)__builtin_readcyclecounter();
-      pacc[0] += tB - tA; pacc[1] += tC - tB; pacc[2] += tD - tC; pacc[3] += tE - tD;
-    }
-#endif
     if (kk < sb) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) up[v] = uB[v];
@@ -396,12 +377,6 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
     for (int v = 0; v < NV; ++v) { qA[v] = qB[v]; qB[v] = qC[v]; uB[v] = uC[v]; uC[v] = uN[v]; }
     if (more) hydro_prim<NV>(g, uN, qC);
   }
-#ifdef RG_SWEEP_PROF
-  if ((t & 63) == 0) {
-    for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)pacc[q]);
-    atomicAdd(&rg_prof[(4 + (t >> 6)) * 4], (unsigned long long)((long long)__builtin_readcyclecounter() - tStart));
-  }
-#endif
   if (dslot) {   // workgroup maximum: wave64 butterfly, one LDS slot per wave (the flux buffer is free now), one atomic
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) inv_dt = fmax(inv_dt, __shfl_down(inv_dt, off, 64));
@@ -420,11 +395,10 @@ template <int TX, int TY, int SPEC, int MINW = 1>
 inline int launch_hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, double* out, double dtdx, double dtdy,
                                 double dtdz, int za, int zb, unsigned long long* dslot = 0, const StepClock* clk = 0, int za2 = 0) {
   TileGrid tg;
-  tg.flags = 0;
   tg.nbx = (g.isize - 1 + (TX - 2) - 1) / (TX - 2);   // owners cover i in [1, nbx*(TX-2)] plus column 0
   tg.nby = (g.jsize - 1 + (TY - 2) - 1) / (TY - 2);
   const int span = zb - za;
-  static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
+  const int zseg_env = rgpu::options().zseg;
   // two workgroups are resident per CU (~200 VGPRs): 64 per XCD; a segment costs two extra iterations (pipeline fill)
   const bool pair = za2 > 0;   // a second range [za2, za2 + span) in the same launch
   tile_grid_plan(tg, span, 64, 12, 2, zseg_env, pair);
@@ -461,7 +435,7 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
   // a 168-VGPR build for three workgroups per CU: 1.46) -- the squarest tile recomputes the least halo (196 of 256 threads
   // update a cell)
   constexpr int TX = 16, TY = 16;
-  static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
+  const bool no_spec = !rgpu::options().spec;
   // planes [lo, hi) and, second > 0, a second range of the same length starting there, in one launch (TileGrid::zsplit)
   auto launch = [&](int lo, int hi, int second) -> int {
     if (!no_spec) {
@@ -477,9 +451,8 @@ inline int hydro3d_sweep(rg_stream_t s, const DevParams& g, const double* in, do
     }
     return launch_hydro3d_sweep<TX, TY, SPEC_NONE>(s, g, in, out, dtdx, dtdy, dtdz, lo, hi, dslot, clk, second);
   };
-  static const bool no_pair = std::getenv("RGPU_NO_SWEEP_PAIR") != 0;
   const bool one = zb[0] > za[0], two = zb[1] > za[1];
-  if (one && two && !no_pair && zb[1] - za[1] == zb[0] - za[0] && za[1] >= zb[0]) return launch(za[0], zb[0], za[1]);   // the two boundary ranges of a slab
+  if (one && two && zb[1] - za[1] == zb[0] - za[0] && za[1] >= zb[0]) return launch(za[0], zb[0], za[1]);   // the two boundary ranges of a slab
   if (one) { const int rc = launch(za[0], zb[0], 0); if (rc) return rc; }
   if (two) return launch(za[1], zb[1], 0);
   return 0;

@@ -249,7 +249,7 @@ inline int hydro2d_step(rg_stream_t s, const DevParams& g, const double* in, dou
   if (!hydro2d_step_covers(g)) return 1;
   ClockFold fold;
   if (fold_in) fold = *fold_in; else { fold.prev = 0; fold.out = 0; fold.in = 0; fold.zero = 0; fold.t0 = 0.0; fold.tEnd = 0.0; }
-  static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
+  const bool no_spec = !rgpu::options().spec;
   constexpr int TX = 16, TY = 16;
 #define RG_TRY(SP) if (spec_matches(SP, g)) return launch_hydro2d_step<TX, TY, SP>(s, g, in, out, dtdx, dtdy, dt_slots, images, clk, fold);
   if (!no_spec) {

@@ -57,45 +57,12 @@ struct MhTile {
 typedef MhTile<16, 8, false> MhMain;
 typedef MhTile<2, 32, true> MhLastX;
 constexpr int MH_THREADS = 512;
-// Loop-invariant per-thread decodes that the compiler hoists out of the z march into VGPRs -- which traced cell is mine (LDS addresses
-// of three passes), the x position of my Riemann cell, which of the 512 edge values is mine -- can instead be recomputed every plane
-// from an opaque copy of the lane index (a dozen integer instructions per plane against ~3000).  With the one-loop form of the
-// contracted build the register file is full: with them recomputed the kernel has no spill left (round 4: 2 VGPRs / 12 B of scratch,
-// reloaded five times per plane) at the same speed -- profiles/r05_sweep_variants.txt, 512^3 sweep: 25.00 / 25.17 ms with the
-// spills, 25.04 / 25.07 with all three decodes per plane, 25.5 with the first two only -- the kernel is issue-bound, not spill-bound.
-// The exact build (one loop per wave role, 249 VGPRs, no spill) does not need them.
-#ifdef RG_ARITH_FAST
-#define RG_DECODE_DEFAULT 1
-#else
-#define RG_DECODE_DEFAULT 0
-#endif
-#ifndef RG_E_DECODE_PER_PLANE
-#define RG_E_DECODE_PER_PLANE RG_DECODE_DEFAULT
-#endif
-#ifndef RG_XPOS_PER_PLANE
-#define RG_XPOS_PER_PLANE RG_DECODE_DEFAULT
-#endif
-#ifndef RG_TRACE_DECODE_PER_PLANE
-#define RG_TRACE_DECODE_PER_PLANE RG_DECODE_DEFAULT
-#endif
-// Prologue of a workgroup (primitives of planes sa-2 .. sa): the loads of the three planes in flight at once (1) or plane after plane (0).
-// Same-box A/B, 512^3 / a 64-plane slab (profiles/r05_sweep_prologue.txt): exact build 30.2-30.6 against 30.85-30.98 ms / 3.82 against 3.85-3.91;
-// contracted build 24.85-25.38 against 24.91-25.03 / 3.26-3.32 against 3.21-3.29 -- it keeps the serial form.
-#ifndef RG_PROLOGUE_LOADS_IN_FLIGHT
-#ifdef RG_ARITH_FAST
-#define RG_PROLOGUE_LOADS_IN_FLIGHT 0
-#else
-#define RG_PROLOGUE_LOADS_IN_FLIGHT 1
-#endif
-#endif
-#ifndef RG_SWEEP_SPLIT_LOOPS   // main loop of the sweep once per wave role (1) or once for all waves (0): see mhd3d_sweep_kernel
-#ifdef RG_ARITH_FAST
-#define RG_SWEEP_SPLIT_LOOPS 0
-#else
-#define RG_SWEEP_SPLIT_LOOPS 1
-#endif
-#endif
-
+// ONE structure of the kernel for both arithmetics (round 6; rounds 3-5 shipped a one-loop form with per-plane decodes and a serial
+// prologue for the contracted build, whose register file was full at 256 VGPRs): per-role main loops, the loads of the three prologue
+// planes in flight at once, loop-invariant decodes kept in registers.  Same-box A/B of the alternatives on the round-6 kernel (205 / 213
+// VGPRs), 512^3 sweep, exact | contracted: one loop for all waves 30.4-30.7 | 24.03-24.08 against 30.05-30.10 | 23.58-23.64; serial
+// prologue 30.25-30.37 | 24.03-24.08 against 30.05-30.10 | 23.13-23.26; per-plane decodes 30.4 | 24.0 against 30.05 | 24.0
+// (profiles/r06_sweep_structure_ab.txt).
 // a copy of an integer that the optimiser cannot fold constants into or derive from another value: the LDS addresses formed from
 // it are "this register + a non-negative immediate"
 RG_DEVFN unsigned rg_opaque(unsigned x) { asm("" : "+v"(x)); return x; }
@@ -160,7 +127,7 @@ struct TLdsPlane {
 // first 70 % of its work both finish together.
 template <class G, int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m, double xPos, double* __restrict__ F,
-                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, int prio_flux) {
   const size_t N = g.ncell;
   const unsigned sx = 1u, sj = (unsigned)G::PX;
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
@@ -169,7 +136,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
-      if (prio_drop) __builtin_amdgcn_s_setprio(0);
+      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
       Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<XD>(g, L, R, xPos, fl);
@@ -183,7 +150,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
-      if (prio_drop) __builtin_amdgcn_s_setprio(0);
+      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
       Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<YD>(g, L, R, xPos, fl);
@@ -196,7 +163,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
-      if (prio_drop) __builtin_amdgcn_s_setprio(0);
+      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
       c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
       Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
       double fl[8];
@@ -207,13 +174,8 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
   }
 }
 
-#ifdef RG_SWEEP_VGPRS
-#define RG_SWEEP_VGPR_ATTR __attribute__((amdgpu_num_vgpr(RG_SWEEP_VGPRS)))
-#else
-#define RG_SWEEP_VGPR_ATTR
-#endif
 template <int SPEC, class G>
-__global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
+__global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, TileGrid tg, const double* __restrict__ U,
                                                                double* __restrict__ F, double* __restrict__ emf,
                                                                double dt, double dtdx, double dtdy, double dtdz, int ra, int rb,
                                                                const StepClock* clk) {
@@ -260,20 +222,12 @@ __global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_ker
   }
   // What a wave keeps from one iteration to the next.  Producers: pu[2][11] = the loaded U (8), Ua(i+1), Ub(j+1), Uc(k+1) and
   // then the primitives (8) + the cell's own face field (3) of their two input cells.  Riemann waves: the two carried states
-  // c0, c1 (8 doubles each).  With ONE main loop for all waves (RG_SWEEP_SPLIT_LOOPS 0) both live in one array, because the
-  // register allocator cannot know that a wave is either a producer or a Riemann wave for its whole life.
-#if RG_SWEEP_SPLIT_LOOPS
+  // c0, c1 (8 doubles each), declared with their loop below.
   double pu[2][11];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int v = 0; v < 11; ++v) pu[r][v] = 0.0;
-#else
-  double keep[22];
-#pragma unroll
-  for (int v = 0; v < 22; ++v) keep[v] = 0.0;
-  double (*pu)[11] = reinterpret_cast<double (*)[11]>(keep);
-#endif
   auto prim_load = [&](int k) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -308,35 +262,39 @@ __global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_ker
 
   // ---- everybody: edge electric field of plane k from Q / B of planes k-1, k.  The trace of the 17 x 9 traced cells reads
   // Ex at (c, c+y), Ey at (c, c+x), Ez at (c, c+x, c+y): 17 x 10 + 18 x 9 + 18 x 10 = 512 values -- one per thread. ----
-  // value e of the 512: computed by thread `first` + n * `stride`
-  auto elec_plane = [&](int k, int first, int stride) {
+  // Which value, where: what does not change from plane to plane (comp < 0: this thread has no such value).
+  struct ESlot { int comp; unsigned q00, store; double xPos; };
+  constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY;
+  constexpr int NE = NEX + NEY + (MH_PX + 1) * (MH_PY + 1);
+  static_assert(NE <= MH_THREADS, "at most one edge value per thread and plane (16 x 8 tile: exactly 512)");
+  auto elec_slot = [&](int e) {
+    ESlot es = {-1, 0u, 0u, 0.0};
+    if (e < 0 || e >= NE) return es;
+    int comp, ex, ey;
+    if (e < NEX) { comp = 0; ey = e / MH_PX; ex = e - ey * MH_PX; }
+    else if (e < NEX + NEY) { comp = 1; const int c = e - NEX; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+    else { comp = 2; const int c = e - NEX - NEY; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
+    const int ei = i0 - 1 + ex, ej = j0 - 1 + ey;
+    if (!(ei < g.isize - 1 && ej < g.jsize - 1)) return es;   // range of mhd_elec_cell (low bounds hold by construction)
+    es.comp = comp;
+    es.q00 = (unsigned)(ey * MH_QX + ex) * (unsigned)MH_NQB;   // the cell diagonally below: (row 0, col 0) of the 2 x 2 cells read
+    es.store = (unsigned)((ey + 1) * MH_QX + ex + 1) * 3u + (unsigned)comp;
+    es.xPos = g.xMin + g.dx / 2 + (ei - gw) * g.dx;
+    return es;
+  };
+  auto elec_value = [&](int k, const ESlot& es) {
+    if (es.comp < 0) return;
     const unsigned qlo = (unsigned)(((k - 1) % 3) * MH_QBSLOT), qhi = (unsigned)((k % 3) * MH_QBSLOT);
-    double* ed = LE + (k & 1) * MH_ESLOT;
-    constexpr int NEX = MH_PX * (MH_PY + 1), NEY = (MH_PX + 1) * MH_PY;
-    constexpr int NE = NEX + NEY + (MH_PX + 1) * (MH_PY + 1);
-    static_assert(NE <= MH_THREADS, "at most one edge value per thread and plane (16 x 8 tile: exactly 512)");
-    for (int e = first; e < NE; e += stride) {
-      int comp, ex, ey;
-      if (e < NEX) { comp = 0; ey = e / MH_PX; ex = e - ey * MH_PX; }
-      else if (e < NEX + NEY) { comp = 1; const int c = e - NEX; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
-      else { comp = 2; const int c = e - NEX - NEY; ey = c / (MH_PX + 1); ex = c - ey * (MH_PX + 1); }
-      const int ei = i0 - 1 + ex, ej = j0 - 1 + ey;
-      if (ei < g.isize - 1 && ej < g.jsize - 1) {   // range of mhd_elec_cell (low bounds hold by construction)
-        const unsigned qm = (unsigned)((ey + 1) * MH_QX + ex + 1);
-        const unsigned q00 = (unsigned)(ey * MH_QX + ex) * (unsigned)MH_NQB;   // the cell diagonally below: (row 0, col 0) of the 2 x 2 cells read
-        TraceInLds<G> in;
-        in.lq = reinterpret_cast<const char*>(LQ); in.le = 0; in.flag = 0; in.want = 0;
-        in.qA[0] = rg_opaque((qlo + q00) * 8u); in.qA[1] = rg_opaque((qhi + q00) * 8u); in.qA[2] = 0;
-        in.qB[0] = in.qB[1] = in.qB[2] = 0; in.eA[0] = in.eA[1] = 0;
-        const double xPos = g.xMin + g.dx / 2 + (ei - gw) * g.dx;
-        constexpr unsigned MC = (unsigned)(MH_QX + 1);   // the cell itself, relative to that neighbourhood
-        double v;
-        if (comp == 0) v = mhd_elec_comp<0>(g, in, xPos, MC);
-        else if (comp == 1) v = mhd_elec_comp<1>(g, in, xPos, MC);
-        else v = mhd_elec_comp<2>(g, in, xPos, MC);
-        ed[qm * 3u + (unsigned)comp] = v;
-      }
-    }
+    TraceInLds<G> in;
+    in.lq = reinterpret_cast<const char*>(LQ); in.le = 0; in.flag = 0; in.want = 0;
+    in.qA[0] = rg_opaque((qlo + es.q00) * 8u); in.qA[1] = rg_opaque((qhi + es.q00) * 8u); in.qA[2] = 0;
+    in.qB[0] = in.qB[1] = in.qB[2] = 0; in.eA[0] = in.eA[1] = 0;
+    constexpr unsigned MC = (unsigned)(MH_QX + 1);   // the cell itself, relative to that neighbourhood
+    double v;
+    if (es.comp == 0) v = mhd_elec_comp<0>(g, in, es.xPos, MC);
+    else if (es.comp == 1) v = mhd_elec_comp<1>(g, in, es.xPos, MC);
+    else v = mhd_elec_comp<2>(g, in, es.xPos, MC);
+    (LE + (k & 1) * MH_ESLOT)[es.store] = v;
   };
 
   // rendezvous of the TWO producer waves (the only readers and writers of Q / B / E) through an LDS counter: lets them
@@ -379,7 +337,8 @@ __global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_ker
   // the six Riemann waves compute the edge electric field of plane kk+2 (384 threads, two trips over its 512 values)
   constexpr int E_NTHREADS = 384, E_NWAVES = E_NTHREADS / 64;
   const int ethread = producer ? -1 : (dir + 3 * half) * 64 + lane;
-  const bool prio_mode = (tg.flags & 1) == 0;             // RGPU_SWEEP_FLAGS=1 switches the priority scheme off
+  // (the z march: the values ethread and ethread + 384 of every plane, decoded once)
+  const ESlot es0 = elec_slot(ethread), es1 = elec_slot(ethread < 0 ? -1 : ethread + E_NTHREADS);
   const int cl = half * 64 + lane;
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
@@ -388,12 +347,8 @@ __global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_ker
   const unsigned cm00 = (unsigned)(oy * MH_PX + ox) * (unsigned)(G::TREC * 8);   // byte offset of the T record of the cell diagonally below
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
 
-#ifdef RG_SWEEP_PROF
-  long long acc[4] = {0, 0, 0, 0};
-#endif
   // prologue: primitives of planes sa-2, sa-1, sa; electric field of plane sa-1
   if (t == 0) { Lsync = 0; Lesync = 0; }
-#if RG_PROLOGUE_LOADS_IN_FLIGHT
   {
     // the loads of all three planes in flight at once (the start-up of a workgroup is 5 % of a 64-plane slab's march): the second and third
     // plane wait in registers of their own, dead before the main loop starts
@@ -425,175 +380,67 @@ __global__ void __launch_bounds__(MH_THREADS) RG_SWEEP_VGPR_ATTR mhd3d_sweep_ker
       prim_store(sa - 1 + q);
     }
     __syncthreads();
-    elec_plane(sa - 1, t, MH_THREADS);
+    elec_value(sa - 1, elec_slot(t));
   }
-#else
-  for (int k = sa - 2; k <= sa; ++k) {
-    prim_load(k);
-    prim_compute();
-    prim_store(k);
-    __syncthreads();
-    if (k == sa - 1) elec_plane(k, t, MH_THREADS);
-  }
-#endif
   __syncthreads();
   // iteration kk.  Riemann waves: electric field of plane kk+2 (from Q / B of planes kk+1, kk+2, complete since the last
   // barrier) into the slot E(kk) vacated, announce it, then the Riemann problems of plane kk.  Producers: loads of U(kk+3),
   // trace(kk+1) (waits for that announcement just before it reads E), prim(kk+3) -> the slot Q / B (kk) vacated.
   // kk = sa-2 only traces plane sa-1, kk = sa-1 traces plane sa and builds the carried states from T(sa-1); the last
   // planes have nothing left to produce.
-  // the two per-plane bodies, as text: the kernel has them either in one loop or in one loop per role (below), and a lambda
-  // capturing the carried arrays by reference kept them in scratch
-#ifdef RG_SWEEP_PROF
-#define RG_TRACE_ON (tracing && !(tg.flags & 4))                    /* RGPU_SWEEP_FLAGS=4 times the kernel without the trace */
-#define RG_RIEMANN_ON (fl_ok && kk >= sa - 1 && !(tg.flags & 2))    /* RGPU_SWEEP_FLAGS=2: without the Riemann problems */
-#else
-#define RG_TRACE_ON tracing
-#define RG_RIEMANN_ON (fl_ok && kk >= sa - 1)
-#endif
-#if RG_TRACE_DECODE_PER_PLANE
-#define RG_TRACE_LANE(v) int v = lane; asm volatile("" : "+v"(v));
-#else
-#define RG_TRACE_LANE(v) const int v = lane;
-#endif
-#define RG_PRODUCER_PLANE(kk, nit) {                                                                                     \
-    const bool more = kk + 3 <= sb;                                                                                      \
-    const bool tracing = kk + 1 < sb;                                                                                    \
-    if (more) prim_load(kk + 3);                                                                                         \
-    if (RG_TRACE_ON) {                                                                                                   \
-      RG_TRACE_LANE(tl)                                                                                                  \
-      if (pid == 0) { trace_cell(kk + 1, tl, E_NWAVES * nit); trace_cell(kk + 1, 128 + tl, E_NWAVES * nit); }            \
-      else trace_cell(kk + 1, 64 + tl, E_NWAVES * nit);                                                                  \
-    }                                                                                                                    \
-    if (more) {                                                                                                          \
-      prim_compute();                                                                                                    \
-      pair_sync();                     /* both producers are done reading Q / B (kk) */                                  \
-      prim_store(kk + 3);              /* -> the Q / B slot of plane kk */                                               \
-    }                                                                                                                    \
-  }
-  // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
+  // One loop per role (the role of a wave never changes): the register allocator sees two independent live sets -- the producers'
+  // input cells, the Riemann waves' carried states -- instead of their union in every wave.  Every wave passes the same number of
+  // workgroup barriers, ONE per plane: T(kk+1) and Q / B (kk+3) complete, T(kk) free.
+  // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues fewer instructions per plane -- made the
   //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-#if RG_XPOS_PER_PLANE   /* x position of the thread's cell: two VGPRs for the whole march, or four integer / fp instructions per plane */
-#define RG_XPOS(v) int xl_ = lane; asm volatile("" : "+v"(xl_)); const double v = g.xMin + g.dx / 2 + (i0 + (xl_ & (MH_OX - 1)) - gw) * g.dx;
-#else
-#define RG_XPOS(v) const double v = xPos;
-#endif
-#if RG_E_DECODE_PER_PLANE
-#define RG_E_FIRST(v) int v = ethread; asm volatile("" : "+v"(v));
-#else
-#define RG_E_FIRST(v) const int v = ethread;
-#endif
-#define RG_E_STEP(kk) if (ethread >= 0) { const bool tracing_e = kk + 1 < sb; RG_E_FIRST(e_first)                        \
-    if (tracing_e) elec_plane(kk + 2, e_first, E_NTHREADS);   /* E(kk+2) -> the slot of E(kk), dead since trace(kk) */   \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                               \
-    if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define RG_RIEMANN_PLANE(kk, c0, c1) {                                                                                   \
-    RG_E_STEP(kk)                                                                                                        \
-    if (RG_RIEMANN_ON) {                                                                                                 \
-      const unsigned tk0 = (unsigned)((kk & 1) * MH_BUF * 8) + cm00;                                                     \
-      const TLdsPlane<G> Tk = {reinterpret_cast<const char*>(LT), rg_opaque(tk0), rg_opaque(tk0 + (unsigned)(MH_PX * G::TREC * 8))};  \
-      const unsigned idx = cidx2 + (unsigned)kk * sk;                                                                    \
-      const bool solve = kk >= sa;                                                                                       \
-      const bool raise = prio_mode && solve && wave >= 4;                                                                \
-      if (raise) __builtin_amdgcn_s_setprio(1);                                                                          \
-      RG_XPOS(xp)                                                                                                        \
-      if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                               \
-      else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                          \
-      else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);                                        \
-    }                                                                                                                    \
-  }
-#ifdef RG_SWEEP_PROF
-#define RG_PLANE_END() { RG_PROF_T(tB); __syncthreads(); const long long tE = (long long)__builtin_readcyclecounter(); acc[0] += tB - tA; acc[1] += tE - tB; }
-#else
-#define RG_PLANE_END() __syncthreads()   /* T(kk+1) and Q / B (kk+3) complete, T(kk) free */
-#endif
-#if RG_SWEEP_SPLIT_LOOPS
-  // One loop per role (the role of a wave never changes): the register allocator sees two independent live sets -- the
-  // producers' input cells, the Riemann waves' carried states -- instead of their union in every wave.  Exact arithmetic: 235
-  // instead of 256 VGPRs, no VGPR spill, sweep 31.7 against 32.2 ms; contracted arithmetic, whose critical chain is the
-  // producers', 25.7 against 25.3 (same boxes), hence the switch.  Every wave passes the same number of barriers.
   if (producer) {
     int nit = 0;
     for (int kk = sa - 2; kk < sb; ++kk) {
-      RG_PROF_T(tA);
       ++nit;
-      RG_PRODUCER_PLANE(kk, nit);
-      RG_PLANE_END();
-    }
-  } else {
-    Prim8 c0 = {0, 0, 0, 0, 0, 0, 0, 0}, c1 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int kk = sa - 2; kk < sb; ++kk) {
-      RG_PROF_T(tA);
-      RG_RIEMANN_PLANE(kk, c0, c1);
-      RG_PLANE_END();
-    }
-  }
-#else   // (the loop as it was before the split, verbatim: small changes of its text move the register allocation)
-  int nit = 0;
-  for (int kk = sa - 2; kk < sb; ++kk) {
-    RG_PROF_T(tA);
-    ++nit;
-    const bool more = kk + 3 <= sb;
-    const bool tracing = kk + 1 < sb;
-    if (producer) {
+      const bool more = kk + 3 <= sb;
+      const bool tracing = kk + 1 < sb;
       if (more) prim_load(kk + 3);
-#ifdef RG_SWEEP_PROF
-      if (tracing && !(tg.flags & 4)) {   // experiment: RGPU_SWEEP_FLAGS=4 times the kernel without the trace
-#else
       if (tracing) {
-#endif
-        RG_TRACE_LANE(tl)
-        if (pid == 0) { trace_cell(kk + 1, tl, E_NWAVES * nit); trace_cell(kk + 1, 128 + tl, E_NWAVES * nit); }
-        else trace_cell(kk + 1, 64 + tl, E_NWAVES * nit);
+        if (pid == 0) { trace_cell(kk + 1, lane, E_NWAVES * nit); trace_cell(kk + 1, 128 + lane, E_NWAVES * nit); }
+        else trace_cell(kk + 1, 64 + lane, E_NWAVES * nit);
       }
       if (more) {
         prim_compute();
         pair_sync();                     // both producers are done reading Q / B (kk)
         prim_store(kk + 3);              // -> the Q / B slot of plane kk
       }
-    } else {
-      // (round 3: E(kk+2) computed by the producer pair instead -- their SIMD issues 28 % fewer instructions per plane -- made the
-      //  sweep SLOWER, 34.25 against 32.29 ms: the producers' chain load -> [E] -> trace -> barrier is the latency-critical one)
-      RG_E_STEP(kk)
-#ifdef RG_SWEEP_PROF
-      if (fl_ok && kk >= sa - 1 && !(tg.flags & 2)) {   // experiment: RGPU_SWEEP_FLAGS=2 times the kernel without the Riemann problems
-#else
+      __syncthreads();
+    }
+  } else {
+    Prim8 c0 = {0, 0, 0, 0, 0, 0, 0, 0}, c1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kk = sa - 2; kk < sb; ++kk) {
+      if (ethread >= 0) {
+        if (kk + 1 < sb) { elec_value(kk + 2, es0); elec_value(kk + 2, es1); }   // E(kk+2) -> the slot of E(kk), dead since trace(kk)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(&Lesync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       if (fl_ok && kk >= sa - 1) {
-#endif
         const unsigned tk0 = (unsigned)((kk & 1) * MH_BUF * 8) + cm00;
         const TLdsPlane<G> Tk = {reinterpret_cast<const char*>(LT), rg_opaque(tk0), rg_opaque(tk0 + (unsigned)(MH_PX * G::TREC * 8))};
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;
-        const bool raise = prio_mode && solve && wave >= 4;
-        if (raise) __builtin_amdgcn_s_setprio(1);
-        Prim8 c0 = {keep[0], keep[1], keep[2], keep[3], keep[4], keep[5], keep[6], keep[7]};
-        Prim8 c1 = {keep[8], keep[9], keep[10], keep[11], keep[12], keep[13], keep[14], keep[15]};
-        RG_XPOS(xp)
-        if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
-        else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
-        else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xp, F, emf, idx, c0, c1, solve, raise);
-        keep[0] = c0.r; keep[1] = c0.p; keep[2] = c0.u; keep[3] = c0.v; keep[4] = c0.w; keep[5] = c0.a; keep[6] = c0.b; keep[7] = c0.c;
-        keep[8] = c1.r; keep[9] = c1.p; keep[10] = c1.u; keep[11] = c1.v; keep[12] = c1.w; keep[13] = c1.a; keep[14] = c1.b; keep[15] = c1.c;
+        // the two Riemann waves of a SIMD are arbitrated oldest first: the younger one is favoured for its EMF (see riemann_dir)
+#ifndef RG_PRIO_EXP
+#define RG_PRIO_EXP 0
+#endif
+        // priority of this wave during the EMF (pe) and during the flux (pf; -1: unchanged)
+        const bool lead = RG_PRIO_EXP == 4 ? ((wave >= 4) != ((kk & 1) != 0)) : wave >= 4;
+        const int pe = (RG_PRIO_EXP == 1 || !solve) ? -1 : (lead ? 1 : -1);
+        const int pf = (RG_PRIO_EXP == 1 || !solve) ? -1 : (RG_PRIO_EXP == 2 ? -1 : (lead ? 0 : (RG_PRIO_EXP >= 3 ? 1 : -1)));
+        if (pe == 1) __builtin_amdgcn_s_setprio(1);
+        if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
+        else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
+        else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
+        if (RG_PRIO_EXP >= 2 && solve) __builtin_amdgcn_s_setprio(0);
       }
+      __syncthreads();
     }
-    RG_PROF_T(tB);
-    __syncthreads();   // T(kk+1) and Q / B (kk+3) complete, T(kk) free
-#ifdef RG_SWEEP_PROF
-    const long long tE = (long long)__builtin_readcyclecounter();
-    acc[0] += tB - tA; acc[1] += tE - tB;
-#endif
   }
-#endif
-#undef RG_PLANE_END
-#undef RG_PRODUCER_PLANE
-#undef RG_E_STEP
-#undef RG_RIEMANN_PLANE
-#undef RG_TRACE_ON
-#undef RG_RIEMANN_ON
-#ifdef RG_SWEEP_PROF
-  if ((t & 63) == 0)
-    for (int q = 0; q < 4; ++q) atomicAdd(&rg_prof[(t >> 6) * 4 + q], (unsigned long long)acc[q]);
-#endif
 }
 
 // Periodic faces: every input of the Riemann problems at the layer j = ny + gw (i = nx + gw) is a ghost copy of what the
@@ -638,8 +485,6 @@ template <int SPEC>
 inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U, double* F,
                               double* emf, double dt, double dtdx, double dtdy, double dtdz, int ra, int rb, int reuse, const StepClock* clk, double* shear_save, int ra2) {
   TileGrid tg;
-  static const int flags_env = std::getenv("RGPU_SWEEP_FLAGS") ? std::atoi(std::getenv("RGPU_SWEEP_FLAGS")) : 0;
-  tg.flags = flags_env;
   constexpr int OX = MhMain::OX, OY = MhMain::OY;
   tg.nbx = (g.isize - 2 * g.gw + 1 + OX - 1) / OX;   // cells gw .. isize-gw
   tg.nby = (g.jsize - 2 * g.gw + 1 + OY - 1) / OY;
@@ -648,11 +493,10 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   if (copy_y) tg.nby -= 1;
   // nx a multiple of the tile width and no periodic image to copy (the shearing box): the face column i = isize - gw would be a tile
   // column of its own with one valid column in 16 -- it goes to a second launch with the 2 x 32 geometry instead (MhLastX)
-  static const bool no_lastx = std::getenv("RGPU_NO_LASTX_TILES") != 0;
-  const bool lastx = !no_lastx && !copy_x && g.nx % OX == 0 && tg.nbx >= 2;
+  const bool lastx = !copy_x && g.nx % OX == 0 && tg.nbx >= 2;
   if (lastx) tg.nbx -= 1;
   const int span = rb - ra;
-  static const int zseg_env = std::getenv("RGPU_ZSEG") ? std::atoi(std::getenv("RGPU_ZSEG")) : 0;
+  const int zseg_env = rgpu::options().zseg;
   // one workgroup is resident per CU: 32 per XCD; a segment costs two extra iterations (pipeline fill).  512^3 shearing box: 2048 tiles
   // of one base segment = 8 rounds of workgroups exactly, then 16 tiles of the last face column in 16 segments = one short round (round
   // 4: 2112 tiles, 8 rounds + 8 items per XCD cut into 4 sub-segments each)
@@ -667,7 +511,6 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   if (hipGetLastError() != hipSuccess) return -1;
   if (lastx) {
     TileGrid tl;
-    tl.flags = flags_env;
     tl.nbx = 1;
     tl.nby = (g.jsize - 2 * g.gw + (copy_y ? 0 : 1) + MhLastX::OY - 1) / MhLastX::OY;   // (rows past the face range are masked in the kernel)
     tile_grid_plan(tl, span, 32, 8, 2, zseg_env, pair);
@@ -686,13 +529,6 @@ inline int launch_mhd3d_sweep(rg_stream_t s, const DevParams& g, const double* U
   }
   return 0;
 }
-
-#ifdef RG_SWEEP_PROF
-extern "C" inline void rgpu_prof_read_impl(unsigned long long* out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(rg_prof), sizeof(unsigned long long) * 32);
-  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rg_prof), z, sizeof(z)); }
-}
-#endif
 
 // configurations the fused sweep covers (everything but the per-cell gravity field, which the driver excludes itself)
 inline bool mhd3d_sweep_covers(const DevParams& g) { return tiled_enabled() && g.three_d && g.mhd; }

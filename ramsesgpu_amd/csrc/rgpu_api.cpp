@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "launchers.h"
+#include "rg_options.h"
 #include "rg_tiled.h"   // LDS-tiled cooperative kernels of the backend (hip/rg_tiled.h)
 
 using namespace rgpu;
@@ -292,17 +293,17 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   if (rg_event_create(&c->ev0) == 0 && rg_event_create(&c->ev1) == 0) c->ev_ok = true;
   c->nchunks = 1;
   // sub-band size (cells) of the XCD-aware workgroup order, 0 = linear order (rg_backend.h: rg_launch_planes)
-  if (std::getenv("RGPU_XCD_SUB")) c->xcd_sub = (unsigned)std::atoi(std::getenv("RGPU_XCD_SUB"));
+  if (rgpu::options().xcd_sub >= 0) c->xcd_sub = (unsigned)rgpu::options().xcd_sub;
   c->g.xcd_sub = (int)c->xcd_sub;
   if (p->mhdEnabled && c->g.three_d) {
+    // (the flat kernels only -- RGPU_TILED=0 or a per-cell gravity field; the tiled sweep marches z inside one launch)
     // default: chunks of ~8 planes (measured best at 512^3: 64 chunks 75.7 ms/step vs 82-84 ms serial; 128 chunks
-    // 77.4, 256 chunks 82.6); RGPU_CHUNKS=1 selects the serial single-stream schedule.  Equal stream priorities
+    // 77.4, 256 chunks 82.6); option "chunks" = 1 selects the serial single-stream schedule.  Equal stream priorities
     // (a low-priority VALU stream measured 3 % slower).
-    int want = std::getenv("RGPU_CHUNKS") ? std::atoi(std::getenv("RGPU_CHUNKS")) : c->g.ksize / 8;
+    int want = rgpu::options().chunks > 0 ? rgpu::options().chunks : c->g.ksize / 8;
     if (want > c->g.ksize / 2) want = c->g.ksize / 2;
     if (want > rgpu_ctx::kMaxChunks) want = rgpu_ctx::kMaxChunks;
-    const int alu_prio = std::getenv("RGPU_ALU_PRIO") ? std::atoi(std::getenv("RGPU_ALU_PRIO")) : 0;
-    if (want > 1 && rg_stream_create(&c->stream2, alu_prio) == 0) {
+    if (want > 1 && rg_stream_create(&c->stream2, 0) == 0) {
       bool ok = c->fork_ok = rg_order_event_create(&c->ev_fork) == 0;
       for (int i = 0; i < want && ok; ++i) {
         if (rg_order_event_create(&c->ev_trace[i])) { ok = false; break; }
@@ -414,10 +415,8 @@ int do_make_boundaries_shear(rgpu_ctx* c, double* U, double totalTime, double dt
 // x and y faces (and the shearing-box remap of the x borders) act within one z plane and leave, in every ghost cell, a function of
 // that plane's interior cells: one thread per ghost cell, one launch for up to two ranges of planes, instead of X, Y (plain) or
 // Y, shear, Y (shearing box) per range.  Possible when the x / y faces are plain (mirror / copy / periodic) or the shearing box
-// with periodic y; the 2D jet (re-imposed after the Y pass) is launched behind it.  RGPU_NO_FUSED_FILL=1: the separate passes.
+// with periodic y; the 2D jet (re-imposed after the Y pass) is launched behind it.
 bool fill_xy_plan(const rgpu_ctx* c, double totalTime, double dt, FillXY* f) {
-  static const bool off = std::getenv("RGPU_NO_FUSED_FILL") != 0;
-  if (off) return false;
   const rgpu_params& p = c->p;
   auto plain = [](int b) { return b == RGPU_BC_DIRICHLET || b == RGPU_BC_NEUMANN || b == RGPU_BC_PERIODIC; };
   f->bx0 = p.bc[0]; f->bx1 = p.bc[1]; f->by0 = p.bc[2]; f->by1 = p.bc[3]; f->shear = 0;
@@ -550,8 +549,7 @@ int launch_planes(rg_stream_t s, const DevParams& g, PlaneRange r, const K& k) {
 bool mhd3d_scan_cond(const rgpu_ctx* c) {
   const rgpu_params& p = c->p;
   const DevParams& g = c->g;
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  if (no_fused_dt || g.grav_on == 2 || p.nu > 0 || p.eta > 0 || p.randomForcingEnabled || p.ouForcingEnabled) return false;
+  if (g.grav_on == 2 || p.nu > 0 || p.eta > 0 || p.randomForcingEnabled || p.ouForcingEnabled) return false;
   if (g.rot) {
     const bool xy_ok = (p.bc[0] == RGPU_BC_PERIODIC || p.bc[0] == RGPU_BC_SHEARINGBOX) && p.bc[1] == p.bc[0];
     auto zok = [](int b) { return b == RGPU_BC_PERIODIC || b == RGPU_BC_COPY; };
@@ -560,8 +558,7 @@ bool mhd3d_scan_cond(const rgpu_ctx* c) {
   return true;
 }
 bool hydro3d_scan_cond(const rgpu_ctx* c) {
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  return !no_fused_dt && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled && rgpu_tiled::hydro3d_sweep_covers(c->g) && c->g.grav_on != 2;
+  return !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled && rgpu_tiled::hydro3d_sweep_covers(c->g) && c->g.grav_on != 2;
 }
 
 // hydro: launch-time specialisation on the Riemann solver and the slope type (launchers.h); the no-gravity instantiations
@@ -601,8 +598,7 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
   }
   // the CFL scan of the new state rides in the kernel that writes it when the whole domain is updated in this call and nothing
   // modifies the state afterwards (2D: the fused step or the flat update kernel; 3D with a per-cell gravity field: the flat one)
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  const bool scan2 = !no_fused_dt && a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
+  const bool scan2 = a <= 0 && b >= ks && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled;
   const bool folding = c->clk_cur && c->fold_mode && c->fold_pending;   // 2D batch: the clock is part of this step's kernel (ClockFold)
   unsigned long long* slots = scan2 ? c->d_red : 0;
   if (st.clk && !(ND == 2 && scan2)) return -1;   // a device-clock step is a fused kernel with the CFL term or nothing
@@ -610,9 +606,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
   if (ND == 2) {   // LDS-tiled fused step: one kernel (hip/tiled_hydro2d.h)
     Phase ph(c, RGPU_T_SWEEP);
     // plain faces, nothing modifying the new state after this kernel: it writes the ghost images too and the next step's fill is skipped
-    static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
     int images = 0;
-    if (!no_images && scan2 && !c->p.enableJet && g.nx >= g.gw && g.ny >= g.gw) {
+    if (rgpu::options().ghost_images && scan2 && !c->p.enableJet && g.nx >= g.gw && g.ny >= g.gw) {
       images = 1 << 12;
       for (int f = 0; f < 4; ++f) {
         const int bc = c->p.bc[f];
@@ -629,9 +624,8 @@ int hydro_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, int a,
   }
   { Phase ph(c, RGPU_T_PRIM); K_hydro_prim<NV> k = {g, in, c->Q}; if (launch_planes<kBlock, 1>(c->stream, g, clip(a - 2, b + 2, ks), k)) return -1; }
   const bool gf = g.grav_on == 2;   // per-cell gravity field: separate instantiations (see half_dt_gravity)
-  static const bool no_spec = std::getenv("RGPU_NO_SPEC") != 0;
   int rc = 1;   // 1 = not handled by a specialisation
-  if (!no_spec && g.grav_on == 0) {
+  if (rgpu::options().spec && g.grav_on == 0) {
     const int SL1 = SPEC_SLOPE1 | SPEC_NO_GRAVITY, SL2 = SPEC_SLOPE2 | SPEC_NO_GRAVITY;
     if (spec_matches(SPEC_HYDRO_APPROX | SL1, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_APPROX | SL1>(c, dtdx, dtdy, dtdz, a, b);
     else if (spec_matches(SPEC_HYDRO_APPROX | SL2, g)) rc = hydro_flux_trace_spec<ND, NV, SPEC_HYDRO_APPROX | SL2>(c, dtdx, dtdy, dtdz, a, b);
@@ -677,8 +671,7 @@ RotCoef rot_coef(const rgpu_ctx* c, double dt) {
 const int kSpecMri = SPEC_HLLD | SPEC_ISOTHERMAL | SPEC_ROTATING | SPEC_NO_GRAVITY | SPEC_SLOPE2;
 const int kSpecPlain = SPEC_HLLD | SPEC_ADIABATIC | SPEC_INERTIAL | SPEC_NO_GRAVITY | SPEC_SLOPE2;
 inline int pick_spec(const DevParams& g) {
-  static const bool off = std::getenv("RGPU_NO_SPEC") != 0;
-  return off ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
+  return !rgpu::options().spec ? 0 : spec_matches(kSpecMri, g) ? 1 : spec_matches(kSpecPlain, g) ? 2 : 0;
 }
 
 int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
@@ -698,16 +691,13 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
     if (faces_ok && g.grav_on != 2) {
       bool scan = !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
       if (scan && g.rot) scan = p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC;
-      static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-      if (no_fused_dt) scan = false;
       if (rgpu_tiled::mhd2d_step_covers(g)) {
         if (st.clk && !scan) return -1;
         if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (the clock kernel zeroed them)
         Phase ph(c, RGPU_T_SWEEP);
         // periodic box on the plain path, nothing modifying the new state after this kernel: it writes the periodic images too and
         // the next step's ghost fill is skipped (step_pre)
-        static const bool no_images = std::getenv("RGPU_NO_GHOST_IMAGES") != 0;
-        bool images = !no_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
+        bool images = rgpu::options().ghost_images && !g.rot && scan && !p.enableJet && g.nx >= g.gw && g.ny >= g.gw;
         for (int f = 0; f < 4; ++f) images = images && p.bc[f] == RGPU_BC_PERIODIC;
         const int rct = rgpu_tiled::mhd2d_step<kSpecPlain>(c->stream, g, rc, pick_spec(g) == 2, in, out, dt, scan ? c->d_red : 0, images ? 1 : 0, st.clk);
         if (rct < 0) return -1;
@@ -735,8 +725,6 @@ int mhd2d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg) {
   const rgpu_params& p = c->p;
   bool scan = !gf && !(p.nu > 0) && !(p.eta > 0) && !p.randomForcingEnabled && !p.ouForcingEnabled;
   if (scan && g.rot) scan = p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC;
-  static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
-  if (no_fused_dt) scan = false;
   unsigned long long* slots = scan ? c->d_red : 0;
   if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   {
@@ -810,17 +798,13 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
     if (r2.hi > r2.lo) {
       lo2 = r2.lo < g.gw ? g.gw : r2.lo;
       const int hi2 = r2.hi > ks - g.gw + 1 ? ks - g.gw + 1 : r2.hi;
-      static const bool no_pair = std::getenv("RGPU_NO_SWEEP_PAIR") != 0;
-      if (no_pair || hi <= lo || hi2 - lo2 != hi - lo || lo2 < hi) return 2;
+      if (hi <= lo || hi2 - lo2 != hi - lo || lo2 < hi) return 2;
     }
     // periodic faces whose fluxes / EMFs are bit-identical copies of the opposite layer (see K_copy_periodic_layer): y when both
     // y faces are periodic; x when both x faces are periodic and the frame does not rotate (the rotating-frame terms carry xPos)
-    static const bool no_reuse = std::getenv("RGPU_NO_PERIODIC_REUSE") != 0;
     int reuse = 0;
-    if (!no_reuse) {
-      if (p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC) reuse |= 2;
-      if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
-    }
+    if (p.bc[2] == RGPU_BC_PERIODIC && p.bc[3] == RGPU_BC_PERIODIC) reuse |= 2;
+    if (p.bc[0] == RGPU_BC_PERIODIC && p.bc[1] == RGPU_BC_PERIODIC && !g.rot) reuse |= 1;
     // shearing box: the launch that copies the periodic y layer also saves the emfY border columns of these planes for the remap
     return rgpu_tiled::mhd3d_sweep<kSpecMri, kSpecPlain>(s, g, spec, in, c->F, c->emf, dt, dtdx, dtdy, dtdz, lo, hi, reuse, st.clk, shear ? c->shear_save : 0, lo2);
   };
@@ -876,19 +860,16 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   if (scan && !c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;
   // the update is a pure stream over F, emf and U: one thread per column and short z segment, linear workgroup order, the plane
   // k+1 entries carried in registers (mhd_update3d_column; 512^3: 8.07 -> 7.42 ms against one thread per cell)
-#ifndef RG_UPD_MINW
-#define RG_UPD_MINW 1
-#endif
-  static const int upd_seg = std::getenv("RGPU_UPD_SEG") ? std::atoi(std::getenv("RGPU_UPD_SEG")) : 3;
+  const int upd_seg = 3;   // planes per thread of the update's z march (512^3: 2 / 3 / 4 / 8 / 32 planes 7.49 / 7.42 / 7.50 / 7.65 / 9.0 ms)
   auto update_planes = [&](rg_stream_t s, PlaneRange r, PlaneRange r2 = PlaneRange{0, 0}) -> int {
     if (r.hi <= r.lo) { r = r2; r2 = PlaneRange{0, 0}; }
     if (r.hi <= r.lo) return 0;
-    const int seg_len = upd_seg > 0 ? upd_seg : 3;
+    const int seg_len = upd_seg;
     const unsigned n1 = g.sk * (unsigned)((r.hi - r.lo + seg_len - 1) / seg_len);
     const bool two = r2.hi > r2.lo;
     const unsigned nt = n1 + (two ? g.sk * (unsigned)((r2.hi - r2.lo + seg_len - 1) / seg_len) : 0u);
     const unsigned split = two ? n1 : 0xffffffffu;
-#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi, st.clk}; return rg_launch_range<kBlock, RG_UPD_MINW>(s, 0u, nt, k); }
+#define RG_UPD(ROT, GF, S) { K_mhd_update3d<ROT, GF, S> k = {g, rc, in, out, F, emf, remap, dt, dtdx, dtdy, dtdz, slots, r.lo, r.hi, seg_len, split, r2.lo, r2.hi, st.clk}; return rg_launch_range<kBlock>(s, 0u, nt, k); }
     if (gf) { if (g.rot) RG_UPD(true, true, SPEC_NONE) else RG_UPD(false, true, SPEC_NONE) }
     if (g.rot) { if (spec == 1) RG_UPD(true, false, kSpecMri) if (spec == 2) RG_UPD(true, false, kSpecPlain) RG_UPD(true, false, SPEC_NONE) }
     if (spec == 1) RG_UPD(false, false, kSpecMri) if (spec == 2) RG_UPD(false, false, kSpecPlain) RG_UPD(false, false, SPEC_NONE)
@@ -896,9 +877,8 @@ int mhd3d_core(rgpu_ctx* c, const double* in, double* out, double dt_arg, double
   };
 
   // the fused sweep marches along z inside one launch: cutting the range into chunks only adds prologues (measured 60.4
-  // against 55.3 ms/step at 512^3), so the two-stream chunk schedule is kept for the flat kernels only (RGPU_CHUNKS forces it)
-  static const bool force_chunks = std::getenv("RGPU_CHUNKS") != 0;
-  const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || (use_sweep && !force_chunks) || c->clk_cur;
+  // against 55.3 ms/step at 512^3), so the two-stream chunk schedule is kept for the flat kernels only
+  const bool serial = what != 0 || c->timers_on || c->nchunks <= 1 || (b - a) < 16 || use_sweep || c->clk_cur;
   const bool pair = what != 0 && b2 > a2;
   if (serial) {
     rg_stream_t s = c->stream;
@@ -971,10 +951,9 @@ int step_core_planes(rgpu_ctx* c, int nStep, double dt, double totalTime, int a,
   const bool acc = (what & RGPU_CORE_SCAN) != 0;
   bool hydro_piece = false;
   if ((what & ~RGPU_CORE_SCAN) != 0 && !splittable) {
-    static const bool no_fused_dt = std::getenv("RGPU_NO_FUSED_DT") != 0;
     if ((what & ~RGPU_CORE_SCAN) == RGPU_CORE_FLUXES) {   // nothing to compute; with SCAN: reset the slot for the pieces that follow
       c->scan_acc_parity = -1;
-      if (acc && c->g.three_d && !c->p.mhdEnabled && !no_fused_dt && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
+      if (acc && c->g.three_d && !c->p.mhdEnabled && !(c->p.nu > 0) && !c->p.randomForcingEnabled && !c->p.ouForcingEnabled &&
           rgpu_tiled::hydro3d_sweep_covers(c->g) && c->p.gravityEnabled != 2) {
         if (!c->clk_cur && rg_memset_async(c->d_red, 0, RG_DT_SLOTS * sizeof(unsigned long long), c->stream)) return -1;   // (a clock kernel zeroed them)
         c->scan_acc_parity = (nStep + 1) % 2;
@@ -1767,6 +1746,17 @@ int rgpu_clock_tick(rgpu_ctx* c) {
 
 int rgpu_clock_stopped(rgpu_ctx* c) { return (c && stop_now(c)) ? 1 : 0; }
 
+// host-checked: waits for the record of the last tick and returns its stop flag (0: the step runs; < 0: error)
+int rgpu_clock_check(rgpu_ctx* c) {
+  RG_CHECK_CTX(c);
+  if (c->clk_n <= 0 || !c->clk_cur) return fail(c, RGPU_EINVAL, "clock_check: no tick in this batch");
+  if (c->fold_mode) return 0;   // (the record is written by the step kernel that follows: nothing to read yet)
+  if (RG_SYNC_LAUNCH) return c->clk_cur->stop;
+  StepClock* h = c->h_clk + (c->clk_n - 1);
+  if (rg_copy_d2h(h, c->d_clk + (c->clk_n - 1), sizeof(StepClock), c->stream) || rg_stream_sync(c->stream)) return RG_HIPFAIL(c, "clock_check");
+  return h->stop;
+}
+
 int rgpu_clock_close(rgpu_ctx* c, int nStep0, int* ran, double* t, double* dt_last, double* dt_log, int* stop) {
   RG_CHECK_CTX(c);
   if (c->clk_n < 0) return fail(c, RGPU_EINVAL, "clock_close: no batch open");
@@ -1922,8 +1912,16 @@ int rgpu_selftest_alfven(const rgpu_params* p, int n, const double* states36, do
   return rc ? RGPU_EHIP : RGPU_OK;
 }
 
-#ifdef RG_SWEEP_PROF
-void rgpu_prof_read(unsigned long long* out, int reset) { rgpu_tiled::rgpu_prof_read_impl(out, reset); }
-#endif
+int rgpu_set_option(const char* name, int value) {
+  int* slot = rgpu::option_slot(name);
+  if (!slot) return -1;
+  const int old = *slot;
+  *slot = value;
+  return old;
+}
+int rgpu_get_option(const char* name) {
+  const int* slot = rgpu::option_slot(name);
+  return slot ? *slot : -1;
+}
 
 }  // extern "C"

@@ -68,6 +68,16 @@ class Library:
         """"exact" or "contracted" (see lib_path)"""
         return self.lib.rgpu_arithmetic().decode()
 
+    def set_option(self, name, value):
+        """diagnostic option of the library (include/rgpu.h, "Environment and options"); returns the previous value"""
+        old = self.lib.rgpu_set_option(name.encode(), int(value))
+        if old < 0 and self.lib.rgpu_get_option(name.encode()) != int(value):
+            raise RgpuError("unknown option %r" % name)
+        return old
+
+    def get_option(self, name):
+        return self.lib.rgpu_get_option(name.encode())
+
     # ---- host side: parameter file and initial condition ------------------------------------------------------
     def params_from_ini(self, ini_path, overrides="", slab=None):
         p = RgpuParams()

@@ -6,6 +6,8 @@
 #   suite           the whole GPU suite (pytest -m gpu)
 #   bench           bench.py at its defaults
 #   prof TAG        scripts/prof_round.sh TAG (bench lines, rocprofv3 kernel stats, PMC passes)
+#   final           what the driver runs at the end of a round: the whole GPU suite, the smoke check, the default bench line
+#   toggles         parts of the suite with the environment / option switches of include/rgpu.h set the other way
 #   cmd "..."       an arbitrary command
 # Output: gpurun_out/$JOB_OUT (default job).   usage: gpurun -- 'JOB_OUT=r6a bash scripts/gpu_job.sh variants golden'
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
@@ -21,6 +23,14 @@ while [ $# -gt 0 ]; do
     suite) timeout 2400 python -m pytest tests -x -q -m gpu --durations=25 > $OUT/suite.log 2>&1; tail -40 $OUT/suite.log | tee -a $OUT/log.txt ;;
     bench) python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-600 $OUT/bench.json | tee -a $OUT/log.txt ;;
     prof) tag=$1; shift; bash scripts/prof_round.sh $tag 2>&1 | tail -5 | tee -a $OUT/log.txt ;;
+    final) ( time timeout 2700 python -m pytest tests -x -q -m gpu --durations=15 2>&1 | tail -30 ) > $OUT/final_tests.log 2>&1; tail -4 $OUT/final_tests.log | tee -a $OUT/log.txt
+           ( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids ) 2>&1 | tail -3 | tee -a $OUT/log.txt
+           python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json | tee -a $OUT/log.txt ;;
+    toggles) ( RGPU_COMM_PACK=0 timeout 900 python -m pytest tests/test_comm_driver.py -x -q -m gpu -k "not whole_box" 2>&1 | tail -2
+               RGPU_COMM_ONE_STREAM=1 timeout 900 python -m pytest tests/test_comm_driver.py -x -q -m gpu -k "not whole_box" 2>&1 | tail -2
+               RGPU_TEST_OPTIONS=step_clock=0 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "run_steps" 2>&1 | tail -2
+               RGPU_TEST_OPTIONS=ghost_images=0 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "golden" 2>&1 | tail -2
+               RGPU_COMM_SCHEDULE=2 timeout 900 python -m pytest tests/test_bench_contract.py -x -q -m gpu 2>&1 | tail -2 ) 2>&1 | tee -a $OUT/log.txt ;;
     cmd) c=$1; shift; ( eval "$c" ) 2>&1 | tee -a $OUT/log.txt ;;
     *) echo "unknown step $step" | tee -a $OUT/log.txt ;;
   esac

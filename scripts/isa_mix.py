@@ -14,8 +14,10 @@
                 wave-uniform branches, so blocks are role-pure; blocks without role-specific lines are loop control);
               * trip counts per plane and workgroup: the compiler emits one copy of the Riemann code per direction, each run by the
                 two waves (cell halves) of that direction -> x 2; one copy of the trace per pass (producer 0: two passes, producer
-                1: one) -> x 1; primitives: both producers -> x 2; electric field: 512 values = 8 wave trips through its loop ->
-                x 8; the producer pair's rendezvous x 2; loop control x 8.  Blocks outside the z loop (prologue) are not counted;
+                1: one) -> x 1; primitives: both producers -> x 2; the producer pair's rendezvous x 2; loop control x 8;
+                electric field: every Riemann thread computes value e = its number (0..383) and, if < 512, e + 384 of the plane's
+                512 (170 Ex, 162 Ey, 180 Ez); the compiler emits one block per (value, component), run by the waves that hold
+                such values -> first value: Ex x 3 waves, Ey x 4, Ez x 1; second value: Ez x 2.  Blocks outside the z loop (prologue) are not counted;
               * the 2D HLLD solver evaluates only the regions of the Riemann fan some lane of the wave needs (dev_numerics.h,
                 "Region selection by sign bits"): in the shearing box every speed is below the fast speed, all lanes take the
                 inner region and the four outer-region blocks are skipped (s_cbranch_execz) -> x 0.
@@ -73,29 +75,47 @@ def kernel_lines(lines, key):
 
 
 def parse_blocks(lines, start, end):
-    """OrderedDict label -> {"ops": [(class, (file, line))], "in_loop": bool}"""
+    """OrderedDict label -> {"ops": [(class, (file, line))], "in_loop": bool, "loops": set of the headers (BBn_m) of the loops around it}"""
     blocks = OrderedDict()
     cur = "entry"
-    blocks[cur] = {"ops": [], "in_loop": False}
+    blocks[cur] = {"ops": [], "in_loop": False, "loops": set()}
     loc = (0, 0)
+
+    def loop_notes(text, b, label):
+        m = re.search(r"in Loop: Header=(BB\w+)", text)
+        if m:
+            b["in_loop"] = True
+            b["loops"].add(m.group(1))
+        m = re.search(r"Parent Loop (BB\w+)", text)
+        if m:
+            b["loops"].add(m.group(1))
+        if "Loop Header" in text:   # "=>This Loop Header: Depth=1" / "=>  This Inner Loop Header"
+            b["in_loop"] = True
+            b["loops"].add(label.lstrip(".L"))
     for l in lines[start + 1:end]:
         m = re.match(r"^(\.LBB\S+):(.*)", l)
         if m:
             cur = m.group(1)
-            blocks[cur] = {"ops": [], "in_loop": "in Loop:" in m.group(2) or "Loop Header" in m.group(2)}
+            blocks[cur] = {"ops": [], "in_loop": False, "loops": set()}
+            loop_notes(m.group(2), blocks[cur], cur)
             continue
         t = l.strip()
         m = re.match(r"^\.loc\s+(\d+)\s+(\d+)", t)
         if m:
             loc = (int(m.group(1)), int(m.group(2)))
             continue
-        if t.startswith("; %bb") or t.startswith(";   in Loop") or "Loop Header" in t:
-            if "in Loop" in t or "Loop Header" in t:
-                blocks[cur]["in_loop"] = True
+        if t.startswith(";") and ("Loop" in t):
+            loop_notes(t, blocks[cur], cur)
             continue
         if not t or t.startswith((";", ".", "//")):
             continue
         blocks[cur]["ops"].append((classify(t.split()[0]), loc))
+    for _ in range(4):   # a block of an inner loop names its own header only: add the loops around that header
+        for b in blocks.values():
+            for h in list(b["loops"]):
+                hb = blocks.get(".L" + h)
+                if hb:
+                    b["loops"] |= hb["loops"]
     return blocks
 
 
@@ -139,7 +159,9 @@ for fn in "mhd_prim prim_load prim_compute prim_store".split():
 for fn in "mhd_elec_comp elec_plane".split():
     ROLE_OF[fn] = "elec"
 ROLE_OF["pair_sync"] = "sync"
-TRIPS = {"riemann": 2, "trace": 1, "prim": 2, "elec": 8, "sync": 2, "control": 8, "riemann_outer": 0}
+for fn in "mhd3d_update_role mhd_update3d_column_at mhd_update3d_apply info_speeds closing_column n_closing rg_slot_max".split():
+    ROLE_OF[fn] = "update"   # the update role of the fused launch: other workgroups, not part of the z march
+TRIPS = {"riemann": 2, "trace": 1, "prim": 2, "elec": 6, "sync": 2, "control": 8, "riemann_outer": 0}
 
 
 def outer_region_lines():
@@ -207,11 +229,48 @@ def dynamic_report(arith, measured, iters):
     per_role = defaultdict(Counter)      # role -> class -> wave instructions per plane and workgroup
     static_role = defaultdict(Counter)
     copies = Counter()
+    # the z march: the loop(s) whose blocks hold Riemann / trace code and no update-role code
+    per_loop = defaultdict(Counter)
     for name, b in blocks.items():
-        if not b["in_loop"] or not b["ops"]:
-            continue
         votes = Counter(r for r in (role_of_loc(loc) for _, loc in b["ops"]) if r)
-        role = votes.most_common(1)[0][0] if votes else "control"
+        b["votes"] = votes
+        for h in b["loops"]:
+            per_loop[h].update(votes)
+    zloops = set(h for h, v in per_loop.items() if (v["riemann"] + v["trace"]) > 0 and v["update"] == 0)
+    def block_role(b):
+        return b["votes"].most_common(1)[0][0] if b["votes"] else "control"
+    # electric field: which component a block computes (source lines of mhd_elec_comp's three branches), which of the thread's two
+    # values (order of appearance), and how many waves hold such values
+    k3 = os.path.join(ROOT, "ramsesgpu_amd", "csrc", "kernels_mhd3d.h")
+    src3 = open(k3).read().splitlines()
+    comp_line = {}
+    cur = None
+    for n, l in enumerate(src3, 1):
+        if "RG_DEVFN double mhd_elec_comp(" in l: cur = -1
+        elif cur is not None and "if (COMP == 0)" in l: cur = 0
+        elif cur is not None and "if (COMP == 1)" in l: cur = 1
+        elif cur is not None and l.strip().startswith("// Ez"): cur = 2
+        elif cur is not None and l.startswith("}"): cur = None
+        if cur is not None and cur >= 0: comp_line[n] = cur
+    PX, PY = 17, 9
+    NEX, NEY, NE = PX * (PY + 1), (PX + 1) * PY, PX * (PY + 1) + (PX + 1) * PY + (PX + 1) * (PY + 1)
+    comp_of = lambda e: 0 if e < NEX else 1 if e < NEX + NEY else 2
+    ewaves = {(n, c): sum(1 for w in range(6) if any(w * 64 + l + 384 * n < NE and comp_of(w * 64 + l + 384 * n) == c for l in range(64))) for n in (0, 1) for c in (0, 1, 2)}
+    seen_comp = Counter()
+    for name, b in blocks.items():
+        if not b["ops"] or not (b["loops"] & zloops):
+            continue
+        votes = b["votes"]
+        role = block_role(b)
+        trips = TRIPS.get(role, 0)
+        if role == "elec":
+            cc = Counter(comp_line[ln] for _, (fid, ln) in b["ops"] if os.path.realpath(files.get(fid, "")) == os.path.realpath(k3) and ln in comp_line)
+            if cc and sum(1 for c, _ in b["ops"] if c in ("fma64", "mul64", "add64")) >= 8:
+                comp = cc.most_common(1)[0][0]
+                trips = ewaves[(min(seen_comp[comp], 1), comp)]
+                seen_comp[comp] += 1
+            else:
+                trips = 6   # dispatch on the component, address set-up: every Riemann wave
         if role == "riemann":   # an outer-region block of the 2D HLLD solver?
             inside = sum(1 for _, (fid, ln) in b["ops"] if os.path.realpath(files.get(fid, "")) == os.path.realpath(dn) and olo <= ln < ohi)
             if 2 * inside > len(b["ops"]):
@@ -221,7 +280,7 @@ def dynamic_report(arith, measured, iters):
             copies[role] += 1
         for k, v in c.items():
             static_role[role][k] += v
-            per_role[role][k] += v * TRIPS[role]
+            per_role[role][k] += v * trips
     print("# dynamic instruction mix of mhd3d_sweep_kernel<107, MhTile<16, 8>>, %s arithmetic" % ("contracted" if arith == "fast" else "exact"))
     print("# wave instructions per z plane and 512-thread workgroup = static count of the role's blocks in the z loop x trips (see the header of scripts/isa_mix.py)")
     print("# large (>= 200 instructions) copies found per role:", dict(copies), " expected: riemann 6 (EMF + flux per direction), trace 3")
@@ -233,7 +292,7 @@ def dynamic_report(arith, measured, iters):
         valu = sum(c[k] for k in VALU_CLASSES)
         if TRIPS[role]:
             tot.update(c)
-        print("%-9s %5d %8d | " % (role if TRIPS[role] else "(outer)", TRIPS[role], valu) + " ".join("%8d" % c[k] for k in classes))
+        print("%-9s %5s %8d | " % (role if TRIPS[role] else "(outer)", "3-4-1/2" if role == "elec" else TRIPS[role], valu) + " ".join("%8d" % c[k] for k in classes))
     valu = sum(tot[k] for k in VALU_CLASSES)
     print("%-9s %5s %8d | " % ("all", "", valu) + " ".join("%8d" % tot[k] for k in classes))
     f64 = sum(tot[k] for k in ("fma64", "mul64", "add64", "trans64", "minmax64"))
@@ -245,9 +304,10 @@ def dynamic_report(arith, measured, iters):
     print("per cell (128 cells per plane and workgroup): %.0f VALU thread-instructions" % (valu * 64.0 / 128.0))
     # per-SIMD view: waves w and w + 4 share a SIMD
     r, t, p, e, s, ctl = (sum(static_role[x][k] for k in VALU_CLASSES) for x in ("riemann", "trace", "prim", "elec", "sync", "control"))
-    print("per SIMD and plane (VALU): Riemann SIMD = 2 x (%.0f + control %.0f) + its share of the electric field (3 of 8 trips x %.0f) = %.0f;  "
+    edyn = sum(per_role["elec"][k] for k in VALU_CLASSES)
+    print("per SIMD and plane (VALU): Riemann SIMD = 2 x (%.0f + control %.0f) + a third of the electric field (%.0f) = %.0f;  "
           "producer SIMD = 3 x %.0f + 2 x (%.0f + %.0f + control %.0f) = %.0f" %
-          (r / 3.0, ctl, e, 2 * (r / 3.0 + ctl) + 3 * e, t / 3.0, p, s, ctl, t + 2 * (p + s + ctl)))
+          (r / 3.0, ctl, edyn / 3.0, 2 * (r / 3.0 + ctl) + edyn / 3.0, t / 3.0, p, s, ctl, t + 2 * (p + s + ctl)))
     if measured:
         pred = valu * iters
         print("reconciliation: predicted %.4g wave instructions per launch (%d workgroup x plane iterations), SQ_INSTS_VALU measured %.4g: %+.1f %%" %

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU probe of the LDS-tiled sweeps: ms/step and phase timers of one workload with the tiled kernels on / off.
 usage: probe_sweep.py implode3d 256 [steps]   |   probe_sweep.py mhd_mri_3d 512   |   probe_sweep.py orszag-tang3d 256
-Env knobs are passed through (RGPU_TILED, RGPU_ZSEG, RGPU_CHUNKS, ...)."""
+RGPU_TILED=0: the flat kernels; PROBE_OPTIONS: diagnostic options of the library; RGPU_LIB: another build of it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,13 +12,9 @@ base = args[0]; n = int(args[1]); nst = int(args[2]) if len(args) > 2 else 10
 ov = "mesh.nx=%d;mesh.ny=%d;mesh.nz=%d" % (n, n, int(os.environ.get("PROBE_NZ", n)))
 if base == "implode3d":
     ov += ";hydro.riemannSolver=hllc"
-prof = "--prof" in sys.argv
-if prof:   # experiment build with per-wave phase cycle counters (RG_SWEEP_PROF)
-    from ramsesgpu_amd import build as rb
-    fast = "--fast" in sys.argv   # the contracted-arithmetic variant of the library
-    L = Library(rb.build(verbose=False, extra_flags=["-DRG_SWEEP_PROF"] + (rb.FAST_FLAGS if fast else []), out_name="librgpu_prof_fast.so" if fast else "librgpu_prof.so"))
-else:
-    L = Library(os.environ.get('RGPU_LIB') or lib_path())   # RGPU_LIB: an experiment build of the library
+L = Library(os.environ.get('RGPU_LIB') or lib_path())   # RGPU_LIB: an experiment build of the library
+for kv in filter(None, os.environ.get("PROBE_OPTIONS", "").split(",")):   # PROBE_OPTIONS="zseg=64,spec=0": diagnostic options of the library
+    L.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 ini = os.path.join(ROOT, "configs", base + ".ini")
 p = L.params_from_ini(ini, ov)
 U0 = L.init_condition(ini, ov, p)
@@ -32,15 +28,6 @@ for _ in range(nst): sv.oneStepIntegration()
 sv.synchronize(); dtw = time.time() - t0
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("RGPU_"))
 print("%-14s %4d^3 [%s] %8.1f Mcell/s  %.3f ms/step" % (base, n, tag, nst * n ** 3 / dtw / 1e6, dtw / nst * 1e3), flush=True)
-if prof:
-    import ctypes as C
-    buf = (C.c_ulonglong * 32)()
-    L.lib.rgpu_prof_read(buf, 1)
-    sv.oneStepIntegration(); sv.synchronize()
-    L.lib.rgpu_prof_read(buf, 1)
-    print("     per-wave cycles of one step [trace work, wait1, riemann work, wait2] (sums over workgroups, 1e9):")
-    for w in range(8):
-        print("       wave %d: " % w + "  ".join("%8.3f" % (buf[w * 4 + q] / 1e9) for q in range(4)))
 sv.enable_timers(True); sv.reset_timers()
 for _ in range(3): sv.oneStepIntegration()
 tm = sv.timers()

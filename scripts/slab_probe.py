@@ -3,8 +3,10 @@
 the halo planes really travel through RCCL send / recv on the halo stream, device-local instead of over xGMI; until round 4 a
 ring of one had NO slab interface and this probe exchanged nothing -- rgpu_comm_halo_bytes now proves the bytes) stepping a
 512 x 512 x (512/N) box through the C++ driver (include/rgpu_comm.h) with the overlapped and the serial schedule -- what a
-rank of bench.py --gpus N does per step.  The device-local self-exchange costs ~0.5 ms for the 103 MB; RGPU_COMM_EMULATE_GBPS=<rate> (a measurement
-knob of csrc/hip/rg_transport.h) holds the halo stream for the time the same bytes need on ONE xGMI link at that rate
+rank of bench.py --gpus N does per step.  The device-local self-exchange costs ~0.5 ms for the 103 MB; with a link rate the probe loads the
+MEASUREMENT build of the driver (ramsesgpu_amd/librgpu_comm_measure.so: `python -m ramsesgpu_amd.build --measure`, built in the container
+before the gpurun call; scripts/measure/link_hold.h) whose RGPU_COMM_EMULATE_GBPS=<rate> holds the halo stream for the time the same
+bytes need on ONE xGMI link at that rate
 (2 x 51.5 MB per rank and step at 512^2 planes: N >= 3 -> two neighbours, two links in parallel, 51.5 MB each; N = 2 -> one
 neighbour, 103 MB over one link), so that the numbers show what the overlapped schedule really hides.  PROBE_LINK_GBPS="0 60 40"
 runs the whole table once per rate."""
@@ -14,10 +16,15 @@ sys.path.insert(0, ROOT)
 from ramsesgpu_amd import comm as rcomm
 from ramsesgpu_amd.solver import load_library
 L = load_library()
-CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))   # the driver built for this arithmetic (RGPU_ARITH)
+rates = [float(x) for x in os.environ.get("PROBE_LINK_GBPS", os.environ.get("RGPU_COMM_EMULATE_GBPS", "0")).split()]
+measure = os.path.join(ROOT, "ramsesgpu_amd", "librgpu_comm_measure.so")
+if any(r > 0 for r in rates):
+    assert os.path.exists(measure) and L.arithmetic == "contracted", "link rates need the measurement build (python -m ramsesgpu_amd.build --measure) and RGPU_ARITH=contracted"
+    CL = rcomm.load_comm_library(measure)
+else:
+    CL = rcomm.load_comm_library(rcomm.comm_lib_path(L.arithmetic))   # the driver built for this arithmetic (RGPU_ARITH)
 ini = os.path.join(ROOT, "configs", "mhd_mri_3d.ini")
 cid = rcomm.unique_id(CL)
-rates = [float(x) for x in os.environ.get("PROBE_LINK_GBPS", os.environ.get("RGPU_COMM_EMULATE_GBPS", "0")).split()]
 for rate, nz in [(r, z) for r in rates for z in ([int(os.environ['PROBE_NZ'])] if os.environ.get('PROBE_NZ') else (512, 256, 128, 64))]:   # PROBE_NZ: one slab thickness (for rocprofv3)
     if rate > 0 and nz == 512:
         continue   # N = 1 has no link

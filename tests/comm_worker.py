@@ -63,6 +63,37 @@ def _allreduce(data, n, op):
         return 1
 
 
+def load_libs(device):
+    """the libraries of one rank.  "cpu": the emulation builds (host loops, callback transport).  "cuda-staged:N": N rank processes on
+    ONE GPU through the PRODUCT library (real tiled HIP kernels) and the product's slab driver compiled against the TEST-ONLY
+    device-aware transport (tests/emu_dev/rg_transport.h): the planes are packed by the product's kernels, staged through pinned
+    memory and carried by gloo (RCCL refuses two ranks on one device).  "cuda:N": the product libraries (HIP + RCCL).
+    Returns (library, comm library, callbacks to keep alive)."""
+    keep = []
+    if device == "cpu":
+        lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
+        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
+        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+        assert b"test" in CL.rgpu_comm_transport_name()
+    elif device.startswith("cuda-staged"):
+        from ramsesgpu_amd.solver import lib_path
+        arith = os.environ.get("COMM_ARITH", "exact")
+        lib = Library(lib_path(arith))
+        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_dev%s.so" % ("" if arith == "exact" else "_fast")))
+        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
+        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
+        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+        assert b"device-staged" in CL.rgpu_comm_transport_name() and lib.arithmetic == arith and "hip" in lib.backend
+    else:
+        from ramsesgpu_amd.solver import load_library
+        lib = load_library()
+        CL = rcomm.load_comm_library()
+        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
+        assert CL.rgpu_comm_transport_name() == b"rccl"
+    return lib, CL, keep
+
+
 def check_pvti(lib, ini, ov, slabs, single, world):
     """per-rank .vti pieces + .pvti index of the slab run (HydroRunBaseMpi::outputVtk) against the single-domain .vti files: every
     piece holds its own planes (ranks > 0 one plane more, below: the format's overlap), the index names them with those extents"""
@@ -162,10 +193,9 @@ def frontend():
     broken = os.environ.get("COMM_BREAK_HDF5_ON_RANK")
     if broken is not None and int(broken) == rank:
         os.environ["RGPU_HDF5_LIB"] = "/nonexistent/libhdf5.so"
-    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
-    CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
-    keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
-    CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+    device = os.environ.get("COMM_DEVICE", "cpu")   # "cuda-staged:0": the product's kernels and driver, every rank a process on the one GPU
+    lib, CL, keep = load_libs(device)
+    dev_index = int(device.split(":")[1]) if ":" in device else 0
     ids = [rcomm.unique_id(CL) if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ini = os.path.join(ROOT, "configs", base + ".ini")
@@ -177,7 +207,7 @@ def frontend():
     err = C.create_string_buffer(512); mc = C.c_double(0)
     CL.rgpuh_run_slabs.restype = C.c_int
     CL.rgpuh_run_slabs.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.c_char_p, C.c_int]
-    n = CL.rgpuh_run_slabs(ini.encode(), (ov + ";output.outputDir=%s" % slabs).encode(), rank, world, 0, ids[0], C.byref(mc), err, 512)
+    n = CL.rgpuh_run_slabs(ini.encode(), (ov + ";output.outputDir=%s" % slabs).encode(), rank, world, dev_index, ids[0], C.byref(mc), err, 512)
     ok, msg = n >= 0, err.value.decode()
     if broken is not None:   # expected outcome: EVERY rank failed, together, with a message that names the count
         flags = [None] * world
@@ -274,31 +304,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     device = os.environ.get("COMM_DEVICE", "cpu")
-    keep = []
-    if device == "cpu":
-        lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
-        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
-        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
-        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
-        assert b"test" in CL.rgpu_comm_transport_name()
-    elif device.startswith("cuda-staged"):
-        # N rank processes on ONE GPU through the PRODUCT library (real tiled HIP kernels) and the product's slab driver compiled
-        # against the TEST-ONLY device-aware transport (tests/emu_dev/rg_transport.h): the planes are packed by the product's
-        # kernels, staged through pinned memory and carried by gloo (RCCL refuses two ranks on one device)
-        from ramsesgpu_amd.solver import lib_path
-        arith = os.environ.get("COMM_ARITH", "exact")
-        lib = Library(lib_path(arith))
-        CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_dev%s.so" % ("" if arith == "exact" else "_fast")))
-        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
-        keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
-        CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
-        assert b"device-staged" in CL.rgpu_comm_transport_name() and lib.arithmetic == arith and "hip" in lib.backend
-    else:
-        from ramsesgpu_amd.solver import load_library
-        lib = load_library()
-        CL = rcomm.load_comm_library()
-        CL.rgpu_comm_set_device(int(device.split(":")[1]) if ":" in device else 0)
-        assert CL.rgpu_comm_transport_name() == b"rccl"
+    lib, CL, keep = load_libs(device)
     ids = [rcomm.unique_id(CL) if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ini = os.path.join(ROOT, "configs", base + ".ini")
@@ -325,7 +331,7 @@ def main():
         assert run.nStep == nsteps and len(dts) == nsteps and run.dt == dts[-1]
         # which loop ran: everything but the first step from the device record, unless the configuration keeps the host loop
         host_loop = (os.environ.get("COMM_OVERLAP", "1") == "0" or run.p.nu > 0 or (run.p.mhdEnabled and run.p.eta > 0) or run.p.randomForcingEnabled
-                     or run.p.ouForcingEnabled or run.p.gravityEnabled != 0 or os.environ.get("RGPU_NO_STEP_CLOCK")
+                     or run.p.ouForcingEnabled or run.p.gravityEnabled != 0 or os.environ.get("RGPU_TEST_NO_STEP_CLOCK")
                      or (device == "cpu" and not run.p.mhdEnabled))   # (emulation: the 3D hydro pieces cannot carry the CFL scan without the tiled sweep)
         want_clocked = 0 if host_loop else nsteps - 1
         if os.environ.get("COMM_EXPECT_CLOCK", "1") == "1":

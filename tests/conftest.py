@@ -94,6 +94,14 @@ def emu_lib():
     return lib
 
 
+def _apply_test_options(lib):
+    """RGPU_TEST_OPTIONS="ghost_images=0,spec=0": the whole GPU suite with diagnostic options of the library switched (a variable of the
+    TESTS, not of the product: the library itself has rgpu_set_option, include/rgpu.h)"""
+    for kv in filter(None, os.environ.get("RGPU_TEST_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        lib.set_option(k.strip(), int(v))
+
+
 @pytest.fixture(scope="session")
 def gpu_lib(product_lib):
     """the product library on a machine that really has a GPU; fails loudly otherwise"""
@@ -101,6 +109,7 @@ def gpu_lib(product_lib):
     from ramsesgpu_amd.solver import Solver
     p = product_lib.params_from_ini(ini("orszag-tang"), "mesh.nx=8;mesh.ny=8")
     Solver(p, product_lib).close()  # raises RgpuError(RGPU_ENODEVICE) without a GPU: no silent fallback
+    _apply_test_options(product_lib)
     return product_lib
 
 
@@ -109,4 +118,5 @@ def gpu_contracted_lib(contracted_lib):
     from ramsesgpu_amd.solver import Solver
     p = contracted_lib.params_from_ini(ini("orszag-tang"), "mesh.nx=8;mesh.ny=8")
     Solver(p, contracted_lib).close()
+    _apply_test_options(contracted_lib)
     return contracted_lib

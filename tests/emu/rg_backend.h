@@ -31,6 +31,8 @@ typedef double rg_event_t;
 struct rg_recip_t { double d; };
 inline rg_recip_t rg_recip(double d) { rg_recip_t R; R.d = d; return R; }
 inline double rg_div(double n, const rg_recip_t& R) { return n / R.d; }
+inline void rg_recip2(double a, double b, rg_recip_t& A, rg_recip_t& B) { A.d = a; B.d = b; }
+inline void rg_recip4(double a, double b, double c, double d, rg_recip_t& A, rg_recip_t& B, rg_recip_t& Cc, rg_recip_t& D) { A.d = a; B.d = b; Cc.d = c; D.d = d; }
 inline double rg_sqrt(double x) { return std::sqrt(x); }
 inline double rg_sqrt_pos(double x) { return std::sqrt(x); }
 inline double rg_sqrt_radicand(double x) { return std::sqrt(x); }

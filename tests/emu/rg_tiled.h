@@ -9,10 +9,10 @@
 #include "step_clock_rec.h"
 namespace rgpu_tiled {
 // the device-side time step (hip/step_clock.h): the same record (csrc/step_clock_rec.h), the fold of the slots as a host loop -- so
-// that the batch logic of rgpu_run_steps / rgpu_comm_run_steps runs in the CPU tests (RGPU_NO_STEP_CLOCK=1: off, as in the product)
+// that the batch logic of rgpu_run_steps / rgpu_comm_run_steps runs in the CPU tests (option step_clock = 0: off, as in the product)
 using rgpu_dev::StepClock;
 using rgpu_dev::ClockConst;
-inline bool step_clock_supported() { return !std::getenv("RGPU_NO_STEP_CLOCK"); }
+inline bool step_clock_supported() { return rgpu::options().step_clock != 0; }
 inline int launch_step_clock(rgpu::rg_stream_t, unsigned long long* slots, const ClockConst& k, double t0, double tEnd, const StepClock* prev, StepClock* out) {
   double m = 0.0;
   for (int s = 0; s < (int)rgpu::RG_DT_SLOTS; ++s) { double v; std::memcpy(&v, slots + s, sizeof(v)); m = std::fmax(m, v); }

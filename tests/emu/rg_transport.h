@@ -76,6 +76,7 @@ inline int barrier(Comm* c, void* s) { double z = 0; return allreduce_sum_host(c
 }  // namespace rgpu_transport
 
 namespace rgpu_transport {
+inline int version(const Comm*) { return 0; }
 inline void set_device(int) {}
 inline int info(Comm* c, int* nranks, int* rank, int* device, char* pci, int pci_len) {
   if (nranks) *nranks = c->nranks;

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, ini
-from test_comm_driver import OPEN_BC, run_worker
+from test_comm_driver import OPEN_BC, run_frontend, run_worker
 
 
 def build_dev_comm(arith):
@@ -151,6 +151,28 @@ BIG = [("mhd_mri_3d", "mesh.nx=512;mesh.ny=512;mesh.nz=128", 3, 2, 1, "exact"),
 def test_bench_size_slabs_of_64_planes(base, ov, nsteps, world, overlap, arith, dev_comm_exact, dev_comm_contracted, gpu_lib, gpu_contracted_lib, tmp_path):
     """2 x and 3 x (512 x 512 x 64) through the product's schedule on the tiled kernels == the single-device run of the whole box"""
     run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH=arith, COMM_CHECK="single"), timeout=1200)
+
+
+FRONTEND_GPU = [
+    # whole-box HDF5 file written rank after rank + XDMF index, and per-rank .vti pieces + .pvti index, from 2 and 3 rank processes
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=40;MRI.amp=0.2;run.nstepmax=6;run.noutput=3;run.tend=1e9;output.outputVtk=yes;output.outputHdf5=yes", 2),
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=16;mesh.nz=36;MRI.amp=0.2;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=yes;output.outputHdf5=yes;output.ghostIncluded=yes", 3),
+    ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=32;hydro.riemannSolver=hllc;run.nstepmax=4;run.noutput=2;run.tend=1e9;output.outputVtk=yes;output.outputHdf5=yes", 2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ov,world", FRONTEND_GPU, ids=["%s-x%d-%d" % (c[0], c[2], n) for n, c in enumerate(FRONTEND_GPU)])
+def test_slab_front_end_on_the_device_writes_the_single_domain_files(base, ov, world, dev_comm_exact, gpu_lib, tmp_path):
+    """SURVEY 8(f3), multi-GPU output on the device path (HydroRunBaseMpi.cpp:4167-4790 pvti / pieces, :4845-6700 parallel HDF5): the
+    product's run loop rgpuh_run_slabs with outputHdf5 = outputVtk = yes, every rank a process on the one GPU, the product's tiled
+    kernels and slab driver (test wire).  The .h5 files equal the single-domain run's dataset by dataset and attribute by
+    attribute (same library, same GPU), the XDMF index is the same text, the .pvti names the pieces with the reference's extents
+    and every piece holds the doubles of the single-domain .vti (the CPU emulation runs the same worker: test_comm_driver.py)."""
+    import h5util
+    if not h5util.available():
+        pytest.skip("no loadable libhdf5 on this machine")
+    run_frontend(base, ov, world, tmp_path / "run", tmp_path, timeout=600, env_extra=dict(ENV, COMM_ARITH="exact"))
 
 
 @pytest.mark.gpu

@@ -87,9 +87,12 @@ def test_bench_launch_geometry_vs_oracle(base, ov, nsteps, gpu_lib, oracle):
                                      ("implode3d", "mesh.nx=208;mesh.ny=224;mesh.nz=8;hydro.riemannSolver=hllc")],
                          ids=["mri-224x208x16", "implode-208x224x8"])
 def test_xcd_sub_band_sizes_vs_oracle(base, ov, sub, gpu_lib, oracle, monkeypatch):
-    """RGPU_XCD_SUB (read at rgpu_create, kept per context): linear order, 2048- and 4096-cell sub-bands on a >= 200^2 plane"""
-    monkeypatch.setenv("RGPU_XCD_SUB", sub)
-    pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, 2)
+    """option "xcd_sub" (read at rgpu_create, kept per context): linear order, 2048- and 4096-cell sub-bands on a >= 200^2 plane"""
+    old = gpu_lib.set_option("xcd_sub", int(sub))
+    try:
+        pc.check_run_vs_oracle(gpu_lib, oracle, base, ov, 2)
+    finally:
+        gpu_lib.set_option("xcd_sub", old)
 
 
 def test_orszag_tang_gate_full_size(gpu_lib, oracle):
@@ -235,24 +238,48 @@ def test_run_driver_writes_inertial_wave_history_file(gpu_lib, tmp_path):
 @pytest.mark.parametrize("base,ov", [("mhd_mri_3d", "mesh.nx=24;mesh.ny=32;mesh.nz=20;MRI.amp=0.3"),
                                      ("orszag-tang3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16"),
                                      ("implode3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16;hydro.riemannSolver=hllc")])
-def test_launch_specialised_kernels_equal_generic_ones(base, ov, tmp_path):
+def test_launch_specialised_kernels_equal_generic_ones(base, ov, gpu_lib):
     """the launch-time specialisations (SPEC template parameter, launchers.h) only tell the optimiser what the host has
-    checked: the same run with RGPU_NO_SPEC=1 (generic kernels) must give the same bits"""
-    import hashlib
-    import subprocess
-    import sys
-    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
-            "from ramsesgpu_amd.solver import Solver, load_library\n"
-            "L = load_library(); p = L.params_from_ini(%r, %r); U0 = L.init_condition(%r, %r, p)\n"
-            "sv = Solver(p, L); sv.start(U0, 6); print(hashlib.sha256(np.ascontiguousarray(sv.getDataHost()).tobytes()).hexdigest())\n"
-            % (ROOT, ini(base), ov, ini(base), ov))
-    digests = []
-    for env_extra in ({}, {"RGPU_NO_SPEC": "1"}):
-        env = dict(os.environ, **env_extra)
-        res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        digests.append(res.stdout.strip().splitlines()[-1])
-    assert digests[0] == digests[1]
+    checked: the same run with option "spec" = 0 (generic kernels) must give the same bits"""
+    p = gpu_lib.params_from_ini(ini(base), ov)
+    U0 = gpu_lib.init_condition(ini(base), ov, p)
+    outs = []
+    for spec in (1, 0):
+        old = gpu_lib.set_option("spec", spec)
+        sv = Solver(p, gpu_lib)
+        try:
+            sv.start(U0, 6)
+            outs.append(sv.getDataHost().copy())
+        finally:
+            sv.close()
+            gpu_lib.set_option("spec", old)
+    assert np.array_equal(outs[0], outs[1])
+
+
+OPTION_CASES = [("orszag-tang", "mesh.nx=40;mesh.ny=24"), ("kelvin_helmholtz_gpu_2d", "mesh.nx=40;mesh.ny=24"), ("implode3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16;hydro.riemannSolver=hllc"),
+                ("mhd_mri_3d", ""), ("orszag-tang3d", "mesh.nx=24;mesh.ny=20;mesh.nz=16")]
+
+
+@pytest.mark.parametrize("option,value", [("ghost_images", 0), ("step_clock", 0), ("zseg", 5), ("spec", 0)])
+@pytest.mark.parametrize("base,ov", OPTION_CASES, ids=[c[0] for c in OPTION_CASES])
+def test_diagnostic_options_keep_the_bits(base, ov, option, value, gpu_lib):
+    """every diagnostic option of the library (include/rgpu.h, "Environment and options") switches a fast path off or pins a launch
+    plan: a batch of steps through rgpu_run_steps gives the same state and the same time steps either way"""
+    p = gpu_lib.params_from_ini(ini(base), ov)
+    U0 = gpu_lib.init_condition(ini(base), ov, p)
+    outs = []
+    for on in (False, True):
+        old = gpu_lib.set_option(option, value) if on else None
+        sv = Solver(p, gpu_lib)
+        try:
+            sv.upload(U0, both=False); sv.make_all_boundaries(0, 0.0, 0.0); sv.upload(sv.getDataHost(0), both=True)
+            assert sv.run_steps(7) == 7
+            outs.append((interior(sv.getDataHost(), p).copy(), sv.totalTime, sv.dt))
+        finally:
+            sv.close()
+            if on:
+                gpu_lib.set_option(option, old)
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
 
 
 def test_shared_reciprocal_division_and_sqrt_are_ieee(gpu_lib):
@@ -359,7 +386,7 @@ def test_orszag_tang_large_box_properties(gpu_lib):
     """the fused 2D MHD kernel at a size the oracle does not run in seconds (2048^2: 137 x 293 tiles, the periodic ghost images
     written by the kernel itself): div B stays at round-off, mass / energy / momentum are conserved to round-off in the periodic
     box, and the flat kernels (RGPU_TILED=0 is read per process, so: a second context through the plane API is not available
-    in 2D) -- instead the run is repeated with the ghost images off (RGPU_NO_GHOST_IMAGES is read once per process too), hence
+    in 2D), hence
     only the properties here; bit-identity of the tiled path is pinned by the 512^2 gate and the fixtures."""
     ov = "mesh.nx=2048;mesh.ny=2048"
     p = gpu_lib.params_from_ini(ini("orszag-tang"), ov)
@@ -383,9 +410,9 @@ def test_orszag_tang_large_box_properties(gpu_lib):
     div = (bx[gw:-gw, gw + 1:-gw + 1] - bx[s]) / p.dx + (by[gw + 1:-gw + 1, gw:-gw] - by[s]) / p.dy
     bscale = float(np.abs(bx[s]).max()) / min(p.dx, p.dy)
     assert float(np.abs(div).max()) < 1e-11 * bscale
-    # the ghost cells the kernel wrote are the periodic images of the interior (RGPU_NO_GHOST_IMAGES / RGPU_TILED=0: the next
+    # the ghost cells the kernel wrote are the periodic images of the interior (option ghost_images = 0 / RGPU_TILED=0: the next
     # step's ghost fill does it, so the output array's ghosts are one step old)
-    if os.environ.get("RGPU_NO_GHOST_IMAGES") or os.environ.get("RGPU_TILED") == "0":
+    if gpu_lib.get_option("ghost_images") == 0 or os.environ.get("RGPU_TILED") == "0":
         return
     nx, ny = p.nx, p.ny
     assert np.array_equal(A[:, gw:-gw, :gw], A[:, gw:-gw, nx:nx + gw]) and np.array_equal(A[:, gw:-gw, nx + gw:], A[:, gw:-gw, gw:2 * gw])
@@ -413,7 +440,7 @@ def test_fused_hydro2d_ghost_images(base, ov, gpu_lib, oracle):
         par = sv.nStep % 2
         assert np.array_equal(np.array(dts), dts_ref)
         assert np.array_equal(interior(A, p), interior(ref, p))
-        if os.environ.get("RGPU_NO_GHOST_IMAGES") or os.environ.get("RGPU_TILED") == "0":
+        if gpu_lib.get_option("ghost_images") == 0 or os.environ.get("RGPU_TILED") == "0":
             return
         sv.make_all_boundaries(par, sv.totalTime, dts[-1])
         B = sv.getDataHost(par)
@@ -442,7 +469,7 @@ def test_kelvin_helmholtz_large_box_properties(gpu_lib):
         a, b = I1[v].sum(dtype=np.longdouble), I0[v].sum(dtype=np.longdouble)
         scale = max(abs(float(b)), float(np.abs(I0[v]).sum(dtype=np.longdouble)))
         assert abs(float(a - b)) < 1e-12 * scale, (v, float(a), float(b))
-    if os.environ.get("RGPU_NO_GHOST_IMAGES") or os.environ.get("RGPU_TILED") == "0":
+    if gpu_lib.get_option("ghost_images") == 0 or os.environ.get("RGPU_TILED") == "0":
         return
     A = A[:, 0]
     nx, ny = p.nx, p.ny
@@ -525,7 +552,7 @@ def test_run_steps_equals_the_reference_loop(base, ov, nsteps, clocked, gpu_lib,
         assert sv.dt == float(dts_ref[cut]), (sv.dt, dts_ref[cut])
     finally:
         sv.close()
-    if clocked is not None and not (os.environ.get("RGPU_TILED") == "0" or os.environ.get("RGPU_NO_STEP_CLOCK") or os.environ.get("RGPU_NO_GHOST_IMAGES")):
+    if clocked is not None and not (os.environ.get("RGPU_TILED") == "0" or gpu_lib.get_option("step_clock") == 0 or gpu_lib.get_option("ghost_images") == 0):
         # which path ran: the phase timers count launches -- a device-clock batch has no ghost fill and no stand-alone CFL scan,
         # and the timers themselves force the plain loop, so count through the dominant-kernel statistics of an untimed run instead
         sv = fresh()
