@@ -40,7 +40,11 @@ enum { RGPU_ID = 0, RGPU_IP = 1, RGPU_IU = 2, RGPU_IV = 3, RGPU_IW = 4, RGPU_IA 
 /* BoundaryConditionType -- constants.h:209-217 */
 enum {
   RGPU_BC_UNDEFINED = 0, RGPU_BC_DIRICHLET = 1, RGPU_BC_NEUMANN = 2, RGPU_BC_PERIODIC = 3,
-  RGPU_BC_SHEARINGBOX = 4, RGPU_BC_COPY = 5 /* ghost planes are supplied by a neighbour slab */,
+  RGPU_BC_SHEARINGBOX = 4,
+  RGPU_BC_COPY = 5 /* ghost planes are supplied by a neighbour slab (or any external z driver).  The planes written into the ghost region of
+                    * such a face must be COMPLETE planes of the neighbour's state -- its x / y ghost cells and corners included, i.e. taken
+                    * after the neighbour's own x / y fill: the library fills x / y ghosts on the interior planes only and does not re-run
+                    * the X / Y passes over received planes (librgpu_comm.so sends such planes) */,
   RGPU_BC_Z_STRATIFIED = 6 /* z faces of the vertically stratified MRI box (3D MHD, isothermal, Omega0 > 0):
                             * make_boundary2_z_stratified, make_boundary_base.h:1356-1647 */
 };

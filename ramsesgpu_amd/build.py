@@ -41,13 +41,14 @@ def resources_path(out_name="librgpu.so"):
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) of the device sources -- csrc/*.h, csrc/hip/*.h, csrc/rgpu_api.cpp with // comments and whitespace runs
+    """sha256 (16 hex digits) of the device sources -- csrc/*.h, csrc/hip/*.h, csrc/api/*.h, csrc/rgpu_api.cpp with // comments and whitespace runs
     removed -- so that numbers MEASURED on one state of the kernels (profiles/pmc_traffic.json: instruction counts, HBM bytes) are
     not quoted for another: scripts/prof_round.sh records it with the counters, bench.py compares before it uses them"""
     import hashlib
     import re
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + \
-        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h") and f not in ("rg_transport.h", "halo_pack.h")] + [os.path.join(CSRC, "rgpu_api.cpp")]
+        [os.path.join(CSRC, "hip", f) for f in sorted(os.listdir(os.path.join(CSRC, "hip"))) if f.endswith(".h") and f not in ("rg_transport.h", "halo_pack.h")] + \
+        [os.path.join(CSRC, "api", f) for f in sorted(os.listdir(os.path.join(CSRC, "api"))) if f.endswith(".h")] + [os.path.join(CSRC, "rgpu_api.cpp")]
     # (rg_transport.h / halo_pack.h are the RCCL transport of librgpu_comm.so: no kernel of librgpu.so comes from them)
     h = hashlib.sha256()
     for f in files:
@@ -94,7 +95,7 @@ def build(verbose=True, force=False, extra_flags=(), out_name="librgpu.so"):
         extra_flags = list(extra_flags) + FAST_FLAGS
     exe = os.path.join(HERE, "euler_hip")
     srcs = [os.path.join(CSRC, "rgpu_api.cpp")] + [os.path.join(CSRC, "host", s) for s in HOST_SRC]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(CSRC, "api", f) for f in os.listdir(os.path.join(CSRC, "api")) if f.endswith(".h")] + \
         [os.path.join(CSRC, "hip", f) for f in os.listdir(os.path.join(CSRC, "hip")) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "rgpu.h")] + \
         [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host")) if f.endswith(".h")]
     if force or _newer(out, deps):

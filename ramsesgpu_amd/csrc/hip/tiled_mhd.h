@@ -127,7 +127,7 @@ struct TLdsPlane {
 // first 70 % of its work both finish together.
 template <class G, int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m, double xPos, double* __restrict__ F,
-                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, int prio_flux) {
+                          double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
   const size_t N = g.ncell;
   const unsigned sx = 1u, sj = (unsigned)G::PX;
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
@@ -136,7 +136,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
-      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<XD>(g, L, R, xPos, fl);
@@ -150,7 +150,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
-      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<YD>(g, L, R, xPos, fl);
@@ -163,7 +163,7 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
       RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
-      if (prio_flux == 0) __builtin_amdgcn_s_setprio(0); else if (prio_flux == 1) __builtin_amdgcn_s_setprio(1);
+      if (prio_drop) __builtin_amdgcn_s_setprio(0);
       c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
       Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
       double fl[8];
@@ -425,18 +425,13 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
         const unsigned idx = cidx2 + (unsigned)kk * sk;
         const bool solve = kk >= sa;
         // the two Riemann waves of a SIMD are arbitrated oldest first: the younger one is favoured for its EMF (see riemann_dir)
-#ifndef RG_PRIO_EXP
-#define RG_PRIO_EXP 0
-#endif
-        // priority of this wave during the EMF (pe) and during the flux (pf; -1: unchanged)
-        const bool lead = RG_PRIO_EXP == 4 ? ((wave >= 4) != ((kk & 1) != 0)) : wave >= 4;
-        const int pe = (RG_PRIO_EXP == 1 || !solve) ? -1 : (lead ? 1 : -1);
-        const int pf = (RG_PRIO_EXP == 1 || !solve) ? -1 : (RG_PRIO_EXP == 2 ? -1 : (lead ? 0 : (RG_PRIO_EXP >= 3 ? 1 : -1)));
-        if (pe == 1) __builtin_amdgcn_s_setprio(1);
-        if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
-        else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
-        else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, pf);
-        if (RG_PRIO_EXP >= 2 && solve) __builtin_amdgcn_s_setprio(0);
+        // (round 6, same box, contracted | exact sweep: this scheme 21.5 | 28.8-29.3 ms; no priorities 21.6; the younger wave favoured for the
+        //  whole phase 21.6-22.3; the older wave favoured for the flux in return 22.3 | 30.1-30.7; roles swapped every plane 22.3 | 30.2)
+        const bool raise = solve && wave >= 4;
+        if (raise) __builtin_amdgcn_s_setprio(1);
+        if (dir == 0) riemann_dir<G, XD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, raise);
+        else if (dir == 1) riemann_dir<G, YD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, raise);
+        else riemann_dir<G, ZD>(g, Tk, (unsigned)(MH_PX + 1), xPos, F, emf, idx, c0, c1, solve, raise);
       }
       __syncthreads();
     }

@@ -83,6 +83,7 @@ def emu_lib():
     csrc = os.path.join(ROOT, "ramsesgpu_amd", "csrc")
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".cpp"))]
     deps += [os.path.join(csrc, "host", f) for f in os.listdir(os.path.join(csrc, "host"))]
+    deps += [os.path.join(csrc, "api", f) for f in os.listdir(os.path.join(csrc, "api"))]
     deps += [os.path.join(ROOT, "tests", "emu", "rg_backend.h"), os.path.join(ROOT, "include", "rgpu.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         os.makedirs(out_dir, exist_ok=True)

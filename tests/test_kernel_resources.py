@@ -37,12 +37,12 @@ def test_mhd3d_sweep_resources(lib_resources):
     for spec in ("107", "117"):   # 107: isothermal rotating box (the 512^3 MRI headline), 117: adiabatic plain box
         (k, r), = pick(R, "mhd3d_sweep_kernel<%s, rgpu_tiled::MhTile<16, 8, false>" % spec).items()   # the 16 x 8 tiles of the sweep
         assert r["lds"] == 160688, (k, r)                      # T 2 x 47.7 KB (records of 39) + Q / B 3 x 18.4 KB + E 2 x 5 KB + 2 counters
-        # round 6 (cell-major LDS records: no address arithmetic in front of the DS instructions): 205 / 213 VGPRs, was 249 / 256
-        assert r["lds"] <= LDS_PER_CU and r["occupancy"] == 2 and r["vgprs"] <= 216 and r["agprs"] == 0, (k, r)
+        # round 6 (cell-major LDS records: no address arithmetic in front of the DS instructions): 204 / 207 VGPRs, was 249 / 256
+        assert r["lds"] <= LDS_PER_CU and r["occupancy"] == 2 and r["vgprs"] <= 208 and r["agprs"] == 0, (k, r)
         # no spilled vector register in either build (round 5: the contracted build's one-loop form recomputes two per-thread decodes
         # every plane instead of keeping them in registers over the z march; rounds 3-4 tolerated 2-3 spilled values there)
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
-        assert r["sgpr_spill"] <= (32 if exact else 24), (k, r)
+        assert r["sgpr_spill"] <= (24 if exact else 16), (k, r)      # (round 5: 40 / 20)
         # the same kernel with the 2 x 32 geometry of the last x face column (a short second launch): no spill either
         (k, r), = pick(R, "mhd3d_sweep_kernel<%s, rgpu_tiled::MhTile<2, 32, true>" % spec).items()
         assert r["lds"] == 116384 and r["occupancy"] == 2 and r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
