@@ -101,6 +101,12 @@ RG_DEVFN double minmod_slope(double qm, double q0, double qp) {
   return (dlft > 0) ? fmin(dlft, drgt) : fmax(dlft, drgt);
 }
 
+// HALF of minmod_slope, compare-free: max(min(a, b), 0) + min(max(a, b), 0) with a = dlft / 2, b = drgt / 2 (same remarks as tvd_half_slope)
+RG_DEVFN double minmod_half_slope(double qm, double q0, double qp) {
+  const double a = 0.5 * (q0 - qm), b = 0.5 * (qp - q0);
+  return fmax(fmin(a, b), 0.0) + fmin(fmax(a, b), 0.0);
+}
+
 // slope_type 3, positivity preserving slopes of slope_unsplit_hydro_2d / _3d (slope_mhd.h:131-168, 336-407):
 // every centred half difference d of a variable is scaled by min(1, min(|vmin|,|vmax|) / (0.5 * sum|d|)), vmin / vmax
 // being the extreme differences to the 3x3(x3) neighbourhood.  lo / hi are the extreme neighbourhood VALUES

@@ -251,9 +251,9 @@ __global__ void __launch_bounds__(TX * TY, MINW) hydro3d_sweep_kernel(DevParams 
       for (int d = 0; d < 3; ++d) {
         double s;
         if (st == 0) s = 0.0;
-        else if (st == 1) s = minmod_slope(nb[d][0], q[v], nb[d][1]);
-        else s = tvd_slope(st, nb[d][0], q[v], nb[d][1]);
-        h[d][v] = s * 0.5;
+        else if (st == 1) s = minmod_half_slope(nb[d][0], q[v], nb[d][1]);
+        else s = tvd_half_slope(st, nb[d][0], q[v], nb[d][1]);
+        h[d][v] = s;
       }
     }
     double qpx[NV], qpy[NV], qpz[NV], qmz_new[NV];

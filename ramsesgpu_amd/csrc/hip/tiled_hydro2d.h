@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(TX * TY) hydro2d_step_kernel(DevParams g, int 
       for (int d = 0; d < 2; ++d) {
         double s;
         if (st == 0) s = 0.0;
-        else s = tvd_slope(st, nb[d][0], q[v], nb[d][1]);
-        h[d][v] = s * 0.5;
+        else s = tvd_half_slope(st, nb[d][0], q[v], nb[d][1]);
+        h[d][v] = s;
       }
     }
     const double r = q[ID], p = q[IP], uu = q[IU], vv = q[IV];

@@ -39,11 +39,11 @@ RG_DEVFN void hydro_trace_cell(const DevParams& g, const double* __restrict__ Q,
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
       const double qm = Qc[idx - strd[d]], qp = Qc[idx + strd[d]];
-      double s;
+      double s;   // the reference's slope x 0.5 (trace.h:350-360), formed as a half slope (dev_numerics.h: tvd_half_slope)
       if (st == 0) s = 0.0;
-      else if (ND == 3 && st == 1) s = minmod_slope(qm, q[v], qp);   // slope_unsplit_3d type 1 (slope.h:351-384)
-      else s = tvd_slope(st, qm, q[v], qp);
-      h[d][v] = s * 0.5;
+      else if (ND == 3 && st == 1) s = minmod_half_slope(qm, q[v], qp);   // slope_unsplit_3d type 1 (slope.h:351-384)
+      else s = tvd_half_slope(st, qm, q[v], qp);
+      h[d][v] = s;
     }
   }
   double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = (NV == 5) ? q[IW] : 0.0;

@@ -93,23 +93,21 @@ RG_DEVFN void mhd_trace2d_at(const DevParams& g, const TIN& in, const TW& tw, do
         }
       const double dfx = 0.5 * (in.q(v, m + 1) - in.q(v, m - 1)), dfy = 0.5 * (in.q(v, m + sj) - in.q(v, m - sj));
       const double dlim = positivity_limiter(lo, hi, q[v], fabs(dfx) + fabs(dfy));
-      dx_[v] = dlim * dfx;
-      dy_[v] = dlim * dfy;
-    } else {
-      dx_[v] = tvd_slope(st, in.q(v, m - 1), q[v], in.q(v, m + 1));
-      dy_[v] = tvd_slope(st, in.q(v, m - sj), q[v], in.q(v, m + sj));
+      dx_[v] = dlim * dfx * 0.5;
+      dy_[v] = dlim * dfy * 0.5;
+    } else {   // (dx_, dy_ hold HALF slopes: dev_numerics.h, tvd_half_slope)
+      dx_[v] = tvd_half_slope(st, in.q(v, m - 1), q[v], in.q(v, m + 1));
+      dy_[v] = tvd_half_slope(st, in.q(v, m - sj), q[v], in.q(v, m + sj));
     }
   }
   double r = q[ID], p = q[IP], u = q[IU], v = q[IV], w = q[IW], A = q[IA], B = q[IB], C = q[IC];
   double AL = in.ua(m), BL = in.ub(m);
   const double AR = in.ua(m + 1), BR = in.ub(m + sj);
-  const double drx = dx_[ID] * 0.5, dpx = dx_[IP] * 0.5, dux = dx_[IU] * 0.5, dvx = dx_[IV] * 0.5, dwx = dx_[IW] * 0.5,
-               dCx = dx_[IC] * 0.5, dBx = dx_[IB] * 0.5;
-  const double dry = dy_[ID] * 0.5, dpy = dy_[IP] * 0.5, duy = dy_[IU] * 0.5, dvy = dy_[IV] * 0.5, dwy = dy_[IW] * 0.5,
-               dCy = dy_[IC] * 0.5, dAy = dy_[IA] * 0.5;
+  const double drx = dx_[ID], dpx = dx_[IP], dux = dx_[IU], dvx = dx_[IV], dwx = dx_[IW], dCx = dx_[IC], dBx = dx_[IB];
+  const double dry = dy_[ID], dpy = dy_[IP], duy = dy_[IU], dvy = dy_[IV], dwy = dy_[IW], dCy = dy_[IC], dAy = dy_[IA];
   // transverse slopes of the low-face field (slope_unsplit_mhd_2d: slope type NOT capped)
-  const double dALy = 0.5 * tvd_slope(st, in.ua(m - sj), AL, in.ua(m + sj));
-  const double dBLx = 0.5 * tvd_slope(st, in.ub(m - 1), BL, in.ub(m + 1));
+  const double dALy = tvd_half_slope(st, in.ua(m - sj), AL, in.ua(m + sj));
+  const double dBLx = tvd_half_slope(st, in.ub(m - 1), BL, in.ub(m + 1));
   const double dAx = 0.5 * (AR - AL), dBy = 0.5 * (BR - BL);
   const double gamma = g.gamma0;
 

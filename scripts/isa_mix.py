@@ -20,7 +20,10 @@
                 such values -> first value: Ex x 3 waves, Ey x 4, Ez x 1; second value: Ez x 2.  Blocks outside the z loop (prologue) are not counted;
               * the 2D HLLD solver evaluates only the regions of the Riemann fan some lane of the wave needs (dev_numerics.h,
                 "Region selection by sign bits"): in the shearing box every speed is below the fast speed, all lanes take the
-                inner region and the four outer-region blocks are skipped (s_cbranch_execz) -> x 0.
+                inner region and the four outer-region blocks are skipped (s_cbranch_execz) -> x 0.  Exact arithmetic: the
+                Alfven speeds come from the selection (dev_numerics.h: alfven_pick / alfven_duel); the reference's own sequence of
+                twelve roots is the fallback of a wave with an unsure lane -> x 0 (rgpu_selftest_alfven counts those waves: none in
+                10^7 smooth states).
             --measured: SQ_INSTS_VALU of one launch (rocprofv3 --pmc, scripts/pmc_ab.sh); --iters: workgroup x plane iterations of
             that launch (default: the 512^3 shearing box, 2048 tiles x 515 iterations) -> the reconciliation line.
 """
@@ -80,6 +83,7 @@ def parse_blocks(lines, start, end):
     cur = "entry"
     blocks[cur] = {"ops": [], "in_loop": False, "loops": set()}
     loc = (0, 0)
+    frames = ()
 
     def loop_notes(text, b, label):
         m = re.search(r"in Loop: Header=(BB\w+)", text)
@@ -100,9 +104,17 @@ def parse_blocks(lines, start, end):
             loop_notes(m.group(2), blocks[cur], cur)
             continue
         t = l.strip()
+        m = re.match(r"^; %bb\.(\d+):(.*)", t)
+        if m:   # a block the previous one falls through into (no label of its own)
+            cur = "%bb." + m.group(1)
+            blocks[cur] = {"ops": [], "in_loop": False, "loops": set()}
+            loop_notes(m.group(2), blocks[cur], cur)
+            continue
         m = re.match(r"^\.loc\s+(\d+)\s+(\d+)", t)
         if m:
             loc = (int(m.group(1)), int(m.group(2)))
+            # the inline stack of the location, innermost first, as (file name, line): "; a.h:10:3 @[ b.h:20:5 @[ c.h:30:1 ] ]"
+            frames = tuple((os.path.basename(f), int(n)) for f, n in re.findall(r"([\w./+-]+\.(?:h|cpp)):(\d+):\d+", t.split(";", 1)[1] if ";" in t else ""))
             continue
         if t.startswith(";") and ("Loop" in t):
             loop_notes(t, blocks[cur], cur)
@@ -110,6 +122,7 @@ def parse_blocks(lines, start, end):
         if not t or t.startswith((";", ".", "//")):
             continue
         blocks[cur]["ops"].append((classify(t.split()[0]), loc))
+        blocks[cur].setdefault("frames", []).append(frames)
     for _ in range(4):   # a block of an inner loop names its own header only: add the loops around that header
         for b in blocks.values():
             for h in list(b["loops"]):
@@ -162,6 +175,19 @@ ROLE_OF["pair_sync"] = "sync"
 for fn in "mhd3d_update_role mhd_update3d_column_at mhd_update3d_apply info_speeds closing_column n_closing rg_slot_max".split():
     ROLE_OF[fn] = "update"   # the update role of the fused launch: other workgroups, not part of the z march
 TRIPS = {"riemann": 2, "trace": 1, "prim": 2, "elec": 6, "sync": 2, "control": 8, "riemann_outer": 0}
+
+
+def refseq_lines():
+    """line range of the reference's own Alfven-speed sequence in mag_hlld_2d (the fallback of the selection; exact arithmetic)"""
+    src = open(os.path.join(ROOT, "ramsesgpu_amd", "csrc", "dev_numerics.h")).read().splitlines()
+    lo = hi = 0
+    for n, l in enumerate(src, 1):
+        if lo == 0 and "const rg_recip_t iqLL = rg_recip_sqrt_pos(rstarLL)" in l:
+            lo = n
+        if lo and "const double SAL = fmin(ustar - calfvenL, 0.0);" in l:
+            hi = n
+            break
+    return lo, hi
 
 
 def outer_region_lines():
@@ -225,14 +251,32 @@ def dynamic_report(arith, measured, iters):
         return ROLE_OF.get(fmaps[path].get(ln))
 
     olo, ohi = outer_region_lines()
+    rlo, rhi = refseq_lines() if arith != "fast" else (0, 0)
     dn = os.path.join(ROOT, "ramsesgpu_amd", "csrc", "dev_numerics.h")
     per_role = defaultdict(Counter)      # role -> class -> wave instructions per plane and workgroup
     static_role = defaultdict(Counter)
     copies = Counter()
     # the z march: the loop(s) whose blocks hold Riemann / trace code and no update-role code
     per_loop = defaultdict(Counter)
+    byname = {}   # source file name -> path (for the inline stacks, which name files by path)
+    for pth in files.values():
+        byname.setdefault(os.path.basename(pth), pth)
+
+    def role_of_frames(fr):
+        """innermost frame of the inline stack whose function belongs to a role"""
+        for fname, ln in fr:
+            path = byname.get(fname)
+            if not path:
+                continue
+            if path not in fmaps:
+                fmaps[path] = function_map(path)
+            r = ROLE_OF.get(fmaps[path].get(ln))
+            if r:
+                return r
+        return None
     for name, b in blocks.items():
-        votes = Counter(r for r in (role_of_loc(loc) for _, loc in b["ops"]) if r)
+        frs = b.get("frames", [])
+        votes = Counter(r for r in (role_of_frames(fr) if fr else role_of_loc(loc) for (_, loc), fr in zip(b["ops"], frs + [()] * (len(b["ops"]) - len(frs)))) if r)
         b["votes"] = votes
         for h in b["loops"]:
             per_loop[h].update(votes)
@@ -272,8 +316,11 @@ def dynamic_report(arith, measured, iters):
             else:
                 trips = 6   # dispatch on the component, address set-up: every Riemann wave
         if role == "riemann":   # an outer-region block of the 2D HLLD solver?
-            inside = sum(1 for _, (fid, ln) in b["ops"] if os.path.realpath(files.get(fid, "")) == os.path.realpath(dn) and olo <= ln < ohi)
+            inside = sum(1 for fr in b.get("frames", []) if any(f == "dev_numerics.h" and olo <= ln < ohi for f, ln in fr))
             if 2 * inside > len(b["ops"]):
+                role = "riemann_outer"
+            inref = sum(1 for fr in b.get("frames", []) if any(f == "dev_numerics.h" and rlo <= ln < rhi for f, ln in fr))
+            if rhi and 2 * inref > len(b["ops"]):
                 role = "riemann_outer"
         c = Counter(x for x, _ in b["ops"])
         if sum(c.values()) >= 200:
@@ -283,7 +330,7 @@ def dynamic_report(arith, measured, iters):
             per_role[role][k] += v * trips
     print("# dynamic instruction mix of mhd3d_sweep_kernel<107, MhTile<16, 8>>, %s arithmetic" % ("contracted" if arith == "fast" else "exact"))
     print("# wave instructions per z plane and 512-thread workgroup = static count of the role's blocks in the z loop x trips (see the header of scripts/isa_mix.py)")
-    print("# large (>= 200 instructions) copies found per role:", dict(copies), " expected: riemann 6 (EMF + flux per direction), trace 3")
+    print("# large (>= 200 instructions) copies found per role:", dict(copies), " (one Riemann wave pair per direction, each solver cut at its wave-uniform branches; riemann_outer = the x 0 blocks: outer regions of the 2D solver, the exact build's cold Alfven fallback; trace 3)")
     classes = list(VALU_CLASSES) + ["lds", "vmem", "salu", "waitcnt", "branch", "barrier"]
     print("%-9s %5s %8s | " % ("role", "trips", "VALU") + " ".join("%8s" % c for c in classes))
     tot = Counter()
