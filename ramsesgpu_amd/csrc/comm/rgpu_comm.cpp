@@ -303,6 +303,8 @@ int rgpu_comm_create(rgpu_ctx* ctx, int rank, int nranks, const char id[RGPU_COM
 
 void rgpu_comm_destroy(rgpu_comm* cm) {
   if (!cm) return;
+  // a rank whose step failed may hold a collective its peers never match (see `poisoned`): abort, do not wait
+  if (cm->tc && cm->poisoned) rgpu_transport::abort_comm(cm->tc);
   if (cm->tc) rgpu_transport::destroy(cm->tc);
   delete cm;
 }
@@ -379,18 +381,26 @@ int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, doub
     RG_TRY(rgpu_clock_open(c, *t, tEnd), "clock_open");
     const int n0 = *nStep;
     int queued = 0, rc = 0, first_fail = -1;
+    bool told = false;   // this rank failed AND a poisoned all-reduce has gone out since
     for (; queued < m; ++queued) {
       const int n = n0 + queued;
       if (rc != 0) {
         // a piece failed on THIS rank at an earlier step of the batch: the other ranks keep queueing theirs, so keep pairing up with
         // them -- +inf into the 1/dt all-reduce (their records say stop = 3 from here on) and the one halo exchange each of their
-        // no-op steps still posts
+        // no-op steps still posts.  A synchronous backend is different: there the others SEE the stop at their tick and leave
+        // before that exchange; this rank ticks too (its record says 3 as well) and leaves at the same place.
         const std::string msg = cm->err;
         (void)rgpu_transport::poison_slot(cm->tc, rgpu_inv_dt_device_slot(c), rgpu_stream_handle(c));
         const bool dead = rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c)) != 0;
-        if (!dead) (void)exchange(cm, (n + 1) % 2);
+        told = !dead;
+        bool left = false;
+        if (!dead) {
+          (void)rgpu_clock_tick(c);
+          left = rgpu_clock_stopped(c) != 0;
+          if (!left) (void)exchange(cm, (n + 1) % 2);
+        }
         cm->err = msg;
-        if (dead) break;
+        if (dead || left) break;
         continue;
       }
       if (cm->nranks > 1 && rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c))) { rc = tr_fail(cm, "allreduce(1/dt)"); first_fail = queued; break; }
@@ -422,6 +432,16 @@ int rgpu_comm_run_steps(rgpu_comm* cm, int nsteps, double tEnd, int* nStep, doub
     const int rc2 = rgpu_clock_close(c, n0, &ran, t, dt, dt_log ? dt_log + done : 0, &stop);
     if (rc2) return ctx_fail(cm, rc2, "clock_close");
     if (rc) {   // this rank's own failure: the steps before it ran; the run is over on every rank (poisoned)
+      // A failure in the LAST step of the batch has not told anybody yet: the others finished their batch in good health, and
+      // unless the records (theirs too, up to the failed step) say that the run has reached tEnd, their next collective is the 1/dt
+      // all-reduce of the next turn -- of this call or the caller's next one, batched or not.  Pair it, poisoned, as
+      // rgpu_comm_one_step_integration does: the first record of a batch is host-checked, an unbatched turn reads 1/dt on the host.
+      // (Should the others never take that turn -- nstepmax reached -- the all-reduce stays unmatched on THIS rank only, whose run
+      // is over; rgpu_comm_destroy aborts a poisoned communicator instead of waiting for it.)
+      if (cm->nranks > 1 && !told && stop == 0 && *t < tEnd) {
+        (void)rgpu_transport::poison_slot(cm->tc, rgpu_inv_dt_device_slot(c), rgpu_stream_handle(c));
+        (void)rgpu_transport::allreduce_max(cm->tc, rgpu_inv_dt_device_slot(c), RGPU_DT_SLOTS, rgpu_stream_handle(c));
+      }
       cm->err = msg;
       *nStep += first_fail < ran ? first_fail : ran;
       cm->primed = -1; cm->scanned = -1; cm->scan_slots = 0;

@@ -274,17 +274,43 @@ def poison():
     run = rcomm.CommRun(ini, ov, rank, world, ids[0], library=lib, comm_library=CL, overlap=int(os.environ.get("COMM_OVERLAP", "1")))
     run.init_simulation()
     failed_at, msg = None, ""
-    for n in range(fstep + 3):
-        if rank == frank and n == fstep:
+    mode = os.environ.get("POISON_RUN_STEPS", "")
+    if mode == "batch":
+        # the same through rgpu_comm_run_steps: the failure sits in the first step of a call of three -- a host-driven step at step 0,
+        # the first of a batch of three later on (the failed rank keeps pairing the collectives of the steps its peers have queued)
+        if fstep:
+            assert run.run_steps(fstep) == fstep
+        if rank == frank:
             lib.lib.rgpu_emu_fail_launch_after(1)
         try:
-            run.oneStepIntegration()
+            run.run_steps(3)
         except Exception as e:  # noqa: BLE001
-            failed_at, msg = n, str(e)
-            break
+            failed_at, msg = run.nStep, str(e)
+    elif mode == "single":
+        # one call per step: from step 1 on every call is a batch of ONE step, the failure sits in its last step and the peers
+        # leave their batch in good health -- the failed rank has to pair the all-reduce of THEIR next call
+        for n in range(fstep + 3):
+            if rank == frank and n == fstep:
+                lib.lib.rgpu_emu_fail_launch_after(1)
+            try:
+                run.run_steps(1)
+            except Exception as e:  # noqa: BLE001
+                failed_at, msg = run.nStep, str(e)
+                break
+    else:
+        for n in range(fstep + 3):
+            if rank == frank and n == fstep:
+                lib.lib.rgpu_emu_fail_launch_after(1)
+            try:
+                run.oneStepIntegration()
+            except Exception as e:  # noqa: BLE001
+                failed_at, msg = n, str(e)
+                break
     flags = [None] * world
     dist.all_gather_object(flags, (failed_at, msg))
-    good = all(f[0] == (fstep if r == frank else fstep + 1) for r, f in enumerate(flags))
+    # (the library's loop all-reduces the next step's 1/dt at the end of a step: a healthy rank sees the poison inside step fail_step)
+    late = (fstep, fstep + 1) if os.environ.get("POISON_RUN_STEPS") else (fstep + 1,)
+    good = all((f[0] == fstep) if r == frank else (f[0] in late) for r, f in enumerate(flags))
     good = good and all("not finite" in f[1] for r, f in enumerate(flags) if r != frank)
     if rank == 0:
         with open(out, "w") as f:

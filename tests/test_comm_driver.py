@@ -127,7 +127,8 @@ def test_cpp_driver_run_steps_matches_single_domain(base, ov, nsteps, world, ove
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=27;MHD.omega0=0.02", 3, 1, 1, 1),   # three slabs, rotating path
     ("orszag-tang3d", "mesh.nx=8;mesh.ny=8;mesh.nz=24", 2, 1, 1, 0),     # serial schedule
 ], ids=["step0", "steady", "x3-rotating", "serial"])
-def test_a_failed_step_piece_on_one_rank_reaches_every_rank(base, ov, world, fail_rank, fail_step, overlap, comm_emu_lib, tmp_path):
+@pytest.mark.parametrize("loop", ["host", "batch", "single"])
+def test_a_failed_step_piece_on_one_rank_reaches_every_rank(base, ov, world, fail_rank, fail_step, overlap, loop, comm_emu_lib, tmp_path):
     """a launch error inside godunov_unsplit on ONE rank: that rank still posts the exchange, poisons the next 1/dt all-reduce with
     +inf -- always RGPU_DT_SLOTS values, so its size cannot differ from the healthy ranks' -- and every rank returns an error"""
     out = str(tmp_path / "result.txt")
@@ -135,6 +136,8 @@ def test_a_failed_step_piece_on_one_rank_reaches_every_rank(base, ov, world, fai
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "tests", "comm_worker.py"), "--poison", base, ov, str(fail_rank), str(fail_step), out]
     env = dict(os.environ, OMP_NUM_THREADS="1", COMM_OVERLAP=str(overlap))
+    if loop != "host":   # the library's own loop (rgpu_comm_run_steps): failure in the first step of a call of three / in a call of one
+        env["POISON_RUN_STEPS"] = loop
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=120)
     assert res.returncode == 0, res.stdout[-3000:]
     assert open(out).read().strip() == "OK", open(out).read()
