@@ -69,6 +69,17 @@ def load_libs(device):
     device-aware transport (tests/emu_dev/rg_transport.h): the planes are packed by the product's kernels, staged through pinned
     memory and carried by gloo (RCCL refuses two ranks on one device).  "cuda:N": the product libraries (HIP + RCCL).
     Returns (library, comm library, callbacks to keep alive)."""
+    key = (device, os.environ.get("COMM_ARITH", "exact"))
+    if key in _LIBS:      # (batch mode: one process, many cases)
+        return _LIBS[key]
+    _LIBS[key] = out = _load_libs(device)
+    return out
+
+
+_LIBS = {}
+
+
+def _load_libs(device):
     keep = []
     if device == "cpu":
         lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
@@ -326,8 +337,47 @@ def main():
         return frontend()
     if sys.argv[1] == "--poison":
         return poison()
-    base, ov, nsteps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    if sys.argv[1] == "--batch":
+        return batch()
+    sys.exit(0 if one_case(sys.argv[1:5]) else 1)
+
+
+def batch():
+    """--batch spec.json: [{"argv": [base, overrides, nsteps, resultfile], "env": {...}}, ...] -- the cases of one test function that
+    share a rank count, in ONE set of rank processes (interpreter start, torch import and the HIP context are most of a small
+    case's wall time).  Every case writes its own result file; the exit code says whether all of them passed."""
+    import json
+    spec = json.load(open(sys.argv[2]))
     dist.init_process_group("gloo")
+    good = True
+    for n, case in enumerate(spec):
+        saved = dict(os.environ)
+        os.environ.update(case.get("env", {}))
+        if dist.get_rank() == 0:
+            print("### case %d: %s" % (n, " ".join(case["argv"][:3])), flush=True)
+        try:
+            good = one_case(case["argv"]) and good
+        finally:
+            os.environ.clear()
+            os.environ.update(saved)
+        dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if good else 1)
+
+
+def one_case(argv):
+    base, ov, nsteps, out = argv[0], argv[1], int(argv[2]), argv[3]
+    alone = not dist.is_initialized()
+    if alone:
+        dist.init_process_group("gloo")
+    try:
+        return _one_case(base, ov, nsteps, out)
+    finally:
+        if alone:
+            dist.destroy_process_group()
+
+
+def _one_case(base, ov, nsteps, out):
     rank, world = dist.get_rank(), dist.get_world_size()
     device = os.environ.get("COMM_DEVICE", "cpu")
     lib, CL, keep = load_libs(device)
@@ -424,8 +474,7 @@ def main():
                 f.write("OK %016x\n" % fingerprint if ok else "MISMATCH %r\n" % (flags,))
         dist.barrier()
         run.close()
-        dist.destroy_process_group()
-        sys.exit(0 if ok else 1)
+        return ok
     local = torch.from_numpy(np.ascontiguousarray(run.local_interior()))
     parts = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
     dist.gather(local, parts, dst=0)
@@ -483,10 +532,10 @@ def main():
                 with open(out, "w") as f:
                     f.write("MISMATCH end time inside the batch: %d doubles differ, per rank (ok, steps, t) = %r, expected %d steps, t = %r\n" % (nbad2, flags, cut, t_cut))
             ok = ok and ok2
-    dist.barrier()
+    oks = [None] * world
+    dist.all_gather_object(oks, bool(ok))
     run.close()
-    dist.destroy_process_group()
-    sys.exit(0 if ok else 1)
+    return all(oks)
 
 
 if __name__ == "__main__":

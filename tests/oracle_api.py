@@ -113,8 +113,42 @@ class Oracle:
         assert rc == 0, rc
         return secs[:nd.value], used.value
 
+    # Large runs (the bench's launch geometry, the long runs of the GPU suite) are asked for twice -- once per arithmetic of the
+    # product -- and dominate the suite's wall time: run() keeps the last few results, and takes the z-slab threaded form of the 3D
+    # MHD step where its scope allows (orc_run_mt: the same doubles as the sequential loop, tests/test_oracle_golden.py
+    # test_threaded_step_equals_sequential).  run_sequential() is the plain call.
+    BIG_RUN = 4e6            # cell-steps
+    MEMO_BYTES = 3 << 30
+
+    def _mt_threads(self, p):
+        import os
+        three_d = p.nz > 1
+        if not (p.mhdEnabled and three_d) or p.gravityEnabled or p.nu > 0 or p.eta > 0 or p.randomForcingEnabled or p.ouForcingEnabled or p.slope_type == 3:
+            return 0
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        return max(0, min(ncpu, 16, p.nz // 2))
+
     def run(self, p, U0, nsteps, tEnd=1e300):
         """start(): returns (U_final incl. ghosts, dts, t_final)"""
+        if float(p.nx) * p.ny * max(p.nz, 1) * max(nsteps, 1) < self.BIG_RUN or self._G is not None or self._F is not None:
+            return self.run_sequential(p, U0, nsteps, tEnd)
+        import hashlib
+        key = (bytes(p), hashlib.sha1(np.ascontiguousarray(U0).view(np.uint8)).hexdigest(), int(nsteps), float(tEnd))
+        memo = self.__dict__.setdefault("_memo", {})
+        if key in memo:
+            U, dts, t = memo[key]
+            return U.copy(), dts.copy(), t
+        nt = self._mt_threads(p)
+        U, dts, t = self.run_mt(p, U0, nsteps, nt, tEnd) if nt > 1 else self.run_sequential(p, U0, nsteps, tEnd)
+        memo[key] = (U.copy(), dts.copy(), t)
+        while sum(v[0].nbytes for v in memo.values()) > self.MEMO_BYTES and len(memo) > 1:
+            memo.pop(next(iter(memo)))
+        return U, dts, t
+
+    def run_sequential(self, p, U0, nsteps, tEnd=1e300):
         U = np.array(U0, dtype=np.float64, order="C", copy=True)
         nd, tf = C.c_int(), C.c_double()
         dts = np.zeros(max(nsteps, 1))

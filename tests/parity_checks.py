@@ -544,6 +544,22 @@ def check_public_ghost_fill_invalidates_fused_dt(lib, oracle, base, ov):
 
 # ---- direct differential test of the Alfven selection in the 2D HLLD edge solver (rgpu_selftest_alfven) -------------------------
 def alfven_samples(n, seed):
+    """(kept for the last few (n, seed): the four parameter sets of the selection test run on the same samples; read-only)"""
+    key = (int(n), int(seed))
+    if key not in _ALFVEN_SAMPLES:
+        while len(_ALFVEN_SAMPLES) >= 3:
+            _ALFVEN_SAMPLES.pop(next(iter(_ALFVEN_SAMPLES)))
+        S, kind = _alfven_samples(n, seed)
+        S.flags.writeable = False
+        kind.flags.writeable = False
+        _ALFVEN_SAMPLES[key] = (S, kind)
+    return _ALFVEN_SAMPLES[key]
+
+
+_ALFVEN_SAMPLES = {}
+
+
+def _alfven_samples(n, seed):
     """n edge problems (SoA [36, n]): half random rough states, half adversarial -- built to sit on the selection's margins:
       * dv / dS = 1 +- k 2^-52 (k <= 2^14): a uniform flow (the star ratio t = dv / dS is exactly 1) whose velocities are nudged
         by k ulp, so that candidates and their star partners tie, nearly tie, or differ by a hair more than the 2^-40 margin;

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, ini
-from test_comm_driver import OPEN_BC, run_frontend, run_worker
+from test_comm_driver import OPEN_BC, run_batched, run_frontend, run_worker
 
 
 def build_dev_comm(arith):
@@ -94,8 +94,8 @@ ENV = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "COMM_DEVICE": "cuda-staged:0"}
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", SMALL, ids=["%s-%d-x%d-%s" % (c[0], n, c[3], SCHED[c[4]]) for n, c in enumerate(SMALL)])
-def test_exact_ranks_on_one_gpu_equal_the_oracle(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path):
-    run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact"), timeout=600)
+def test_exact_ranks_on_one_gpu_equal_the_oracle(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path_factory):
+    run_batched("small_exact", SMALL, (base, ov, nsteps, world, overlap), tmp_path_factory, env_extra=dict(ENV, COMM_ARITH="exact"))
 
 
 @pytest.mark.gpu
@@ -109,10 +109,10 @@ RUN_STEPS = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[7], SMALL[9
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", RUN_STEPS, ids=["%s-%d-x%d-%s" % (c[0], n, c[3], SCHED[c[4]]) for n, c in enumerate(RUN_STEPS)])
-def test_exact_ranks_run_steps_with_the_time_step_on_the_device(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path):
+def test_exact_ranks_run_steps_with_the_time_step_on_the_device(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path_factory):
     """rgpu_comm_run_steps on the real kernels with a real neighbour: the 1/dt slots all-reduced in place, the clock kernel, the sweeps /
     update / shear remap / fused ghost fill reading the record; one plain step then a batch of 5, and an end time inside a batch"""
-    run_worker(base, ov, 6, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), timeout=600)
+    run_batched("run_steps_exact", RUN_STEPS, (base, ov, nsteps, world, overlap), tmp_path_factory, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), nsteps=6)
 
 
 # the rank counts of the scaling run (SCALE: N = 2, 4, 8): every rank a process of its own on the one GPU
@@ -124,10 +124,10 @@ MANY = [("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=64;" + MRI, 4, 4, 1),
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", MANY, ids=["%s-x%d-%s" % (c[0], c[3], SCHED[c[4]]) for c in MANY])
-def test_exact_four_and_eight_ranks_on_one_gpu(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path):
+def test_exact_four_and_eight_ranks_on_one_gpu(base, ov, nsteps, world, overlap, dev_comm_exact, gpu_lib, oracle, tmp_path_factory):
     """4 and 8 rank processes (the rank counts of the scaling run) through the batched loop: == the single-domain oracle, dt sequence,
     fingerprint and an end time inside a batch included"""
-    run_worker(base, ov, 6, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), timeout=900)
+    run_batched("many_exact", MANY, (base, ov, nsteps, world, overlap), tmp_path_factory, env_extra=dict(ENV, COMM_ARITH="exact", COMM_RUN_STEPS="1"), nsteps=6)
 
 
 CONTRACTED = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[9], SMALL[14]]
@@ -135,8 +135,8 @@ CONTRACTED = [SMALL[0], SMALL[1], SMALL[3], SMALL[4], SMALL[6], SMALL[9], SMALL[
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", CONTRACTED, ids=["%s-%d-x%d-%s" % (c[0], n, c[3], SCHED[c[4]]) for n, c in enumerate(CONTRACTED)])
-def test_contracted_ranks_on_one_gpu_equal_their_single_device_run(base, ov, nsteps, world, overlap, dev_comm_contracted, gpu_contracted_lib, tmp_path):
-    run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH="contracted", COMM_CHECK="single"), timeout=600)
+def test_contracted_ranks_on_one_gpu_equal_their_single_device_run(base, ov, nsteps, world, overlap, dev_comm_contracted, gpu_contracted_lib, tmp_path_factory):
+    run_batched("small_contracted", CONTRACTED, (base, ov, nsteps, world, overlap), tmp_path_factory, env_extra=dict(ENV, COMM_ARITH="contracted", COMM_CHECK="single"))
 
 
 # bench geometry: the 512 x 512 cross-section of the headline box in slabs of 64 planes (the N = 8 per-rank slab), 2 and 3 of them

@@ -101,6 +101,40 @@ def run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=None, timeo
     return open(out).read().split()[1:]
 
 
+# The GPU suite's small cases: interpreter start, the torch import and the HIP context of every rank process are most of a case's wall
+# time, so the cases of one test function that share a rank count run in ONE set of rank processes (comm_worker.py --batch), launched
+# by the first test of the group; every test then reads its own case's result file.
+_BATCHES = {}
+
+
+def run_batched(group, cases, case, tmp_path_factory, env_extra=None, nsteps=None, timeout=900):
+    """cases: (base, ov, nsteps, world, overlap) tuples of one test function; `case` is the one asked about.  nsteps overrides the tuple's."""
+    import json
+    world = case[3]
+    key = (group, world)
+    if key not in _BATCHES:
+        d = tmp_path_factory.mktemp("batch_%s_x%d" % (group, world))
+        mine = [c for c in cases if c[3] == world]
+        spec = [{"argv": [c[0], c[1], str(nsteps or c[2]), str(d / ("result_%d.txt" % n))], "env": {"COMM_OVERLAP": str(c[4])}} for n, c in enumerate(mine)]
+        (d / "spec.json").write_text(json.dumps(spec))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+               os.path.join(ROOT, "tests", "comm_worker.py"), "--batch", str(d / "spec.json")]
+        env = dict(os.environ, OMP_NUM_THREADS="1", **(env_extra or {}))
+        try:
+            res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=timeout)
+            log = res.stdout[-3000:]
+        except subprocess.TimeoutExpired as e:
+            log = "TIMEOUT after %d s\n%s" % (timeout, (e.stdout or "")[-3000:])
+        _BATCHES[key] = ({c: (d / ("result_%d.txt" % n)) for n, c in enumerate(mine)}, log)
+    files, log = _BATCHES[key]
+    f = files[case]
+    assert f.exists(), "no result for this case; the batch's output:\n" + log
+    text = f.read_text()
+    assert text.split()[0] == "OK", text + "\n" + log
+    return text.split()[1:]
+
+
 @pytest.mark.parametrize("base,ov,nsteps,world,overlap", CASES,
                          ids=["%s-%d-x%d-%s" % (c[0], n, c[3], ("serial", "overlap", "boundary-first")[c[4]]) for n, c in enumerate(CASES)])
 def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm_emu_lib, oracle, tmp_path):
@@ -238,9 +272,10 @@ GPU_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("base,ov,nsteps,overlap", GPU_CASES, ids=["%s-%s" % (c[0], ("serial", "overlap", "boundary-first")[c[3]]) for c in GPU_CASES])
-def test_rccl_driver_single_rank_on_gpu(base, ov, nsteps, overlap, gpu_lib, oracle, tmp_path):
+def test_rccl_driver_single_rank_on_gpu(base, ov, nsteps, overlap, gpu_lib, oracle, tmp_path_factory):
     """the RCCL transport with nranks = 1 on the 1-GPU box (a ring of one): product libraries, no torch in the data path"""
-    run_worker(base, ov, nsteps, 1, overlap, tmp_path, env_extra={"COMM_DEVICE": "cuda:0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
+    cases = [(c[0], c[1], c[2], 1, c[3]) for c in GPU_CASES]
+    run_batched("rccl1", cases, (base, ov, nsteps, 1, overlap), tmp_path_factory, env_extra={"COMM_DEVICE": "cuda:0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
 
 
 @pytest.mark.gpu
