@@ -6,9 +6,11 @@ OUT=$R/gpurun_out/${JOB_OUT:-job}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for so in "$@"; do
   tag=$(basename $so .so)
-  for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-             "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
-    d=$OUT/pmc_${tag}_$(echo $grp | cut -c1-12 | tr ' ' _)
+  # PMC_GROUPS="A B C|D E": other counter groups, one pass each (default: the two SQ groups below)
+  DEFAULT_GROUPS="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES|SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"
+  IFS='|' read -ra GROUPS_ <<< "${PMC_GROUPS:-$DEFAULT_GROUPS}"
+  for grp in "${GROUPS_[@]}"; do
+    d=$OUT/pmc_${tag}_$(echo $grp | md5sum | cut -c1-8)
     RGPU_LIB=$R/ramsesgpu_amd/$tag.so rocprofv3 --pmc $grp --output-format csv -d $d -o pmc -- python $R/scripts/probe_sweep.py mhd_mri_3d ${PMC_N:-512} 2 > /dev/null 2> $d.err
   done
   python - "$OUT" "$tag" <<'PY'
