@@ -286,7 +286,7 @@ def pmc_summary():
     return _PMC["d"]
 
 
-def pmc_traffic(workload, kernel_phase, doubled_fetch=False):
+def pmc_traffic(workload, kernel_phase, doubled_fetch=False, scale=1.0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (separate FETCH_SIZE / WRITE_SIZE passes,
     KiB x 1024), or None.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section: exactly 1/2 for
     16 B per lane streaming reads, "other widths uncalibrated"); calibrated on this code's own 8 B per lane SoA streams against known byte
@@ -298,8 +298,8 @@ def pmc_traffic(workload, kernel_phase, doubled_fetch=False):
     try:
         d = d.get(workload, d).get(kernel_phase, {})
         if doubled_fetch:
-            return 2.0 * d["fetch_bytes"] + d["write_bytes"]
-        return d.get("hbm_bytes_per_launch")
+            return scale * (2.0 * d["fetch_bytes"] + d["write_bytes"])
+        return scale * d["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -310,14 +310,14 @@ PARITY = {"exact": "librgpu.so: bit-identical to euler_cpu on all golden fixture
                         "Orszag-Tang gate (<= 9e-16 per variable), 300-400 step runs (<= 2.1e-15) and the headline-size property checks"}
 
 
-def valu_ceiling(workload, kernel_phase, launch_ms):
+def valu_ceiling(workload, kernel_phase, launch_ms, scale=1.0):
     """The second ceiling of SURVEY.md 8(d): share of the fp64 vector-issue capacity the dominant kernel uses.  Wave-level
     VALU instruction counts per launch come from the committed rocprofv3 --pmc summary (SQ_INSTS_VALU,
     SQ_INSTS_VALU_TRANS_F64); an fp64 instruction occupies a SIMD for 4 cycles (16 lanes per cycle), rcp / rsq / sqrt for 16;
-    1024 SIMDs at the 2.4 GHz peak clock.  None without the summary."""
+    1024 SIMDs at the 2.4 GHz peak clock.  None without the summary.  scale: cells per launch of this run / of the profiled one."""
     try:
         d = pmc_summary()[workload][kernel_phase]
-        insts, trans = d["valu_wave_insts"], d.get("valu_trans_f64_wave_insts", 0.0)
+        insts, trans = scale * d["valu_wave_insts"], scale * d.get("valu_trans_f64_wave_insts", 0.0)
     except Exception:
         return None
     cycles = 4.0 * insts + 12.0 * trans
@@ -334,7 +334,7 @@ def valu_ceiling(workload, kernel_phase, launch_ms):
                     "measured duration; frac_of_measured_issue_rate: the same against the rates instruction streams of the kernel's mix reach at 2 waves "
                     "per SIMD (4.7 cycles per instruction, 16.8 per rcp/rsq: profiles/r03_valu_mix.txt), averaged over all SIMDs -- in the exact MHD "
                     "sweep the three SIMDs of the Riemann waves are the critical path (~95 % busy) and the producer pair's SIMD carries ~72 % of their "
-                    "load; in the contracted one the producer pair's chain (loads, trace, barrier) is the critical one: DESIGN.md section 3.2"}
+                    "load; the contracted one is balanced (profiles/r06_sweep_isa_mix.txt, DESIGN.md section 3.1.1)"}
 
 
 class Control:
@@ -476,12 +476,17 @@ def roofline_of(wname, w, arith, step_bytes, elapsed, steps, prof):
     dom_ms = dom_ms * dom_launches / nprof
     achieved = step_bytes / (dom_ms * 1e-3)
     pkey = wname if arith == "exact" else wname + "_contracted"   # key of the committed PMC summary (profiles/pmc_traffic.json)
-    vc = valu_ceiling(pkey, dom_name, dom_ms / max(dom_launches / nprof, 1.0))
+    # the committed counters are per launch of the workload's DEFAULT box (what scripts/prof_round.sh runs): another box, or a slab of
+    # it in several launches per step, takes them in proportion to the cells a launch covers
+    per_step = max(dom_launches / nprof, 1.0)
+    scale = (step_bytes / w["bytes"]) / (float(w["size"][0]) * w["size"][1] * w["size"][2]) / per_step
+    vc = valu_ceiling(pkey, dom_name, dom_ms / per_step, scale)
     # what binds the dominant kernel: the 3D MHD sweep is bound by fp64 vector issue ("valu_f64": its share of the issue slots is
     # valu_ceiling.frac), the other sweeps by HBM; `achieved` / `peak` / `frac` stay the contract's HBM figures either way (= hbm_frac)
     bound = "valu_f64" if (w["bytes"] == 128.0 and w["size"][2] > 1 and vc is not None and vc["frac"] > achieved / HBM_PEAK) else "hbm"
     roof = {"bound": bound, "kernel": dom_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "hbm_frac": achieved / HBM_PEAK, "valu_frac": (vc or {}).get("frac"), "traffic": pmc_traffic(pkey, dom_name), "traffic_fetch_doubled": pmc_traffic(pkey, dom_name, True),
+            "frac": achieved / HBM_PEAK, "hbm_frac": achieved / HBM_PEAK, "valu_frac": (vc or {}).get("frac"), "traffic": pmc_traffic(pkey, dom_name, False, scale), "traffic_fetch_doubled": pmc_traffic(pkey, dom_name, True, scale),
+            "pmc_scale": scale,
             "traffic_note": "HBM bytes per launch from rocprofv3 --pmc (profiles/pmc_traffic.json): FETCH_SIZE + WRITE_SIZE as counted = a lower bound (gfx950 tallies "
                             "128-B read requests at 64 B; 0.49-0.77 of known byte counts on this code's 8 B per lane streams), and with FETCH_SIZE doubled as "
                             "MI355X_MICROARCH.md prescribes for wide streaming reads = an upper bound",

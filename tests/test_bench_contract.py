@@ -35,7 +35,12 @@ def test_bench_line_single_gpu(args, gpu_lib):
     d = last_json(res.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # achieved / peak / frac are the contract's HBM figures whatever binds the kernel; the 3D MHD sweep is labelled by what does bind it
+    # (fp64 vector issue) once the committed counters belong to this state of the sources, with its share of the issue slots beside
+    assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["hbm_frac"] == r["frac"]
+    assert r["bound"] == ("valu_f64" if (args[1] == "mri" and r["valu_ceiling"] and r["valu_frac"] > r["frac"]) else "hbm")
+    if r["valu_ceiling"]:
+        assert r["valu_frac"] == r["valu_ceiling"]["frac"] and 0 < r["valu_frac"] < 1.0 and 0 < r["pmc_scale"] < 1.0
     # the headline is the tolerance-grade library (north_star's bar: relative L2 < 1e-12, gated by tests/test_contracted.py) and says so;
     # the bit-identical library is measured beside it the same way: a value with its own roofline
     assert d["config"]["arithmetic"] == "contracted" and "not bit-identical" in d["config"]["parity"] and "1e-12" in d["config"]["parity"]
