@@ -256,6 +256,7 @@ def dynamic_report(arith, measured, iters):
     per_role = defaultdict(Counter)      # role -> class -> wave instructions per plane and workgroup
     static_role = defaultdict(Counter)
     copies = Counter()
+    by_function = Counter()
     # the z march: the loop(s) whose blocks hold Riemann / trace code and no update-role code
     per_loop = defaultdict(Counter)
     byname = {}   # source file name -> path (for the inline stacks, which name files by path)
@@ -323,6 +324,21 @@ def dynamic_report(arith, measured, iters):
             if rhi and 2 * inref > len(b["ops"]):
                 role = "riemann_outer"
         c = Counter(x for x, _ in b["ops"])
+        if "--functions" in sys.argv and trips:
+            # (per source function: the innermost frame, and the outermost numerics function the instruction was inlined through)
+            for (cls, loc), fr in zip(b["ops"], b.get("frames", [])):
+                if cls not in VALU_CLASSES:
+                    continue
+                names = []
+                for fname, ln in fr:
+                    path = byname.get(fname)
+                    if path:
+                        if path not in fmaps:
+                            fmaps[path] = function_map(path)
+                        names.append(fmaps[path].get(ln) or "?")
+                inner = names[0] if names else "?"
+                outer = next((n for n in reversed(names) if n in ROLE_OF), "?")
+                by_function[(role, outer, inner)] += trips
         if sum(c.values()) >= 200:
             copies[role] += 1
         for k, v in c.items():
@@ -355,6 +371,10 @@ def dynamic_report(arith, measured, iters):
     print("per SIMD and plane (VALU): Riemann SIMD = 2 x (%.0f + control %.0f) + a third of the electric field (%.0f) = %.0f;  "
           "producer SIMD = 3 x %.0f + 2 x (%.0f + %.0f + control %.0f) = %.0f" %
           (r / 3.0, ctl, edyn / 3.0, 2 * (r / 3.0 + ctl) + edyn / 3.0, t / 3.0, p, s, ctl, t + 2 * (p + s + ctl)))
+    if by_function:
+        print("VALU wave instructions per plane and workgroup by (role, numerics function it was inlined through, innermost function):")
+        for (role, outer, inner), n in by_function.most_common(45):
+            print("  %6d  %-8s %-22s %s" % (n, role, outer, inner))
     if measured:
         pred = valu * iters
         print("reconciliation: predicted %.4g wave instructions per launch (%d workgroup x plane iterations), SQ_INSTS_VALU measured %.4g: %+.1f %%" %
