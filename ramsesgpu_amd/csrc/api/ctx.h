@@ -150,6 +150,17 @@ void fill_dev_params(const rgpu_params& p, DevParams* g) {
   g->sj = (unsigned)g->isize;
   g->sk = (unsigned)g->isize * (unsigned)g->jsize;
   g->ncell = (unsigned long long)g->isize * g->jsize * g->ksize;
+  g->fsj = g->sj; g->fsk = g->sk; g->foff = 0; g->fN = g->ncell;
+  if (g->three_d && g->mhd) {
+    // F / emf of the 3D MHD step: rows of whole 128-byte lines (a multiple of 16 doubles), cell i = gw of every row on a line boundary,
+    // so that the 16-cell row segments a wave of the sweep writes are whole lines.  Same-box A/B at 512^3 over seven boxes
+    // (profiles/r06_flux_pitch_ab.txt): sweep -1.0 ... -1.2 ms in both builds, WRITE_SIZE 26.4 -> 20.6 GB, update level; rows of 520
+    // doubles (64-byte granules only) gave the same sweep but an update 0.1 ... 1.3 ms slower, depending on the box.
+    g->fsj = (((unsigned)g->isize + 15u) / 16u) * 16u;
+    g->foff = (16u - (unsigned)g->gw % 16u) % 16u;
+    g->fsk = g->fsj * (unsigned)g->jsize;
+    g->fN = ((unsigned long long)g->fsk * g->ksize + g->foff + 15ull) & ~15ull;
+  }
   g->dx = p.dx; g->dy = p.dy; g->dz = p.dz; g->xMin = p.xMin; g->deltaX = p.xMax - p.xMin;
   g->gamma0 = p.gamma0; g->cIso = p.cIso; g->smallr = p.smallr; g->smallc = p.smallc; g->smallp = p.smallp;
   g->smallpp = p.smallpp; g->gamma6 = p.gamma6; g->Omega0 = p.Omega0;
@@ -259,7 +270,7 @@ int create_common(const rgpu_params* p, double* dU, double* dU2, void* hip_strea
   }
   if (p->gravityEnabled == 2 && alloc_zero(c, &c->G, c->ncell * 3)) return fail(c, RGPU_ENOMEM, "device allocation of the gravity field failed");
   if (alloc_zero(c, &c->Q, c->ncell * sp.q) || alloc_zero(c, &c->E, c->ncell * sp.e) || alloc_zero(c, &c->T, c->ncell * sp.t) ||
-      alloc_zero(c, &c->F, c->ncell * sp.f) || alloc_zero(c, &c->emf, c->ncell * sp.emf))
+      alloc_zero(c, &c->F, (size_t)c->g.fN * sp.f) || alloc_zero(c, &c->emf, (size_t)c->g.fN * sp.emf))
     return fail(c, RGPU_ENOMEM, "device allocation of the scratch arrays failed");
   if (c->g.shearbox) {
     const size_t P = (size_t)c->g.jsize * c->g.ksize;

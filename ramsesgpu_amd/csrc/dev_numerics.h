@@ -32,6 +32,12 @@ struct DevParams {
   int zlo_copy, zhi_copy;      // z faces that are slab interfaces (RGPU_BC_COPY): the neighbour's cells continue there
   unsigned sj, sk;             // flat strides of +1 in j and k
   unsigned long long ncell;    // component stride
+  // F / emf of the 3D MHD step (scratch, not part of the ABI) have a pitch of their own: rows of fsj doubles, a multiple of 16, and
+  // the first interior cell of every row (i = gw) on a 128-byte boundary (foff), so that the 16-cell row segments a wave of the sweep
+  // writes are whole lines (rows of isize = nx + 6 doubles start 24 B off a granule: 1.3-1.45 x write amplification, rounds 3-5).
+  // Every other solver family: the state's own layout (fsj = sj, fsk = sk, foff = 0, fN = ncell).
+  unsigned fsj, fsk, foff;
+  unsigned long long fN;       // component stride of F / emf
   double dx, dy, dz, xMin, deltaX;   // deltaX = xMax - xMin
   double gamma0, cIso, smallr, smallc, smallp, smallpp, gamma6, Omega0;
   double slope_type, mag_slope_type;
@@ -58,6 +64,9 @@ RG_DEVFN void half_dt_gravity(const DevParams& g, unsigned m, double& gx, double
     gx = g.hgx; gy = g.hgy; gz = g.hgz;
   }
 }
+
+// flat index of cell (i, j, k) in F / emf
+RG_DEVFN unsigned flux_index(const DevParams& g, int i, int j, int k) { return g.foff + (unsigned)i + (unsigned)j * g.fsj + (unsigned)k * g.fsk; }
 
 struct Prim8 {  // primitive MHD state in some frame: density, pressure, 3 velocities, 3 field components
   double r, p, u, v, w, a, b, c;

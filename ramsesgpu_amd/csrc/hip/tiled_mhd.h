@@ -66,6 +66,10 @@ constexpr int MH_THREADS = 512;
 // a copy of an integer that the optimiser cannot fold constants into or derive from another value: the LDS addresses formed from
 // it are "this register + a non-negative immediate"
 RG_DEVFN unsigned rg_opaque(unsigned x) { asm("" : "+v"(x)); return x; }
+// a wave-uniform value the compiler must take afresh where this stands (volatile: not hoisted out of the z loop): what is derived from
+// it -- the component offsets of the flux stores, ten scalar registers per direction -- is recomputed by a few SALU instructions at the
+// end of every solve instead of living in (spilled) scalar registers across it
+RG_DEVFN size_t rg_fresh(size_t x) { asm volatile("" : "+s"(x)); return x; }
 
 template <class G>
 struct TLdsWrite {   // bound to the record of one traced cell
@@ -128,19 +132,19 @@ struct TLdsPlane {
 template <class G, int DIR>
 RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m, double xPos, double* __restrict__ F,
                           double* __restrict__ emf, unsigned idx, Prim8& c0, Prim8& c1, bool solve, bool prio_drop) {
-  const size_t N = g.ncell;
+  // idx = flux_index of the cell (where its fluxes / EMFs go; the traced states take no global index here: no gravity field)
   const unsigned sx = 1u, sj = (unsigned)G::PX;
   if (DIR == XD) {   // edge along x: t1 = y, t2 = z.  rt = (+,+) from c-y-z, rb = (+,-) from c-y, lt = (-,+) from c-z, lb = (-,-) from c
     if (solve) {
       c0.b = Tk.get(T_CL, m - sj) + Tk.get(T_DCLY, m - sj);        // b2 = CL(m2) + s1 * dCLy(m2), s1 = +1, m2 = the cell above
       c1.b = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLY, m);         // s1 = -1
       const Prim8 rb = edge_state3d<0, +1, -1, false>(g, Tk, m - sj, idx), lb = edge_state3d<0, -1, -1, false>(g, Tk, m, idx);
-      RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, c0, rb, c1, lb, xPos));
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * rg_fresh(g.fN)], edge_emf<0>(g, c0, rb, c1, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<XD, +1, false>(g, Tk, m - sx, idx), R = face_state3d<XD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<XD>(g, L, R, xPos, fl);
-      store_flux<XD>(g, F, idx, fl);
+      store_flux<XD>(F, rg_fresh(g.fN), idx, fl);
     }
     c0 = edge_state3d<0, +1, +1, false>(g, Tk, m - sj, idx);
     c1 = edge_state3d<0, -1, +1, false>(g, Tk, m, idx);
@@ -149,12 +153,12 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
       c0.a = Tk.get(T_CL, m - sx) + Tk.get(T_DCLX, m - sx);        // b1 = CL(m1) + s2 * dCLx(m1), s2 = +1
       c1.a = Tk.get(T_CL, m) + (-1.0) * Tk.get(T_DCLX, m);
       const Prim8 lt = edge_state3d<1, -1, +1, false>(g, Tk, m - sx, idx), lb = edge_state3d<1, -1, -1, false>(g, Tk, m, idx);
-      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, c0, c1, lt, lb, xPos));
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * rg_fresh(g.fN)], edge_emf<1>(g, c0, c1, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
       Prim8 L = face_state3d<YD, +1, false>(g, Tk, m - sj, idx), R = face_state3d<YD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<YD>(g, L, R, xPos, fl);
-      store_flux<YD>(g, F, idx, fl);
+      store_flux<YD>(F, rg_fresh(g.fN), idx, fl);
     }
     c0 = edge_state3d<1, +1, +1, false>(g, Tk, m - sx, idx);
     c1 = edge_state3d<1, +1, -1, false>(g, Tk, m, idx);
@@ -162,13 +166,13 @@ RG_DEVFN void riemann_dir(const DevParams& g, const TLdsPlane<G>& Tk, unsigned m
     if (solve) {
       const Prim8 rt = edge_state3d<2, +1, +1, false>(g, Tk, m - sx - sj, idx), rb = edge_state3d<2, +1, -1, false>(g, Tk, m - sx, idx);
       const Prim8 lt = edge_state3d<2, -1, +1, false>(g, Tk, m - sj, idx), lb = edge_state3d<2, -1, -1, false>(g, Tk, m, idx);
-      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
+      RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * rg_fresh(g.fN)], edge_emf<2>(g, rt, rb, lt, lb, xPos));
       if (prio_drop) __builtin_amdgcn_s_setprio(0);
       c0.a = Tk.get(T_CL, m);                                      // bn of the left state: the face it shares with cell m
       Prim8 R = face_state3d<ZD, -1, false>(g, Tk, m, idx);
       double fl[8];
       mhd_face_flux<ZD>(g, c0, R, xPos, fl);
-      store_flux<ZD>(g, F, idx, fl);
+      store_flux<ZD>(F, rg_fresh(g.fN), idx, fl);
     }
     c0 = face_state3d<ZD, +1, false>(g, Tk, m, idx);
   }
@@ -343,7 +347,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
   const int oy = cl / MH_OX, ox = cl - oy * MH_OX;
   const int ci = i0 + ox, cj = j0 + oy;
   const bool fl_ok = !producer && cl < MH_OX * MH_OY && ci <= g.isize - gw && cj <= g.jsize - gw;
-  const unsigned cidx2 = fl_ok ? (unsigned)ci + (unsigned)cj * g.sj : 0u;
+  const unsigned cidx2 = fl_ok ? flux_index(g, ci, cj, 0) : 0u;   // (F / emf have a pitch of their own)
   const unsigned cm00 = (unsigned)(oy * MH_PX + ox) * (unsigned)(G::TREC * 8);   // byte offset of the T record of the cell diagonally below
   const double xPos = g.xMin + g.dx / 2 + (ci - gw) * g.dx;
 
@@ -422,7 +426,7 @@ __global__ void __launch_bounds__(MH_THREADS) mhd3d_sweep_kernel(DevParams g, Ti
       if (fl_ok && kk >= sa - 1) {
         const unsigned tk0 = (unsigned)((kk & 1) * MH_BUF * 8) + cm00;
         const TLdsPlane<G> Tk = {reinterpret_cast<const char*>(LT), rg_opaque(tk0), rg_opaque(tk0 + (unsigned)(MH_PX * G::TREC * 8))};
-        const unsigned idx = cidx2 + (unsigned)kk * sk;
+        const unsigned idx = cidx2 + (unsigned)kk * g.fsk;
         const bool solve = kk >= sa;
         // the two Riemann waves of a SIMD are arbitrated oldest first: the younger one is favoured for its EMF (see riemann_dir)
         // (round 6, same box, contracted | exact sweep: this scheme 21.5 | 28.8-29.3 ms; no priorities 21.6; the younger wave favoured for the
@@ -456,8 +460,8 @@ struct K_copy_periodic_layer {
       const unsigned q = t - n_copy;
       const unsigned j = q % (unsigned)g.jsize, k = plane(q / (unsigned)g.jsize);
       const unsigned js = (copy_on && (int)j == g.jsize - g.gw) ? (unsigned)g.gw : j;
-      const size_t N = g.ncell, P = (size_t)g.jsize * g.ksize;
-      const size_t row = (size_t)g.sj * js + (size_t)g.sk * k;
+      const size_t N = g.fN, P = (size_t)g.jsize * g.ksize;
+      const size_t row = (size_t)g.fsj * js + (size_t)g.fsk * k + g.foff;
       const unsigned idx2 = j + (unsigned)g.jsize * k;
       shear_save[idx2] = emf[row + g.gw + (size_t)EMF_Y * N];
       shear_save[idx2 + P] = emf[row + g.nx + g.gw + (size_t)EMF_Y * N];
@@ -465,10 +469,10 @@ struct K_copy_periodic_layer {
     }
     const unsigned n = (axis == 1) ? (unsigned)g.isize : (unsigned)g.jsize;
     const unsigned a = t % n, k = plane(t / n);
-    const size_t N = g.ncell;
+    const size_t N = g.fN;
     size_t src, dst;
-    if (axis == 1) { src = a + (size_t)g.sj * g.gw + (size_t)g.sk * k; dst = a + (size_t)g.sj * (g.jsize - g.gw) + (size_t)g.sk * k; }
-    else { src = g.gw + (size_t)g.sj * a + (size_t)g.sk * k; dst = (g.isize - g.gw) + (size_t)g.sj * a + (size_t)g.sk * k; }
+    if (axis == 1) { src = flux_index(g, (int)a, g.gw, (int)k); dst = flux_index(g, (int)a, g.jsize - g.gw, (int)k); }
+    else { src = flux_index(g, g.gw, (int)a, (int)k); dst = flux_index(g, g.isize - g.gw, (int)a, (int)k); }
     for (int v = 0; v < F_COUNT; ++v) F[dst + (size_t)v * N] = F[src + (size_t)v * N];
     for (int v = 0; v < 3; ++v) emf[dst + (size_t)v * N] = emf[src + (size_t)v * N];
   }

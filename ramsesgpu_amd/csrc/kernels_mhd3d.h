@@ -375,8 +375,7 @@ RG_DEVFN Prim8 edge_state3d(const DevParams& g, const TA& T, unsigned m, unsigne
 enum { DO_FLUX_X = 1, DO_FLUX_Y = 2, DO_FLUX_Z = 4, DO_EMF_X = 8, DO_EMF_Y = 16, DO_EMF_Z = 32, DO_ALL = 63 };
 
 template <int D>
-RG_DEVFN void store_flux(const DevParams& g, double* __restrict__ F, unsigned idx, const double* fl) {
-  const size_t N = g.ncell;
+RG_DEVFN void store_flux(double* __restrict__ F, size_t N, unsigned idx, const double* fl) {   // idx: flux_index of the cell, N = g.fN
   const int base = (D == XD) ? F_X : (D == YD) ? F_Y : F_Z;
 #pragma unroll
   for (int v = 0; v < 5; ++v) RG_STREAM_STORE(&F[idx + (size_t)(base + v) * N], fl[v]);
@@ -406,44 +405,44 @@ RG_DEVFN void mhd_face_flux(const DevParams& g, Prim8& L, Prim8& R, double xPos,
 }
 
 // The Riemann problems selected by MASK at the low faces / low edges of the cell whose traced state is T(m); idx is its
-// global flat index (output location, gravity field), xPos its x coordinate.  The cell is known to be in range.
+// global flat index (gravity field), fidx its flux_index (output location), xPos its x coordinate.  The cell is known to be in range.
 template <int MASK, bool GF, class TA>
 RG_DEVFN void mhd_flux3d_at(const DevParams& g, const TA& T, unsigned m, double xPos, double* __restrict__ F,
-                            double* __restrict__ emf, unsigned idx) {
-  const size_t N = g.ncell;
+                            double* __restrict__ emf, unsigned idx, unsigned fidx) {
+  const size_t N = g.fN;
   const unsigned sx = T.stride(XD), sj = T.stride(YD), sk = T.stride(ZD);
   const unsigned gsj = g.sj, gsk = g.sk;
   double fl[8];
   if (MASK & DO_FLUX_X) {
     Prim8 L = face_state3d<XD, +1, GF>(g, T, m - sx, idx - 1), R = face_state3d<XD, -1, GF>(g, T, m, idx);
     mhd_face_flux<XD>(g, L, R, xPos, fl);
-    store_flux<XD>(g, F, idx, fl);
+    store_flux<XD>(F, N, fidx, fl);
   }
   if (MASK & DO_FLUX_Y) {
     Prim8 L = face_state3d<YD, +1, GF>(g, T, m - sj, idx - gsj), R = face_state3d<YD, -1, GF>(g, T, m, idx);
     mhd_face_flux<YD>(g, L, R, xPos, fl);
-    store_flux<YD>(g, F, idx, fl);
+    store_flux<YD>(F, N, fidx, fl);
   }
   if (MASK & DO_FLUX_Z) {
     Prim8 L = face_state3d<ZD, +1, GF>(g, T, m - sk, idx - gsk), R = face_state3d<ZD, -1, GF>(g, T, m, idx);
     mhd_face_flux<ZD>(g, L, R, xPos, fl);
-    store_flux<ZD>(g, F, idx, fl);
+    store_flux<ZD>(F, N, fidx, fl);
   }
   // EMFs: slot order (RT, RB, LT, LB) = (+,+) from c-t1-t2, (+,-) from c-t1, (-,+) from c-t2, (-,-) from c
   if (MASK & DO_EMF_Z) {  // t1 = x, t2 = y
     const Prim8 rt = edge_state3d<2, +1, +1, GF>(g, T, m - sx - sj, idx - 1 - gsj), rb = edge_state3d<2, +1, -1, GF>(g, T, m - sx, idx - 1);
     const Prim8 lt = edge_state3d<2, -1, +1, GF>(g, T, m - sj, idx - gsj), lb = edge_state3d<2, -1, -1, GF>(g, T, m, idx);
-    RG_STREAM_STORE(&emf[idx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
+    RG_STREAM_STORE(&emf[fidx + (size_t)EMF_Z * N], edge_emf<2>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_Y) {  // t1 = z, t2 = x
     const Prim8 rt = edge_state3d<1, +1, +1, GF>(g, T, m - sk - sx, idx - gsk - 1), rb = edge_state3d<1, +1, -1, GF>(g, T, m - sk, idx - gsk);
     const Prim8 lt = edge_state3d<1, -1, +1, GF>(g, T, m - sx, idx - 1), lb = edge_state3d<1, -1, -1, GF>(g, T, m, idx);
-    RG_STREAM_STORE(&emf[idx + (size_t)EMF_Y * N], edge_emf<1>(g, rt, rb, lt, lb, xPos));
+    RG_STREAM_STORE(&emf[fidx + (size_t)EMF_Y * N], edge_emf<1>(g, rt, rb, lt, lb, xPos));
   }
   if (MASK & DO_EMF_X) {  // t1 = y, t2 = z
     const Prim8 rt = edge_state3d<0, +1, +1, GF>(g, T, m - sj - sk, idx - gsj - gsk), rb = edge_state3d<0, +1, -1, GF>(g, T, m - sj, idx - gsj);
     const Prim8 lt = edge_state3d<0, -1, +1, GF>(g, T, m - sk, idx - gsk), lb = edge_state3d<0, -1, -1, GF>(g, T, m, idx);
-    RG_STREAM_STORE(&emf[idx + (size_t)EMF_X * N], edge_emf<0>(g, rt, rb, lt, lb, xPos));
+    RG_STREAM_STORE(&emf[fidx + (size_t)EMF_X * N], edge_emf<0>(g, rt, rb, lt, lb, xPos));
   }
 }
 
@@ -458,7 +457,7 @@ RG_DEVFN void mhd_flux3d_cell(const DevParams& g, const double* __restrict__ T, 
   if (!flux3d_in_range(g, c)) return;
   const double xPos = g.xMin + g.dx / 2 + (c.i - g.gw) * g.dx;
   const TGlobalRead ta = {T, (size_t)g.ncell, g.sj, g.sk};
-  mhd_flux3d_at<MASK, GF>(g, ta, idx, xPos, F, emf, idx);
+  mhd_flux3d_at<MASK, GF>(g, ta, idx, xPos, F, emf, idx, flux_index(g, c.i, c.j, c.k));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -473,8 +472,8 @@ struct ShearRemap {   // computed on the host from totalTime, dt (fmod / integer
 // step 1: save the two emfY columns (they are rewritten in place by step 2).  idx2 = j + jsize*k
 RG_DEVFN void shear_save_emf_cell(const DevParams& g, const double* __restrict__ emf, double* __restrict__ save, unsigned idx2) {
   const unsigned j = idx2 % (unsigned)g.jsize, k = idx2 / (unsigned)g.jsize;
-  const size_t N = g.ncell;
-  const size_t row = (size_t)g.sj * j + (size_t)g.sk * k;
+  const size_t N = g.fN;
+  const size_t row = (size_t)g.fsj * j + (size_t)g.fsk * k + g.foff;
   const size_t P = (size_t)g.jsize * g.ksize;
   save[idx2] = emf[row + g.gw + (size_t)EMF_Y * N];
   save[idx2 + P] = emf[row + g.nx + g.gw + (size_t)EMF_Y * N];
@@ -485,11 +484,12 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
                                double* __restrict__ emf, const double* __restrict__ save, double* __restrict__ remap,
                                double dtdx, unsigned idx2) {
   const int j = (int)(idx2 % (unsigned)g.jsize), k = (int)(idx2 / (unsigned)g.jsize);
-  const size_t N = g.ncell;
+  const size_t N = g.fN;
   const size_t P = (size_t)g.jsize * g.ksize;
   const int gw = g.gw, ny = g.ny, nx = g.nx;
   const double* Fd = F + (size_t)(F_X + ID) * N;   // density flux through the low x face
-  const size_t krow = (size_t)g.sk * k;
+  const size_t krow = (size_t)g.fsk * k + g.foff;   // (F / emf have their own pitch: flux_index)
+  const size_t fsj = g.fsj;
   const bool inner = (j >= gw && j < g.jsize - gw + 1 && k >= gw && k < g.ksize - gw + 1);
   // ---- xmin border: looks at the xmax border, shifted by -(jplus+1) ----
   {
@@ -498,9 +498,9 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
     if (jremap < gw) jremap += ny;
     if (jremapp1 < gw) jremapp1 += ny;
     if (inner) {
-      const double own = Fd[krow + (size_t)g.sj * j + gw] * dtdx;
-      const double o0 = Fd[krow + (size_t)g.sj * jremap + nx + gw] * dtdx;
-      const double o1 = Fd[krow + (size_t)g.sj * jremapp1 + nx + gw] * dtdx;
+      const double own = Fd[krow + fsj * j + gw] * dtdx;
+      const double o0 = Fd[krow + fsj * jremap + nx + gw] * dtdx;
+      const double o1 = Fd[krow + fsj * jremapp1 + nx + gw] * dtdx;
       double rv = own + (1.0 - eps) * o0 + eps * o1;
       rv *= 0.5;
       remap[idx2] = rv;
@@ -508,7 +508,7 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
     double e = save[idx2];
     e += (1.0 - eps) * save[P + jremap + (size_t)g.jsize * k] + eps * save[P + jremapp1 + (size_t)g.jsize * k];
     e *= 0.5;
-    emf[krow + (size_t)g.sj * j + gw + (size_t)EMF_Y * N] = e;
+    emf[krow + fsj * j + gw + (size_t)EMF_Y * N] = e;
   }
   // ---- xmax border: looks at the xmin border, shifted by +jplus ----
   {
@@ -517,9 +517,9 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
     if (jremap > ny + gw - 1) jremap -= ny;
     if (jremapp1 > ny + gw - 1) jremapp1 -= ny;
     if (inner) {
-      const double own = Fd[krow + (size_t)g.sj * j + nx + gw] * dtdx;
-      const double o0 = Fd[krow + (size_t)g.sj * jremap + gw] * dtdx;
-      const double o1 = Fd[krow + (size_t)g.sj * jremapp1 + gw] * dtdx;
+      const double own = Fd[krow + fsj * j + nx + gw] * dtdx;
+      const double o0 = Fd[krow + fsj * jremap + gw] * dtdx;
+      const double o1 = Fd[krow + fsj * jremapp1 + gw] * dtdx;
       double rv = own + (1.0 - eps) * o0 + eps * o1;
       rv *= 0.5;
       remap[P + idx2] = rv;
@@ -527,7 +527,7 @@ RG_DEVFN void shear_remap_cell(const DevParams& g, const ShearRemap sr, const do
     double e = save[P + idx2];
     e += (1.0 - eps) * save[jremap + (size_t)g.jsize * k] + eps * save[jremapp1 + (size_t)g.jsize * k];
     e *= 0.5;
-    emf[krow + (size_t)g.sj * j + nx + gw + (size_t)EMF_Y * N] = e;
+    emf[krow + fsj * j + nx + gw + (size_t)EMF_Y * N] = e;
   }
 }
 
@@ -669,14 +669,15 @@ RG_DEVFN void mhd_update3d_column(const DevParams& g, const RotCoef rc, const do
                                   double* __restrict__ Unew, const double* __restrict__ F, const double* __restrict__ emf,
                                   const double* __restrict__ remap, double dt, double dtdx, double dtdy, double dtdz,
                                   unsigned t, int k_lo, int k_hi, int seg_len, unsigned long long* dt_slots = 0) {
-  const size_t N = g.ncell;
-  const unsigned sj = g.sj, sk = g.sk;
+  const size_t N = g.ncell, NF = g.fN;
+  const unsigned sj = g.sj, sk = g.sk, fsj = g.fsj, fsk = g.fsk;   // (F / emf have a pitch of their own: flux_index)
   const int gw = g.gw;
   const unsigned seg = t / sk, col = t - seg * sk;
   IJK c = unflatten(g, col);
   const int ka = k_lo + (int)seg * seg_len;
   const int kb = (ka + seg_len < k_hi) ? ka + seg_len : k_hi;
   unsigned idx = col + (unsigned)ka * sk;
+  unsigned fidx = flux_index(g, c.i, c.j, ka);
   const bool in_col = c.i >= gw && c.i < g.isize - gw && c.j >= gw && c.j < g.jsize - gw;
   const bool ct_col = c.i >= gw && c.i <= g.isize - gw && c.j >= gw && c.j <= g.jsize - gw;
   if (!ct_col) {   // ghost columns: the new array gets the old values (refilled by the next ghost fill)
@@ -686,34 +687,34 @@ RG_DEVFN void mhd_update3d_column(const DevParams& g, const RotCoef rc, const do
     }
     return;
   }
-  const double* eZ = emf + (size_t)EMF_Z * N; const double* eY = emf + (size_t)EMF_Y * N; const double* eX = emf + (size_t)EMF_X * N;
+  const double* eZ = emf + (size_t)EMF_Z * NF; const double* eY = emf + (size_t)EMF_Y * NF; const double* eX = emf + (size_t)EMF_X * NF;
   // this plane's share of the carried entries
   double fz[5], eX00, eX10, eY00, eY10, uC;
 #pragma unroll
-  for (int v = 0; v < 5; ++v) fz[v] = in_col ? F[idx + (size_t)(F_Z + v) * N] : 0.0;
-  eX00 = eX[idx]; eX10 = eX[idx + sj]; eY00 = eY[idx]; eY10 = eY[idx + 1];
+  for (int v = 0; v < 5; ++v) fz[v] = in_col ? F[fidx + (size_t)(F_Z + v) * NF] : 0.0;
+  eX00 = eX[fidx]; eX10 = eX[fidx + fsj]; eY00 = eY[fidx]; eY10 = eY[fidx + 1];
   uC = Uold[idx + IC * N];
-  for (int k = ka; k < kb; ++k, idx += sk) {
+  for (int k = ka; k < kb; ++k, idx += sk, fidx += fsk) {
     c.k = k;
     UpdIn in;
     const bool up = k + 1 < g.ksize;   // (the top plane is a ghost plane: nothing of plane k+1 is used there)
-    const unsigned nx_ = idx + sk;
+    const unsigned nx_ = idx + sk, fnx = fidx + fsk;
 #pragma unroll
     for (int v = 0; v < 8; ++v) in.u[v] = (v == IC) ? uC : Uold[idx + v * N];
 #pragma unroll
     for (int v = 0; v < 5; ++v) {
-      in.fx0[v] = in_col ? F[idx + (size_t)(F_X + v) * N] : 0.0;
-      in.fy0[v] = in_col ? F[idx + (size_t)(F_Y + v) * N] : 0.0;
+      in.fx0[v] = in_col ? F[fidx + (size_t)(F_X + v) * NF] : 0.0;
+      in.fy0[v] = in_col ? F[fidx + (size_t)(F_Y + v) * NF] : 0.0;
       in.fz0[v] = fz[v];
-      in.fx1[v] = in_col ? F[idx + 1 + (size_t)(F_X + v) * N] : 0.0;
-      in.fy1[v] = in_col ? F[idx + sj + (size_t)(F_Y + v) * N] : 0.0;
-      in.fz1[v] = (in_col && up) ? F[nx_ + (size_t)(F_Z + v) * N] : 0.0;
+      in.fx1[v] = in_col ? F[fidx + 1 + (size_t)(F_X + v) * NF] : 0.0;
+      in.fy1[v] = in_col ? F[fidx + fsj + (size_t)(F_Y + v) * NF] : 0.0;
+      in.fz1[v] = (in_col && up) ? F[fnx + (size_t)(F_Z + v) * NF] : 0.0;
     }
-    in.eZ00 = eZ[idx]; in.eZ10 = eZ[idx + 1]; in.eZ01 = eZ[idx + sj]; in.eZ11 = eZ[idx + sj + 1];
+    in.eZ00 = eZ[fidx]; in.eZ10 = eZ[fidx + 1]; in.eZ01 = eZ[fidx + fsj]; in.eZ11 = eZ[fidx + fsj + 1];
     in.eY00 = eY00; in.eY10 = eY10;
     in.eX00 = eX00; in.eX10 = eX10;
-    in.eY01 = up ? eY[nx_] : 0.0; in.eY11 = up ? eY[nx_ + 1] : 0.0;
-    in.eX01 = up ? eX[nx_] : 0.0; in.eX11 = up ? eX[nx_ + sj] : 0.0;
+    in.eY01 = up ? eY[fnx] : 0.0; in.eY11 = up ? eY[fnx + 1] : 0.0;
+    in.eX01 = up ? eX[fnx] : 0.0; in.eX11 = up ? eX[fnx + fsj] : 0.0;
     in.uA1 = Uold[idx + 1 + IA * N];
     in.uB1 = Uold[idx + sj + IB * N];
     in.uC1 = up ? Uold[nx_ + IC * N] : 0.0;

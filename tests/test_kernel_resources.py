@@ -42,7 +42,9 @@ def test_mhd3d_sweep_resources(lib_resources):
         # no spilled vector register in either build (round 5: the contracted build's one-loop form recomputes two per-thread decodes
         # every plane instead of keeping them in registers over the z march; rounds 3-4 tolerated 2-3 spilled values there)
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
-        assert r["sgpr_spill"] <= (24 if exact else 16), (k, r)      # (round 5: 40 / 20)
+        # (round 5: 40 / 20 spilled scalar registers; round 6: 2 / 0 -- the component offsets of the flux stores are recomputed at the
+        #  end of every solve, rg_fresh in tiled_mhd.h, instead of living across it)
+        assert r["sgpr_spill"] <= 8, (k, r)
         # the same kernel with the 2 x 32 geometry of the last x face column (a short second launch): no spill either
         (k, r), = pick(R, "mhd3d_sweep_kernel<%s, rgpu_tiled::MhTile<2, 32, true>" % spec).items()
         assert r["lds"] == 116384 and r["occupancy"] == 2 and r["scratch"] == 0 and r["vgpr_spill"] == 0, (k, r)
