@@ -100,7 +100,9 @@ class CommRun:
         here = os.path.dirname(os.path.abspath(__file__))
         cpath = getattr(self.CL, "_rgpu_path", "")
         if os.path.dirname(cpath) == here and os.path.dirname(os.path.abspath(self.L.path)) == here:
-            if os.path.basename(cpath) != os.path.basename(comm_lib_path(self.L.arithmetic)):
+            # (librgpu_comm_measure.so: the measurement build of scripts/slab_probe.py, linked against librgpu_fast.so by build.py --measure)
+            ok_names = [os.path.basename(comm_lib_path(self.L.arithmetic))] + (["librgpu_comm_measure.so"] if self.L.arithmetic == "contracted" else [])
+            if os.path.basename(cpath) not in ok_names:
                 raise RgpuError("CommRun: %s does not drive %s (arithmetic %s)" % (os.path.basename(cpath), os.path.basename(self.L.path), self.L.arithmetic))
         self.rank, self.world = rank, world
         self.ini_path, self.overrides = ini_path, overrides
