@@ -688,7 +688,7 @@ def main():
                 sys.exit(5)
             step, timers_src = srun.oneStepIntegration, srun.solver
             slab_batch = srun.run_steps      # rgpu_comm_run_steps: the K timed steps as ONE call, the time step on the device between them
-            sched = {"2": "2 (boundary-first)"}.get(os.environ.get("RGPU_COMM_SCHEDULE", ""), "1 (overlap)")
+            sched = {0: "0 (serial)", 1: "1 (overlap)", 2: "2 (boundary-first)"}.get(srun.schedule(), "?")
             driver = "%sC++ slab driver librgpu_comm%s.so over %s (include/rgpu_comm.h), schedule %s, %s exchange, %.1f MB sent per rank and step" % (
                 "TEST TRANSPORT (RGPU_BENCH_DRIVER=staged-test) -- " if os.environ.get("RGPU_BENCH_DRIVER") == "staged-test" else "",
                 "" if args.arith == "exact" else "_fast", info["transport"], sched,

@@ -399,7 +399,7 @@ int rgpu_selftest_alfven(const rgpu_params* p, int n, const double* states36, do
  * Environment variables the libraries read (all optional; everything else is an argument of an entry point):
  *   RGPU_TILED=0              librgpu.so: the flat per-cell kernels everywhere instead of the LDS-tiled cooperative ones (a second,
  *                             independently tested implementation of every step; 3-10x slower)
- *   RGPU_COMM_SCHEDULE=1|2    librgpu_comm.so: default step schedule of the slab driver (rgpu_comm_set_overlap, rgpu_comm.h)
+ *   RGPU_COMM_SCHEDULE=1|2    librgpu_comm.so: step schedule of the slab driver where the caller leaves the choice to it (rgpu_comm_set_overlap(-1), rgpu_comm.h)
  *   RGPU_COMM_PACK=0          ... one send / recv per variable and face instead of the packed exchange
  *   RGPU_HALO_PRIO=high|low   ... priority of the halo stream (default: normal)
  *   RGPU_COMM_ONE_STREAM=1    ... halo traffic on the compute stream (no overlap): fallback should two streams on one RCCL

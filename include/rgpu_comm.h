@@ -118,9 +118,11 @@ double rgpu_comm_last_exchange_ms(rgpu_comm* cm);
  * planes, exchange behind the update of the inner planes.  2: boundary-first (3D MHD; other solvers: same as 1) -- fluxes and
  * update of the boundary planes first (two short launches of the z-marching sweep), exchange behind the sweep AND the update of
  * the inner planes; costs two extra pipeline fills of the sweep, hides a link time up to the whole inner step (for thin slabs on slow
- * links: at 512^2 x 64 per rank it overtakes schedule 1 when a face takes longer than ~1.3 ms).  -1 (default): 1, or what
- * RGPU_COMM_SCHEDULE=1|2 in the environment says.  Every schedule gives the same doubles. */
+ * links).  -1 (default): what RGPU_COMM_SCHEDULE=1|2 in the environment says, else by the thickness of the slab -- 2 for 3D MHD slabs
+ * of up to 96 planes (N = 8 at 512^3: the inner update alone is shorter than an exchange over xGMI), 1 otherwise.  Every schedule gives
+ * the same doubles.  rgpu_comm_schedule: the schedule the next step will run under (0 / 1 / 2). */
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap);
+int rgpu_comm_schedule(rgpu_comm* cm);
 
 /* hipSetDevice for launchers without a HIP binding of their own: call before rgpu_create / rgpu_comm_create */
 int rgpu_comm_set_device(int device);

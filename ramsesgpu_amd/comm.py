@@ -47,6 +47,8 @@ def load_comm_library(path=None):
     lib.rgpu_comm_halo_bytes.argtypes = [cm]
     lib.rgpu_comm_set_overlap.restype = C.c_int
     lib.rgpu_comm_set_overlap.argtypes = [cm, C.c_int]
+    lib.rgpu_comm_schedule.restype = C.c_int
+    lib.rgpu_comm_schedule.argtypes = [cm]
     for name in ("rgpu_comm_exchange_z_wait",):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [cm]
@@ -76,7 +78,7 @@ def load_comm_library(path=None):
 DECLARED_SYMBOLS = [
     "rgpu_comm_unique_id", "rgpu_comm_create", "rgpu_comm_destroy", "rgpu_comm_last_error", "rgpu_comm_exchange_z_start",
     "rgpu_comm_exchange_z_wait", "rgpu_comm_make_all_boundaries", "rgpu_comm_compute_dt", "rgpu_comm_godunov_unsplit",
-    "rgpu_comm_one_step_integration", "rgpu_comm_run_steps", "rgpu_comm_clocked_steps", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_rccl_version", "rgpu_comm_transport_name", "rgpuh_run_slabs",
+    "rgpu_comm_one_step_integration", "rgpu_comm_run_steps", "rgpu_comm_clocked_steps", "rgpu_comm_history_mri", "rgpu_comm_history_turbulence", "rgpu_comm_set_overlap", "rgpu_comm_schedule", "rgpu_comm_halo_bytes", "rgpu_comm_last_exchange_ms", "rgpu_comm_set_device", "rgpu_comm_info", "rgpu_comm_rccl_version", "rgpu_comm_transport_name", "rgpuh_run_slabs",
 ]
 
 
@@ -128,6 +130,10 @@ class CommRun:
     def _chk(self, rc, what):
         if rc != 0:
             raise RgpuError("%s: %s (%d)" % (what, self.CL.rgpu_comm_last_error(self.cm).decode(), rc))
+
+    def schedule(self):
+        """the step schedule in force (0 serial, 1 overlapped, 2 boundary-first): rgpu_comm_schedule"""
+        return int(self.CL.rgpu_comm_schedule(self.cm))
 
     def halo_bytes(self):
         """bytes this rank sends per halo exchange (0: nothing is exchanged)"""

@@ -186,6 +186,20 @@ int godunov_unsplit(rgpu_comm* cm, int nStep, double dt, double t) {
   return rc;
 }
 
+// The schedule of a step when the caller left the choice to the driver (rgpu_comm_set_overlap(-1), the default): RGPU_COMM_SCHEDULE=1|2
+// if set, else by the thickness of the slab.  One-GPU probe with the link time emulated (profiles/r06_slab_probe.log, 512^2 planes, 103 MB
+// per rank and step): slabs of 64 planes (N = 8 at 512^3) take 4.2-4.3 ms per step under schedule 2 whatever the link delivers, and
+// 5.0 / 4.4 / 4.3 / 4.1 ms under schedule 1 at 40 / 60 / 80 / 100 GB/s per link -- the window of the inner update (~0.6 ms) is shorter
+// than an exchange over xGMI at the rates RCCL's send / recv reach; slabs of 128 planes and more are ahead under schedule 1 at every
+// rate (7.7 against 8.0 ms at 40 GB/s).  Every rank takes the same decision (all slabs have the same thickness).
+int effective_schedule(const rgpu_comm* cm) {
+  if (cm->overlap >= 0) return cm->overlap;
+  static const char* e_mode = std::getenv("RGPU_COMM_SCHEDULE");   // 1 / 2 (include/rgpu_comm.h)
+  static const int env_mode = e_mode ? std::atoi(e_mode) : -1;
+  if (env_mode >= 1 && env_mode <= 2) return env_mode;
+  return (cm->p.mhdEnabled && cm->p.nz <= 96) ? 2 : 1;
+}
+
 int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // the dissipative stage needs a second exchange inside the step, the random forcing a global sum and a change of the
   // whole updated state: both use the serial schedule
@@ -220,15 +234,8 @@ int godunov_unsplit_pieces(rgpu_comm* cm, int nStep, double dt, double t) {
   // Mode 2, boundary-first (3D MHD, the one solver whose update is a kernel of its own): the fluxes of the planes the boundary
   // updates read come from two short launches of the sweep, so that the exchange starts BEFORE the sweep of the inner planes and
   // hides behind it and the inner update (N = 8, 512^2 x 64 slab: a window of ~4 ms instead of the ~0.85 ms of the inner update
-  // alone), for two extra pipeline fills of the z march (+0.39 ms at that size).  Mode -1 = schedule 1 unless RGPU_COMM_SCHEDULE says
-  // otherwise: with the packed exchange (rg_transport.h) the one-GPU probe has schedule 1 ahead down to a 60 GB/s link even at N = 8
-  // (5.66 against 5.88 ms), level at 40 GB/s; schedule 2 is for links slower than that, to be decided by the first multi-GPU run.
-  int mode = cm->overlap;
-  if (mode < 0) {
-    static const char* e_mode = std::getenv("RGPU_COMM_SCHEDULE");   // 1 / 2 (include/rgpu_comm.h)
-    static const int env_mode = e_mode ? std::atoi(e_mode) : -1;
-    mode = env_mode >= 1 && env_mode <= 2 ? env_mode : 1;
-  }
+  // alone), for two extra pipeline fills of the z march (+0.3 ms at that size).  Mode -1: effective_schedule above.
+  const int mode = effective_schedule(cm);
   const bool early = mode == 2 && has_inner && cm->p.mhdEnabled && nz > 4 * gw + 2;
   // both boundary ranges go through the *_pair entry points: one launch of the update kernel and one of the ghost fill for the two
   // of them -- what separates the end of the sweep from the start of the exchange is a handful of launches
@@ -334,6 +341,7 @@ long long rgpu_comm_halo_bytes(rgpu_comm* cm) {
   return b;
 }
 long long rgpu_comm_clocked_steps(rgpu_comm* cm) { return cm ? cm->clocked_steps : 0; }
+int rgpu_comm_schedule(rgpu_comm* cm) { return cm ? effective_schedule(cm) : -1; }
 int rgpu_comm_set_overlap(rgpu_comm* cm, int overlap) { RG_CHECK_CM(cm); cm->overlap = (overlap < -1 || overlap > 2) ? 1 : overlap; return RGPU_OK; }
 
 int rgpu_comm_one_step_integration(rgpu_comm* cm, int* nStep, double* t, double* dt) {

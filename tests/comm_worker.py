@@ -394,6 +394,11 @@ def _one_case(base, ov, nsteps, out):
         faces = int(run.p.bc[4] == _capi.BC_COPY) + int(run.p.bc[5] == _capi.BC_COPY)
         want = faces * gw * (run.p.nx + 2 * gw) * (run.p.ny + 2 * gw) * run.p.nbVar * 8
         assert run.halo_bytes() == want and (want > 0 or not ring1), (run.halo_bytes(), want)
+    # the schedule in force: what the test asked for, or (COMM_OVERLAP=-1, the driver's choice) boundary-first for 3D MHD slabs of up to
+    # 96 planes, overlapped otherwise (include/rgpu_comm.h; RGPU_COMM_SCHEDULE is not set by the tests that leave the choice open)
+    asked = int(os.environ.get("COMM_OVERLAP", "1"))
+    want_sched = asked if asked >= 0 else (int(os.environ["RGPU_COMM_SCHEDULE"]) if os.environ.get("RGPU_COMM_SCHEDULE") in ("1", "2") else (2 if (run.p.mhdEnabled and run.p.nz <= 96) else 1))
+    assert run.schedule() == want_sched, (run.schedule(), want_sched)
     run.init_simulation()
     # COMM_RUN_STEPS=k: the steps through rgpu_comm_run_steps in two calls (k, then the rest) instead of one oneStepIntegration per step:
     # where the configuration allows it the time step stays on the device between steps and the host reads a batch of records once

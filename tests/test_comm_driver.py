@@ -141,6 +141,14 @@ def test_cpp_driver_matches_single_domain(base, ov, nsteps, world, overlap, comm
     run_worker(base, ov, nsteps, world, overlap, tmp_path)
 
 
+@pytest.mark.parametrize("base,ov,nsteps,world", [("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=24;MHD.omega0=0.02", 3, 2),     # thin MHD slabs: boundary-first
+                                                  ("implode3d", "mesh.nx=8;mesh.ny=8;mesh.nz=16;hydro.riemannSolver=hllc", 3, 2)],   # hydro: overlapped
+                         ids=["mhd-thin-slabs", "hydro"])
+def test_default_schedule_follows_the_slab_thickness(base, ov, nsteps, world, comm_emu_lib, oracle, tmp_path):
+    """rgpu_comm_set_overlap(-1): the driver picks the schedule (comm_worker.py asserts rgpu_comm_schedule) -- and the run equals the oracle"""
+    run_worker(base, ov, nsteps, world, -1, tmp_path)
+
+
 RUN_STEPS = [CASES[n] for n in (0, 2, 4, 6, 7, 9, 10, 11, 12, 14, 18, 19, 20, 21, 22, 23)] + [
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=32;MHD.omega0=0.02", 3, 4, 1),      # four slabs
     ("mhd_mri_3d", "mesh.nx=6;mesh.ny=8;mesh.nz=64;MHD.omega0=0.02", 3, 4, 2)]
