@@ -275,10 +275,16 @@ def poison():
     base, ov, frank, fstep, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = Library(os.path.join(ROOT, "tests", "_build", "librgpu_emu.so"))
-    CL = rcomm.load_comm_library(os.path.join(ROOT, "tests", "_build", "librgpu_comm_emu.so"))
-    keep = [EXCHANGE_FN(_exchange), ALLREDUCE_FN(_allreduce)]
-    CL.rgpu_comm_test_set_callbacks(keep[0], keep[1])
+    device = os.environ.get("COMM_DEVICE", "cpu")
+    lib, CL, keep = load_libs(device)
+    if device == "cpu":
+        fail_next = lambda: lib.lib.rgpu_emu_fail_launch_after(1)
+    else:
+        # the device backend: the product libraries have no failure injection; tests/shim/fail_shim.cpp, preloaded into this process,
+        # stands between the driver and rgpu_step_fill_planes_pair (one call per step of the overlapped schedules)
+        shim = C.CDLL(os.environ["LD_PRELOAD"].split(":")[0])
+        shim.rgpu_test_fail_after.argtypes = [C.c_int]
+        fail_next = lambda: shim.rgpu_test_fail_after(1)
     ids = [rcomm.unique_id(CL) if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
     ini = os.path.join(ROOT, "configs", base + ".ini")
@@ -292,7 +298,7 @@ def poison():
         if fstep:
             assert run.run_steps(fstep) == fstep
         if rank == frank:
-            lib.lib.rgpu_emu_fail_launch_after(1)
+            fail_next()
         try:
             run.run_steps(3)
         except Exception as e:  # noqa: BLE001
@@ -302,7 +308,7 @@ def poison():
         # leave their batch in good health -- the failed rank has to pair the all-reduce of THEIR next call
         for n in range(fstep + 3):
             if rank == frank and n == fstep:
-                lib.lib.rgpu_emu_fail_launch_after(1)
+                fail_next()
             try:
                 run.run_steps(1)
             except Exception as e:  # noqa: BLE001
@@ -311,7 +317,7 @@ def poison():
     else:
         for n in range(fstep + 3):
             if rank == frank and n == fstep:
-                lib.lib.rgpu_emu_fail_launch_after(1)
+                fail_next()
             try:
                 run.oneStepIntegration()
             except Exception as e:  # noqa: BLE001

@@ -153,6 +153,54 @@ def test_bench_size_slabs_of_64_planes(base, ov, nsteps, world, overlap, arith, 
     run_worker(base, ov, nsteps, world, overlap, tmp_path, env_extra=dict(ENV, COMM_ARITH=arith, COMM_CHECK="single"), timeout=1200)
 
 
+def build_fail_shim():
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so, src = os.path.join(out_dir, "librgpu_fail_shim.so"), os.path.join(ROOT, "tests", "shim", "fail_shim.cpp")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", src, "-ldl", "-o", so])
+    return so
+
+
+def test_fail_shim_builds_and_exports_the_step_piece():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", build_fail_shim()], universal_newlines=True)
+    assert " T rgpu_step_fill_planes_pair" in out and " T rgpu_test_fail_after" in out
+
+
+POISON_GPU = [
+    # (ini, overrides, world, failing rank, failing step, loop): a step piece fails on ONE rank of the device backend, where the host does
+    # not see the records of a batch until it ends -- every rank must come back with an error, nobody may wait in a collective
+    ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=32", 2, 1, 0, "host"),      # the reference's per-step loop
+    ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=32", 2, 0, 2, "batch"),     # first step of a batch of three: the failed rank pairs the queued steps
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=16;mesh.nz=60;" + MRI, 3, 1, 1, "batch"),
+    ("orszag-tang3d", "mesh.nx=16;mesh.ny=16;mesh.nz=32", 2, 1, 1, "single"),    # last (only) step of a batch: told through the next call's all-reduce,
+    ("mhd_mri_3d", "mesh.nx=16;mesh.ny=16;mesh.nz=60;" + MRI, 3, 0, 2, "single"),    # whose first record the healthy ranks check on the host
+    ("implode3d", "mesh.nx=24;mesh.ny=24;mesh.nz=32;hydro.riemannSolver=hllc", 2, 1, 1, "batch"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,ov,world,fail_rank,fail_step,loop", POISON_GPU, ids=["%s-x%d-r%d-s%d-%s" % (c[0], c[2], c[3], c[4], c[5]) for c in POISON_GPU])
+def test_a_failed_step_piece_on_one_rank_reaches_every_rank_on_the_device(base, ov, world, fail_rank, fail_step, loop, dev_comm_exact, gpu_lib, tmp_path):
+    """round-5 ADVICE (medium), on the backend it was about: the product's slab driver + tiled kernels, rank processes on one GPU (test
+    wire), a step piece failing on one rank (tests/shim/fail_shim.cpp between librgpu_comm and librgpu).  The failing rank posts the
+    exchange its neighbours wait for and poisons the 1/dt all-reduce; healthy ranks that have queued a batch find stop = 3 in its records
+    (or in the host-checked first record of their next batch) and return "1/dt is not finite"."""
+    from ramsesgpu_amd.solver import lib_path
+    from test_comm_driver import free_port
+    import sys
+    out = str(tmp_path / "result.txt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "comm_worker.py"), "--poison", base, ov, str(fail_rank), str(fail_step), out]
+    env = dict(os.environ, OMP_NUM_THREADS="1", COMM_OVERLAP="1", COMM_ARITH="exact", LD_PRELOAD=build_fail_shim(), RGPU_SHIM_REAL=lib_path("exact"), **ENV)
+    if loop != "host":
+        env["POISON_RUN_STEPS"] = loop
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert open(out).read().strip() == "OK", open(out).read()
+
+
 FRONTEND_GPU = [
     # whole-box HDF5 file written rank after rank + XDMF index, and per-rank .vti pieces + .pvti index, from 2 and 3 rank processes
     ("mhd_mri_3d", "mesh.nx=16;mesh.ny=24;mesh.nz=40;MRI.amp=0.2;run.nstepmax=6;run.noutput=3;run.tend=1e9;output.outputVtk=yes;output.outputHdf5=yes", 2),
